@@ -1,0 +1,151 @@
+"""ctypes binding of libssn_hip.so (C ABI declared in include/ssn_hip.h).
+
+The library is built in-tree by :func:`build` (``hipcc --offload-arch=gfx950``) and loaded
+lazily.  There is NO CPU fallback: if the shared object is missing or a tensor is not on a
+HIP device the ops raise.  (The CPU-only test tier drives the same C ABI through a host
+emulation build of the very same kernel sources, ``tests/emu``; it has to be installed
+explicitly with :func:`use_library_for_testing` and is never picked up by the product path.)
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "elementwise.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
+
+STPP_MAX_PARTS = 24
+
+
+class SsnStppTable(ctypes.Structure):
+    _fields_ = [("n_parts", ctypes.c_int), ("n_seg", ctypes.c_int),
+                ("act_lo", ctypes.c_int), ("act_hi", ctypes.c_int),
+                ("lo", ctypes.c_int * STPP_MAX_PARTS), ("hi", ctypes.c_int * STPP_MAX_PARTS),
+                ("norm", ctypes.c_int * STPP_MAX_PARTS), ("col", ctypes.c_int * STPP_MAX_PARTS)]
+
+
+# signature codes: p pointer, i int, l long, f float, u unsigned long long
+_SIGS = {
+    "ssn_conv_bn_relu_fwd": "pppppiiiiliiiliiiiip",
+    "ssn_bn_fold": "pppppfppip",
+    "ssn_relu_bn_bwd": "pppiiillp",
+    "ssn_conv_dgrad": "pppiiiiliiiliiiiip",
+    "ssn_weight_transpose": "ppiiip",
+    "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
+    "ssn_pool_fwd": "ipppiiiiliiliiip",
+    "ssn_pool_bwd": "ipppiiiiliiliiiip",
+    "ssn_global_avgpool_fwd": "ppiiilp",
+    "ssn_global_avgpool_bwd": "ppiiilip",
+    "ssn_dropout_fwd": "ppplfup",
+    "ssn_dropout_bwd": "ppplfp",
+    "ssn_stpp_fwd": "ppppiipp",
+    "ssn_stpp_bwd": "ppppiipp",
+    "ssn_stpp_reorg": "piippppiiiiipppp",
+    "ssn_linear_fwd": "ppppiiip",
+    "ssn_linear_bwd": "ppppppiiiip",
+    "ssn_row_gather": "pppiip",
+    "ssn_row_scatter": "pppiiip",
+    "ssn_ce_loss_fwd": "ppppiip",
+    "ssn_ce_loss_bwd": "pppppiip",
+    "ssn_completeness_loss_fwd": "pppppiiiiiifp",
+    "ssn_completeness_loss_bwd": "ppppiifp",
+    "ssn_cw_smoothl1_fwd": "pppppiip",
+    "ssn_cw_smoothl1_bwd": "ppppiip",
+    "ssn_sgd_step": "ppplffffip",
+    "ssn_sumsq": "plpipp",
+    "ssn_scale": "plpfp",
+}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float,
+       "u": ctypes.c_ulonglong}
+
+EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
+                                "ssn_conv_pick_tile"])
+
+
+class SsnLibrary:
+    """A loaded libssn_hip.so (or, in tests only, the host-emulation build of the same ABI)."""
+
+    def __init__(self, path, is_emulator=False):
+        self.path = path
+        self.is_emulator = is_emulator
+        self.cdll = ctypes.CDLL(path)
+        self.cdll.ssn_last_error.restype = ctypes.c_char_p
+        self.cdll.ssn_last_error.argtypes = []
+        self.cdll.ssn_abi_version.restype = ctypes.c_int
+        self.cdll.ssn_conv_wgrad_workspace_bytes.restype = ctypes.c_long
+        self.cdll.ssn_conv_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 7
+        self.cdll.ssn_conv_pick_tile.restype = ctypes.c_int
+        self.cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
+        self._fn = {}
+        for name, sig in _SIGS.items():
+            fn = getattr(self.cdll, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [_CT[c] for c in sig]
+            self._fn[name] = fn
+
+    def call(self, name, *args):
+        rc = self._fn[name](*args)
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (name, rc, self.cdll.ssn_last_error().decode()))
+
+    def wgrad_workspace_bytes(self, n, cin, cout, ho, wo, ksize, tile_cfg=-1):
+        return int(self.cdll.ssn_conv_wgrad_workspace_bytes(n, cin, cout, ho, wo, ksize, tile_cfg))
+
+
+_lock = threading.Lock()
+_lib = None
+_test_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into the in-tree libssn_hip.so (cross-compiles on CPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "ssn_common.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(CSRC, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if verbose and out:
+            print(out.decode())
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def get_lib():
+    """The product library.  Raises if it has not been built -- never falls back to anything else."""
+    global _lib
+    if _test_lib is not None:
+        return _test_lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "libssn_hip.so is missing (%s). Build it with __graft_entry__.build() / "
+                        "action_detection_amd.build(); there is no CPU fallback." % LIB_PATH)
+                _lib = SsnLibrary(LIB_PATH)
+    return _lib
+
+
+def use_library_for_testing(lib):
+    """Install (or with None remove) an alternative ABI implementation.  Tests only."""
+    global _test_lib
+    _test_lib = lib
+
+
+def emulator_active():
+    return _test_lib is not None and _test_lib.is_emulator

@@ -1,0 +1,340 @@
+// Weight (and bias) gradient of the backbone convolutions on the exact-f32 MFMA, gfx950.
+//
+// Replaces the cuDNN wgrad the reference reaches through loss.backward()
+// (/root/reference/ssn_train.py:236) for every Conv2d of model_zoo.BNInception.
+//
+//   dW[co][kk] = sum_p G[co][p] * X[kk][p]        kk = (ci, r, s),  p = (n, ho, wo)
+//   db[co]     = sum_p G[co][p]
+//
+// G is the gradient w.r.t. the conv output (already multiplied by the ReLU mask and the folded
+// BN scale, see ssn_relu_bn_bwd).  Both operands are contiguous along p in NCHW, so both LDS
+// tiles are filled with coalesced loads; the reduction dimension of the MFMA is the pixel
+// index.  The pixel range is split over `splits` workgroups (split-K); each writes its partial
+// [Cout][K(+1)] slab, and ssn_conv_wgrad's second kernel sums the slabs in a fixed order, so the
+// result is deterministic (no float atomics).
+#include "ssn_common.h"
+
+namespace {
+
+struct WgradArgs {
+    const float* g;  // [N][..Cout..][Ho][Wo] channel-slice base
+    const float* x;  // [N][..Cin..][H][W] channel-slice base
+    float* part;     // [splits][M][ldp]
+    int N, Cin, H, W;
+    long x_img_stride;
+    int M, Ho, Wo;
+    long g_img_stride;
+    int K;    // Cin*KS*KS
+    int ldp;  // K + 1 (last column = bias gradient)
+    int P;    // N*Ho*Wo
+    int pad;
+    int splits, chunks_per_split;  // chunk = 32 pixels
+    int n_mtiles, n_ktiles;
+    FastDiv div_hw, div_w, div_tiles, div_kt;
+};
+
+constexpr int BP = 32;      // pixels per LDS slab
+constexpr int PITCH = 36;   // floats; rows of 144 B keep ds_read_b128 column reads conflict-free
+
+template <int KS, int S, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int NA = BM / 8;
+    constexpr int NBR = BN / 8;
+    constexpr int KK = KS * KS;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PITCH];
+    float* As0 = lds;
+    float* Bs0 = lds + 2 * BM * PITCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const uint32_t tiles = (uint32_t)p.n_mtiles * (uint32_t)p.n_ktiles;
+    const uint32_t nblk = tiles * (uint32_t)p.splits;
+    const uint32_t logical = xcd_remap(blockIdx.x, nblk);
+    uint32_t z, tile, mt, kt;
+    fd_divmod(logical, p.div_tiles, z, tile);
+    fd_divmod(tile, p.div_kt, mt, kt);
+    const int m0 = (int)mt * BM;
+    const int kk0 = (int)kt * BN;
+
+    const int pix = tid & 31;
+    const int rgrp = tid >> 5;  // 0..7
+    const int HW = p.H * p.W;
+    const int howo = p.Ho * p.Wo;
+
+    // per-thread constant decode of the kk rows this thread gathers
+    int b_off[NBR];
+    int b_rs[NBR];
+#pragma unroll
+    for (int i = 0; i < NBR; ++i) {
+        const int kk = kk0 + rgrp + 8 * i;
+        int c, r, s;
+        if (KS == 1) {
+            c = kk;
+            r = 0;
+            s = 0;
+        } else {
+            c = kk / KK;
+            const int rem = kk - c * KK;
+            r = rem / KS;
+            s = rem - r * KS;
+        }
+        b_off[i] = (kk < p.K) ? (c * HW + r * p.W + s) : -1;
+        b_rs[i] = (r << 8) | s;
+    }
+
+    float areg[NA], breg[NBR];
+
+    auto load_slab = [&](int chunk) {
+        const int pp = chunk * BP + pix;
+        const bool valid = pp < p.P;
+        uint32_t n, hw, ho, wo;
+        fd_divmod((uint32_t)(valid ? pp : 0), p.div_hw, n, hw);
+        fd_divmod(hw, p.div_w, ho, wo);
+        const float* gp = p.g + (long)n * p.g_img_stride + hw;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + rgrp + 8 * i;
+            areg[i] = (valid && m < p.M) ? gp[(long)m * howo] : 0.f;
+        }
+        const int h0 = (int)ho * S - p.pad;
+        const int w0 = (int)wo * S - p.pad;
+        const float* xp = p.x + (long)n * p.x_img_stride + h0 * p.W + w0;
+#pragma unroll
+        for (int i = 0; i < NBR; ++i) {
+            const int r = b_rs[i] >> 8, s = b_rs[i] & 255;
+            const bool ok = valid && b_off[i] >= 0 && ((unsigned)(h0 + r) < (unsigned)p.H) &&
+                            ((unsigned)(w0 + s) < (unsigned)p.W);
+            breg[i] = ok ? xp[b_off[i]] : 0.f;
+        }
+    };
+    auto store_slab = [&](int buf) {
+        float* As = As0 + buf * BM * PITCH;
+        float* Bs = Bs0 + buf * BN * PITCH;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) As[(rgrp + 8 * i) * PITCH + pix] = areg[i];
+#pragma unroll
+        for (int i = 0; i < NBR; ++i) Bs[(rgrp + 8 * i) * PITCH + pix] = breg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float rowsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rowsum[i] = 0.f;
+    const bool do_bias = (kt == 0) && (wn == 0);
+
+    const int total_chunks = (p.P + BP - 1) / BP;
+    const int c_begin = (int)z * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+    const int nch = c_end - c_begin;
+
+    if (nch > 0) {
+        load_slab(c_begin);
+        store_slab(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nch; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nch) load_slab(c_begin + t + 1);
+        const float* As = As0 + buf * BM * PITCH + (wm * TM * 32 + li) * PITCH + 4 * lh;
+        const float* Bs = Bs0 + buf * BN * PITCH + (wn * TN * 32 + li) * PITCH + 4 * lh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * PITCH + 8 * u);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * PITCH + 8 * u);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rowsum[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nch) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- partial slab store: part[z][m][kk] (kk contiguous across lanes) ----
+    float* out = p.part + (long)z * p.M * p.ldp;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int kk = kk0 + (wn * TN + j) * 32 + li;
+        if (kk >= p.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) out[(long)m * p.ldp + kk] = acc[i][j][r];
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float tot = rowsum[i] + __shfl_xor(rowsum[i], 32, 64);
+            const int m = m0 + (wm * TM + i) * 32 + li;
+            if (lh == 0 && m < p.M) out[(long)m * p.ldp + p.K] = tot;
+        }
+    }
+}
+
+// dst[m*K + kk] = sum_z part[z][m][kk];  db[m] = sum_z part[z][m][K]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, float* db, int M, int K,
+                                                           int ldp, int splits) {
+    const long total = (long)M * ldp;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += part[(long)z * total + idx];
+        const int m = (int)(idx / ldp);
+        const int kk = (int)(idx - (long)m * ldp);
+        if (kk < K)
+            dw[(long)m * K + kk] = s;
+        else if (db)
+            db[m] = s;
+    }
+}
+
+template <int KS, int S, int WM, int WN, int TM, int TN>
+int launch_wgrad(WgradArgs& a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.n_ktiles = (a.K + BN - 1) / BN;
+    const unsigned tiles = (unsigned)a.n_mtiles * (unsigned)a.n_ktiles;
+    a.div_tiles = make_fastdiv(tiles);
+    a.div_kt = make_fastdiv((uint32_t)a.n_ktiles);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, WM, WN, TM, TN>), dim3(tiles * (unsigned)a.splits), dim3(256), 0,
+                       stream, a);
+    SSN_CHECK_LAUNCH("conv_wgrad");
+    return SSN_OK;
+}
+
+// tile configs: 0: 2,2,1,1 -> 64(co) x 64(kk)   1: 1,4,1,1 -> 32 x 128   2: 2,2,2,2 -> 128 x 128
+//               3: 2,2,1,2 -> 64 x 128          4: 1,4,3,1 -> 96 x 128
+const int kWgBM[5] = {64, 32, 128, 64, 96};
+const int kWgBN[5] = {64, 128, 128, 128, 128};
+
+template <int KS, int S>
+int launch_wgrad_tile(WgradArgs& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_wgrad<KS, S, 2, 2, 1, 1>(a, stream);
+        case 1: return launch_wgrad<KS, S, 1, 4, 1, 1>(a, stream);
+        case 2: return launch_wgrad<KS, S, 2, 2, 2, 2>(a, stream);
+        case 3: return launch_wgrad<KS, S, 2, 2, 1, 2>(a, stream);
+        case 4: return launch_wgrad<KS, S, 1, 4, 3, 1>(a, stream);
+    }
+    ssn_set_error("conv_wgrad: unknown tile config %d", cfg);
+    return SSN_ERR_ARG;
+}
+
+int pick_wgrad_tile(int M, int K) {
+    double best = 1e300;
+    int bc = 0;
+    for (int c = 0; c < 5; ++c) {
+        const double padded = (double)((M + kWgBM[c] - 1) / kWgBM[c]) * kWgBM[c] *
+                              (double)((K + kWgBN[c] - 1) / kWgBN[c]) * kWgBN[c];
+        const double reuse = (kWgBM[c] * kWgBN[c] >= 128 * 64) ? 1.0 : 1.12;
+        if (padded * reuse < best) {
+            best = padded * reuse;
+            bc = c;
+        }
+    }
+    return bc;
+}
+
+void plan_wgrad(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
+    const long tiles = (long)((M + kWgBM[cfg] - 1) / kWgBM[cfg]) * ((K + kWgBN[cfg] - 1) / kWgBN[cfg]);
+    const long chunks = (P + BP - 1) / BP;
+    long want = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
+    if (want < 1) want = 1;
+    long cps = (chunks + want - 1) / want;
+    if (cps < 8) cps = chunks < 8 ? chunks : 8;  // keep at least 256 pixels per workgroup
+    if (cps < 1) cps = 1;
+    *chunks_per_split = (int)cps;
+    *splits = (int)((chunks + cps - 1) / cps);
+}
+
+}  // namespace
+
+extern "C" long ssn_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int ksize, int tile_cfg) {
+    const int K = Cin * ksize * ksize;
+    const int cfg = tile_cfg >= 0 ? tile_cfg : pick_wgrad_tile(Cout, K);
+    int splits, cps;
+    plan_wgrad(Cout, K, (long)N * Ho * Wo, cfg, &splits, &cps);
+    return (long)splits * Cout * (K + 1) * (long)sizeof(float);
+}
+
+extern "C" int ssn_conv_wgrad(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                              long x_img_stride, int Cout, int Ho, int Wo, long g_img_stride, int ksize, int stride,
+                              int pad, void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream) {
+    SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad: null pointer");
+    SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 7, "conv wgrad: ksize %d unsupported", ksize);
+    WgradArgs a;
+    a.g = g;
+    a.x = x;
+    a.part = (float*)workspace;
+    a.N = N;
+    a.Cin = Cin;
+    a.H = H;
+    a.W = W;
+    a.x_img_stride = x_img_stride;
+    a.M = Cout;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.g_img_stride = g_img_stride;
+    a.K = Cin * ksize * ksize;
+    a.ldp = a.K + 1;
+    a.P = N * Ho * Wo;
+    a.pad = pad;
+    a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
+    a.div_w = make_fastdiv((uint32_t)Wo);
+    const int cfg = tile_cfg >= 0 ? tile_cfg : pick_wgrad_tile(Cout, a.K);
+    plan_wgrad(Cout, a.K, a.P, cfg, &a.splits, &a.chunks_per_split);
+    const long need = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
+    if (ws_bytes < need) {
+        ssn_set_error("conv wgrad: workspace %ld < %ld bytes", ws_bytes, need);
+        return SSN_ERR_WORKSPACE;
+    }
+    int rc;
+    if (ksize == 1 && stride == 1)
+        rc = launch_wgrad_tile<1, 1>(a, cfg, stream);
+    else if (ksize == 3 && stride == 1)
+        rc = launch_wgrad_tile<3, 1>(a, cfg, stream);
+    else if (ksize == 3 && stride == 2)
+        rc = launch_wgrad_tile<3, 2>(a, cfg, stream);
+    else if (ksize == 7 && stride == 2)
+        rc = launch_wgrad_tile<7, 2>(a, cfg, stream);
+    else {
+        ssn_set_error("conv wgrad: (k=%d, s=%d) has no kernel", ksize, stride);
+        return SSN_ERR_ARG;
+    }
+    if (rc != SSN_OK) return rc;
+    const long total = (long)Cout * a.ldp;
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)a.part, dw,
+                       db, Cout, a.K, a.ldp, a.splits);
+    SSN_CHECK_LAUNCH("wgrad_reduce");
+    return SSN_OK;
+}

@@ -1,0 +1,235 @@
+// HBM-bound helper kernels of the backbone: BN folding, the fused ReLU+frozen-BN backward mask,
+// weight re-layout for dgrad, dropout, and the fused multi-tensor SGD step.
+// All are plain coalesced grid-stride kernels (no LDS needed); float4 where the plane allows.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "ssn_common.h"
+
+// ---- error string (shared by every translation unit of the library) ----
+static thread_local char g_err[512] = "";
+void ssn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* ssn_last_error(void) { return g_err; }
+extern "C" int ssn_abi_version(void) { return 1; }
+
+namespace {
+
+// Frozen BatchNorm (eval mode, /root/reference/ssn_models.py:156-174) folded with the conv bias:
+//   y = relu(conv(x) * scale + shift),  scale = gamma / sqrt(var + eps),
+//   shift = (bias - mean) * scale + beta
+__global__ void bn_fold_kernel(const float* bias, const float* gamma, const float* beta, const float* mean,
+                               const float* var, float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(var[c] + eps);
+    scale[c] = s;
+    shift[c] = ((bias ? bias[c] : 0.f) - mean[c]) * s + beta[c];
+}
+
+// g = dy * (y > 0) * scale[c], in place on dy.  Tensors are NCHW channel slices.
+__global__ __launch_bounds__(256) void relu_bn_bwd_kernel(float* dy, const float* y, const float* scale, int C,
+                                                          int HW, long dy_img_stride, long y_img_stride,
+                                                          long total, FastDiv div_chw, FastDiv div_hw) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        uint32_t n, rem, c, hw;
+        fd_divmod((uint32_t)idx, div_chw, n, rem);
+        fd_divmod(rem, div_hw, c, hw);
+        const long di = (long)n * dy_img_stride + rem;
+        const long yi = (long)n * y_img_stride + rem;
+        const float yv = y[yi];
+        dy[di] = (yv > 0.f) ? dy[di] * scale[c] : 0.f;
+    }
+}
+
+// wt[ci][co*KK + t] = w[co][ci*KK + t]   (operand A of the dgrad implicit GEMM)
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* w, float* wt, int Cout, int Cin, int KK) {
+    const long total = (long)Cout * Cin * KK;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int t = (int)(idx % KK);
+        const long r = idx / KK;
+        const int ci = (int)(r % Cin);
+        const int co = (int)(r / Cin);
+        wt[((long)ci * Cout + co) * KK + t] = w[idx];
+    }
+}
+
+// Counter-based RNG for dropout: Philox-4x32-10 keyed by (seed), counter = element index / 4.
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                             uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0;
+    c1 = n1;
+    c2 = n2;
+    c3 = n3;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t out[4]) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+// y = x * mask / (1-p); mask bit saved as uint8 (1 = kept).  nn.Dropout semantics
+// (/root/reference/ssn_models.py:74); the reference RNG stream itself is not reproducible.
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* x, float* y, uint8_t* mask, long total,
+                                                          float p, uint64_t seed) {
+    const float inv = 1.f / (1.f - p);
+    const long nquad = (total + 3) / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long)gridDim.x * 256) {
+        uint32_t r[4];
+        philox4(seed, (uint64_t)q, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long i = q * 4 + j;
+            if (i < total) {
+                const float u = (float)(r[j] >> 8) * (1.f / 16777216.f);
+                const uint8_t keep = u >= p;
+                mask[i] = keep;
+                y[i] = keep ? x[i] * inv : 0.f;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, long total,
+                                                          float p) {
+    const float inv = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        dx[i] = mask[i] ? dy[i] * inv : 0.f;
+}
+
+// torch.optim.SGD semantics as used at /root/reference/ssn_train.py:141-144,252 with the
+// per-group lr_mult / decay_mult of ssn_models.py:240-251, over one flat parameter segment:
+//   g = grad * grad_scale + wd * w;  buf = momentum * buf + g (buf = g on the first step);  w -= lr * buf
+__global__ __launch_bounds__(256) void sgd_kernel(float* w, const float* grad, float* buf, long n, float lr,
+                                                  float momentum, float wd, float grad_scale, int first_step) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float g = grad[i] * grad_scale + wd * w[i];
+        float b = first_step ? g : momentum * buf[i] + g;
+        buf[i] = b;
+        w[i] = w[i] - lr * b;
+    }
+}
+
+// sum of squares of a flat segment -> one partial per block (deterministic second stage on host side
+// of the ABI: ssn_sumsq reduces partials in a single-block kernel).
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* x, long n, float* partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const float* partial, int nb, float* out, int accumulate) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+__global__ __launch_bounds__(256) void scale_kernel(float* x, long n, const float* coef_dev, float coef) {
+    const float c = coef_dev ? coef_dev[0] : coef;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= c;
+}
+
+inline unsigned grid_for(long total, int cap = 4096) {
+    long b = (total + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int ssn_bn_fold(const float* conv_bias, const float* gamma, const float* beta, const float* mean,
+                           const float* var, float eps, float* scale, float* shift, int C, hipStream_t stream) {
+    SSN_CHECK_ARG(gamma && beta && mean && var && scale && shift && C > 0, "bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, conv_bias, gamma, beta, mean, var,
+                       eps, scale, shift, C);
+    SSN_CHECK_LAUNCH("bn_fold");
+    return SSN_OK;
+}
+
+extern "C" int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C, int HW,
+                               long dy_img_stride, long y_img_stride, hipStream_t stream) {
+    SSN_CHECK_ARG(dy && y && scale, "relu_bn_bwd: null pointer");
+    const long total = (long)N * C * HW;
+    SSN_CHECK_ARG(total < (1l << 31), "relu_bn_bwd: tensor too large");
+    hipLaunchKernelGGL(relu_bn_bwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, stream, dy, y, scale, C, HW,
+                       dy_img_stride, y_img_stride, total, make_fastdiv((uint32_t)(C * HW)),
+                       make_fastdiv((uint32_t)HW));
+    SSN_CHECK_LAUNCH("relu_bn_bwd");
+    return SSN_OK;
+}
+
+extern "C" int ssn_weight_transpose(const float* w, float* wt, int Cout, int Cin, int ksize, hipStream_t stream) {
+    SSN_CHECK_ARG(w && wt, "weight_transpose: null pointer");
+    const long total = (long)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(weight_transpose_kernel, dim3(grid_for(total)), dim3(256), 0, stream, w, wt, Cout, Cin,
+                       ksize * ksize);
+    SSN_CHECK_LAUNCH("weight_transpose");
+    return SSN_OK;
+}
+
+extern "C" int ssn_dropout_fwd(const float* x, float* y, unsigned char* mask, long total, float p,
+                               unsigned long long seed, hipStream_t stream) {
+    SSN_CHECK_ARG(x && y && mask && p >= 0.f && p < 1.f, "dropout_fwd: bad arguments");
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for((total + 3) / 4)), dim3(256), 0, stream, x, y,
+                       (uint8_t*)mask, total, p, (uint64_t)seed);
+    SSN_CHECK_LAUNCH("dropout_fwd");
+    return SSN_OK;
+}
+extern "C" int ssn_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long total, float p,
+                               hipStream_t stream) {
+    SSN_CHECK_ARG(dy && dx && mask, "dropout_bwd: null pointer");
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, (const uint8_t*)mask, dx,
+                       total, p);
+    SSN_CHECK_LAUNCH("dropout_bwd");
+    return SSN_OK;
+}
+
+extern "C" int ssn_sgd_step(float* w, const float* grad, float* momentum_buf, long n, float lr, float momentum,
+                            float weight_decay, float grad_scale, int first_step, hipStream_t stream) {
+    SSN_CHECK_ARG(w && grad && momentum_buf, "sgd_step: null pointer");
+    if (n == 0) return SSN_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, stream, w, grad, momentum_buf, n, lr,
+                       momentum, weight_decay, grad_scale, first_step);
+    SSN_CHECK_LAUNCH("sgd_step");
+    return SSN_OK;
+}
+
+// out[0] (+)= sum(x^2); workspace: >= 1024 floats
+extern "C" int ssn_sumsq(const float* x, long n, float* out, int accumulate, float* workspace, hipStream_t stream) {
+    SSN_CHECK_ARG(x && out && workspace, "sumsq: null pointer");
+    const unsigned nb = grid_for(n, 1024);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, x, n, workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)workspace, (int)nb, out,
+                       accumulate);
+    SSN_CHECK_LAUNCH("sumsq");
+    return SSN_OK;
+}
+
+// x *= coef  (coef read from device memory when coef_dev != nullptr, e.g. a clip coefficient)
+extern "C" int ssn_scale(float* x, long n, const float* coef_dev, float coef, hipStream_t stream) {
+    SSN_CHECK_ARG(x, "scale: null pointer");
+    if (n == 0) return SSN_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, stream, x, n, coef_dev, coef);
+    SSN_CHECK_LAUNCH("scale");
+    return SSN_OK;
+}

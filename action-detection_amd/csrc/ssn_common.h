@@ -1,0 +1,88 @@
+// Shared device/host helpers for the SSN gfx950 kernels.
+// Everything here is wave64 / CDNA4-only by construction (no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SSN_WAVE 64
+
+// ---- error plumbing (C ABI returns 0 / negative code; message via ssn_last_error) ----
+enum {
+    SSN_OK = 0,
+    SSN_ERR_ARG = -1,      // bad argument / unsupported shape
+    SSN_ERR_LAUNCH = -2,   // hipLaunch failed
+    SSN_ERR_WORKSPACE = -3 // workspace too small
+};
+void ssn_set_error(const char* fmt, ...);
+#define SSN_CHECK_ARG(cond, ...)             \
+    do {                                     \
+        if (!(cond)) {                       \
+            ssn_set_error(__VA_ARGS__);      \
+            return SSN_ERR_ARG;              \
+        }                                    \
+    } while (0)
+#define SSN_CHECK_LAUNCH(name)                                                      \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            ssn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));    \
+            return SSN_ERR_LAUNCH;                                                  \
+        }                                                                           \
+    } while (0)
+
+// ---- division by a runtime-constant divisor (host computes the magic once per launch) ----
+// Valid for 0 <= n < 2^31 and 1 <= d < 2^31 (round-up method, 64-bit intermediate).
+struct FastDiv {
+    uint32_t mul;
+    uint32_t shift;
+    uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d == 1) {
+        f.mul = 0;
+        f.shift = 0;
+        return f;
+    }
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;  // ceil(log2 d)
+    uint64_t m = ((1ull << (32 + l)) + d - 1) / d;  // ceil(2^(32+l)/d), fits in 33 bits
+    f.mul = (uint32_t)(m - (1ull << 32));            // low 32 bits; implicit +2^32
+    f.shift = l;
+    return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+    if (f.d == 1) return n;
+    // q = (n + mulhi(n, mul)) >> shift, done in 64 bits to keep the carry
+    uint64_t t = (uint64_t)__umulhi(n, f.mul) + (uint64_t)n;
+    return (uint32_t)(t >> f.shift);
+}
+__device__ __forceinline__ void fd_divmod(uint32_t n, const FastDiv& f, uint32_t& q, uint32_t& r) {
+    q = fd_div(n, f);
+    r = n - q * f.d;
+}
+
+// ---- wave64 reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// XCD-aware remap of a 1-D block id: consecutive logical ids land on the same XCD
+// (hardware places block b on XCD b % 8 -- speed only, never correctness).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+    const uint32_t q = nblk >> 3, r = nblk & 7;
+    const uint32_t xcd = bid & 7, slot = bid >> 3;
+    const uint32_t base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}

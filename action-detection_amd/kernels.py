@@ -1,0 +1,265 @@
+"""Thin tensor-level wrappers over the C ABI (include/ssn_hip.h).
+
+Every function launches on the caller's current HIP stream and writes into caller-provided
+tensors (PyTorch owns all device memory).  ``ChanSlice`` addresses a channel range of an NCHW
+tensor, which is how the concat-free Inception block outputs are written and read.
+"""
+import ctypes
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+from ._lib import SsnStppTable, STPP_MAX_PARTS
+
+
+class ChanSlice(namedtuple("ChanSlice", "t c0 c")):
+    """Channels [c0, c0+c) of a contiguous NCHW tensor ``t``."""
+
+    @property
+    def ptr(self):
+        _, _, h, w = self.t.shape
+        return self.t.data_ptr() + 4 * self.c0 * h * w
+
+    @property
+    def img_stride(self):
+        _, ct, h, w = self.t.shape
+        return ct * h * w
+
+    @property
+    def n(self):
+        return self.t.shape[0]
+
+    @property
+    def hw(self):
+        return self.t.shape[2], self.t.shape[3]
+
+
+def full(t):
+    return ChanSlice(t, 0, t.shape[1])
+
+
+def _check(*tensors):
+    lib = _lib.get_lib()
+    for t in tensors:
+        if t is None:
+            continue
+        tt = t.t if isinstance(t, ChanSlice) else t
+        if not tt.is_contiguous():
+            raise ValueError("SSN HIP ops need contiguous tensors")
+        if not lib.is_emulator and not tt.is_cuda:
+            raise RuntimeError("SSN HIP ops need HIP (cuda) tensors; there is no CPU fallback")
+    return lib
+
+
+def _stream(lib, t):
+    if lib.is_emulator:
+        return None
+    tt = t.t if isinstance(t, ChanSlice) else t
+    return torch.cuda.current_stream(tt.device).cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    return t.ptr if isinstance(t, ChanSlice) else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------ backbone
+def bn_fold(conv_bias, gamma, beta, mean, var, eps, scale, shift):
+    lib = _check(conv_bias, gamma, beta, mean, var, scale, shift)
+    lib.call("ssn_bn_fold", _p(conv_bias), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(scale),
+             _p(shift), gamma.numel(), _stream(lib, gamma))
+
+
+def conv_fwd(x, w, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
+    """x, y: ChanSlice.  w: [Cout, Cin, k, k]."""
+    lib = _check(x, w, scale, shift, y)
+    h, wd = x.hw
+    ho, wo = y.hw
+    assert w.shape[0] == y.c and w.shape[1] == x.c, (w.shape, x.c, y.c)
+    lib.call("ssn_conv_bn_relu_fwd", _p(x), _p(w), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd, x.img_stride,
+             y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg, _stream(lib, w))
+
+
+def relu_bn_bwd(dy, y, scale):
+    """In place: dy <- dy * (y > 0) * scale[c].  dy, y: ChanSlice with equal channel counts."""
+    lib = _check(dy, y, scale)
+    h, w = y.hw
+    lib.call("ssn_relu_bn_bwd", _p(dy), _p(y), _p(scale), y.n, y.c, h * w, dy.img_stride, y.img_stride,
+             _stream(lib, scale))
+
+
+def weight_transpose(w, wt):
+    lib = _check(w, wt)
+    lib.call("ssn_weight_transpose", _p(w), _p(wt), w.shape[0], w.shape[1], w.shape[2], _stream(lib, w))
+
+
+def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1):
+    """dy: ChanSlice (grad of conv output), dx: ChanSlice (grad of conv input), wt: transposed weights."""
+    lib = _check(dy, wt, dx)
+    ho, wo = dy.hw
+    h, w = dx.hw
+    lib.call("ssn_conv_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
+             dx.img_stride, ksize, stride, pad, int(accumulate), tile_cfg, _stream(lib, wt))
+
+
+def wgrad_workspace_bytes(n, cin, cout, ho, wo, ksize, tile_cfg=-1):
+    return _lib.get_lib().wgrad_workspace_bytes(n, cin, cout, ho, wo, ksize, tile_cfg)
+
+
+def conv_wgrad(g, x, dw, db, ksize, stride, pad, workspace, tile_cfg=-1):
+    """g: ChanSlice (masked grad of conv output), x: ChanSlice (conv input); dw [Cout,Cin,k,k], db [Cout] or None."""
+    lib = _check(g, x, dw, db, workspace)
+    ho, wo = g.hw
+    h, w = x.hw
+    lib.call("ssn_conv_wgrad", _p(g), _p(x), _p(dw), _p(db), x.n, x.c, h, w, x.img_stride, g.c, ho, wo,
+             g.img_stride, ksize, stride, pad, _p(workspace), workspace.numel() * workspace.element_size(),
+             tile_cfg, _stream(lib, dw))
+
+
+def pool_fwd(kind, x, y, argmax, ksize, stride, pad):
+    lib = _check(x, y, argmax)
+    h, w = x.hw
+    ho, wo = y.hw
+    lib.call("ssn_pool_fwd", int(kind == "max"), _p(x), _p(y), _p(argmax), x.n, x.c, h, w, x.img_stride, ho, wo,
+             y.img_stride, ksize, stride, pad, _stream(lib, x))
+
+
+def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate):
+    lib = _check(dy, dx, argmax)
+    h, w = dx.hw
+    ho, wo = dy.hw
+    lib.call("ssn_pool_bwd", int(kind == "max"), _p(dy), _p(argmax), _p(dx), dx.n, dx.c, h, w, dx.img_stride, ho,
+             wo, dy.img_stride, ksize, stride, pad, int(accumulate), _stream(lib, dx))
+
+
+def gap_fwd(x, y):
+    lib = _check(x, y)
+    h, w = x.hw
+    lib.call("ssn_global_avgpool_fwd", _p(x), _p(y), x.n, x.c, h * w, x.img_stride, _stream(lib, y))
+
+
+def gap_bwd(dy, dx, accumulate=False):
+    lib = _check(dy, dx)
+    h, w = dx.hw
+    lib.call("ssn_global_avgpool_bwd", _p(dy), _p(dx), dx.n, dx.c, h * w, dx.img_stride, int(accumulate),
+             _stream(lib, dy))
+
+
+def dropout_fwd(x, y, mask, p, seed):
+    lib = _check(x, y, mask)
+    lib.call("ssn_dropout_fwd", _p(x), _p(y), _p(mask), x.numel(), float(p), int(seed), _stream(lib, x))
+
+
+def dropout_bwd(dy, mask, dx, p):
+    lib = _check(dy, mask, dx)
+    lib.call("ssn_dropout_bwd", _p(dy), _p(mask), _p(dx), dy.numel(), float(p), _stream(lib, dy))
+
+
+# ------------------------------------------------------------------------------------ STPP / heads / losses
+def make_stpp_table(parts, n_seg, act_lo, act_hi):
+    """parts: list of (lo, hi, norm, col)."""
+    if len(parts) > STPP_MAX_PARTS:
+        raise ValueError("STPP config has %d parts (max %d)" % (len(parts), STPP_MAX_PARTS))
+    t = SsnStppTable()
+    t.n_parts, t.n_seg, t.act_lo, t.act_hi = len(parts), n_seg, act_lo, act_hi
+    for i, (lo, hi, norm, col) in enumerate(parts):
+        t.lo[i], t.hi[i], t.norm[i], t.col[i] = lo, hi, norm, col
+    return t
+
+
+def stpp_fwd(ft, scaling, act_ft, stpp_ft, table):
+    lib = _check(ft, scaling, act_ft, stpp_ft)
+    lib.call("ssn_stpp_fwd", _p(ft), _p(scaling), _p(act_ft), _p(stpp_ft), act_ft.shape[0], ft.shape[1],
+             ctypes.addressof(table), _stream(lib, ft))
+
+
+def stpp_bwd(d_act, d_stpp, scaling, d_ft, table):
+    lib = _check(d_act, d_stpp, scaling, d_ft)
+    lib.call("ssn_stpp_bwd", _p(d_act), _p(d_stpp), _p(scaling), _p(d_ft), d_stpp.shape[0], d_ft.shape[1],
+             ctypes.addressof(table), _stream(lib, d_ft))
+
+
+def stpp_reorg(scores, ranges, act_range, scaling, part_scale_col, act_len, comp_len, reg_len, out_act, out_comp,
+               out_reg):
+    lib = _check(scores, ranges, act_range, scaling, part_scale_col, out_act, out_comp, out_reg)
+    lib.call("ssn_stpp_reorg", _p(scores), scores.shape[0], scores.shape[1], _p(ranges), _p(act_range),
+             _p(scaling), _p(part_scale_col), ranges.shape[0], ranges.shape[1], act_len, comp_len, reg_len,
+             _p(out_act), _p(out_comp), _p(out_reg), _stream(lib, scores))
+
+
+def linear_fwd(x, w, b, out):
+    lib = _check(x, w, b, out)
+    lib.call("ssn_linear_fwd", _p(x), _p(w), _p(b), _p(out), x.shape[0], w.shape[0], w.shape[1], _stream(lib, x))
+
+
+def linear_bwd(dout, x, w, dx, dw, db, accumulate_dx=False):
+    lib = _check(dout, x, w, dx, dw, db)
+    lib.call("ssn_linear_bwd", _p(dout), _p(x), _p(w), _p(dx), _p(dw), _p(db), x.shape[0], w.shape[0], w.shape[1],
+             int(accumulate_dx), _stream(lib, x))
+
+
+def row_gather(src, index, dst):
+    lib = _check(src, index, dst)
+    width = src[0].numel() if src.shape[0] else 0
+    lib.call("ssn_row_gather", _p(src), _p(index), _p(dst), index.numel(), width, _stream(lib, src))
+
+
+def row_scatter(src, index, dst):
+    lib = _check(src, index, dst)
+    width = dst[0].numel()
+    lib.call("ssn_row_scatter", _p(src), _p(index), _p(dst), index.numel(), dst.shape[0], width, _stream(lib, dst))
+
+
+def ce_loss_fwd(logits, target, loss, workspace):
+    lib = _check(logits, target, loss, workspace)
+    lib.call("ssn_ce_loss_fwd", _p(logits), _p(target), _p(loss), _p(workspace), logits.shape[0], logits.shape[1],
+             _stream(lib, logits))
+
+
+def ce_loss_bwd(logits, target, lse, gout, dlogits):
+    lib = _check(logits, target, lse, gout, dlogits)
+    lib.call("ssn_ce_loss_bwd", _p(logits), _p(target), _p(lse), _p(gout), _p(dlogits), logits.shape[0],
+             logits.shape[1], _stream(lib, logits))
+
+
+def completeness_loss_fwd(pred, labels, loss, coef, workspace, group, split, keep_pos, keep_neg, den):
+    lib = _check(pred, labels, loss, coef, workspace)
+    lib.call("ssn_completeness_loss_fwd", _p(pred), _p(labels), _p(loss), _p(coef), _p(workspace), pred.shape[0],
+             pred.shape[1], group, split, keep_pos, keep_neg, float(den), _stream(lib, pred))
+
+
+def completeness_loss_bwd(labels, coef, gout, dpred, den):
+    lib = _check(labels, coef, gout, dpred)
+    lib.call("ssn_completeness_loss_bwd", _p(labels), _p(coef), _p(gout), _p(dpred), dpred.shape[0], dpred.shape[1],
+             float(den), _stream(lib, dpred))
+
+
+def cw_smoothl1_fwd(pred, labels, targets, loss, diff):
+    lib = _check(pred, labels, targets, loss, diff)
+    lib.call("ssn_cw_smoothl1_fwd", _p(pred), _p(labels), _p(targets), _p(loss), _p(diff), pred.shape[0],
+             pred.shape[1], _stream(lib, pred))
+
+
+def cw_smoothl1_bwd(labels, diff, gout, dpred):
+    lib = _check(labels, diff, gout, dpred)
+    lib.call("ssn_cw_smoothl1_bwd", _p(labels), _p(diff), _p(gout), _p(dpred), dpred.shape[0], dpred.shape[1],
+             _stream(lib, dpred))
+
+
+# ------------------------------------------------------------------------------------ optimiser
+def sgd_step(w, grad, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False):
+    lib = _check(w, grad, buf)
+    lib.call("ssn_sgd_step", _p(w), _p(grad), _p(buf), w.numel(), float(lr), float(momentum), float(weight_decay),
+             float(grad_scale), int(first_step), _stream(lib, w))
+
+
+def sumsq(x, out, accumulate, workspace):
+    lib = _check(x, out, workspace)
+    lib.call("ssn_sumsq", _p(x), x.numel(), _p(out), int(accumulate), _p(workspace), _stream(lib, x))
+
+
+def scale_(x, coef_dev=None, coef=1.0):
+    lib = _check(x, coef_dev)
+    lib.call("ssn_scale", _p(x), x.numel(), _p(coef_dev), float(coef), _stream(lib, x))

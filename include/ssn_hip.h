@@ -1,0 +1,159 @@
+/* ssn_hip.h -- C ABI of libssn_hip.so: the MI355X (gfx950) kernels behind the SSN hot path.
+ *
+ * The reference (yjxiong/action-detection) has no FFI layer: its hot path is Python that calls
+ * torch ops, which in turn call cuDNN / cuBLAS.  Each entry point below replaces one of those
+ * implicit native calls; the reference call site it stands in for is cited per function
+ * (paths relative to /root/reference).  The Python mirror of the reference's nn.Module API
+ * (action-detection_amd/ssn_models.py, ops/ssn_ops.py) binds these with ctypes; INTEGRATION.md
+ * shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every buffer is device memory owned by the caller (PyTorch); the library allocates nothing
+ *    persistent and never synchronises the stream;
+ *  - tensors are fp32, NCHW, W-contiguous; "img_stride" arguments are the float distance between
+ *    consecutive images, so a channel slice of a wider (concat) tensor is addressed by offsetting
+ *    the base pointer to the slice's first channel and passing the wide tensor's C*H*W;
+ *  - index / label tensors are int64 as in the reference;
+ *  - return value: 0 on success, negative SSN_ERR_* otherwise (message: ssn_last_error());
+ *    nothing throws across the ABI;
+ *  - all launches go to `stream` (the caller's current HIP stream); re-entrant per stream.
+ */
+#ifndef SSN_HIP_H
+#define SSN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+#define SSN_ERR_ARG (-1)
+#define SSN_ERR_LAUNCH (-2)
+#define SSN_ERR_WORKSPACE (-3)
+
+const char* ssn_last_error(void);
+int ssn_abi_version(void);
+
+/* ------------------------------------------------------------------ backbone: conv + BN + ReLU
+ * Replaces cuDNN conv fwd + cudnnBatchNorm(eval) + ReLU of every "conv / bn / relu" triple of
+ * model_zoo.BNInception, reached from ssn_models.py:266 (train) and :298 (test).
+ * y[n][co][ho][wo] = relu?( scale[co] * sum_{ci,r,s} w[co][ci][r][s] * x[n][ci][ho*S-pad+r][wo*S-pad+s]
+ *                           + shift[co] )        scale/shift may be NULL (plain convolution).
+ * ksize in {1,3,7}, stride in {1,2}.  tile_cfg < 0 selects the tile heuristically. */
+int ssn_conv_bn_relu_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                         int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
+                         long y_img_stride, int ksize, int stride, int pad, int relu, int tile_cfg,
+                         hipStream_t stream);
+
+/* Frozen-BN folding (ssn_models.py:156-174 puts every BatchNorm2d in eval mode):
+ * scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta. */
+int ssn_bn_fold(const float* conv_bias, const float* gamma, const float* beta, const float* mean,
+                const float* var, float eps, float* scale, float* shift, int C, hipStream_t stream);
+
+/* Backward of ReLU + frozen BN, in place on dy:  dy <- dy * (y > 0) * scale[c]
+ * (autograd of the same triples, entered from ssn_train.py:236 loss.backward()). */
+int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C, int HW, long dy_img_stride,
+                    long y_img_stride, hipStream_t stream);
+
+/* cuDNN dgrad replacement.  wt is the weight re-laid-out as [Cin][Cout*k*k] (ssn_weight_transpose).
+ * dx[n][ci][hi][wi] (+)= sum_{co,r,s} wt[ci][(co,r,s)] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]. */
+int ssn_conv_dgrad(const float* dy, const float* wt, float* dx, int N, int Cout, int Ho, int Wo,
+                   long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int stride,
+                   int pad, int accumulate, int tile_cfg, hipStream_t stream);
+int ssn_weight_transpose(const float* w, float* wt, int Cout, int Cin, int ksize, hipStream_t stream);
+
+/* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
+ * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */
+long ssn_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int ksize, int tile_cfg);
+int ssn_conv_wgrad(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                   long x_img_stride, int Cout, int Ho, int Wo, long g_img_stride, int ksize, int stride, int pad,
+                   void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream);
+int ssn_conv_pick_tile(int M, long P);
+
+/* ------------------------------------------------------------------ backbone: pooling
+ * Max / average pools of BN-Inception (ceil_mode output sizes computed by the caller, avg with
+ * count_include_pad=True) and the global average pool before `fc` (ssn_models.py:266 -> backbone).
+ * argmax: uint8 [N][C][Ho][Wo] window-local index, written by fwd(max) and consumed by bwd(max). */
+int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W,
+                 long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
+                 hipStream_t stream);
+int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H, int W,
+                 long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride, int pad,
+                 int accumulate, hipStream_t stream);
+int ssn_global_avgpool_fwd(const float* x, float* y, int N, int C, int HW, long x_img_stride, hipStream_t stream);
+int ssn_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, long dx_img_stride, int accumulate,
+                           hipStream_t stream);
+
+/* nn.Dropout standing in for the backbone's `fc` (ssn_models.py:71-74). mask: uint8 per element. */
+int ssn_dropout_fwd(const float* x, float* y, unsigned char* mask, long total, float p, unsigned long long seed,
+                    hipStream_t stream);
+int ssn_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long total, float p,
+                    hipStream_t stream);
+
+/* ------------------------------------------------------------------ STPP
+ * StructuredTemporalPyramidPooling.forward (ops/ssn_ops.py:39-70).  The part table carries the
+ * reference's integer tick truncation (ops/ssn_ops.py:53-55), computed once on the host. */
+#define SSN_STPP_MAX_PARTS 24
+typedef struct SsnStppTable {
+    int n_parts;
+    int n_seg;
+    int act_lo, act_hi;
+    int lo[SSN_STPP_MAX_PARTS];
+    int hi[SSN_STPP_MAX_PARTS];
+    int norm[SSN_STPP_MAX_PARTS];
+    int col[SSN_STPP_MAX_PARTS];
+} SsnStppTable;
+int ssn_stpp_fwd(const float* ft, const float* scaling, float* act_ft, float* stpp_ft, int P, int D,
+                 const SsnStppTable* table, hipStream_t stream);
+int ssn_stpp_bwd(const float* d_act, const float* d_stpp, const float* scaling, float* d_ft, int P, int D,
+                 const SsnStppTable* table, hipStream_t stream);
+/* STPPReorgainzed.forward (ops/ssn_ops.py:109-170), stand-alone activity classifier form.
+ * ranges: int32 [P][n_parts][2] row ranges (pr<=pl: skipped); act_range: int32 [P][2]. */
+int ssn_stpp_reorg(const float* scores, int T, int D, const int* ranges, const int* act_range,
+                   const float* scaling, const int* part_scale_col, int P, int n_parts, int act_len, int comp_len,
+                   int reg_len, float* out_act, float* out_comp, float* out_reg, hipStream_t stream);
+
+/* ------------------------------------------------------------------ heads
+ * nn.Linear fwd/bwd for activity_fc / completeness_fc / regressor_fc / test_fc
+ * (ssn_models.py:77-78,87,272-273,283,300; cuBLAS GEMMs in the reference). */
+int ssn_linear_fwd(const float* x, const float* w, const float* b, float* out, int R, int O, int D,
+                   hipStream_t stream);
+int ssn_linear_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db, int R,
+                   int O, int D, int accumulate_dx, hipStream_t stream);
+/* prop_type row selection (ssn_models.py:275-289). */
+int ssn_row_gather(const float* src, const long* index, float* dst, int n_idx, int width, hipStream_t stream);
+int ssn_row_scatter(const float* src, const long* index, float* dst, int n_idx, int n_rows, int width,
+                    hipStream_t stream);
+
+/* ------------------------------------------------------------------ losses
+ * CrossEntropyLoss (ssn_train.py:133,210).  workspace: 2*R floats; the first R (lse) feed the bwd. */
+int ssn_ce_loss_fwd(const float* logits, const long* target, float* loss, float* workspace, int R, int C,
+                    hipStream_t stream);
+int ssn_ce_loss_bwd(const float* logits, const long* target, const float* lse, const float* gout, float* dlogits,
+                    int R, int C, hipStream_t stream);
+/* CompletenessLoss + OHEMHingeLoss (ops/ssn_ops.py:173-239).  den = pos_cnt + neg_cnt as the
+ * reference truncates it (ops/ssn_ops.py:236-239).  coef: R floats kept for bwd; workspace 2*R floats. */
+int ssn_completeness_loss_fwd(const float* pred, const long* labels, float* loss, float* coef, float* workspace,
+                              int R, int C, int group, int split, int keep_pos, int keep_neg, float den,
+                              hipStream_t stream);
+int ssn_completeness_loss_bwd(const long* labels, const float* coef, const float* gout, float* dpred, int R, int C,
+                              float den, hipStream_t stream);
+/* ClassWiseRegressionLoss (ops/ssn_ops.py:242-258).  diff: 2*n floats kept for bwd. */
+int ssn_cw_smoothl1_fwd(const float* pred, const long* labels, const float* targets, float* loss, float* diff,
+                        int n, int C, hipStream_t stream);
+int ssn_cw_smoothl1_bwd(const long* labels, const float* diff, const float* gout, float* dpred, int n, int C,
+                        hipStream_t stream);
+
+/* ------------------------------------------------------------------ optimiser step
+ * torch.optim.SGD(momentum, weight_decay) over one flat segment (ssn_train.py:141-144,252);
+ * per-group lr_mult / decay_mult of ssn_models.py:240-251 are folded into lr / weight_decay. */
+int ssn_sgd_step(float* w, const float* grad, float* momentum_buf, long n, float lr, float momentum,
+                 float weight_decay, float grad_scale, int first_step, hipStream_t stream);
+/* clip_grad_norm support (ssn_train.py:245-249): out[0] (+)= sum(x^2); workspace >= 1024 floats. */
+int ssn_sumsq(const float* x, long n, float* out, int accumulate, float* workspace, hipStream_t stream);
+int ssn_scale(float* x, long n, const float* coef_dev, float coef, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSN_HIP_H */

@@ -1,0 +1,427 @@
+"""CPU oracle for the SSN hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain torch-CPU fp32 / numpy, the algorithm of the reference's
+data-parallel hot path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
+product package never does (the product fails loudly if its HIP library is missing).
+
+Pinning status
+--------------
+* STPP, STPPReorgainzed, OHEM hinge / completeness loss, class-wise regression loss,
+  the SSN head wiring, ``prepare_test_fc`` folding and ``get_optim_policies`` are pinned
+  against the reference's own classes imported from /root/reference (see
+  ``oracle/make_golden.py``; fixtures in ``tests/golden/``).
+* The BN-Inception backbone is NOT in the reference tree (un-vendored ``model_zoo``
+  submodule tracking ``branch=master``, /root/reference/.gitmodules:1-4; no pinned SHA, no
+  network).  Its arithmetic is restated from the published BN-Inception topology
+  (Ioffe & Szegedy 2015; Caffe layer naming used by yjxiong/tensorflow-model-zoo.torch):
+  **backbone parity is unpinned against upstream**; it is well-defined between this oracle
+  and the HIP path because both consume the same weights.
+
+Each function cites the reference file:line it follows.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+# --------------------------------------------------------------------------------------
+# Backbone (restated; see "Pinning status")
+# --------------------------------------------------------------------------------------
+
+# (name, 1x1, 3x3reduce, 3x3, dbl_reduce, dbl_a, dbl_b, pool kind, pool proj, stride)
+INCEPTION_ROWS = (
+    ("3a", 64, 64, 64, 64, 96, 96, "avg", 32, 1),
+    ("3b", 64, 64, 96, 64, 96, 96, "avg", 64, 1),
+    ("3c", None, 128, 160, 64, 96, 96, "max", None, 2),
+    ("4a", 224, 64, 96, 96, 128, 128, "avg", 128, 1),
+    ("4b", 192, 96, 128, 96, 128, 128, "avg", 128, 1),
+    ("4c", 160, 128, 160, 128, 160, 160, "avg", 128, 1),
+    ("4d", 96, 128, 192, 160, 192, 192, "avg", 128, 1),
+    ("4e", None, 128, 192, 192, 256, 256, "max", None, 2),
+    ("5a", 352, 192, 320, 160, 224, 224, "avg", 128, 1),
+    ("5b", 352, 192, 320, 192, 224, 224, "max", 128, 1),
+)
+
+
+class OracleBNInception(nn.Module):
+    """torch-CPU BN-Inception with upstream layer ids as attribute names.
+
+    Every conv has bias=True and is followed by BatchNorm2d(eps=1e-5) + ReLU; all pools
+    use ceil_mode=True, average pools count_include_pad=True.
+    Exposes ``fc`` (Linear 1024->num_classes) and ``last_layer_name`` handling exactly as
+    the reference expects at /root/reference/ssn_models.py:121-127,69-74.
+    """
+
+    def __init__(self, num_classes=1000, in_channels=3):
+        super().__init__()
+        self._order = []
+
+        def add_conv(name, cin, cout, k, stride=1, pad=0):
+            setattr(self, name, nn.Conv2d(cin, cout, k, stride, pad, bias=True))
+            setattr(self, name + "_bn", nn.BatchNorm2d(cout, eps=1e-5))
+            self._order.append(name)
+
+        add_conv("conv1_7x7_s2", in_channels, 64, 7, 2, 3)
+        add_conv("conv2_3x3_reduce", 64, 64, 1)
+        add_conv("conv2_3x3", 64, 192, 3, 1, 1)
+        cin = 192
+        for (nm, c1, r3, c3, rd, da, db, pk, pp, st) in INCEPTION_ROWS:
+            p = "inception_%s_" % nm
+            if c1:
+                add_conv(p + "1x1", cin, c1, 1)
+            add_conv(p + "3x3_reduce", cin, r3, 1)
+            add_conv(p + "3x3", r3, c3, 3, st, 1)
+            add_conv(p + "double_3x3_reduce", cin, rd, 1)
+            add_conv(p + "double_3x3_1", rd, da, 3, 1, 1)
+            add_conv(p + "double_3x3_2", da, db, 3, st, 1)
+            if pp:
+                add_conv(p + "pool_proj", cin, pp, 1)
+            cin = (c1 or 0) + c3 + db + (pp if pp else cin)
+        self.fc = nn.Linear(cin, num_classes)
+
+    def _cbr(self, name, x):
+        conv = getattr(self, name)
+        bn = getattr(self, name + "_bn")
+        return F.relu(bn(conv(x)))
+
+    def features(self, x):
+        x = self._cbr("conv1_7x7_s2", x)
+        x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+        x = self._cbr("conv2_3x3_reduce", x)
+        x = self._cbr("conv2_3x3", x)
+        x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+        for (nm, c1, r3, c3, rd, da, db, pk, pp, st) in INCEPTION_ROWS:
+            p = "inception_%s_" % nm
+            outs = []
+            if c1:
+                outs.append(self._cbr(p + "1x1", x))
+            outs.append(self._cbr(p + "3x3", self._cbr(p + "3x3_reduce", x)))
+            d = self._cbr(p + "double_3x3_reduce", x)
+            d = self._cbr(p + "double_3x3_1", d)
+            outs.append(self._cbr(p + "double_3x3_2", d))
+            if pp:
+                if pk == "avg":
+                    q = F.avg_pool2d(x, 3, 1, 1, ceil_mode=True, count_include_pad=True)
+                else:
+                    q = F.max_pool2d(x, 3, 1, 1, ceil_mode=True)
+                outs.append(self._cbr(p + "pool_proj", q))
+            else:
+                outs.append(F.max_pool2d(x, 3, 2, 0, ceil_mode=True))
+            x = torch.cat(outs, 1)
+        x = F.avg_pool2d(x, x.shape[-1], 1, 0, ceil_mode=True, count_include_pad=True)
+        return x.flatten(1)
+
+    def forward(self, x):
+        return self.fc(self.features(x))
+
+
+# --------------------------------------------------------------------------------------
+# STPP (training) -- /root/reference/ops/ssn_ops.py:13-79
+# --------------------------------------------------------------------------------------
+
+def parse_stage_config(cfg):
+    """/root/reference/ops/ssn_ops.py:13-19."""
+    if isinstance(cfg, int):
+        return (cfg,), cfg
+    if isinstance(cfg, (tuple, list)):
+        return tuple(cfg), sum(cfg)
+    raise ValueError("Incorrect STPP config {}".format(cfg))
+
+
+def stage_ticks(stage_len, n_part):
+    """Integer part boundaries of one pyramid level.
+
+    Follows /root/reference/ops/ssn_ops.py:53-55: ``torch.arange(0, len + 1e-5, len / n_part)``
+    (float32 result of a double-precision ``start + i*step``) followed by ``int()``.
+    Restated with numpy float64 -> float32 -> truncation.
+    """
+    step = stage_len / n_part
+    n = int(math.ceil((stage_len + 1e-5) / step))
+    vals = (np.arange(n, dtype=np.float64) * step).astype(np.float32)
+    return [int(v) for v in vals]
+
+
+def stpp_part_table(seg_split, configs):
+    """List of (seg_lo, seg_hi, norm, scale_col) for every STPP output part, in output order.
+
+    scale_col: 0 -> multiply by scaling[:,0] (starting stage), 1 -> scaling[:,1] (ending),
+    -1 -> unscaled (course stage).  /root/reference/ops/ssn_ops.py:49-64.
+    """
+    x1, x2, n_seg = seg_split
+    bounds = ((0, x1, 0), (x1, x2, -1), (x2, n_seg, 1))
+    table = []
+    for (lo, hi, col), cfg in zip(bounds, configs):
+        parts, mult = parse_stage_config(cfg)
+        length = hi - lo
+        for n_part in parts:
+            t = stage_ticks(length, n_part)
+            for i in range(n_part):
+                table.append((lo + t[i], lo + t[i + 1], mult, col))
+    return table
+
+
+def stpp_forward(ft, scaling, seg_split, configs=(1, (1, 2), 1), standalone_classifier=True):
+    """/root/reference/ops/ssn_ops.py:39-70.  ft [P*S, D], scaling [..., 2] -> (act_ft, stpp_ft)."""
+    n_seg = seg_split[2]
+    d = ft.shape[1]
+    src = ft.reshape(-1, n_seg, d)
+    scaling = scaling.reshape(-1, 2)
+    feats = []
+    for lo, hi, norm, col in stpp_part_table(seg_split, configs):
+        part = src[:, lo:hi, :].mean(dim=1) / norm
+        if col >= 0:
+            part = part * scaling[:, col].reshape(-1, 1)
+        feats.append(part)
+    stpp_ft = torch.cat(feats, dim=1)
+    if not standalone_classifier:
+        return stpp_ft, stpp_ft
+    course = src[:, seg_split[0]:seg_split[1], :].mean(dim=1)
+    return course, stpp_ft
+
+
+# --------------------------------------------------------------------------------------
+# STPPReorgainzed (dense testing) -- /root/reference/ops/ssn_ops.py:82-170
+# --------------------------------------------------------------------------------------
+
+def stpp_reorganized(scores, proposal_ticks, scaling, act_len, comp_len, reg_len,
+                     stpp_cfg=(1, 1, 1), standalone_classifier=True, with_regression=True):
+    """scores [T, D] fp32, proposal_ticks [P,4] int, scaling [P,2] -> (act, comp, reg)."""
+    scores = np.asarray(scores, dtype=np.float32)
+    ticks_all = np.asarray(proposal_ticks).astype(np.int64)
+    scaling = np.asarray(scaling)
+    cfg = [parse_stage_config(c)[0] for c in stpp_cfg]
+    mult = sum(sum(c) for c in cfg)
+    a_stop = act_len if standalone_classifier else act_len * mult
+    c_stop = a_stop + comp_len * mult
+    r_stop = c_stop + reg_len * mult
+    assert scores.shape[1] == r_stop if with_regression else scores.shape[1] >= c_stop
+    T = scores.shape[0]
+    P = ticks_all.shape[0]
+
+    def pspool(raw, ticks, sc, score_len):
+        out = np.zeros(score_len, dtype=np.float32)
+        offset = 0
+        for si, stage in enumerate(cfg):
+            s = sc[0] if si == 0 else (sc[1] if si == len(cfg) - 1 else 1.0)
+            left = int(ticks[si])
+            right = int(max(ticks[si] + 1, ticks[si + 1]))
+            if right <= 0 or left >= T:
+                offset += sum(stage)
+                continue
+            for n_part in stage:
+                pt = np.arange(left, right + 1e-5, (right - left) / n_part)
+                for i in range(n_part):
+                    pl, pr = int(pt[i]), int(pt[i + 1])
+                    if pr - pl >= 1:
+                        blk = raw[pl:pr, offset * score_len:(offset + 1) * score_len]
+                        out += (torch.from_numpy(np.ascontiguousarray(blk)).mean(dim=0).numpy()
+                                * np.float32(s)).astype(np.float32)
+                    offset += 1
+        return out
+
+    act = np.zeros((P, act_len), np.float32)
+    comp = np.zeros((P, comp_len), np.float32)
+    reg = np.zeros((P, reg_len), np.float32) if with_regression else None
+    raw_a, raw_c, raw_r = scores[:, :a_stop], scores[:, a_stop:c_stop], scores[:, c_stop:r_stop]
+    for i in range(P):
+        tk = ticks_all[i]
+        if standalone_classifier:
+            lo, hi = int(tk[1]), int(max(tk[1] + 1, tk[2]))
+            act[i] = torch.from_numpy(np.ascontiguousarray(raw_a[lo:hi])).mean(dim=0).numpy()
+        else:
+            act[i] = pspool(raw_a, tk, scaling[i], act_len)
+        comp[i] = pspool(raw_c, tk, scaling[i], comp_len)
+        if with_regression:
+            reg[i] = pspool(raw_r, tk, scaling[i], reg_len)
+    return act, comp, reg
+
+
+# --------------------------------------------------------------------------------------
+# Losses -- /root/reference/ops/ssn_ops.py:173-258, /root/reference/ssn_train.py:133,210-214
+# --------------------------------------------------------------------------------------
+
+def ohem_hinge(pred, labels, is_positive, ohem_ratio, group_size):
+    """/root/reference/ops/ssn_ops.py:179-213.  Returns (loss scalar, grad wrt pred for d(loss)=1)."""
+    pred_np = pred.detach().numpy()
+    n = pred_np.shape[0]
+    assert n == len(labels)
+    losses = np.zeros(n, np.float32)
+    slopes = np.zeros(n, np.float32)
+    for i in range(n):
+        v = np.float32(1) - np.float32(is_positive) * pred_np[i, int(labels[i]) - 1]
+        losses[i] = max(np.float32(0), v)
+        slopes[i] = -is_positive if losses[i] != 0 else 0
+    grp = losses.reshape(-1, group_size)
+    keep = int(group_size * ohem_ratio)
+    order = np.argsort(-grp, axis=1, kind="stable")[:, :keep]
+    total = np.float32(0)
+    grad = np.zeros_like(pred_np)
+    for g in range(grp.shape[0]):
+        total = np.float32(total + np.float32(grp[g, order[g]].sum(dtype=np.float32)))
+        for idx in order[g]:
+            loc = idx + g * group_size
+            grad[loc, int(labels[loc]) - 1] = slopes[loc]
+    return total, grad
+
+
+def completeness_loss(pred, labels, sample_split, sample_group_size, ohem_ratio=0.17):
+    """/root/reference/ops/ssn_ops.py:223-239.  Returns (loss, dloss/dpred)."""
+    c = pred.shape[1]
+    p3 = pred.reshape(-1, sample_group_size, c)
+    l2 = np.asarray(labels).reshape(-1, sample_group_size)
+    pos = p3[:, :sample_split, :].reshape(-1, c)
+    neg = p3[:, sample_split:, :].reshape(-1, c)
+    pos_ls, pos_g = ohem_hinge(pos, l2[:, :sample_split].reshape(-1), 1, 1.0, sample_split)
+    neg_ls, neg_g = ohem_hinge(neg, l2[:, sample_split:].reshape(-1), -1, ohem_ratio,
+                               sample_group_size - sample_split)
+    pos_cnt = pos.shape[0]
+    neg_cnt = int(neg.shape[0] * ohem_ratio)
+    den = float(pos_cnt + neg_cnt)
+    loss = np.float32(pos_ls / den + neg_ls / den)
+    g3 = np.zeros((p3.shape[0], sample_group_size, c), np.float32)
+    g3[:, :sample_split, :] = pos_g.reshape(-1, sample_split, c) / den
+    g3[:, sample_split:, :] = neg_g.reshape(-1, sample_group_size - sample_split, c) / den
+    return loss, g3.reshape(-1, c)
+
+
+def classwise_regression_loss(pred, labels, targets):
+    """/root/reference/ops/ssn_ops.py:251-258: pick pred[i, label_i-1, :], SmoothL1(mean) * 2."""
+    idx = labels.long() - 1
+    rows = torch.arange(pred.shape[0])
+    picked = pred[rows, idx, :]
+    return F.smooth_l1_loss(picked.reshape(-1), targets.reshape(-1)) * 2
+
+
+def activity_loss(logits, target):
+    """/root/reference/ssn_train.py:133,210 (torch.nn.CrossEntropyLoss, mean)."""
+    return F.cross_entropy(logits, target.long())
+
+
+# --------------------------------------------------------------------------------------
+# SSN wiring -- /root/reference/ssn_models.py
+# --------------------------------------------------------------------------------------
+
+class OracleSSN(nn.Module):
+    """Restatement of the reference SSN for BNInception (ssn_models.py:10-300)."""
+
+    def __init__(self, num_class, starting_segment=2, course_segment=5, ending_segment=2,
+                 modality="RGB", new_length=None, dropout=0.8, no_regression=False,
+                 test_mode=False, stpp_cfg=(1, (1, 2), 1), bn_mode="frozen"):
+        super().__init__()
+        self.modality = modality
+        self.starting_segment, self.course_segment, self.ending_segment = (
+            starting_segment, course_segment, ending_segment)
+        self.num_segments = starting_segment + course_segment + ending_segment
+        self.new_length = (1 if modality == "RGB" else 5) if new_length is None else new_length
+        self.dropout = dropout
+        self.with_regression = not no_regression
+        self.test_mode = test_mode
+        self.stpp_cfg = stpp_cfg
+        self.num_class = num_class
+        # ssn_models.py:121-131 + :318-343 (flow: first conv gets 2*new_length input channels)
+        cin = 3 if modality == "RGB" else 2 * self.new_length
+        self.base_model = OracleBNInception(in_channels=3)
+        feat = self.base_model.fc.in_features
+        # ssn_models.py:69-74
+        self.base_model.fc = nn.Identity() if dropout == 0 else nn.Dropout(p=dropout)
+        if modality == "Flow":
+            old = self.base_model.conv1_7x7_s2
+            new = nn.Conv2d(cin, 64, 7, 2, 3, bias=True)
+            new.weight.data = old.weight.data.mean(dim=1, keepdim=True).expand(-1, cin, -1, -1).contiguous()
+            new.bias.data = old.bias.data
+            self.base_model.conv1_7x7_s2 = new
+        mult = sum(parse_stage_config(c)[1] for c in stpp_cfg)
+        self.feat_multiplier = mult
+        # ssn_models.py:76-91
+        self.activity_fc = nn.Linear(feat, num_class + 1)
+        self.completeness_fc = nn.Linear(feat * mult, num_class)
+        self.regressor_fc = nn.Linear(feat * mult, 2 * num_class) if self.with_regression else None
+        for fc in (self.activity_fc, self.completeness_fc, self.regressor_fc):
+            if fc is not None:
+                nn.init.normal_(fc.weight, 0, 0.001)
+                nn.init.constant_(fc.bias, 0)
+        self.test_fc = None
+        # ssn_models.py:95-105
+        self.freeze_count = {"partial": 2, "frozen": 1, "full": None}[bn_mode]
+
+    def train(self, mode=True):
+        """ssn_models.py:156-174."""
+        super().train(mode)
+        if self.freeze_count is None:
+            return self
+        count = 0
+        for m in self.base_model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                count += 1
+                if count >= self.freeze_count:
+                    m.eval()
+                    m.weight.requires_grad = False
+                    m.bias.requires_grad = False
+        return self
+
+    def forward(self, input, aug_scaling=None, target=None, reg_target=None, prop_type=None):
+        sample_len = (3 if self.modality == "RGB" else 2) * self.new_length
+        x = input.reshape((-1, sample_len) + tuple(input.shape[-2:]))
+        base_out = self.base_model.fc(self.base_model.features(x))
+        if self.test_mode:
+            # ssn_models.py:291-300
+            return self.test_fc(base_out), base_out
+        # ssn_models.py:259-289
+        seg_split = [self.starting_segment, self.starting_segment + self.course_segment, self.num_segments]
+        act_ft, comp_ft = stpp_forward(base_out, aug_scaling, seg_split, self.stpp_cfg, True)
+        raw_act = self.activity_fc(act_ft)
+        raw_comp = self.completeness_fc(comp_ft)
+        t = prop_type.reshape(-1)
+        act_idx = torch.nonzero((t == 0) | (t == 2)).reshape(-1)
+        comp_idx = torch.nonzero((t == 0) | (t == 1)).reshape(-1)
+        target = target.reshape(-1)
+        if not self.with_regression:
+            return raw_act[act_idx], target[act_idx], raw_comp[comp_idx], target[comp_idx]
+        reg_idx = torch.nonzero(t == 0).reshape(-1)
+        raw_reg = self.regressor_fc(comp_ft).reshape(-1, self.num_class, 2)
+        reg_target = reg_target.reshape(-1, 2)
+        return (raw_act[act_idx], target[act_idx], raw_comp[comp_idx], target[comp_idx],
+                raw_reg[reg_idx], target[reg_idx], reg_target[reg_idx])
+
+    def prepare_test_fc(self):
+        """ssn_models.py:176-201: fold the three heads into one Linear over per-snippet features."""
+        m = self.feat_multiplier
+        d = self.activity_fc.in_features
+
+        def fold(fc):
+            w = fc.weight.data.reshape(fc.out_features, m, d).permute(1, 0, 2).reshape(-1, d)
+            b = fc.bias.data.reshape(1, -1).repeat(m, 1).reshape(-1) / m
+            return w, b
+
+        ws, bs = [self.activity_fc.weight.data], [self.activity_fc.bias.data]
+        for fc in (self.completeness_fc, self.regressor_fc):
+            if fc is not None:
+                w, b = fold(fc)
+                ws.append(w)
+                bs.append(b)
+        w, b = torch.cat(ws), torch.cat(bs)
+        self.test_fc = nn.Linear(d, w.shape[0])
+        self.test_fc.weight.data = w
+        self.test_fc.bias.data = b
+
+
+def ssn_total_loss(outputs, num_videos, comp_weight=0.1, reg_weight=0.1, ohem_ratio=0.17,
+                   fg_per_video=1, group_size=7):
+    """Loss mix of /root/reference/ssn_train.py:210-214 with differentiable torch pieces.
+
+    The completeness term uses the numpy OHEM restatement for the value and injects its
+    analytic gradient through a surrogate (sum(pred * g)), so .backward() reproduces the
+    reference's autograd.Function backward (ops/ssn_ops.py:203-213).
+    """
+    act, act_t, comp, comp_t, reg, reg_l, reg_t = outputs
+    act_loss = activity_loss(act, act_t)
+    c_val, c_grad = completeness_loss(comp.detach(), comp_t.numpy(), fg_per_video, group_size, ohem_ratio)
+    surrogate = (comp * torch.from_numpy(c_grad)).sum()
+    comp_loss = surrogate - surrogate.detach() + torch.tensor(float(c_val))
+    reg_loss = classwise_regression_loss(reg, reg_l, reg_t)
+    total = act_loss + comp_weight * comp_loss + reg_weight * reg_loss
+    return total, act_loss, comp_loss, reg_loss

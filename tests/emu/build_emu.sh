@@ -1,0 +1,19 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY: build the product's .hip sources for the host through the HIP emulator
+# header so CPU-only tests can drive the very same C ABI (libssn_emu.so) on host memory.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+SRC="$HERE/../../action-detection_amd/csrc"
+CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
+OUT="$HERE/libssn_emu.so"
+OBJS=()
+for f in "$SRC"/*.hip "$HERE/emu_globals.cpp"; do
+  o="$HERE/.obj_$(basename "$f").o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ "$SRC/ssn_common.h" -nt "$o" ]; then
+    "$CXX" -x c++ -std=c++17 -O1 -fPIC -Wno-unused-value -I "$HERE" -I "$SRC" -c "$f" -o "$o" &
+  fi
+  OBJS+=("$o")
+done
+wait
+"$CXX" -shared -o "$OUT" "${OBJS[@]}"
+echo "built $OUT"

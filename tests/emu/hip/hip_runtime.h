@@ -1,0 +1,293 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny host-side emulator of the HIP execution model.
+//
+// The product kernels in action-detection_amd/csrc/*.hip are written for gfx950 only.  To
+// exercise their index logic (gather loaders, LDS tiling, MFMA fragment maps, epilogues) in
+// the CPU-only test tier, the test build compiles the SAME sources with the host clang and
+// this header shadowing <hip/hip_runtime.h> (-I tests/emu).  One workgroup runs at a time;
+// each work-item is a ucontext fiber; __syncthreads / wave shuffles / MFMA are rendezvous
+// points resolved by a cooperative scheduler (deadlock -> abort with a message).
+//
+// The MFMA emulation implements the documented gfx950 lane->element maps
+// (/opt/skills/guides/cdna_hip_programming.md section 3): for v_mfma_f32_32x32x2_f32 lane l
+// supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31] and owns D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
+#pragma once
+#include <ucontext.h>
+
+#include <cassert>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 {
+    float x, y, z, w;
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct float2 {
+    float x, y;
+};
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+
+namespace emu {
+
+enum Wait { W_NONE = 0, W_WAVE = 1, W_BLOCK = 2 };
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    dim3 tid;
+    int lin = 0, lane = 0, wave = 0;
+    bool done = false;
+    int wait = W_NONE;
+    uint64_t wave_seq = 0;   // number of wave ops this lane has entered
+    uint64_t block_seq = 0;  // number of block barriers this thread has entered
+};
+
+struct WaveX {
+    // double-buffered exchange area: 4 dwords per lane
+    uint32_t buf[2][64][4];
+};
+
+struct BlockState {
+    std::vector<Fiber> fibers;
+    std::vector<WaveX> waves;
+    dim3 bid, bdim, gdim;
+    ucontext_t sched;
+    std::function<void()> body;
+};
+
+extern BlockState* g_blk;
+extern Fiber* g_cur;
+
+inline void yield_to_sched() { swapcontext(&g_cur->ctx, &g_blk->sched); }
+
+inline bool can_run(const Fiber& f) {
+    BlockState& b = *g_blk;
+    if (f.wait == W_NONE) return true;
+    if (f.wait == W_WAVE) {
+        for (auto& o : b.fibers)
+            if (o.wave == f.wave && !o.done && o.wave_seq < f.wave_seq) return false;
+        return true;
+    }
+    for (auto& o : b.fibers)
+        if (!o.done && o.block_seq < f.block_seq) return false;
+    return true;
+}
+
+inline void fiber_entry() {
+    g_blk->body();
+    g_cur->done = true;
+    swapcontext(&g_cur->ctx, &g_blk->sched);
+}
+
+inline char* stack_pool(unsigned i, size_t bytes) {
+    static std::vector<char*> pool;
+    if (pool.size() <= i) pool.resize(i + 1, nullptr);
+    if (!pool[i]) pool[i] = (char*)malloc(bytes);
+    return pool[i];
+}
+
+inline void run_block(BlockState& b) {
+    g_blk = &b;
+    const unsigned n = b.bdim.x * b.bdim.y * b.bdim.z;
+    b.fibers.resize(n);
+    b.waves.assign((n + 63) / 64, WaveX());
+    const size_t stk = 512 * 1024;
+    for (unsigned i = 0; i < n; ++i) {
+        Fiber& f = b.fibers[i];
+        f.lin = i;
+        f.tid = dim3(i % b.bdim.x, (i / b.bdim.x) % b.bdim.y, i / (b.bdim.x * b.bdim.y));
+        f.lane = i & 63;
+        f.wave = i >> 6;
+        f.done = false;
+        f.wait = W_NONE;
+        f.wave_seq = f.block_seq = 0;
+        f.stack = stack_pool(i, stk);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = stk;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    for (;;) {
+        bool all_done = true, progressed = false;
+        for (unsigned i = 0; i < n; ++i) {
+            Fiber& f = b.fibers[i];
+            if (f.done) continue;
+            all_done = false;
+            if (!can_run(f)) continue;
+            f.wait = W_NONE;
+            g_cur = &f;
+            swapcontext(&b.sched, &f.ctx);
+            progressed = true;
+        }
+        if (all_done) break;
+        if (!progressed) {
+            fprintf(stderr, "[hip-emu] deadlock: divergent barrier / wave op in block (%u,%u,%u)\n", b.bid.x,
+                    b.bid.y, b.bid.z);
+            abort();
+        }
+    }
+}
+
+// ---- rendezvous primitives ----
+inline void block_barrier() {
+    g_cur->block_seq++;
+    g_cur->wait = W_BLOCK;
+    yield_to_sched();
+}
+
+// deposit up to 4 dwords, wait for the whole wave, return pointer to the wave's slot array
+inline uint32_t (*wave_exchange(const uint32_t* v, int n))[4] {
+    Fiber* f = g_cur;
+    WaveX& w = g_blk->waves[f->wave];
+    const int slot = (int)(f->wave_seq & 1);
+    for (int i = 0; i < n; ++i) w.buf[slot][f->lane][i] = v[i];
+    f->wave_seq++;
+    f->wait = W_WAVE;
+    yield_to_sched();
+    return w.buf[slot];
+}
+
+inline int wave_lanes() {
+    // number of live lanes in the current wave (last wave of a block may be partial)
+    const unsigned n = g_blk->bdim.x * g_blk->bdim.y * g_blk->bdim.z;
+    const unsigned base = (unsigned)g_cur->wave * 64u;
+    return (int)((n - base) < 64u ? (n - base) : 64u);
+}
+
+template <class T>
+inline T shfl_idx(T v, int src) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    auto* buf = wave_exchange(&u, 1);
+    uint32_t r = buf[src & 63][0];
+    if ((src & 63) >= wave_lanes()) r = u;
+    T o;
+    memcpy(&o, &r, 4);
+    return o;
+}
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+inline f32x16_t mfma_32x32x2(float a, float b, f32x16_t c) {
+    uint32_t u[2];
+    memcpy(&u[0], &a, 4);
+    memcpy(&u[1], &b, 4);
+    auto* buf = wave_exchange(u, 2);
+    const int lane = g_cur->lane;
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, &buf[k * 32 + row][0], 4);
+            memcpy(&bv, &buf[k * 32 + col][1], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+
+inline f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
+    uint32_t u[2];
+    memcpy(&u[0], &a, 4);
+    memcpy(&u[1], &b, 4);
+    auto* buf = wave_exchange(u, 2);
+    const int lane = g_cur->lane;
+    const int col = lane & 15, grp = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = grp * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, &buf[k * 16 + row][0], 4);
+            memcpy(&bv, &buf[k * 16 + col][1], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+
+template <class K, class... Args>
+inline void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+    BlockState b;
+    b.gdim = grid;
+    b.bdim = block;
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) {
+                b.bid = dim3(x, y, z);
+                b.body = [&]() { kernel(args...); };
+                run_block(b);
+            }
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::g_cur->tid)
+#define blockIdx (emu::g_blk->bid)
+#define blockDim (emu::g_blk->bdim)
+#define gridDim (emu::g_blk->gdim)
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+
+static inline void __syncthreads() { emu::block_barrier(); }
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    (void)width;
+    return emu::shfl_idx(v, emu::g_cur->lane ^ mask);
+}
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+    (void)width;
+    return emu::shfl_idx(v, src);
+}
+template <class T>
+static inline T __shfl_down(T v, int delta, int width = 64) {
+    (void)width;
+    int src = emu::g_cur->lane + delta;
+    return emu::shfl_idx(v, src > 63 ? emu::g_cur->lane : src);
+}
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static inline float atomicAdd(float* p, float v) {
+    float o = *p;
+    *p = o + v;
+    return o;
+}
+static inline int atomicAdd(int* p, int v) {
+    int o = *p;
+    *p = o + v;
+    return o;
+}
+static inline float __fdividef(float a, float b) { return a / b; }
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4(a, b, c)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
