@@ -1,0 +1,229 @@
+"""BN-Inception backbone executor: the stand-in for ``model_zoo.BNInception``.
+
+The reference builds its backbone with ``getattr(model_zoo, 'BNInception')()``
+(/root/reference/ssn_models.py:121-124) and runs it through torch/cuDNN.  Here the module keeps
+the same parameter surface (``<layer>.weight/.bias``, ``<layer>_bn.weight/.bias/.running_*``,
+``fc``) so checkpoints, ``get_optim_policies`` and the first-conv surgery
+of the reference keep working, but ``forward`` is ONE autograd node that walks the manifest of
+``bninception_spec`` and launches the gfx950 kernels of include/ssn_hip.h:
+
+  forward : bn_fold -> conv_bn_relu_fwd per conv (branches write straight into their channel
+            slice of the block output: no concat), pool_fwd, global_avgpool_fwd
+  backward: per conv  relu_bn_bwd (in place on the output gradient) -> conv_wgrad (+bias grad)
+            -> conv_dgrad (accumulating into the input gradient when the input feeds several
+            branches); pool_bwd / global_avgpool_bwd for the pools.
+
+Gradients of all conv parameters are produced into one flat buffer (forward layer order), so a
+data-parallel wrapper can all-reduce finished tail ranges while earlier layers are still in
+backward (see parallel.py).
+"""
+import torch
+from torch import nn
+
+from . import kernels as K
+from .bninception_spec import FEATURE_DIM, build_manifest
+from .kernels import ChanSlice, full
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        need_grad = any(ctx.needs_input_grad)
+        feat, saved = net._run_forward(x, keep=need_grad)
+        ctx.net = net
+        ctx.saved = saved
+        ctx.n_params = len(params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        net, saved = ctx.net, ctx.saved
+        ctx.saved = None
+        if saved is None:
+            raise RuntimeError("backbone forward ran without grad bookkeeping")
+        grads = net._run_backward(dfeat.contiguous(), saved)
+        return (None, None) + tuple(grads)
+
+
+class BNInception(nn.Module):
+    """Drop-in for ``model_zoo.BNInception`` (ctor signature of the upstream zoo: num_classes)."""
+
+    def __init__(self, num_classes=1000, in_channels=3, input_size=224):
+        super().__init__()
+        self.in_channels = in_channels
+        self.input_size_hint = input_size
+        ops, _ = build_manifest(in_channels, input_size)
+        self._conv_ids = []
+        for op in ops:
+            if op[0] == "conv":
+                _, lid, _, _, _, cin, cout, k, s, p = op
+                setattr(self, lid, nn.Conv2d(cin, cout, k, s, p, bias=True))
+                setattr(self, lid + "_bn", nn.BatchNorm2d(cout, eps=1e-5))
+                self._conv_ids.append(lid)
+        self.fc = nn.Linear(FEATURE_DIM, num_classes)
+        self.grad_ready_hook = None   # object with range_ready(flat, start, end) / finish() (parallel.GradReducer)
+        self._ws = None
+        self._flat_layout = None
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _param_list(self):
+        ps = []
+        for lid in self._conv_ids:
+            conv = getattr(self, lid)
+            ps.append(conv.weight)
+            ps.append(conv.bias)
+        return ps
+
+    def flat_grad_layout(self):
+        """[(layer id, weight offset, weight numel, bias offset, bias numel)], total -- forward order."""
+        off, lay = 0, []
+        for lid in self._conv_ids:
+            conv = getattr(self, lid)
+            wn, bn = conv.weight.numel(), conv.bias.numel()
+            lay.append((lid, off, wn, off + wn, bn))
+            off += wn + bn
+        return lay, off
+
+    def features(self, x):
+        if x.dim() != 4:
+            raise ValueError("expected NCHW input")
+        for lid in self._conv_ids:
+            if getattr(self, lid + "_bn").training:
+                raise NotImplementedError(
+                    "bn_mode 'partial'/'full' (training-mode BatchNorm) is not built yet; "
+                    "SSN's default bn_mode='frozen' keeps every BatchNorm2d in eval mode")
+        return _BackboneFn.apply(x.contiguous(), self, *self._param_list())
+
+    def forward(self, x):
+        return self.fc(self.features(x))
+
+    # ------------------------------------------------------------------ forward executor
+    def _manifest(self, x):
+        cin = getattr(self, self._conv_ids[0]).in_channels  # may differ after flow surgery
+        if x.shape[1] != cin:
+            raise ValueError("input has %d channels, first conv expects %d" % (x.shape[1], cin))
+        if x.shape[2] != x.shape[3]:
+            raise ValueError("square inputs only")
+        return build_manifest(cin, x.shape[2])
+
+    def _run_forward(self, x, keep):
+        ops, shapes = self._manifest(x)
+        n, dev = x.shape[0], x.device
+        acts = {"data": x}
+        argmax = {}
+        folds = {}
+        last_use = {}
+        for i, op in enumerate(ops):
+            src = op[2] if op[0] != "pool" else op[3]
+            last_use[src] = i
+
+        def get(name):
+            if name not in acts:
+                c, h, w = shapes[name]
+                acts[name] = torch.empty((n, c, h, w), device=dev, dtype=torch.float32)
+            return acts[name]
+
+        feat = None
+        for i, op in enumerate(ops):
+            if op[0] == "conv":
+                _, lid, src, dst, c0, cin, cout, k, s, p = op
+                conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
+                scale = torch.empty(cout, device=dev, dtype=torch.float32)
+                shift = torch.empty(cout, device=dev, dtype=torch.float32)
+                K.bn_fold(conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                          bn.running_var, bn.eps, scale, shift)
+                K.conv_fwd(full(acts[src]), conv.weight.detach(), scale, shift, ChanSlice(get(dst), c0, cout),
+                           k, s, p, True)
+                folds[lid] = scale
+            elif op[0] == "pool":
+                _, lid, kind, src, dst, c0, k, s, p, _ceil = op
+                c = shapes[src][0]
+                out = ChanSlice(get(dst), c0, c)
+                am = None
+                if kind == "max" and keep:
+                    _, ho, wo = shapes[dst]
+                    am = torch.empty((n, c, ho, wo), device=dev, dtype=torch.uint8)
+                    argmax[lid] = am
+                K.pool_fwd(kind, full(acts[src]), out, am, k, s, p)
+            else:
+                _, lid, src, dst = op
+                feat = torch.empty((n, shapes[src][0]), device=dev, dtype=torch.float32)
+                K.gap_fwd(full(acts[src]), feat)
+            if not keep:
+                # inference: drop activations as soon as their last consumer has been launched
+                for name in [nm for nm, last in last_use.items() if last == i and nm != "data"]:
+                    acts.pop(name, None)
+        saved = (ops, shapes, acts, argmax, folds) if keep else None
+        return feat, saved
+
+    # ------------------------------------------------------------------ backward executor
+    def _workspace(self, nbytes, dev):
+        if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
+            self._ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+        return self._ws
+
+    def _run_backward(self, dfeat, saved):
+        ops, shapes, acts, argmax, folds = saved
+        n, dev = dfeat.shape[0], dfeat.device
+        layout, total = self.flat_grad_layout()
+        lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
+        flat = torch.empty(total, device=dev, dtype=torch.float32)
+        grads = {}
+        inited = set()
+
+        def gbuf(name):
+            if name not in grads:
+                c, h, w = shapes[name]
+                grads[name] = torch.empty((n, c, h, w), device=dev, dtype=torch.float32)
+            return grads[name]
+
+        ws_bytes = 0
+        for op in ops:
+            if op[0] == "conv":
+                _, lid, src, dst, c0, cin, cout, k, s, p = op
+                ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(n, cin, cout, shapes[dst][1], shapes[dst][2], k))
+        ws = self._workspace(ws_bytes, dev)
+
+        pending_end = total
+        for op in reversed(ops):
+            if op[0] == "gap":
+                _, lid, src, dst = op
+                K.gap_bwd(dfeat, full(gbuf(src)), accumulate=src in inited)
+                inited.add(src)
+            elif op[0] == "pool":
+                _, lid, kind, src, dst, c0, k, s, p, _ceil = op
+                c = shapes[src][0]
+                K.pool_bwd(kind, ChanSlice(grads[dst], c0, c), argmax.get(lid), full(gbuf(src)), k, s, p,
+                           accumulate=src in inited)
+                inited.add(src)
+            else:
+                _, lid, src, dst, c0, cin, cout, k, s, p = op
+                conv = getattr(self, lid)
+                g = ChanSlice(grads[dst], c0, cout)
+                K.relu_bn_bwd(g, ChanSlice(acts[dst], c0, cout), folds[lid])
+                wo, wn, bo, bn = lay[lid]
+                dw = flat[wo:wo + wn].view_as(conv.weight)
+                db = flat[bo:bo + bn]
+                K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws)
+                if src != "data":
+                    wt = torch.empty((cin, cout * k * k), device=dev, dtype=torch.float32)
+                    K.weight_transpose(conv.weight.detach(), wt)
+                    K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=src in inited)
+                    inited.add(src)
+                if self.grad_ready_hook is not None and (lid.endswith("_1x1") or lid == self._conv_ids[0]
+                                                         or lid == "inception_3c_3x3_reduce"
+                                                         or lid == "inception_4e_3x3_reduce"):
+                    # the first conv of a block (forward order) closes that block's contiguous range
+                    self.grad_ready_hook.range_ready(flat, wo, pending_end)
+                    pending_end = wo
+        if self.grad_ready_hook is not None:
+            if pending_end > 0:
+                self.grad_ready_hook.range_ready(flat, 0, pending_end)
+            self.grad_ready_hook.finish()
+        out = []
+        for lid in self._conv_ids:
+            conv = getattr(self, lid)
+            wo, wn, bo, bn = lay[lid]
+            out.append(flat[wo:wo + wn].view_as(conv.weight) if conv.weight.requires_grad else None)
+            out.append(flat[bo:bo + bn] if conv.bias.requires_grad else None)
+        return out

@@ -1,0 +1,49 @@
+"""SGD with the reference's parameter-group policy, stepping through the ssn_sgd_step kernel.
+
+Mirrors ``torch.optim.SGD(policies, lr, momentum, weight_decay)`` +
+``adjust_learning_rate`` of /root/reference/ssn_train.py:141-144,391-398: every group carries
+``lr_mult`` / ``decay_mult`` (from ``SSN.get_optim_policies``) and the effective
+``lr = base_lr * lr_mult``, ``weight_decay = base_wd * decay_mult``.
+"""
+import torch
+
+from . import kernels as K
+
+
+class SSNSGD(torch.optim.Optimizer):
+    def __init__(self, policies, lr, momentum=0.9, weight_decay=5e-4):
+        groups = []
+        for g in policies:
+            if len(g["params"]) == 0:
+                continue
+            g = dict(g)
+            g.setdefault("lr_mult", 1)
+            g.setdefault("decay_mult", 1)
+            groups.append(g)
+        defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, lr_mult=1, decay_mult=1)
+        super().__init__(groups, defaults)
+        self.base_lr = lr
+        self.base_wd = weight_decay
+        self.adjust_learning_rate(0, [])
+
+    def adjust_learning_rate(self, epoch, lr_steps):
+        """lr = base * 0.1 ** (#steps passed); per-group multipliers (ssn_train.py:391-398)."""
+        decay = 0.1 ** sum(1 for s in lr_steps if epoch >= s)
+        for g in self.param_groups:
+            g["lr"] = self.base_lr * decay * g["lr_mult"]
+            g["weight_decay"] = self.base_wd * g["decay_mult"]
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                first = "momentum_buffer" not in st
+                if first:
+                    st["momentum_buffer"] = torch.empty_like(p)
+                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                K.sgd_step(p.data, grad, st["momentum_buffer"], g["lr"], g["momentum"], g["weight_decay"],
+                           grad_scale, first)
+        return None

@@ -1,0 +1,111 @@
+"""Data parallelism for the SSN hot path: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference uses single-process ``torch.nn.DataParallel`` (/root/reference/ssn_train.py:67):
+parameters are re-broadcast every forward, outputs are gathered to GPU 0 where all losses are
+computed, and gradients are reduced to GPU 0.  Here every rank owns whole videos (8 proposals
+each -- CompletenessLoss groups rows per video, ops/ssn_ops.py:225-226), computes its own
+losses, and the gradients are summed with ``torch.distributed`` (backend "nccl" == RCCL):
+
+* backbone gradients live in one flat buffer; ``BNInception._run_backward`` reports contiguous
+  tail ranges as soon as an Inception block's wgrads have been launched, and each range is
+  all-reduced asynchronously while earlier blocks are still in backward;
+* the three head layers are reduced in one flat bucket after ``loss.backward()``.
+
+To reproduce the reference's numbers exactly, the completeness loss must use the GLOBAL
+denominator (``CompletenessLoss(..., global_rows=)``); cross-entropy and smooth-L1 are means
+over equal per-rank counts, so averaging per-rank gradients is exact.
+"""
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+from . import _lib
+
+
+def _scale_inplace(t, coef):
+    if t.is_cuda or _lib.emulator_active():
+        K.scale_(t, None, coef)
+    else:  # gloo CPU tensors in the multi-process CPU tests (no HIP device to launch on)
+        t.mul_(coef)
+
+
+class GradReducer:
+    """Bucketed, overlapped gradient averaging for ``SSN`` across ``torch.distributed`` ranks."""
+
+    def __init__(self, model, process_group=None, min_bucket_elems=1 << 20):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.min_bucket = min_bucket_elems
+        self._handles = []
+        self._flat = None
+        self._pend = None  # (start, end) of ranges reported but not yet launched
+        model.base_model.grad_ready_hook = self
+        self.launched = []  # (start, end) history of the last backward, for tests / profiling
+
+    # --- protocol used by BNInception._run_backward
+    def range_ready(self, flat, start, end):
+        if self._flat is None:
+            self._flat = flat
+            self.launched = []
+        if self._pend is None:
+            self._pend = (start, end)
+        else:
+            assert end == self._pend[0], "ranges must arrive tail-first and contiguous"
+            self._pend = (start, self._pend[1])
+        if self._pend[1] - self._pend[0] >= self.min_bucket or start == 0:
+            self._launch()
+
+    def _launch(self):
+        s, e = self._pend
+        self._pend = None
+        if self.world > 1:
+            self._handles.append(dist.all_reduce(self._flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+        self.launched.append((s, e))
+
+    def finish(self):
+        """Called at the end of the backbone backward, before autograd consumes the gradients."""
+        if self._pend is not None:
+            self._launch()
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        if self._flat is not None and self.world > 1:
+            _scale_inplace(self._flat, 1.0 / self.world)
+        self._flat = None
+
+    # --- heads
+    def head_parameters(self):
+        ps = []
+        for name in ("activity_fc", "completeness_fc", "regressor_fc"):
+            fc = getattr(self.model, name, None)
+            if fc is not None:
+                ps.extend(p for p in fc.parameters() if p.grad is not None)
+        return ps
+
+    def reduce_heads(self):
+        """Average the head gradients (call after loss.backward())."""
+        if self.world == 1:
+            return
+        ps = self.head_parameters()
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        _scale_inplace(flat, 1.0 / self.world)
+        off = 0
+        for p in ps:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+
+def shard_videos(num_videos_global, rank, world):
+    """Whole-video sharding: rank r owns videos [lo, hi)."""
+    if num_videos_global % world:
+        raise ValueError("%d videos do not split evenly over %d ranks" % (num_videos_global, world))
+    per = num_videos_global // world
+    return rank * per, (rank + 1) * per

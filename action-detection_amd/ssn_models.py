@@ -1,0 +1,301 @@
+"""Mirror of the reference's ``ssn_models.SSN`` (/root/reference/ssn_models.py:10-395) on the
+MI355X-native kernels.
+
+Same constructor, ``forward`` 7-tuple / test 2-tuple, ``prepare_test_fc``,
+``get_optim_policies``, BN-freezing ``train()`` and ``state_dict`` keys as the reference, so it
+drops into the loops of ssn_train.py:205-253 and ssn_test.py:78-92.  Differences that are
+deliberate and documented in DESIGN.md:
+  * only the BNInception backbone family is built (resnet/vgg/InceptionV3 raise);
+  * the backbone is this repo's ``bninception.BNInception`` executor instead of ``model_zoo``;
+  * ``bn_mode`` other than 'frozen' raises at forward time;
+  * one host sync per forward (prop_type -> row indices) instead of the reference's three
+    ``nonzero()`` syncs.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import functional as FN
+from .bninception import BNInception
+from .ops.ssn_ops import Identity, StructuredTemporalPyramidPooling
+
+_dropout_calls = [0]
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear whose forward/backward are the ssn_linear_* kernels (state_dict-compatible)."""
+
+    def forward(self, input):
+        lead = input.shape[:-1]
+        out = FN.LinearFn.apply(input.reshape(-1, input.shape[-1]), self.weight, self.bias)
+        return out.reshape(lead + (self.out_features,))
+
+
+class HipDropout(nn.Dropout):
+    """nn.Dropout on the ssn_dropout_* kernels (own Philox stream seeded from torch's CPU RNG)."""
+
+    def forward(self, input):
+        if not self.training or self.p == 0:
+            return input
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        return FN.DropoutFn.apply(input, float(self.p), seed)
+
+
+class SSN(torch.nn.Module):
+    def __init__(self, num_class,
+                 starting_segment, course_segment, ending_segment, modality,
+                 base_model='BNInception', new_length=None,
+                 dropout=0.8,
+                 crop_num=1, no_regression=False, test_mode=False,
+                 stpp_cfg=(1, (1, 2), 1), bn_mode='frozen', verbose=False):
+        super(SSN, self).__init__()
+        self.modality = modality
+        self.num_segments = starting_segment + course_segment + ending_segment
+        self.starting_segment = starting_segment
+        self.course_segment = course_segment
+        self.ending_segment = ending_segment
+        self.reshape = True
+        self.dropout = dropout
+        self.crop_num = crop_num
+        self.with_regression = not no_regression
+        self.test_mode = test_mode
+        self.bn_mode = bn_mode
+
+        if new_length is None:
+            self.new_length = 1 if modality == "RGB" else 5
+        else:
+            self.new_length = new_length
+
+        if verbose:
+            print("Initializing SSN with base model: {} ({} / {}+{}+{} segments / dropout {} / regression {} / "
+                  "bn_mode {} / stpp {})".format(base_model, modality, starting_segment, course_segment,
+                                                 ending_segment, dropout, self.with_regression, bn_mode, stpp_cfg))
+
+        self._prepare_base_model(base_model)
+        self._prepare_ssn(num_class, stpp_cfg)
+
+        if self.modality == 'Flow':
+            self.base_model = self._construct_flow_model(self.base_model)
+        elif self.modality == 'RGBDiff':
+            raise NotImplementedError("RGBDiff modality is outside the built hot path (SURVEY.md section 8f-4)")
+
+        self.prepare_bn()
+
+    # ---- /root/reference/ssn_models.py:69-93
+    def _prepare_ssn(self, num_class, stpp_cfg):
+        feature_dim = getattr(self.base_model, self.base_model.last_layer_name).in_features
+        if self.dropout == 0:
+            setattr(self.base_model, self.base_model.last_layer_name, Identity())
+        else:
+            setattr(self.base_model, self.base_model.last_layer_name, HipDropout(p=self.dropout))
+
+        self.stpp = StructuredTemporalPyramidPooling(feature_dim, True, configs=stpp_cfg)
+        self.activity_fc = HipLinear(self.stpp.activity_feat_dim(), num_class + 1)
+        self.completeness_fc = HipLinear(self.stpp.completeness_feat_dim(), num_class)
+
+        nn.init.normal_(self.activity_fc.weight.data, 0, 0.001)
+        nn.init.constant_(self.activity_fc.bias.data, 0)
+        nn.init.normal_(self.completeness_fc.weight.data, 0, 0.001)
+        nn.init.constant_(self.completeness_fc.bias.data, 0)
+
+        self.test_fc = None
+        if self.with_regression:
+            self.regressor_fc = HipLinear(self.stpp.completeness_feat_dim(), 2 * num_class)
+            nn.init.normal_(self.regressor_fc.weight.data, 0, 0.001)
+            nn.init.constant_(self.regressor_fc.bias.data, 0)
+        else:
+            self.regressor_fc = None
+
+        return feature_dim
+
+    # ---- /root/reference/ssn_models.py:95-105
+    def prepare_bn(self):
+        if self.bn_mode == 'partial':
+            self.freeze_count = 2
+        elif self.bn_mode == 'frozen':
+            self.freeze_count = 1
+        elif self.bn_mode == 'full':
+            self.freeze_count = None
+        else:
+            raise ValueError("unknown bn mode")
+
+    # ---- /root/reference/ssn_models.py:107-154
+    def _prepare_base_model(self, base_model):
+        if base_model == 'BNInception':
+            self.base_model = BNInception()
+            self.base_model.last_layer_name = 'fc'
+            self.input_size = 224
+            self.input_mean = [104, 117, 128]
+            self.input_std = [1]
+
+            if self.modality == 'Flow':
+                self.input_mean = [128]
+            elif self.modality == 'RGBDiff':
+                self.input_mean = self.input_mean * (1 + self.new_length)
+        elif ('resnet' in base_model or 'vgg' in base_model or base_model == 'InceptionV3'
+              or 'inception' in base_model):
+            raise NotImplementedError(
+                "base model {} is not built: the MI355X hot path covers BNInception "
+                "(BASELINE.json configs 1-4)".format(base_model))
+        else:
+            raise ValueError('Unknown base model: {}'.format(base_model))
+
+    # ---- /root/reference/ssn_models.py:156-174
+    def train(self, mode=True):
+        super(SSN, self).train(mode)
+        count = 0
+        if self.freeze_count is None:
+            return self
+        for m in self.base_model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                count += 1
+                if count >= self.freeze_count:
+                    m.eval()
+                    # shutdown update in frozen mode
+                    m.weight.requires_grad = False
+                    m.bias.requires_grad = False
+        return self
+
+    # ---- /root/reference/ssn_models.py:176-201
+    def prepare_test_fc(self):
+        m = self.stpp.feat_multiplier
+        d = self.activity_fc.in_features
+        n_out = (self.activity_fc.out_features + self.completeness_fc.out_features * m
+                 + (self.regressor_fc.out_features * m if self.with_regression else 0))
+        self.test_fc = HipLinear(d, n_out)
+        dev = self.activity_fc.weight.device
+
+        def reorganise(fc):
+            w = fc.weight.data.view(fc.out_features, m, d).transpose(0, 1).contiguous().view(-1, d)
+            b = fc.bias.data.view(1, -1).expand(m, fc.out_features).contiguous().view(-1) / m
+            return w, b
+
+        weights, biases = [self.activity_fc.weight.data], [self.activity_fc.bias.data]
+        weights_b = reorganise(self.completeness_fc)
+        weights.append(weights_b[0])
+        biases.append(weights_b[1])
+        if self.with_regression:
+            wr, br = reorganise(self.regressor_fc)
+            weights.append(wr)
+            biases.append(br)
+        self.test_fc.weight.data = torch.cat(weights).to(dev)
+        self.test_fc.bias.data = torch.cat(biases).to(dev)
+
+    # ---- /root/reference/ssn_models.py:203-251
+    def get_optim_policies(self):
+        first_conv_weight, first_conv_bias, normal_weight, normal_bias, bn = [], [], [], [], []
+        conv_cnt = 0
+        for m in self.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv1d)):
+                ps = list(m.parameters())
+                conv_cnt += 1
+                if conv_cnt == 1:
+                    first_conv_weight.append(ps[0])
+                    if len(ps) == 2:
+                        first_conv_bias.append(ps[1])
+                else:
+                    normal_weight.append(ps[0])
+                    if len(ps) == 2:
+                        normal_bias.append(ps[1])
+            elif isinstance(m, torch.nn.Linear):
+                ps = list(m.parameters())
+                normal_weight.append(ps[0])
+                if len(ps) == 2:
+                    normal_bias.append(ps[1])
+            elif isinstance(m, torch.nn.BatchNorm1d):
+                bn.extend(list(m.parameters()))
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                pass  # BN layers are all frozen in SSN
+            elif len(m._modules) == 0:
+                if len(list(m.parameters())) > 0:
+                    raise ValueError("New atomic module type: {}. Need to give it a learning policy".format(type(m)))
+        return [
+            {'params': first_conv_weight, 'lr_mult': 1, 'decay_mult': 1, 'name': "first_conv_weight"},
+            {'params': first_conv_bias, 'lr_mult': 2, 'decay_mult': 0, 'name': "first_conv_bias"},
+            {'params': normal_weight, 'lr_mult': 1, 'decay_mult': 1, 'name': "normal_weight"},
+            {'params': normal_bias, 'lr_mult': 2, 'decay_mult': 0, 'name': "normal_bias"},
+            {'params': bn, 'lr_mult': 1, 'decay_mult': 0, 'name': "BN scale/shift"},
+        ]
+
+    # ---- /root/reference/ssn_models.py:253-300
+    def forward(self, input, aug_scaling=None, target=None, reg_target=None, prop_type=None):
+        if not self.test_mode:
+            return self.train_forward(input, aug_scaling, target, reg_target, prop_type)
+        else:
+            return self.test_forward(input)
+
+    def _backbone(self, input):
+        sample_len = (3 if self.modality == "RGB" else 2) * self.new_length
+        x = input.reshape((-1, sample_len) + tuple(input.shape[-2:]))
+        feat = self.base_model.features(x)
+        return getattr(self.base_model, self.base_model.last_layer_name)(feat)
+
+    def train_forward(self, input, aug_scaling, target, reg_target, prop_type):
+        base_out = self._backbone(input)
+        activity_ft, completeness_ft = self.stpp(base_out, aug_scaling,
+                                                 [self.starting_segment,
+                                                  self.starting_segment + self.course_segment,
+                                                  self.num_segments])
+        raw_act_fc = self.activity_fc(activity_ft)
+        raw_comp_fc = self.completeness_fc(completeness_ft)
+
+        # the reference's three nonzero() calls (ssn_models.py:275-282) -> one host read of prop_type
+        type_host = prop_type.reshape(-1).cpu()
+        dev = raw_act_fc.device
+        act_indexer = torch.nonzero((type_host == 0) | (type_host == 2)).reshape(-1).to(dev)
+        comp_indexer = torch.nonzero((type_host == 0) | (type_host == 1)).reshape(-1).to(dev)
+        target = target.reshape(-1).to(dev)
+
+        def sel(t, idx):
+            return t.index_select(0, idx)  # integer / target bookkeeping (not arithmetic)
+
+        if self.with_regression:
+            reg_target = reg_target.reshape(-1, 2).to(dev)
+            reg_indexer = torch.nonzero(type_host == 0).reshape(-1).to(dev)
+            raw_regress_fc = self.regressor_fc(completeness_ft).reshape(-1, self.completeness_fc.out_features, 2)
+            return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), sel(target, act_indexer),
+                    FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), sel(target, comp_indexer),
+                    FN.RowGatherFn.apply(raw_regress_fc, reg_indexer), sel(target, reg_indexer),
+                    sel(reg_target, reg_indexer))
+        else:
+            return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), sel(target, act_indexer),
+                    FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), sel(target, comp_indexer))
+
+    def test_forward(self, input):
+        base_out = self._backbone(input)
+        return self.test_fc(base_out), base_out
+
+    # ---- /root/reference/ssn_models.py:318-343
+    def _construct_flow_model(self, base_model):
+        modules = list(self.base_model.modules())
+        first_conv_idx = list(filter(lambda x: isinstance(modules[x], nn.Conv2d), list(range(len(modules)))))[0]
+        conv_layer = modules[first_conv_idx]
+        container = modules[first_conv_idx - 1]
+
+        params = [x.clone() for x in conv_layer.parameters()]
+        kernel_size = params[0].size()
+        new_kernel_size = kernel_size[:1] + (2 * self.new_length,) + kernel_size[2:]
+        new_kernels = params[0].data.mean(dim=1, keepdim=True).expand(new_kernel_size).contiguous()
+
+        new_conv = nn.Conv2d(2 * self.new_length, conv_layer.out_channels,
+                             conv_layer.kernel_size, conv_layer.stride, conv_layer.padding,
+                             bias=True if len(params) == 2 else False)
+        new_conv.weight.data = new_kernels
+        if len(params) == 2:
+            new_conv.bias.data = params[1].data
+        layer_name = list(container.state_dict().keys())[0][:-7]
+        setattr(container, layer_name, new_conv)
+        return base_model
+
+    # ---- /root/reference/ssn_models.py:378-395
+    @property
+    def crop_size(self):
+        return self.input_size
+
+    @property
+    def scale_size(self):
+        return self.input_size * 256 // 224
+
+    def get_augmentation(self):
+        raise NotImplementedError(
+            "CPU image augmentation (transforms.py) is outside the hot path; see SURVEY.md section 2 row 7")
