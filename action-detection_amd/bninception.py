@@ -63,7 +63,18 @@ class BNInception(nn.Module):
         self.fc = nn.Linear(FEATURE_DIM, num_classes)
         self.grad_ready_hook = None   # object with range_ready(flat, start, end) / finish() (parallel.GradReducer)
         self._ws = None
-        self._flat_layout = None
+        self.profiler = None          # list; when set, every conv launch is bracketed by HIP events
+
+    def _timed(self, family, lid, flops, fn):
+        """Run one conv launch; with a profiler attached, bracket it with events on the current stream."""
+        if self.profiler is None:
+            fn()
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.profiler.append((family, lid, flops, s, e))
 
     # ------------------------------------------------------------------ parameter plumbing
     def _param_list(self):
@@ -132,8 +143,11 @@ class BNInception(nn.Module):
                 shift = torch.empty(cout, device=dev, dtype=torch.float32)
                 K.bn_fold(conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                           bn.running_var, bn.eps, scale, shift)
-                K.conv_fwd(full(acts[src]), conv.weight.detach(), scale, shift, ChanSlice(get(dst), c0, cout),
-                           k, s, p, True)
+                ho = shapes[dst][1]
+                flops = 2.0 * n * ho * ho * cout * cin * k * k
+                self._timed("conv_fwd", lid, flops,
+                            lambda: K.conv_fwd(full(acts[src]), conv.weight.detach(), scale, shift,
+                                               ChanSlice(get(dst), c0, cout), k, s, p, True))
                 folds[lid] = scale
             elif op[0] == "pool":
                 _, lid, kind, src, dst, c0, k, s, p, _ceil = op
@@ -204,11 +218,15 @@ class BNInception(nn.Module):
                 wo, wn, bo, bn = lay[lid]
                 dw = flat[wo:wo + wn].view_as(conv.weight)
                 db = flat[bo:bo + bn]
-                K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws)
+                ho = shapes[dst][1]
+                flops = 2.0 * n * ho * ho * cout * cin * k * k
+                self._timed("conv_wgrad", lid, flops, lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws))
                 if src != "data":
                     wt = torch.empty((cin, cout * k * k), device=dev, dtype=torch.float32)
                     K.weight_transpose(conv.weight.detach(), wt)
-                    K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=src in inited)
+                    acc_flag = src in inited
+                    self._timed("conv_dgrad", lid, flops,
+                                lambda: K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=acc_flag))
                     inited.add(src)
                 if self.grad_ready_hook is not None and (lid.endswith("_1x1") or lid == self._conv_ids[0]
                                                          or lid == "inception_3c_3x3_reduce"

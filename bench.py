@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""SSN hot-path benchmark (BASELINE.json metric: proposals/s, 9-segment BNInception SSN fwd+bwd).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = the loop body of /root/reference/ssn_train.py:205-253 on synthetic THUMOS14-shape
+data that is already resident in HBM: SSN forward (backbone -> dropout -> STPP -> heads -> row
+selection), the three losses, backward, gradient all-reduce (N > 1) and the SGD update.
+Workload per GPU = BASELINE.json configs[1]: 4 videos x 8 proposals x 9 segments = 288 RGB frames
+of 224x224 (weak scaling: per-GPU work is fixed as N grows).
+
+Rank 0 prints ONE JSON line.  `roofline` is the MFMA roofline of the dominant kernel family (the
+f32-MFMA implicit-GEMM convolution, `conv_igemm_kernel`, forward + dgrad launches), measured live
+with HIP events around every launch during the timed steps; `cpu_baseline` times the CPU oracle
+(oracle/ssn_oracle.py, torch fp32 on the host cores) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+FWD_GFLOP_PER_IMAGE = {"RGB": 4.063152128, "Flow": 4.613883904}  # 2 * conv MACs
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--videos-per-gpu", type=int, default=4)
+    ap.add_argument("--modality", default="RGB", choices=["RGB", "Flow"])
+    ap.add_argument("--num-class", type=int, default=20)
+    ap.add_argument("--cpu-baseline-videos", type=int, default=2,
+                    help="videos in the CPU-oracle sample (0 disables the cpu_baseline leg)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP event timing")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import action_detection_amd as pkg
+    from action_detection_amd.ops.ssn_ops import ActivityLoss, ClassWiseRegressionLoss, CompletenessLoss
+    from action_detection_amd.optim import SSNSGD
+    from action_detection_amd.parallel import GradReducer
+    from action_detection_amd.ssn_models import SSN
+    from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic, make_batch
+
+    pkg.build()
+    v = args.videos_per_gpu
+    torch.manual_seed(1234 + rank)
+    model = SSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1))
+    init_backbone_synthetic(model.base_model)  # same weights on every rank (same seed)
+    init_heads_synthetic(model, std=0.001)
+    model.to(dev).train()
+    policies = model.get_optim_policies()
+    opt = SSNSGD(policies, lr=0.001, momentum=0.9, weight_decay=5e-4)
+    reducer = GradReducer(model) if world > 1 else None
+    act_crit, comp_crit, reg_crit = ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss()
+    batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank)]
+    global_comp_rows = 7 * v * world
+
+    def step():
+        out = model(*batch)
+        loss = (act_crit(out[0], out[1]) + 0.1 * comp_crit(out[2], out[3], 1, 7, global_rows=global_comp_rows)
+                + 0.1 * reg_crit(out[4], out[5], out[6]))
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce_heads()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prof = None if args.no_kernel_events else []
+    model.base_model.profiler = prof
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    model.base_model.profiler = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    proposals = 8 * v * world * args.steps
+    value = proposals / elapsed
+    result = {
+        "metric": "proposals/sec (9-seg BNInception SSN fwd+bwd)",
+        "value": round(value, 3),
+        "unit": "proposals/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BNInception %s SSN, %d videos x 8 proposals x 9 segments per GPU (224x224), "
+                               "fwd + losses + bwd + SGD, THUMOS14 shape (C=%d, stpp [1,1,1], dropout 0.8)"
+                               % (args.modality, v, args.num_class),
+                   "global_batch_proposals": 8 * v * world, "images_per_gpu": 72 * v,
+                   "parallelism": "dp%d" % world},
+        "final_loss": float(loss.item()),
+    }
+
+    if rank == 0:
+        # ---------------- roofline of the dominant kernel family (HIP events, timed region) ----------------
+        if prof:
+            fam = {}
+            for family, lid, flops, s, e in prof:
+                ms = s.elapsed_time(e)
+                f = fam.setdefault(family, [0.0, 0.0, 0])
+                f[0] += flops
+                f[1] += ms
+                f[2] += 1
+            gemm_fl = sum(fam[k][0] for k in ("conv_fwd", "conv_dgrad") if k in fam)
+            gemm_ms = sum(fam[k][1] for k in ("conv_fwd", "conv_dgrad") if k in fam)
+            gemm_n = sum(fam[k][2] for k in ("conv_fwd", "conv_dgrad") if k in fam)
+            achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+            result["roofline"] = {
+                "bound": "mfma", "kernel": "conv_igemm_kernel (f32 MFMA implicit GEMM; fwd + dgrad launches)",
+                "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2), "launches": gemm_n,
+                "algorithmic_gflop_per_launch": round(gemm_fl / gemm_n / 1e9, 4),
+            }
+            result["roofline_detail"] = {
+                k: {"tflops": round(f[0] / (f[1] * 1e-3) / 1e12, 3), "frac": round(f[0] / (f[1] * 1e-3) / 1e12
+                                                                                 / F32_MFMA_PEAK_TFLOPS, 4),
+                    "ms_per_step": round(f[1] / args.steps, 3), "launches_per_step": f[2] // args.steps}
+                for k, f in fam.items()}
+            conv_ms = sum(f[1] for f in fam.values()) / args.steps
+            result["roofline_detail"]["conv_ms_per_step"] = round(conv_ms, 3)
+            result["roofline_detail"]["whole_step_frac_of_f32_mfma_peak"] = round(
+                (3 * FWD_GFLOP_PER_IMAGE[args.modality] * 72 * v * 1e9 / (elapsed / args.steps)) / 1e12
+                / F32_MFMA_PEAK_TFLOPS, 4)
+
+        # ---------------- CPU baseline: the oracle on the host cores, bounded sample ----------------
+        if args.cpu_baseline_videos > 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import ssn_oracle as O
+            cv = args.cpu_baseline_videos
+            oracle = O.OracleSSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1))
+            sd = {k: t.detach().cpu() for k, t in model.state_dict().items()}
+            oracle.load_state_dict(sd)
+            oracle.train()
+            cb = make_batch(cv, args.modality, args.num_class, seed=10_000)
+            times = []
+            for rep in range(2):
+                c0 = time.perf_counter()
+                ref = oracle(*cb)
+                tot, _, _, _ = O.ssn_total_loss(ref, cv)
+                tot.backward()
+                times.append(time.perf_counter() - c0)
+                oracle.zero_grad(set_to_none=True)
+            ct = min(times)
+            result["cpu_baseline"] = {
+                "value": round(8 * cv / ct, 4), "unit": "proposals/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": "oracle/ssn_oracle.py (torch-CPU fp32 restatement of the reference SSN), %d videos = %d "
+                          "proposals = %d frames, fwd + losses + bwd, best of 2 (%.2f s)" % (cv, 8 * cv, 72 * cv, ct),
+            }
+            # parity in the same run (eval mode: dropout off on both sides)
+            model.eval()
+            oracle.eval()
+            with torch.no_grad():
+                g = model(*[t.to(dev) for t in cb])
+                r = oracle(*cb)
+            model.train()
+            rel = max(((a.float().cpu() - b.float()).abs().max() / (b.float().abs().max() + 1e-20)).item()
+                      for a, b in zip(g[0::2], r[0::2]))
+            result["parity_max_rel_logits_vs_cpu_oracle"] = rel
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes (test infrastructure).
+
+Runs only in the build container, where /root/reference exists; the fixtures it writes are
+committed so the GPU box (which has no /root/reference) can check against them.
+
+The reference's hot-path classes import and run unmodified on torch 2.10 CPU with three shims
+(SURVEY.md section 8c): a ``torchvision`` stub, a ``model_zoo`` stub whose ``BNInception`` is the
+oracle's torch-CPU backbone (the real one is an un-vendored submodule), and a no-op
+``Tensor.cuda``.  Every fixture stores the reference's outputs for seeded inputs; the tests then
+hold the oracle restatement (oracle/ssn_oracle.py) -- and on the GPU the HIP path -- to them.
+
+    python oracle/make_golden.py            # writes tests/golden/ref_*.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ssn_oracle as O  # noqa: E402
+import action_detection_amd  # noqa: E402,F401
+from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic, make_batch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def install_shims():
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    for name in ("Compose", "CenterCrop", "Scale"):
+        setattr(tv.transforms, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tv.models
+    sys.modules["torchvision.transforms"] = tv.transforms
+    mz = types.ModuleType("model_zoo")
+    mz.BNInception = lambda: O.OracleBNInception()
+    sys.modules["model_zoo"] = mz
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+def golden_stpp(ref_ops):
+    rng = np.random.RandomState(11)
+    out = {}
+    cases = [((1, 1, 1), [2, 7, 9]), ((1, (1, 2), 1), [2, 7, 9]), ((2, (1, 2, 3), 1), [2, 7, 9]),
+             ((1, (1, 2), (1, 2)), [1, 4, 6])]
+    for ci, (cfg, split) in enumerate(cases):
+        p, d = 5, 16
+        ft = rng.standard_normal((p * split[2], d)).astype(np.float32)
+        sc = rng.uniform(0, 1, (p, 2)).astype(np.float32)
+        mod = ref_ops.StructuredTemporalPyramidPooling(d, True, configs=cfg)
+        ft_t = torch.from_numpy(ft).requires_grad_()
+        act, stpp = mod(ft_t, torch.from_numpy(sc), split)
+        ga = rng.standard_normal(act.shape).astype(np.float32)
+        gs = rng.standard_normal(stpp.shape).astype(np.float32)
+        (act * torch.from_numpy(ga)).sum().add((stpp * torch.from_numpy(gs)).sum()).backward()
+        out.update({"c%d_ft" % ci: ft, "c%d_sc" % ci: sc, "c%d_act" % ci: act.detach().numpy(),
+                    "c%d_stpp" % ci: stpp.detach().numpy(), "c%d_ga" % ci: ga, "c%d_gs" % ci: gs,
+                    "c%d_dft" % ci: ft_t.grad.numpy(), "c%d_split" % ci: np.array(split),
+                    "c%d_cfg" % ci: np.array(repr(cfg))})
+    # known-answer table of the integer tick truncation (ops/ssn_ops.py:53-55)
+    kat = []
+    for length in range(1, 10):
+        for n_part in range(1, 5):
+            t = torch.arange(0, length + 1e-5, length / n_part)
+            kat.append([length, n_part] + [int(v) for v in t] + [-1] * (6 - len(t)))
+    out["ticks_kat"] = np.array(kat, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "ref_stpp.npz"), **out)
+
+
+def golden_losses(ref_ops):
+    rng = np.random.RandomState(12)
+    out = {}
+    for ci, v in enumerate((4, 16)):
+        c = 20
+        pred = (rng.standard_normal((7 * v, c)) * 1.5).astype(np.float32)
+        labels = rng.randint(1, c + 1, size=7 * v).astype(np.int64)
+        pt = torch.from_numpy(pred).requires_grad_()
+        loss = ref_ops.CompletenessLoss()(pt, torch.from_numpy(labels), 1, 7)
+        loss.backward()
+        out.update({"comp%d_pred" % ci: pred, "comp%d_labels" % ci: labels,
+                    "comp%d_loss" % ci: loss.detach().numpy(), "comp%d_grad" % ci: pt.grad.numpy()})
+    n, c = 6, 20
+    pred = (rng.standard_normal((n, c, 2)) * 1.2).astype(np.float32)
+    labels = rng.randint(1, c + 1, size=n).astype(np.int64)
+    tg = rng.standard_normal((n, 2)).astype(np.float32)
+    pt = torch.from_numpy(pred).requires_grad_()
+    loss = ref_ops.ClassWiseRegressionLoss()(pt, torch.from_numpy(labels), torch.from_numpy(tg))
+    loss.backward()
+    out.update({"reg_pred": pred, "reg_labels": labels, "reg_targets": tg, "reg_loss": loss.detach().numpy(),
+                "reg_grad": pt.grad.numpy()})
+    # OHEM hinge alone, ratio 0.5 on groups of 4 (exercises keep > 1)
+    pred = (rng.standard_normal((16, 5)) * 1.5).astype(np.float32)
+    labels = rng.randint(1, 6, size=16).astype(np.int64)
+    pt = torch.from_numpy(pred).requires_grad_()
+    loss = ref_ops.OHEMHingeLoss.apply(pt, torch.from_numpy(labels), -1, 0.5, 4)
+    loss.backward()
+    out.update({"ohem_pred": pred, "ohem_labels": labels, "ohem_loss": loss.detach().numpy(),
+                "ohem_grad": pt.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, "ref_losses.npz"), **out)
+
+
+def golden_reorg(ref_ops):
+    rng = np.random.RandomState(13)
+    out = {}
+    for ci, cfg in enumerate(((1, 1, 1), (1, (1, 2), 1))):
+        mult = sum(sum(c) if isinstance(c, tuple) else c for c in cfg)
+        a, c, r = 21, 20, 40
+        d = a + (c + r) * mult
+        t = 40
+        scores = rng.standard_normal((t, d)).astype(np.float32)
+        starts = rng.randint(0, t - 2, size=12)
+        ends = np.minimum(starts + rng.randint(1, 12, size=12), t)
+        dur = ends - starts
+        # ticks are clamped to [0, T] and non-decreasing by construction in the reference
+        # (real_rel_starting / real_rel_ending, ssn_dataset.py:417-424)
+        ticks = np.stack([np.maximum(starts - dur // 2, 0), starts, ends, np.minimum(ends + dur // 2, t)], 1)
+        ticks[0] = [0, 0, 3, 6]        # proposal at the very start (starting stage of length 0 -> 1 row)
+        ticks[1] = [30, 38, 40, 40]    # proposal ending at T: ending stage starts at T -> skipped (:140-142)
+        ticks[2] = [5, 5, 5, 5]        # degenerate (length-0 stages -> max(t+1, .))
+        ticks[3] = [0, 0, 0, 2]
+        scaling = rng.uniform(0, 1, (12, 2))
+        mod = ref_ops.STPPReorgainzed(d, a, c, r, True, True, stpp_cfg=cfg)
+        oa, oc, orr = mod.forward(torch.from_numpy(scores), torch.from_numpy(ticks.astype(np.int64)), scaling)
+        out.update({"r%d_scores" % ci: scores, "r%d_ticks" % ci: ticks.astype(np.int64), "r%d_scaling" % ci: scaling,
+                    "r%d_act" % ci: oa.numpy(), "r%d_comp" % ci: oc.numpy(), "r%d_reg" % ci: orr.numpy()})
+    np.savez_compressed(os.path.join(OUT, "ref_reorg.npz"), **out)
+
+
+def golden_ssn(ref_models, ref_ops):
+    """Reference SSN wiring (heads, row selection, losses, test_fc folding, optimiser groups)."""
+    out = {}
+    for tag, modality, cfg, size in (("rgb", "RGB", (1, 1, 1), 32), ("flow", "Flow", (1, (1, 2), 1), 32)):
+        torch.manual_seed(0)
+        c, v = 20, 2
+        m = ref_models.SSN(c, 2, 5, 2, modality, base_model="BNInception", dropout=0, stpp_cfg=cfg)
+        init_backbone_synthetic(m.base_model)
+        init_heads_synthetic(m)
+        m.train()
+        batch = make_batch(v, modality, c, seed=3, input_size=size)
+        res = m(*batch)
+        act_l = torch.nn.CrossEntropyLoss()(res[0], res[1])
+        comp_l = ref_ops.CompletenessLoss()(res[2], res[3], 1, 7)
+        reg_l = ref_ops.ClassWiseRegressionLoss()(res[4], res[5], res[6])
+        loss = act_l + 0.1 * comp_l + 0.1 * reg_l
+        loss.backward()
+        for i, t in enumerate(res):
+            out["%s_out%d" % (tag, i)] = t.detach().numpy()
+        out["%s_losses" % tag] = np.array([act_l.item(), comp_l.item(), reg_l.item(), loss.item()], np.float64)
+        gn, names = [], []
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                gn.append([float(p.grad.double().norm()), float(p.grad.double().sum())])
+        out["%s_grad_names" % tag] = np.array(names)
+        out["%s_grad_stats" % tag] = np.array(gn)
+        out["%s_grad_act_w" % tag] = m.activity_fc.weight.grad.numpy()
+        out["%s_grad_conv1_b" % tag] = m.base_model.conv1_7x7_s2.bias.grad.numpy()
+        out["%s_grad_5b_1x1_w" % tag] = m.base_model.inception_5b_1x1.weight.grad.numpy()
+        pol = m.get_optim_policies()
+        out["%s_policy_sizes" % tag] = np.array([[len(g["params"]), sum(p.numel() for p in g["params"])] for g in pol])
+        out["%s_state_keys" % tag] = np.array(sorted(m.state_dict().keys()))
+        # dense-test path
+        m.test_mode = True
+        m.prepare_test_fc()
+        m.eval()
+        with torch.no_grad():
+            frames = batch[0].reshape(-1, batch[0].shape[1] // 72 * 1, size, size)[:12]
+            scores, base = m(frames.reshape(12, -1, size, size), None, None, None, None)
+        out["%s_test_scores" % tag] = scores.numpy()
+        out["%s_test_base" % tag] = base.numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_ssn.npz"), **out)
+
+
+def main():
+    assert os.path.isdir(REF), "this script needs /root/reference (build container only)"
+    os.makedirs(OUT, exist_ok=True)
+    install_shims()
+    import ssn_models as ref_models
+    from ops import ssn_ops as ref_ops
+    golden_stpp(ref_ops)
+    golden_losses(ref_ops)
+    golden_reorg(ref_ops)
+    golden_ssn(ref_models, ref_ops)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,211 @@
+"""Golden vectors produced by the REFERENCE's own classes (oracle/make_golden.py) hold
+
+  (a) the oracle restatement (oracle/ssn_oracle.py)            -- CPU tier: pins the oracle;
+  (b) the product ops (mirror classes -> C ABI -> HIP kernels)   -- emulator on CPU, real library with -m gpu.
+
+STPP segment assignment, OHEM selection and row routing are exact; floating point within 1e-5 relative
+for single ops and 1e-4 relative (the north-star tolerance) for the end-to-end SSN logits / losses.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import action_detection_amd  # noqa: F401
+import ssn_oracle as O
+from action_detection_amd.ops import ssn_ops as P
+from conftest import GOLDEN
+from test_kernels import rel_err
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+# ----------------------------------------------------------------------------- (a) oracle vs reference
+def test_oracle_stpp_matches_reference():
+    g = load("ref_stpp.npz")
+    for ci in range(4):
+        cfg = eval(str(g["c%d_cfg" % ci]))
+        split = [int(v) for v in g["c%d_split" % ci]]
+        ft = torch.from_numpy(g["c%d_ft" % ci]).requires_grad_()
+        act, stpp = O.stpp_forward(ft, torch.from_numpy(g["c%d_sc" % ci]), split, cfg, True)
+        assert rel_err(act, torch.from_numpy(g["c%d_act" % ci])) < 1e-6
+        assert rel_err(stpp, torch.from_numpy(g["c%d_stpp" % ci])) < 1e-6
+        ((act * torch.from_numpy(g["c%d_ga" % ci])).sum() + (stpp * torch.from_numpy(g["c%d_gs" % ci])).sum()).backward()
+        assert rel_err(ft.grad, torch.from_numpy(g["c%d_dft" % ci])) < 1e-6
+    for row in g["ticks_kat"]:
+        length, n_part = int(row[0]), int(row[1])
+        want = [int(v) for v in row[2:] if v >= 0]
+        assert O.stage_ticks(length, n_part) == want, (length, n_part)       # index-exact
+        assert P._stage_ticks(length, n_part) == want, (length, n_part)      # host side of the product
+
+
+def test_oracle_losses_match_reference():
+    g = load("ref_losses.npz")
+    for ci in range(2):
+        pred = torch.from_numpy(g["comp%d_pred" % ci])
+        loss, grad = O.completeness_loss(pred, g["comp%d_labels" % ci], 1, 7)
+        assert abs(loss - g["comp%d_loss" % ci][0]) < 1e-6 * abs(g["comp%d_loss" % ci][0])
+        np.testing.assert_allclose(grad, g["comp%d_grad" % ci], rtol=1e-6, atol=0)
+    pred = torch.from_numpy(g["reg_pred"]).requires_grad_()
+    loss = O.classwise_regression_loss(pred, torch.from_numpy(g["reg_labels"]), torch.from_numpy(g["reg_targets"]))
+    loss.backward()
+    assert rel_err(loss.reshape(1), torch.from_numpy(g["reg_loss"]).reshape(1)) < 1e-6
+    assert rel_err(pred.grad, torch.from_numpy(g["reg_grad"])) < 1e-6
+    loss, grad = O.ohem_hinge(torch.from_numpy(g["ohem_pred"]), g["ohem_labels"], -1, 0.5, 4)
+    assert abs(loss - g["ohem_loss"][0]) < 1e-6 * abs(g["ohem_loss"][0])
+    np.testing.assert_array_equal(grad, g["ohem_grad"])
+
+
+def test_oracle_reorg_matches_reference():
+    g = load("ref_reorg.npz")
+    for ci, cfg in enumerate(((1, 1, 1), (1, (1, 2), 1))):
+        a, c, r = O.stpp_reorganized(g["r%d_scores" % ci], g["r%d_ticks" % ci], g["r%d_scaling" % ci], 21, 20, 40, cfg)
+        for got, key in ((a, "act"), (c, "comp"), (r, "reg")):
+            assert rel_err(torch.from_numpy(got), torch.from_numpy(g["r%d_%s" % (ci, key)])) < 1e-6
+
+
+def _build_pair(tag, cls, size=32):
+    from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic, make_batch
+    modality, cfg = ("RGB", (1, 1, 1)) if tag == "rgb" else ("Flow", (1, (1, 2), 1))
+    torch.manual_seed(0)
+    m = cls(20, 2, 5, 2, modality, dropout=0, stpp_cfg=cfg)
+    init_backbone_synthetic(m.base_model)
+    init_heads_synthetic(m)
+    m.train()
+    return m, make_batch(2, modality, 20, seed=3, input_size=size)
+
+
+@pytest.mark.parametrize("tag", ["rgb", "flow"])
+def test_oracle_ssn_matches_reference(tag):
+    """Whole SSN wiring (heads, row selection, losses, grads, test_fc folding) of the restatement."""
+    g = load("ref_ssn.npz")
+    m, batch = _build_pair(tag, O.OracleSSN)
+    out = m(*batch)
+    for i, t in enumerate(out):
+        assert rel_err(t.float(), torch.from_numpy(g["%s_out%d" % (tag, i)]).float()) < 1e-6, i
+    total, a, c, r = O.ssn_total_loss(out, 2)
+    np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["%s_losses" % tag], rtol=1e-6)
+    total.backward()
+    grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
+    names = [str(n) for n in g["%s_grad_names" % tag]]
+    assert sorted(names) == sorted(grads)
+    for n, (norm, s) in zip(names, g["%s_grad_stats" % tag]):
+        assert abs(float(grads[n].double().norm()) - norm) <= 1e-5 * norm + 1e-12, n
+    assert rel_err(m.activity_fc.weight.grad, torch.from_numpy(g["%s_grad_act_w" % tag])) < 1e-5
+    assert rel_err(m.base_model.inception_5b_1x1.weight.grad, torch.from_numpy(g["%s_grad_5b_1x1_w" % tag])) < 1e-5
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["%s_state_keys" % tag]]
+    m.test_mode = True
+    m.prepare_test_fc()
+    m.eval()
+    size = batch[0].shape[-1]
+    frames = batch[0].reshape(-1, batch[0].shape[1] // 72, size, size)[:12]
+    with torch.no_grad():
+        scores, base = m(frames)
+    assert rel_err(scores, torch.from_numpy(g["%s_test_scores" % tag])) < 1e-6
+    assert rel_err(base, torch.from_numpy(g["%s_test_base" % tag])) < 1e-6
+
+
+# ----------------------------------------------------------------------------- (b) product ops vs reference
+def test_product_stpp_matches_reference(backend):
+    g = load("ref_stpp.npz")
+    for ci in range(4):
+        cfg = eval(str(g["c%d_cfg" % ci]))
+        split = [int(v) for v in g["c%d_split" % ci]]
+        mod = P.StructuredTemporalPyramidPooling(16, True, configs=cfg)
+        # index-exact segment assignment: the part table equals the oracle's (which equals the reference)
+        assert mod.part_table(tuple(split)) == O.stpp_part_table(split, cfg)
+        ft = backend.put(torch.from_numpy(g["c%d_ft" % ci])).requires_grad_()
+        act, stpp = mod(ft, backend.put(torch.from_numpy(g["c%d_sc" % ci])), split)
+        assert rel_err(act, torch.from_numpy(g["c%d_act" % ci])) < 1e-6
+        assert rel_err(stpp, torch.from_numpy(g["c%d_stpp" % ci])) < 1e-6
+        torch.autograd.backward([act, stpp], [backend.put(torch.from_numpy(g["c%d_ga" % ci])),
+                                              backend.put(torch.from_numpy(g["c%d_gs" % ci]))])
+        assert rel_err(ft.grad, torch.from_numpy(g["c%d_dft" % ci])) < 1e-6
+
+
+def test_product_losses_match_reference(backend):
+    g = load("ref_losses.npz")
+    for ci in range(2):
+        pred = backend.put(torch.from_numpy(g["comp%d_pred" % ci])).requires_grad_()
+        loss = P.CompletenessLoss()(pred, backend.put(torch.from_numpy(g["comp%d_labels" % ci])), 1, 7)
+        loss.backward()
+        assert rel_err(loss, torch.from_numpy(g["comp%d_loss" % ci])) < 1e-6
+        got, want = pred.grad.cpu().numpy(), g["comp%d_grad" % ci]
+        assert np.array_equal(got != 0, want != 0), "OHEM kept a different row set"     # exact selection
+        np.testing.assert_allclose(got, want, rtol=1e-6)
+    pred = backend.put(torch.from_numpy(g["reg_pred"])).requires_grad_()
+    loss = P.ClassWiseRegressionLoss()(pred, backend.put(torch.from_numpy(g["reg_labels"])),
+                                       backend.put(torch.from_numpy(g["reg_targets"])))
+    loss.backward()
+    assert rel_err(loss.reshape(1), torch.from_numpy(g["reg_loss"]).reshape(1)) < 1e-6
+    assert rel_err(pred.grad, torch.from_numpy(g["reg_grad"])) < 1e-6
+    pred = backend.put(torch.from_numpy(g["ohem_pred"])).requires_grad_()
+    loss = P.OHEMHingeLoss.apply(pred, backend.put(torch.from_numpy(g["ohem_labels"])), -1, 0.5, 4)
+    loss.backward()
+    assert rel_err(loss, torch.from_numpy(g["ohem_loss"])) < 1e-6
+    assert np.array_equal(pred.grad.cpu().numpy(), g["ohem_grad"])
+
+
+def test_product_reorg_matches_reference(backend):
+    g = load("ref_reorg.npz")
+    for ci, cfg in enumerate(((1, 1, 1), (1, (1, 2), 1))):
+        scores = g["r%d_scores" % ci]
+        mod = P.STPPReorgainzed(scores.shape[1], 21, 20, 40, True, True, stpp_cfg=cfg)
+        a, c, r = mod.forward(backend.put(torch.from_numpy(scores)), torch.from_numpy(g["r%d_ticks" % ci]),
+                              g["r%d_scaling" % ci])
+        for got, key in ((a, "act"), (c, "comp"), (r, "reg")):
+            assert rel_err(got, torch.from_numpy(g["r%d_%s" % (ci, key)])) < 1e-6, key
+
+
+def _product_vs_golden(tag, device):
+    from action_detection_amd.ssn_models import SSN
+    g = load("ref_ssn.npz")
+    m, batch = _build_pair(tag, SSN)
+    m.to(device)
+    out = m(*[t.to(device) for t in batch])
+    for i, t in enumerate(out):
+        want = torch.from_numpy(g["%s_out%d" % (tag, i)])
+        if i % 2 == 1 or i == 6:
+            assert torch.equal(t.cpu(), want), i                        # labels / targets: exact routing
+        else:
+            assert rel_err(t, want) < 1e-4, i                           # logits: north-star tolerance
+    a = P.ActivityLoss()(out[0], out[1])
+    c = P.CompletenessLoss()(out[2], out[3], 1, 7)
+    r = P.ClassWiseRegressionLoss()(out[4], out[5], out[6])
+    total = a + 0.1 * c + 0.1 * r
+    np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["%s_losses" % tag], rtol=1e-4)
+    total.backward()
+    grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
+    for n, (norm, s) in zip([str(x) for x in g["%s_grad_names" % tag]], g["%s_grad_stats" % tag]):
+        assert abs(float(grads[n].double().norm()) - norm) <= 1e-4 * norm + 1e-10, n
+    assert rel_err(m.base_model.conv1_7x7_s2.bias.grad, torch.from_numpy(g["%s_grad_conv1_b" % tag])) < 1e-4
+    assert rel_err(m.base_model.inception_5b_1x1.weight.grad, torch.from_numpy(g["%s_grad_5b_1x1_w" % tag])) < 1e-4
+    assert rel_err(m.activity_fc.weight.grad, torch.from_numpy(g["%s_grad_act_w" % tag])) < 1e-4
+    pol = m.get_optim_policies()
+    assert [[len(x["params"]), sum(p.numel() for p in x["params"])] for x in pol] == g["%s_policy_sizes" % tag].tolist()
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["%s_state_keys" % tag]]
+    m.test_mode = True
+    m.prepare_test_fc()
+    m.eval()
+    size = batch[0].shape[-1]
+    frames = batch[0].reshape(-1, batch[0].shape[1] // 72, size, size)[:12].to(device)
+    with torch.no_grad():
+        scores, base = m(frames)
+    assert rel_err(scores, torch.from_numpy(g["%s_test_scores" % tag])) < 1e-4
+    assert rel_err(base, torch.from_numpy(g["%s_test_base" % tag])) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["rgb", "flow"])
+def test_product_ssn_matches_reference_gpu(tag, hip_library):
+    """Full SSN (144 frames of 32x32 through all 69 convs) on the MI355X vs the reference's own numbers."""
+    _product_vs_golden(tag, "cuda:0")
+
+
+@pytest.mark.slow_emu
+@pytest.mark.skipif(os.environ.get("SSN_SLOW") != "1", reason="~10 min through the host emulator; set SSN_SLOW=1")
+def test_product_ssn_matches_reference_emulated(emu):
+    _product_vs_golden("rgb", "cpu")

@@ -1,0 +1,242 @@
+"""Per-kernel parity: every C-ABI entry point against a plain torch-CPU fp32 reference of the same op.
+
+Each test runs twice: through the host emulator build of the kernel sources (CPU tier, small
+shapes) and, with ``-m gpu``, through libssn_hip.so on the MI355X (larger shapes).  Tolerances are
+stated per test; integer outputs (argmax routing, STPP segment assignment, OHEM selection) are exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import action_detection_amd  # noqa: F401
+from action_detection_amd import kernels as K
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+CONV_CASES_SMALL = [
+    # N, Cin, H, Cout, k, s, p, tile
+    (2, 8, 9, 40, 3, 1, 1, 3), (1, 3, 20, 64, 7, 2, 3, 1), (2, 16, 7, 96, 1, 1, 0, 2), (3, 8, 10, 33, 3, 2, 1, 4),
+    (1, 16, 8, 130, 1, 1, 0, 0), (1, 4, 12, 160, 3, 1, 1, 5), (2, 4, 6, 128, 3, 1, 1, 6), (2, 4, 6, 100, 3, 1, 1, 7),
+    (2, 8, 9, 40, 3, 1, 1, -1),
+]
+CONV_CASES_GPU = [
+    (9, 3, 224, 64, 7, 2, 3, -1), (9, 64, 56, 192, 3, 1, 1, -1), (18, 192, 28, 64, 1, 1, 0, -1),
+    (18, 128, 28, 160, 3, 2, 1, -1), (18, 576, 14, 224, 1, 1, 0, -1), (18, 160, 14, 192, 3, 1, 1, -1),
+    (36, 256, 14, 256, 3, 2, 1, -1), (36, 1056, 7, 352, 1, 1, 0, -1), (36, 224, 7, 224, 3, 1, 1, -1),
+    (5, 96, 28, 96, 3, 1, 1, 0), (5, 96, 28, 96, 3, 1, 1, 1), (5, 96, 28, 96, 3, 1, 1, 2), (5, 96, 28, 96, 3, 1, 1, 3),
+    (5, 96, 28, 96, 3, 1, 1, 4), (5, 96, 28, 160, 3, 1, 1, 5), (5, 96, 28, 96, 3, 1, 1, 6), (5, 96, 28, 96, 3, 1, 1, 7),
+    (3, 10, 224, 64, 7, 2, 3, -1),
+]
+
+
+def conv_cases(backend):
+    return CONV_CASES_GPU if backend.is_gpu else CONV_CASES_SMALL
+
+
+def test_conv_bn_relu_fwd(backend):
+    """cuDNN conv+BN(eval)+ReLU replacement; tolerance 2e-5 relative (fp32 summation order only)."""
+    g = torch.Generator().manual_seed(0)
+    for (n, cin, h, cout, k, s, p, tile) in conv_cases(backend):
+        x = torch.randn(n, cin, h, h, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g) * 0.1
+        ref = F.relu(F.conv2d(x, w, None, s, p) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        ho = ref.shape[2]
+        c0, ctot = 16, cout + 48      # write into a channel slice of a wider (concat) tensor
+        y = torch.full((n, ctot, ho, ho), 7.0)
+        yd = backend.put(y)
+        K.conv_fwd(K.full(backend.put(x)), backend.put(w), backend.put(scale), backend.put(shift),
+                   K.ChanSlice(yd, c0, cout), k, s, p, True, tile)
+        got = yd.cpu()
+        assert rel_err(got[:, c0:c0 + cout], ref) < 2e-5, (n, cin, h, cout, k, s, tile)
+        assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all(), "wrote outside its slice"
+
+
+def test_conv_dgrad_and_wgrad(backend):
+    """cuDNN dgrad / wgrad(+bias) replacement vs torch autograd; tolerance 5e-5 relative."""
+    g = torch.Generator().manual_seed(1)
+    for (n, cin, h, cout, k, s, p, tile) in conv_cases(backend):
+        x = torch.randn(n, cin, h, h, generator=g).requires_grad_()
+        w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).requires_grad_()
+        b = torch.zeros(cout, requires_grad=True)
+        y = F.conv2d(x, w, b, s, p)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        ho = y.shape[2]
+        gd, xd, wd = backend.put(gy), backend.put(x.detach()), backend.put(w.detach())
+        if k != 7:
+            wt = backend.put(torch.empty(cin, cout * k * k))
+            K.weight_transpose(wd, wt)
+            dx = backend.put(torch.full(x.shape, 0.5))
+            K.conv_dgrad(K.full(gd), wt, K.full(dx), k, s, p, True, tile)
+            assert rel_err(dx.cpu() - 0.5, x.grad) < 5e-5, ("dgrad", n, cin, h, cout, k, s)
+            K.conv_dgrad(K.full(gd), wt, K.full(dx), k, s, p, False, tile)
+            assert rel_err(dx, x.grad) < 5e-5
+        ws = backend.put(torch.empty(K.wgrad_workspace_bytes(n, cin, cout, ho, ho, k) // 4))
+        dw, db = backend.put(torch.empty(w.shape)), backend.put(torch.empty(cout))
+        K.conv_wgrad(K.full(gd), K.full(xd), dw, db, k, s, p, ws)
+        assert rel_err(dw, w.grad) < 5e-5, ("wgrad", n, cin, h, cout, k, s)
+        assert rel_err(db, b.grad) < 5e-5
+
+
+def test_wgrad_tiles(backend):
+    g = torch.Generator().manual_seed(2)
+    n, cin, h, cout, k, s, p = (6, 24, 14, 80, 3, 1, 1) if backend.is_gpu else (2, 6, 8, 40, 3, 1, 1)
+    x = torch.randn(n, cin, h, h, generator=g)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    for cfg in range(5):
+        ws = backend.put(torch.empty(K.wgrad_workspace_bytes(n, cin, cout, h, h, k, cfg) // 4))
+        dw = backend.put(torch.empty(w.shape))
+        K.conv_wgrad(K.full(backend.put(gy)), K.full(backend.put(x)), dw, None, k, s, p, ws, cfg)
+        assert rel_err(dw, w.grad) < 5e-5, cfg
+
+
+def test_bn_fold_and_relu_bn_bwd(backend):
+    g = torch.Generator().manual_seed(3)
+    c, n, h = 24, 3, 7
+    bias, gamma, beta = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    mean, var = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    scale, shift = backend.put(torch.empty(c)), backend.put(torch.empty(c))
+    K.bn_fold(*[backend.put(t) for t in (bias, gamma, beta, mean, var)], 1e-5, scale, shift)
+    s_ref = gamma / torch.sqrt(var + 1e-5)
+    assert rel_err(scale, s_ref) < 1e-6
+    assert rel_err(shift, (bias - mean) * s_ref + beta) < 1e-6
+    y = torch.relu(torch.randn(n, c + 8, h, h, generator=g))
+    dy = torch.randn(n, c + 4, h, h, generator=g)
+    dyd = backend.put(dy.clone())
+    K.relu_bn_bwd(K.ChanSlice(dyd, 4, c), K.ChanSlice(backend.put(y), 8, c), backend.put(s_ref))
+    ref = dy.clone()
+    ref[:, 4:] = dy[:, 4:] * (y[:, 8:] > 0) * s_ref.view(1, -1, 1, 1)
+    assert rel_err(dyd, ref) < 1e-6
+
+
+POOLS = [("max", 3, 2, 0), ("max", 3, 1, 1), ("avg", 3, 1, 1)]
+
+
+def test_pools(backend):
+    """ceil_mode max/avg pools: forward exact; backward routes ties exactly like torch (post-ReLU zeros)."""
+    g = torch.Generator().manual_seed(4)
+    for kind, k, s, p in POOLS:
+        for h in ((112, 28, 7) if backend.is_gpu else (12, 7, 5)):
+            n, c = 2, 6
+            x = torch.relu(torch.randn(n, c, h, h, generator=g)).requires_grad_()   # many exact ties at 0
+            if kind == "max":
+                ref = F.max_pool2d(x, k, s, p, ceil_mode=True)
+            else:
+                ref = F.avg_pool2d(x, k, s, p, ceil_mode=True, count_include_pad=True)
+            gy = torch.randn(ref.shape, generator=g)
+            ref.backward(gy)
+            ho = ref.shape[2]
+            y = backend.put(torch.zeros(n, c + 3, ho, ho))
+            am = backend.put(torch.zeros(n, c, ho, ho, dtype=torch.uint8)) if kind == "max" else None
+            K.pool_fwd(kind, K.full(backend.put(x.detach())), K.ChanSlice(y, 3, c), am, k, s, p)
+            assert torch.equal(y.cpu()[:, 3:], ref.detach()) or rel_err(y.cpu()[:, 3:], ref) < 1e-6, (kind, h)
+            gfull = torch.zeros(n, c + 3, ho, ho)
+            gfull[:, 3:] = gy
+            dx = backend.put(torch.ones(n, c, h, h))
+            K.pool_bwd(kind, K.ChanSlice(backend.put(gfull), 3, c), am, K.full(dx), k, s, p, True)
+            assert rel_err(dx.cpu() - 1.0, x.grad) < 1e-6, (kind, h, "bwd")
+
+
+def test_global_avgpool_and_dropout(backend):
+    g = torch.Generator().manual_seed(5)
+    n, c, h = 4, 32, 7
+    x = torch.randn(n, c, h, h, generator=g)
+    y = backend.put(torch.empty(n, c))
+    K.gap_fwd(K.full(backend.put(x)), y)
+    assert rel_err(y, x.mean(dim=(2, 3))) < 1e-6
+    gy = torch.randn(n, c, generator=g)
+    dx = backend.put(torch.empty(n, c, h, h))
+    K.gap_bwd(backend.put(gy), K.full(dx))
+    assert rel_err(dx, (gy / (h * h)).view(n, c, 1, 1).expand(n, c, h, h)) < 1e-6
+    # dropout: mask statistics, scaling, backward consistency, determinism in the seed
+    v = torch.randn(64, 1024, generator=g)
+    out, mask = backend.put(torch.empty_like(v)), backend.put(torch.empty(v.shape, dtype=torch.uint8))
+    K.dropout_fwd(backend.put(v), out, mask, 0.8, 1234)
+    m = mask.cpu().bool()
+    assert abs(m.float().mean().item() - 0.2) < 0.01
+    assert rel_err(out.cpu()[m], v[m] * 5.0) < 1e-6 and (out.cpu()[~m] == 0).all()
+    out2, mask2 = backend.put(torch.empty_like(v)), backend.put(torch.empty(v.shape, dtype=torch.uint8))
+    K.dropout_fwd(backend.put(v), out2, mask2, 0.8, 1234)
+    assert torch.equal(mask.cpu(), mask2.cpu())
+    K.dropout_fwd(backend.put(v), out2, mask2, 0.8, 99)
+    assert not torch.equal(mask.cpu(), mask2.cpu())
+    dv = backend.put(torch.empty_like(v))
+    K.dropout_bwd(backend.put(v), mask, dv, 0.8)
+    assert rel_err(dv, out) < 1e-6
+
+
+def test_linear(backend):
+    g = torch.Generator().manual_seed(6)
+    for (r, o, d) in ((32, 21, 1024), (32, 40, 3072), (5, 7, 30)):
+        x = torch.randn(r, d, generator=g).requires_grad_()
+        w = (torch.randn(o, d, generator=g) * 0.05).requires_grad_()
+        b = torch.randn(o, generator=g).requires_grad_()
+        ref = F.linear(x, w, b)
+        go = torch.randn(ref.shape, generator=g)
+        ref.backward(go)
+        out = backend.put(torch.empty(r, o))
+        K.linear_fwd(backend.put(x.detach()), backend.put(w.detach()), backend.put(b.detach()), out)
+        assert rel_err(out, ref) < 1e-5
+        dx, dw, db = backend.put(torch.ones(r, d)), backend.put(torch.empty(o, d)), backend.put(torch.empty(o))
+        K.linear_bwd(backend.put(go), backend.put(x.detach()), backend.put(w.detach()), dx, dw, db, True)
+        assert rel_err(dx.cpu() - 1.0, x.grad) < 1e-5 and rel_err(dw, w.grad) < 1e-5 and rel_err(db, b.grad) < 1e-5
+
+
+def test_row_gather_scatter(backend):
+    g = torch.Generator().manual_seed(7)
+    src = torch.randn(16, 20, 2, generator=g)
+    idx = torch.tensor([0, 8, 3, 15])
+    out = backend.put(torch.empty(4, 20, 2))
+    K.row_gather(backend.put(src), backend.put(idx), out)
+    assert torch.equal(out.cpu(), src[idx])
+    back = backend.put(torch.full((16, 20, 2), 3.0))
+    K.row_scatter(out, backend.put(idx), back)
+    ref = torch.zeros(16, 20, 2)
+    ref[idx] = src[idx]
+    assert torch.equal(back.cpu(), ref)
+
+
+def test_ce_loss(backend):
+    g = torch.Generator().manual_seed(8)
+    for r, c in ((8, 21), (64, 101), (3, 5)):
+        x = (torch.randn(r, c, generator=g) * 3).requires_grad_()
+        t = torch.randint(0, c, (r,), generator=g)
+        ref = F.cross_entropy(x, t)
+        ref.backward()
+        loss, ws = backend.put(torch.empty(1)), backend.put(torch.empty(2 * r))
+        K.ce_loss_fwd(backend.put(x.detach()), backend.put(t), loss, ws)
+        assert rel_err(loss, ref.reshape(1)) < 1e-5
+        dl = backend.put(torch.empty(r, c))
+        K.ce_loss_bwd(backend.put(x.detach()), backend.put(t), ws, backend.put(torch.ones(1)), dl)
+        assert rel_err(dl, x.grad) < 1e-5
+
+
+def test_sgd_and_norm(backend):
+    g = torch.Generator().manual_seed(9)
+    w0, gr = torch.randn(5000, generator=g), torch.randn(5000, generator=g)
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    w, buf = backend.put(w0.clone()), backend.put(torch.zeros(5000))
+    for it in range(3):
+        p.grad = gr.clone() * (it + 1)
+        opt.step()
+        K.sgd_step(w, backend.put(gr * (it + 1)), buf, 0.01, 0.9, 5e-4, 1.0, it == 0)
+    assert rel_err(w, p.detach()) < 1e-6
+    out, ws = backend.put(torch.zeros(1)), backend.put(torch.empty(1024))
+    K.sumsq(backend.put(gr), out, False, ws)
+    K.sumsq(backend.put(w0), out, True, ws)
+    assert rel_err(out, ((gr ** 2).sum() + (w0 ** 2).sum()).reshape(1)) < 1e-5
+    x = backend.put(gr.clone())
+    K.scale_(x, backend.put(torch.tensor([0.25])))
+    K.scale_(x, None, 2.0)
+    assert rel_err(x, gr * 0.5) < 1e-7
