@@ -43,8 +43,16 @@ struct ConvArgs {
     int pad;
     int relu, accumulate;
     int n_ptiles, n_mtiles;
+    uint32_t x_bytes, a_bytes;  // extents of the gather source / weight matrix (buffer descriptors)
     FastDiv div_hw, div_w, div_mt;
 };
+
+// Raw buffer descriptor over [base, base + bytes): loads whose byte offset is >= bytes return 0, which is
+// how padding taps, pixel tails and K tails are zero-filled without a single branch in the gather.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+constexpr uint32_t OOB = 0x80000000u;  // any offset >= num_records (extents are checked < 2^31 on the host)
 
 constexpr int BK = 16;
 constexpr int A_PITCH = 20;  // floats; 80 B rows keep ds_read_b128 conflict-free
@@ -58,9 +66,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int A_PASSES = (BM + 63) / 64;
     constexpr int KK = KS * KS;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(BN <= 256 && (256 % BN) == 0, "BN must divide 256");
+    static_assert(BN >= 64 && BN <= 256 && (256 % BN) == 0, "a wave must gather one k row: BN in {64,128,256}");
 
-    __shared__ float lds[2 * (BM * A_PITCH + BK * BN)];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM * A_PITCH + BK * BN)];
     float* As0 = lds;
     float* Bs0 = lds + 2 * BM * A_PITCH;
 
@@ -77,18 +85,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int m0 = (int)mtile * BM;
     const int p0 = (int)ptile * BN;
 
-    // ---- per-thread gather column ----
+    // ---- per-thread gather column; the k rows a wave gathers are wave-uniform (SGPR decode) ----
     const int gcol = tid % BN;
-    const int gk0 = tid / BN;
+    const int gk0 = __builtin_amdgcn_readfirstlane(tid / BN);
     const int gp = p0 + gcol;
     const bool gvalid = gp < p.P;
     int gh0 = 0, gw0 = 0;
-    const float* gsrc = p.x;
+    uint32_t gbase = 0;  // byte offset of this pixel's image inside the gather source
     {
         uint32_t n, hw, ho, wo;
         fd_divmod((uint32_t)(gvalid ? gp : 0), p.div_hw, n, hw);
         fd_divmod(hw, p.div_w, ho, wo);
-        gsrc += (long)n * p.x_img_stride;
+        gbase = (uint32_t)((long)n * p.x_img_stride * 4);
         if (MODE == MODE_FWD) {
             gh0 = (int)ho * S - p.pad;
             gw0 = (int)wo * S - p.pad;
@@ -98,8 +106,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     }
     const int HW = p.H * p.W;
+    const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.a, p.a_bytes);
 
-    auto gather = [&](int k) -> float {
+    auto gather = [&](int k) -> float {  // k is wave-uniform: (c, r, s) decode runs on the scalar unit
         int c, r, s;
         if (KS == 1) {
             c = k;
@@ -126,13 +136,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             }
         }
         ok = ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-        return ok ? gsrc[c * HW + hi * p.W + wi] : 0.f;
+        const uint32_t off = gbase + (uint32_t)(c * HW + hi * p.W + wi) * 4u;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ok ? off : OOB, 0, 0));
     };
 
     // ---- per-thread weight-tile slot ----
     const int arow = tid >> 2;
     const int akq = (tid & 3) * 4;
-    const bool a_vec = (p.K & 3) == 0;
+    const bool a_vec = (p.K & 15) == 0;  // every layer but the 7x7 stem (K = 147 / 490)
 
     float breg[NB];
     f32x4 areg[A_PASSES];
@@ -145,17 +156,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const int row = arow + 64 * q;
             const int m = m0 + row;
             const int k = k0 + akq;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < BM && m < p.M) {
-                const float* ap = p.a + (long)m * p.K + k;
-                if (a_vec) {
-                    if (k < p.K) v = *reinterpret_cast<const f32x4*>(ap);
-                } else {
-                    if (k + 0 < p.K) v.x = ap[0];
-                    if (k + 1 < p.K) v.y = ap[1];
-                    if (k + 2 < p.K) v.z = ap[2];
-                    if (k + 3 < p.K) v.w = ap[3];
-                }
+            const bool rok = (row < BM) && (m < p.M);
+            const uint32_t off = (uint32_t)(m * p.K + k) * 4u;
+            f32x4 v;
+            if (a_vec) {
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, rok ? off : OOB, 0, 0));
+            } else {
+                v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 0 < p.K) ? off : OOB, 0, 0));
+                v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 1 < p.K) ? off + 4 : OOB, 0, 0));
+                v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 2 < p.K) ? off + 8 : OOB, 0, 0));
+                v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 3 < p.K) ? off + 12 : OOB, 0, 0));
             }
             areg[q] = v;
         }
@@ -257,7 +267,7 @@ int launch_cfg(ConvArgs& a, hipStream_t stream) {
 // Tile configurations: id -> (WM, WN, TM, TN) -> BM x BN
 //   0: 2,2,2,2 -> 128x128     1: 2,2,1,2 -> 64x128     2: 1,4,3,1 -> 96x128
 //   3: 2,2,1,1 -> 64x64       4: 1,4,1,1 -> 32x128     5: 1,4,5,1 -> 160x128
-//   6: 4,1,1,1 -> 128x32      7: 2,2,2,1 -> 128x64
+//   6: alias of 3            7: 2,2,2,1 -> 128x64
 template <int KS, int S, int MODE>
 int launch_tile(ConvArgs& a, int cfg, hipStream_t stream) {
     switch (cfg) {
@@ -267,15 +277,15 @@ int launch_tile(ConvArgs& a, int cfg, hipStream_t stream) {
         case 3: return launch_cfg<KS, S, MODE, 2, 2, 1, 1>(a, stream);
         case 4: return launch_cfg<KS, S, MODE, 1, 4, 1, 1>(a, stream);
         case 5: return launch_cfg<KS, S, MODE, 1, 4, 5, 1>(a, stream);
-        case 6: return launch_cfg<KS, S, MODE, 4, 1, 1, 1>(a, stream);
+        case 6: return launch_cfg<KS, S, MODE, 2, 2, 1, 1>(a, stream);  // (retired 128x32: alias of 3)
         case 7: return launch_cfg<KS, S, MODE, 2, 2, 2, 1>(a, stream);
     }
     ssn_set_error("conv_igemm: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
 }
 
-const int kTileBM[8] = {128, 64, 96, 64, 32, 160, 128, 128};
-const int kTileBN[8] = {128, 128, 128, 64, 128, 128, 32, 64};
+const int kTileBM[8] = {128, 64, 96, 64, 32, 160, 64, 128};
+const int kTileBN[8] = {128, 128, 128, 64, 128, 128, 64, 64};
 
 // Pick the tile that minimises (padded MACs) x (wave-quantisation of the grid over 256 CUs).
 int pick_tile(int M, long P) {
@@ -335,6 +345,10 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w, const float*
     a.accumulate = 0;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
+    const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4, ab = (long)Cout * a.K * 4;
+    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31), "conv fwd: operand larger than 2 GiB (buffer addressing)");
+    a.x_bytes = (uint32_t)xb;
+    a.a_bytes = (uint32_t)ab;
     const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, a.P);
     if (ksize == 1 && stride == 1) return launch_tile<1, 1, MODE_FWD>(a, cfg, stream);
     if (ksize == 3 && stride == 1) return launch_tile<3, 1, MODE_FWD>(a, cfg, stream);
@@ -373,6 +387,10 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt, float* dx, int N
     a.accumulate = accumulate;
     a.div_hw = make_fastdiv((uint32_t)(H * W));
     a.div_w = make_fastdiv((uint32_t)W);
+    const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4, ab = (long)Cin * a.K * 4;
+    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31), "conv dgrad: operand larger than 2 GiB (buffer addressing)");
+    a.x_bytes = (uint32_t)xb;
+    a.a_bytes = (uint32_t)ab;
     const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cin, a.P);
     if (ksize == 1 && stride == 1) return launch_tile<1, 1, MODE_DGRAD>(a, cfg, stream);
     if (ksize == 3 && stride == 1) return launch_tile<3, 1, MODE_DGRAD>(a, cfg, stream);

@@ -289,5 +289,29 @@ static inline int atomicAdd(int* p, int v) {
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4(a, b, c)
+#define __builtin_amdgcn_readfirstlane(x) (x)   /* only used on wave-uniform values */
+struct __amdgpu_buffer_rsrc_t {
+    const char* base;
+    uint32_t bytes;
+};
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
+    return __amdgpu_buffer_rsrc_t{(const char*)p, (uint32_t)bytes};
+}
+typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));
+// raw buffer loads: offsets at or beyond num_records return zero (hardware range check)
+static inline unsigned int __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
+                                                               int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    unsigned int v = 0;
+    if (o + 4 <= r.bytes) memcpy(&v, r.base + o, 4);
+    return v;
+}
+static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
+                                                              int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    emu_u32x4 v = {0, 0, 0, 0};
+    if (o + 16 <= r.bytes) memcpy(&v, r.base + o, 16);
+    return v;
+}
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
