@@ -17,12 +17,36 @@ Gradients of all conv parameters are produced into one flat buffer (forward laye
 data-parallel wrapper can all-reduce finished tail ranges while earlier layers are still in
 backward (see parallel.py).
 """
+import json
+import os
+
 import torch
 from torch import nn
 
 from . import kernels as K
 from .bninception_spec import FEATURE_DIM, build_manifest
 from .kernels import ChanSlice, full
+
+
+def _load_tuned():
+    """Per-shape tile choices measured on the MI355X by tools/autotune.py (optional file)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get("tiles", {}), int(d.get("n_images", 0))
+    except (OSError, ValueError):
+        return {}, 0
+
+
+_TUNED, _TUNED_N = _load_tuned()
+
+
+def tuned_tile(kind, n, cin, cout, k, s, hin):
+    """Tile config for a conv launch: the autotuned entry when the batch is comparable, else -1 (heuristic)."""
+    if not _TUNED or n * 2 < _TUNED_N:
+        return -1
+    return _TUNED.get("%s|%d|%d|%d|%d|%d" % (kind, cin, cout, k, s, hin), -1)
 
 
 class _BackboneFn(torch.autograd.Function):
@@ -147,7 +171,8 @@ class BNInception(nn.Module):
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
                 self._timed("conv_fwd", lid, flops,
                             lambda: K.conv_fwd(full(acts[src]), conv.weight.detach(), scale, shift,
-                                               ChanSlice(get(dst), c0, cout), k, s, p, True))
+                                               ChanSlice(get(dst), c0, cout), k, s, p, True,
+                                               tuned_tile("fwd", n, cin, cout, k, s, shapes[src][1])))
                 folds[lid] = scale
             elif op[0] == "pool":
                 _, lid, kind, src, dst, c0, k, s, p, _ceil = op
@@ -195,7 +220,9 @@ class BNInception(nn.Module):
         for op in ops:
             if op[0] == "conv":
                 _, lid, src, dst, c0, cin, cout, k, s, p = op
-                ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(n, cin, cout, shapes[dst][1], shapes[dst][2], k))
+                ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(
+                    n, cin, cout, shapes[dst][1], shapes[dst][2], k,
+                    tuned_tile("wgrad", n, cin, cout, k, s, shapes[src][1])))
         ws = self._workspace(ws_bytes, dev)
 
         pending_end = total
@@ -220,13 +247,17 @@ class BNInception(nn.Module):
                 db = flat[bo:bo + bn]
                 ho = shapes[dst][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
-                self._timed("conv_wgrad", lid, flops, lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws))
+                hin = shapes[src][1]
+                wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
+                self._timed("conv_wgrad", lid, flops,
+                            lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws, wcfg))
                 if src != "data":
                     wt = torch.empty((cin, cout * k * k), device=dev, dtype=torch.float32)
                     K.weight_transpose(conv.weight.detach(), wt)
                     acc_flag = src in inited
                     self._timed("conv_dgrad", lid, flops,
-                                lambda: K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=acc_flag))
+                                lambda: K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=acc_flag,
+                                                     tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin)))
                     inited.add(src)
                 if self.grad_ready_hook is not None and (lid.endswith("_1x1") or lid == self._conv_ids[0]
                                                          or lid == "inception_3c_3x3_reduce"

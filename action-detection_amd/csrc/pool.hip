@@ -22,36 +22,41 @@ struct PoolArgs {
     FastDiv div_chw, div_hw, div_w;
 };
 
-template <bool MAX>
+// KC/SC/PC > 0: compile-time window (the two shapes BN-Inception uses: 3/2/0 and 3/1/1) so the tap
+// loops unroll; KC == 0: runtime fallback.
+template <bool MAX, int KC, int SC, int PC>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
     const int howo = p.Ho * p.Wo;
+    const int K_ = KC ? KC : p.k, S_ = KC ? SC : p.stride, P_ = KC ? PC : p.pad;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw, ho, wo;
         fd_divmod((uint32_t)i, p.div_chw, n, rem);
         fd_divmod(rem, p.div_hw, c, hw);
         fd_divmod(hw, p.div_w, ho, wo);
         const float* xp = p.x + (long)n * p.x_img_stride + (long)c * p.H * p.W;
-        const int h0 = (int)ho * p.stride - p.pad, w0 = (int)wo * p.stride - p.pad;
+        const int h0 = (int)ho * S_ - P_, w0 = (int)wo * S_ - P_;
         float out;
         if (MAX) {
             float best = -INFINITY;
             int bi = 0;
             bool first = true;
-            for (int r = 0; r < p.k; ++r) {
+#pragma unroll
+            for (int r = 0; r < K_; ++r) {
                 const int hi = h0 + r;
                 if ((unsigned)hi >= (unsigned)p.H) continue;
-                for (int s = 0; s < p.k; ++s) {
+#pragma unroll
+                for (int s = 0; s < K_; ++s) {
                     const int wi = w0 + s;
                     if ((unsigned)wi >= (unsigned)p.W) continue;
                     const float v = xp[hi * p.W + wi];
                     // torch rule: start at the first in-bounds element, move on (v > best) or NaN
                     if (first) {
-                        bi = r * p.k + s;
+                        bi = r * K_ + s;
                         first = false;
                     }
                     if (v > best || v != v) {
                         best = v;
-                        bi = r * p.k + s;
+                        bi = r * K_ + s;
                     }
                 }
             }
@@ -59,19 +64,21 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
             if (p.idx) p.idx[(long)n * p.C * howo + rem] = (uint8_t)bi;
         } else {
             float s_ = 0.f;
-            for (int r = 0; r < p.k; ++r) {
+#pragma unroll
+            for (int r = 0; r < K_; ++r) {
                 const int hi = h0 + r;
                 if ((unsigned)hi >= (unsigned)p.H) continue;
-                for (int s = 0; s < p.k; ++s) {
+#pragma unroll
+                for (int s = 0; s < K_; ++s) {
                     const int wi = w0 + s;
                     if ((unsigned)wi >= (unsigned)p.W) continue;
                     s_ += xp[hi * p.W + wi];
                 }
             }
             // count_include_pad=True: divisor = window clipped to the PADDED extent (torch avg_pool2d)
-            int he = h0 + p.k, we = w0 + p.k;
-            if (he > p.H + p.pad) he = p.H + p.pad;
-            if (we > p.W + p.pad) we = p.W + p.pad;
+            int he = h0 + K_, we = w0 + K_;
+            if (he > p.H + P_) he = p.H + P_;
+            if (we > p.W + P_) we = p.W + P_;
             out = s_ / (float)((he - h0) * (we - w0));
         }
         p.y[(long)n * p.y_img_stride + rem] = out;
@@ -89,9 +96,11 @@ struct PoolBwdArgs {
     FastDiv div_chw, div_hw, div_w;
 };
 
-template <bool MAX>
+template <bool MAX, int KC, int SC, int PC>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
     const int howo = p.Ho * p.Wo;
+    const int K_ = KC ? KC : p.k, S_ = KC ? SC : p.stride, P_ = KC ? PC : p.pad;
+    constexpr int NWIN = KC ? (KC + SC - 1) / SC : 0;  // max windows per axis covering one input pixel
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw, hi, wi;
         fd_divmod((uint32_t)i, p.div_chw, n, rem);
@@ -100,29 +109,36 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
         const float* dyp = p.dy + (long)n * p.dy_img_stride + (long)c * howo;
         const uint8_t* ip = MAX ? p.idx + ((long)n * p.C + c) * howo : nullptr;
         // output windows that contain (hi, wi): ho in [ceil((hi+pad-k+1)/s), floor((hi+pad)/s)]
-        const int hp = (int)hi + p.pad, wp = (int)wi + p.pad;
-        int ho_lo = hp - p.k + 1;
-        ho_lo = ho_lo <= 0 ? 0 : (ho_lo + p.stride - 1) / p.stride;
-        int wo_lo = wp - p.k + 1;
-        wo_lo = wo_lo <= 0 ? 0 : (wo_lo + p.stride - 1) / p.stride;
-        int ho_hi = hp / p.stride, wo_hi = wp / p.stride;
+        const int hp = (int)hi + P_, wp = (int)wi + P_;
+        int ho_lo = hp - K_ + 1;
+        ho_lo = ho_lo <= 0 ? 0 : (ho_lo + S_ - 1) / S_;
+        int wo_lo = wp - K_ + 1;
+        wo_lo = wo_lo <= 0 ? 0 : (wo_lo + S_ - 1) / S_;
+        int ho_hi = hp / S_, wo_hi = wp / S_;
         if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
         if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
         float g = 0.f;
-        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-            const int r = hp - ho * p.stride;
-            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                const int s = wp - wo * p.stride;
-                if (MAX) {
-                    if (ip[ho * p.Wo + wo] == (uint8_t)(r * p.k + s)) g += dyp[ho * p.Wo + wo];
-                } else {
-                    const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
-                    int he = h0 + p.k, we = w0 + p.k;
-                    if (he > p.H + p.pad) he = p.H + p.pad;
-                    if (we > p.W + p.pad) we = p.W + p.pad;
-                    g += dyp[ho * p.Wo + wo] / (float)((he - h0) * (we - w0));
-                }
+        auto visit = [&](int ho, int wo) {
+            const int r = hp - ho * S_, s = wp - wo * S_;
+            if (MAX) {
+                if (ip[ho * p.Wo + wo] == (uint8_t)(r * K_ + s)) g += dyp[ho * p.Wo + wo];
+            } else {
+                const int h0 = ho * S_ - P_, w0 = wo * S_ - P_;
+                int he = h0 + K_, we = w0 + K_;
+                if (he > p.H + P_) he = p.H + P_;
+                if (we > p.W + P_) we = p.W + P_;
+                g += dyp[ho * p.Wo + wo] / (float)((he - h0) * (we - w0));
             }
+        };
+        if (KC) {
+#pragma unroll
+            for (int a = 0; a < NWIN; ++a)
+#pragma unroll
+                for (int b = 0; b < NWIN; ++b)
+                    if (ho_lo + a <= ho_hi && wo_lo + b <= wo_hi) visit(ho_lo + a, wo_lo + b);
+        } else {
+            for (int ho = ho_lo; ho <= ho_hi; ++ho)
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) visit(ho, wo);
         }
         float* dst = p.dx + (long)n * p.dx_img_stride + rem;
         *dst = p.accumulate ? *dst + g : g;
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* dy, float* dx
     }
 }
 
-inline unsigned grid_for(long total, int cap = 8192) {
+inline unsigned grid_for(long total, int cap = 65536) {
     long b = (total + 255) / 256;
     if (b > cap) b = cap;
     if (b < 1) b = 1;
@@ -190,10 +206,17 @@ extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char*
     a.div_chw = make_fastdiv((uint32_t)(C * Ho * Wo));
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
-    if (is_max)
-        hipLaunchKernelGGL(pool_fwd_kernel<true>, dim3(grid_for(a.total)), dim3(256), 0, stream, a);
+    const dim3 grid(grid_for(a.total));
+    if (ksize == 3 && stride == 2 && pad == 0 && is_max)
+        hipLaunchKernelGGL((pool_fwd_kernel<true, 3, 2, 0>), grid, dim3(256), 0, stream, a);
+    else if (ksize == 3 && stride == 1 && pad == 1 && is_max)
+        hipLaunchKernelGGL((pool_fwd_kernel<true, 3, 1, 1>), grid, dim3(256), 0, stream, a);
+    else if (ksize == 3 && stride == 1 && pad == 1)
+        hipLaunchKernelGGL((pool_fwd_kernel<false, 3, 1, 1>), grid, dim3(256), 0, stream, a);
+    else if (is_max)
+        hipLaunchKernelGGL((pool_fwd_kernel<true, 0, 0, 0>), grid, dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(pool_fwd_kernel<false>, dim3(grid_for(a.total)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((pool_fwd_kernel<false, 0, 0, 0>), grid, dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("pool_fwd");
     return SSN_OK;
 }
@@ -223,10 +246,17 @@ extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* ar
     a.div_chw = make_fastdiv((uint32_t)(C * H * W));
     a.div_hw = make_fastdiv((uint32_t)(H * W));
     a.div_w = make_fastdiv((uint32_t)W);
-    if (is_max)
-        hipLaunchKernelGGL(pool_bwd_kernel<true>, dim3(grid_for(a.total)), dim3(256), 0, stream, a);
+    const dim3 grid(grid_for(a.total));
+    if (ksize == 3 && stride == 2 && pad == 0 && is_max)
+        hipLaunchKernelGGL((pool_bwd_kernel<true, 3, 2, 0>), grid, dim3(256), 0, stream, a);
+    else if (ksize == 3 && stride == 1 && pad == 1 && is_max)
+        hipLaunchKernelGGL((pool_bwd_kernel<true, 3, 1, 1>), grid, dim3(256), 0, stream, a);
+    else if (ksize == 3 && stride == 1 && pad == 1)
+        hipLaunchKernelGGL((pool_bwd_kernel<false, 3, 1, 1>), grid, dim3(256), 0, stream, a);
+    else if (is_max)
+        hipLaunchKernelGGL((pool_bwd_kernel<true, 0, 0, 0>), grid, dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL(pool_bwd_kernel<false>, dim3(grid_for(a.total)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((pool_bwd_kernel<false, 0, 0, 0>), grid, dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("pool_bwd");
     return SSN_OK;
 }

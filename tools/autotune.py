@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Pick the fastest tile configuration per distinct conv shape on the MI355X (fwd / dgrad / wgrad).
+
+Writes action-detection_amd/tuned_tiles.json; the executor (bninception.py) looks shapes up there
+and falls back to the C-side heuristic for unknown shapes.  Run on the GPU box:
+    python tools/autotune.py [N_IMAGES]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import action_detection_amd as pkg  # noqa: E402
+from action_detection_amd import kernels as K  # noqa: E402
+from action_detection_amd.bninception_spec import build_manifest  # noqa: E402
+
+pkg.build()
+dev = torch.device("cuda:0")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
+out_path = os.path.join(ROOT, "action-detection_amd", "tuned_tiles.json")
+shapes = {}
+for cin0 in (3, 10):
+    ops, t = build_manifest(cin0, 224)
+    for op in ops:
+        if op[0] == "conv":
+            _, lid, src, dst, c0, cin, cout, k, s, p = op
+            shapes[(cin, cout, k, s, p, t[src][1], t[dst][1])] = lid
+
+
+def timeit(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e))
+    return best
+
+
+table = {}
+report = []
+for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
+    x = torch.randn(n, cin, hi, hi, device=dev)
+    w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    y = torch.empty(n, cout, ho, ho, device=dev)
+    g = torch.randn(n, cout, ho, ho, device=dev)
+    scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    wt = torch.empty(cin, cout * k * k, device=dev)
+    K.weight_transpose(w, wt)
+    dx = torch.empty_like(x)
+    dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
+    flops = 2.0 * n * ho * ho * cout * cin * k * k
+    res = {}
+    for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 7]), ("wgrad", [0, 1, 2, 3, 4])):
+        if kind == "dgrad" and k == 7:
+            continue
+        best = (1e9, -1)
+        for cfg in cfgs:
+            if kind == "fwd":
+                fn = lambda: K.conv_fwd(K.full(x), w, scale, shift, K.full(y), k, s, p, True, cfg)
+            elif kind == "dgrad":
+                fn = lambda: K.conv_dgrad(K.full(g), wt, K.full(dx), k, s, p, False, cfg)
+            else:
+                ws = torch.empty(K.wgrad_workspace_bytes(n, cin, cout, ho, ho, k, cfg) // 4, device=dev)
+                fn = lambda: K.conv_wgrad(K.full(g), K.full(x), dw, db, k, s, p, ws, cfg)
+            ms = timeit(fn)
+            if ms < best[0]:
+                best = (ms, cfg)
+        key = "%s|%d|%d|%d|%d|%d" % (kind, cin, cout, k, s, hi)
+        table[key] = best[1]
+        res[kind] = (best[1], best[0], flops / best[0] / 1e9)
+    report.append((lid, cin, cout, k, s, ho, res))
+    print(lid, cin, cout, k, s, ho, {kk: "cfg%d %.3fms %.1fTF" % v for kk, v in res.items()}, flush=True)
+json.dump({"n_images": n, "tiles": table}, open(out_path, "w"), indent=0, sort_keys=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump({"n_images": n, "tiles": table}, open(os.path.join(ROOT, "gpurun_out", "tuned_tiles.json"), "w"), indent=0,
+          sort_keys=True)
+print("wrote", out_path)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Per-layer conv timing table on the GPU (HIP events around every launch): shape, tile, ms, TFLOP/s."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import action_detection_amd as pkg
+from action_detection_amd.ssn_models import SSN
+from action_detection_amd.synthetic import init_backbone_synthetic, make_batch
+from action_detection_amd.bninception_spec import build_manifest
+from action_detection_amd import _lib
+pkg.build()
+dev = torch.device("cuda:0")
+v = int(os.environ.get("VIDEOS", "4"))
+m = SSN(20, 2, 5, 2, "RGB", dropout=0.8, stpp_cfg=(1, 1, 1))
+init_backbone_synthetic(m.base_model)
+m.to(dev).train()
+x = make_batch(v, "RGB", 20, seed=0)[0].to(dev).reshape(-1, 3, 224, 224)
+ops, shapes = build_manifest(3, 224)
+info = {}
+for op in ops:
+    if op[0] == "conv":
+        _, lid, src, dst, c0, cin, cout, k, s, p = op
+        info[lid] = (cin, cout, k, s, shapes[src][1], shapes[dst][1])
+def run():
+    f = m.base_model.features(x)
+    f.sum().backward()
+for _ in range(2):
+    run()
+prof = []
+m.base_model.profiler = prof
+reps = 3
+for _ in range(reps):
+    run()
+torch.cuda.synchronize()
+agg = {}
+for fam, lid, flops, s, e in prof:
+    a = agg.setdefault((lid, fam), [0.0, flops])
+    a[0] += s.elapsed_time(e) / reps
+lib = _lib.get_lib()
+n = x.shape[0]
+print("%-34s %5s %5s %2s %2s %4s | %-4s %8s %6s | %8s %6s | %8s %6s" % ("layer", "cin", "cout", "k", "s", "Ho", "tile", "fwd_ms", "TF", "dgrad_ms", "TF", "wgrad_ms", "TF"))
+tot = {"conv_fwd": 0, "conv_dgrad": 0, "conv_wgrad": 0}
+for lid, (cin, cout, k, s, hi, ho) in info.items():
+    tile = lib.cdll.ssn_conv_pick_tile(cout, n * ho * ho)
+    row = []
+    for fam in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
+        a = agg.get((lid, fam))
+        if a:
+            tot[fam] += a[0]
+            row += ["%8.3f" % a[0], "%6.1f" % (a[1] / a[0] / 1e9)]
+        else:
+            row += ["       -", "     -"]
+    print("%-34s %5d %5d %2d %2d %4d | %-4d %s %s | %s %s | %s %s" % ((lid, cin, cout, k, s, ho, tile) + tuple(row)))
+print("totals ms:", tot)
