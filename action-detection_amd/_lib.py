@@ -32,7 +32,7 @@ _SIGS = {
     "ssn_bn_fold": "pppppfppip",
     "ssn_relu_bn_bwd": "pppiiillp",
     "ssn_conv_dgrad": "pppiiiiliiiliiiiip",
-    "ssn_weight_transpose": "ppiiip",
+    "ssn_conv_pack_weights": "ppiiiip",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
     "ssn_pool_bwd": "ipppiiiiliiliiiip",
@@ -61,7 +61,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
-                                "ssn_conv_pick_tile"])
+                                "ssn_conv_pick_tile", "ssn_conv_packed_floats"])
 
 
 class SsnLibrary:
@@ -76,6 +76,8 @@ class SsnLibrary:
         self.cdll.ssn_abi_version.restype = ctypes.c_int
         self.cdll.ssn_conv_wgrad_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_conv_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 7
+        self.cdll.ssn_conv_packed_floats.restype = ctypes.c_long
+        self.cdll.ssn_conv_packed_floats.argtypes = [ctypes.c_int] * 4
         self.cdll.ssn_conv_pick_tile.restype = ctypes.c_int
         self.cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
         self._fn = {}

@@ -170,7 +170,7 @@ class BNInception(nn.Module):
                 ho = shapes[dst][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
                 self._timed("conv_fwd", lid, flops,
-                            lambda: K.conv_fwd(full(acts[src]), conv.weight.detach(), scale, shift,
+                            lambda: K.conv_fwd(full(acts[src]), K.pack_weights(conv.weight.detach(), False), scale, shift,
                                                ChanSlice(get(dst), c0, cout), k, s, p, True,
                                                tuned_tile("fwd", n, cin, cout, k, s, shapes[src][1])))
                 folds[lid] = scale
@@ -252,8 +252,7 @@ class BNInception(nn.Module):
                 self._timed("conv_wgrad", lid, flops,
                             lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws, wcfg))
                 if src != "data":
-                    wt = torch.empty((cin, cout * k * k), device=dev, dtype=torch.float32)
-                    K.weight_transpose(conv.weight.detach(), wt)
+                    wt = K.pack_weights(conv.weight.detach(), True)
                     acc_flag = src in inited
                     self._timed("conv_dgrad", lid, flops,
                                 lambda: K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=acc_flag,

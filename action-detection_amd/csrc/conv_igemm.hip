@@ -5,32 +5,51 @@
 // Conv+BN+ReLU blocks of the backbone.
 //
 //   D[m][p] = sum_k A[m][k] * G[k][p]
-//     m : output channel            (A = weights, row-major [M][K], k = (c, r, s))
+//     m : output channel            (A = weights, k = (c, r, s))
 //     p : flattened (n, ho, wo)     (NCHW: p is contiguous inside an image plane, so both the
 //                                    gather loads and the epilogue stores are coalesced)
-//     G : the im2col gather of the NCHW input, never materialised: each workgroup gathers a
-//         [16 x BN] slab straight into LDS (zero-filled at borders / tails).
+//     G : the im2col gather of the NCHW input, never materialised.
 //
 // MODE_FWD      G[k][p] = x[n][c][ho*S - pad + r][wo*S - pad + s]
 // MODE_DGRAD    pixels enumerate the conv INPUT (n, hi, wi); the source is dY:
 //               G[k][p] = dy[n][co][(hi + pad - r)/S][(wi + pad - s)/S]   (0 unless divisible)
-//               with A = W transposed to [Cin][Cout*KH*KW] (see ssn_weight_transpose).
+//
+// K loop design (what makes the loop MFMA-bound instead of VALU-bound):
+//  * K is consumed in slabs of CPS whole channels x KS*KS taps (1x1: 16 ch, 3x3: 2 ch = 18 rows,
+//    7x7: 1 ch = 49 rows).  Because a slab always starts on a channel boundary, the (r, s) tap of
+//    every gather row -- and therefore its border validity and its byte offset relative to the
+//    slab's first channel -- is the same in every slab.  Each thread computes its gather offsets
+//    ONCE (invalid taps / pixel tails get an out-of-range offset) and the loop body is just
+//    `buffer_load_dword v, voff[i], rsrc, soffset` with the slab base in an SGPR: no per-element
+//    address arithmetic, no bounds checks, no branches (the buffer unit returns 0 out of range).
+//  * Weights are pre-packed (ssn_conv_pack_weights) into the same slab structure, split by the
+//    MFMA lane-half that consumes them: Ap[slab][m][h*HP + t] = A[m][slab, k = 2t + h].  A tile is
+//    then a contiguous block: float4 loads at loop-invariant offsets, and each lane's A operands
+//    for four consecutive MFMAs are one conflict-free ds_read_b128.
+//  * Two LDS buffers, one barrier per slab; the next slab's loads are issued before the MFMAs of
+//    the current one.
 //
 // Tiling: 256 threads = 4 waves as WM x WN; each wave owns TM x TN MFMA tiles of 32x32.
-// K is consumed in slabs of 16 through two LDS buffers (one barrier per slab); the next
-// slab's global loads are issued before the MFMAs of the current one.  Within a slab the
-// k index is permuted (k = 8u + 4h + s for lane-half h) so that A fragments are one
-// ds_read_b128 per 4 MFMAs; A and B use the same permutation, so only the fp32 summation
-// order changes.
 #include "ssn_common.h"
 
 namespace {
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
+// slab geometry per kernel size (host and device agree through these)
+template <int KS>
+struct Slab {
+    static constexpr int KK = KS * KS;
+    static constexpr int CPS = KS == 1 ? 16 : (KS == 3 ? 2 : 1);   // channels per slab
+    static constexpr int ROWS = CPS * KK;                          // real k rows per slab
+    static constexpr int T = (ROWS + 1) / 2;                       // MFMA steps per slab (k pairs)
+    static constexpr int HP = (T + 3) / 4 * 4;                     // per-half row length, float4 padded
+    static constexpr int AP = 2 * HP;                              // packed weight row length (floats)
+};
+
 struct ConvArgs {
     const float* x;      // gather source (channel-slice base)
-    const float* a;      // [M][K]
+    const float* ap;     // packed weights [nslab][M][AP]
     float* y;            // output (channel-slice base)
     const float* scale;  // [M] or nullptr
     const float* shift;  // [M] or nullptr
@@ -39,38 +58,41 @@ struct ConvArgs {
     int M;               // output channels
     int Ho, Wo;          // enumerated pixel grid
     long y_img_stride;
-    int K, P;            // K = C*KS*KS, P = N*Ho*Wo
+    int P;               // N*Ho*Wo
     int pad;
     int relu, accumulate;
-    int n_ptiles, n_mtiles;
-    uint32_t x_bytes, a_bytes;  // extents of the gather source / weight matrix (buffer descriptors)
+    int n_ptiles, n_mtiles, nslab;
+    uint32_t x_bytes, a_bytes;  // extents of the gather source / packed weights (buffer descriptors)
     FastDiv div_hw, div_w, div_mt;
 };
 
 // Raw buffer descriptor over [base, base + bytes): loads whose byte offset is >= bytes return 0, which is
-// how padding taps, pixel tails and K tails are zero-filled without a single branch in the gather.
+// how padding taps, pixel tails and channel tails are zero-filled without a branch in the gather.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-constexpr uint32_t OOB = 0x80000000u;  // any offset >= num_records (extents are checked < 2^31 on the host)
-
-constexpr int BK = 16;
-constexpr int A_PITCH = 20;  // floats; 80 B rows keep ds_read_b128 conflict-free
+// Out-of-range marker: extents are < 2^31 (checked on the host) and the per-slab scalar offset is added
+// by the hardware in 32 bits, so 0x80000000 + soffset stays >= num_records for every slab.
+constexpr uint32_t OOB = 0x80000000u;
 
 template <int KS, int S, int MODE, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    using SL = Slab<KS>;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    constexpr int KSTEP = 256 / BN;         // k rows gathered concurrently
-    constexpr int NB = BK / KSTEP;          // gather elements per thread per slab
-    constexpr int A_PASSES = (BM + 63) / 64;
-    constexpr int KK = KS * KS;
+    constexpr int KSTEP = 256 / BN;                          // gather rows handled concurrently
+    constexpr int NB = (2 * SL::T + KSTEP - 1) / KSTEP;      // gather elements per thread per slab
+    constexpr int BROWS = NB * KSTEP;                        // LDS rows of the gathered slab (>= 2T)
+    constexpr int AP = SL::AP, HP = SL::HP, T = SL::T;
+    constexpr int APITCH = AP + 4;                           // floats; keeps ds_read_b128 conflict-free
+    constexpr int A_F4 = BM * AP / 4;                        // float4s in one weight tile
+    constexpr int NA = (A_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(BN >= 64 && BN <= 256 && (256 % BN) == 0, "a wave must gather one k row: BN in {64,128,256}");
+    static_assert(BN >= 64 && BN <= 256 && (256 % BN) == 0, "a wave must gather whole rows: BN in {64,128,256}");
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM * A_PITCH + BK * BN)];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM * APITCH + BROWS * BN)];
     float* As0 = lds;
-    float* Bs0 = lds + 2 * BM * A_PITCH;
+    float* Bs0 = lds + 2 * BM * APITCH;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -85,101 +107,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int m0 = (int)mtile * BM;
     const int p0 = (int)ptile * BN;
 
-    // ---- per-thread gather column; the k rows a wave gathers are wave-uniform (SGPR decode) ----
+    // ---- loop-invariant gather offsets of this thread's pixel column ----
     const int gcol = tid % BN;
     const int gk0 = __builtin_amdgcn_readfirstlane(tid / BN);
-    const int gp = p0 + gcol;
-    const bool gvalid = gp < p.P;
-    int gh0 = 0, gw0 = 0;
-    uint32_t gbase = 0;  // byte offset of this pixel's image inside the gather source
+    uint32_t voff[NB];
     {
+        const int gp = p0 + gcol;
+        const bool gvalid = gp < p.P;
         uint32_t n, hw, ho, wo;
         fd_divmod((uint32_t)(gvalid ? gp : 0), p.div_hw, n, hw);
         fd_divmod(hw, p.div_w, ho, wo);
-        gbase = (uint32_t)((long)n * p.x_img_stride * 4);
-        if (MODE == MODE_FWD) {
-            gh0 = (int)ho * S - p.pad;
-            gw0 = (int)wo * S - p.pad;
-        } else {
-            gh0 = (int)ho + p.pad;
-            gw0 = (int)wo + p.pad;
+        const uint32_t gbase = (uint32_t)((long)n * p.x_img_stride * 4);
+        const int HW = p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = gk0 + KSTEP * i;   // wave-uniform
+            const int cl = row / SL::KK;
+            const int tap = row - cl * SL::KK;
+            const int r = tap / KS, s = tap - r * KS;
+            int hi, wi;
+            bool ok = gvalid && (row < SL::ROWS);
+            if (MODE == MODE_FWD) {
+                hi = (int)ho * S - p.pad + r;
+                wi = (int)wo * S - p.pad + s;
+            } else {
+                hi = (int)ho + p.pad - r;
+                wi = (int)wo + p.pad - s;
+                if (S == 2) {
+                    ok = ok && (((hi | wi) & 1) == 0);
+                    hi >>= 1;
+                    wi >>= 1;
+                }
+            }
+            ok = ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+            voff[i] = ok ? gbase + (uint32_t)(cl * HW + hi * p.W + wi) * 4u : OOB;
         }
     }
-    const int HW = p.H * p.W;
+    // ---- loop-invariant weight-tile offsets ----
+    uint32_t aoff[NA];
+    int alds[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        const int f = tid + 256 * q;
+        const int row = f / (AP / 4), c4 = f - row * (AP / 4);
+        const bool ok = (f < A_F4) && (m0 + row < p.M);
+        aoff[q] = ok ? (uint32_t)((m0 + row) * AP + c4 * 4) * 4u : OOB;
+        alds[q] = (f < A_F4) ? row * APITCH + c4 * 4 : -1;
+    }
     const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.x_bytes);
-    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.a, p.a_bytes);
-
-    auto gather = [&](int k) -> float {  // k is wave-uniform: (c, r, s) decode runs on the scalar unit
-        int c, r, s;
-        if (KS == 1) {
-            c = k;
-            r = 0;
-            s = 0;
-        } else {
-            c = k / KK;
-            const int rem = k - c * KK;
-            r = rem / KS;
-            s = rem - r * KS;
-        }
-        int hi, wi;
-        bool ok = gvalid && (k < p.K);
-        if (MODE == MODE_FWD) {
-            hi = gh0 + r;
-            wi = gw0 + s;
-        } else {
-            hi = gh0 - r;
-            wi = gw0 - s;
-            if (S == 2) {
-                ok = ok && (((hi | wi) & 1) == 0);
-                hi >>= 1;
-                wi >>= 1;
-            }
-        }
-        ok = ok && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-        const uint32_t off = gbase + (uint32_t)(c * HW + hi * p.W + wi) * 4u;
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, ok ? off : OOB, 0, 0));
-    };
-
-    // ---- per-thread weight-tile slot ----
-    const int arow = tid >> 2;
-    const int akq = (tid & 3) * 4;
-    const bool a_vec = (p.K & 15) == 0;  // every layer but the 7x7 stem (K = 147 / 490)
+    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.ap, p.a_bytes);
+    const uint32_t x_step = (uint32_t)(SL::CPS * p.H * p.W) * 4u;   // bytes per slab in the source
+    const uint32_t a_step = (uint32_t)(p.M * AP) * 4u;             // bytes per slab in the packed weights
 
     float breg[NB];
-    f32x4 areg[A_PASSES];
-
-    auto load_slab = [&](int k0) {
+    f32x4 areg[NA];
+    // c_left < CPS only for the last slab of a source whose channel count is not a multiple of CPS (never
+    // in BN-Inception; arbitrary shapes stay correct): rows of channels past the end are forced out of range.
+    auto load_slab = [&](uint32_t xso, uint32_t aso, int c_left) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) breg[i] = gather(k0 + gk0 + KSTEP * i);
-#pragma unroll
-        for (int q = 0; q < A_PASSES; ++q) {
-            const int row = arow + 64 * q;
-            const int m = m0 + row;
-            const int k = k0 + akq;
-            const bool rok = (row < BM) && (m < p.M);
-            const uint32_t off = (uint32_t)(m * p.K + k) * 4u;
-            f32x4 v;
-            if (a_vec) {
-                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, rok ? off : OOB, 0, 0));
-            } else {
-                v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 0 < p.K) ? off : OOB, 0, 0));
-                v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 1 < p.K) ? off + 4 : OOB, 0, 0));
-                v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 2 < p.K) ? off + 8 : OOB, 0, 0));
-                v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (rok && k + 3 < p.K) ? off + 12 : OOB, 0, 0));
-            }
-            areg[q] = v;
+        for (int i = 0; i < NB; ++i) {
+            const int cl = (gk0 + KSTEP * i) / SL::KK;
+            const uint32_t vo = (cl < c_left) ? voff[i] : OOB;
+            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo, xso, 0));
         }
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            areg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[q], aso, 0));
     };
+    auto load_full = [&](uint32_t xso, uint32_t aso) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, voff[i], xso, 0));
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            areg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[q], aso, 0));
+    };
+    const int c_tail = p.C - (p.nslab - 1) * SL::CPS;   // channels in the last slab (== CPS when exact)
     auto store_slab = [&](int buf) {
-        float* As = As0 + buf * BM * A_PITCH;
-        float* Bs = Bs0 + buf * BK * BN;
+        float* As = As0 + buf * BM * APITCH;
+        float* Bs = Bs0 + buf * BROWS * BN + gk0 * BN + gcol;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[(gk0 + KSTEP * i) * BN + gcol] = breg[i];
+        for (int i = 0; i < NB; ++i) Bs[KSTEP * i * BN] = breg[i];
 #pragma unroll
-        for (int q = 0; q < A_PASSES; ++q) {
-            const int row = arow + 64 * q;
-            if (row < BM) *reinterpret_cast<f32x4*>(&As[row * A_PITCH + akq]) = areg[q];
-        }
+        for (int q = 0; q < NA; ++q)
+            if (alds[q] >= 0) *reinterpret_cast<f32x4*>(&As[alds[q]]) = areg[q];
     };
 
     f32x16 acc[TM][TN];
@@ -190,38 +201,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nslab = (p.K + BK - 1) / BK;
-    load_slab(0);
+    uint32_t xso = 0, aso = 0;
+    if (p.nslab == 1)
+        load_slab(xso, aso, c_tail);
+    else
+        load_full(xso, aso);
     store_slab(0);
     __syncthreads();
 
-    for (int t = 0; t < nslab; ++t) {
+    for (int t = 0; t < p.nslab; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nslab) load_slab((t + 1) * BK);
+        xso += x_step;
+        aso += a_step;
+        if (t + 2 < p.nslab)
+            load_full(xso, aso);
+        else if (t + 1 < p.nslab)
+            load_slab(xso, aso, c_tail);
 
-        const float* As = As0 + buf * BM * A_PITCH + (wm * TM * 32 + li) * A_PITCH + 4 * lh;
-        const float* Bs = Bs0 + buf * BK * BN + (4 * lh) * BN + wn * TN * 32 + li;
+        const float* As = As0 + buf * BM * APITCH + (wm * TM * 32 + li) * APITCH + lh * HP;
+        const float* Bs = Bs0 + buf * BROWS * BN + lh * BN + wn * TN * 32 + li;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int q = 0; q < HP / 4; ++q) {
             f32x4 af[TM];
-            float bf[4][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * A_PITCH + 8 * u);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * APITCH + 4 * q);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
+                const int step = 4 * q + s;
+                if (step < T) {
+                    float bf[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[s][j] = Bs[(8 * u + s) * BN + j * 32];
+                    for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * step) * BN + j * 32];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j], acc[i][j], 0, 0, 0);
+                }
+            }
         }
 
-        if (t + 1 < nslab) store_slab(buf ^ 1);
+        if (t + 1 < p.nslab) store_slab(buf ^ 1);
         __syncthreads();
     }
 
@@ -251,6 +271,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 }
 
+// Ap[slab][m][h*HP + t] = A[m][c = slab*CPS + cl][tap], (cl, tap) = decode(k = 2t + h); zero padded.
+//   transposed == 0 (forward operand):  A[m][c][tap] = w[m][c][tap]          (w is [M][C][KK])
+//   transposed == 1 (dgrad operand):    A[m][c][tap] = w[c][m][tap]          (w is [C][M][KK])
+template <int KS>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* ap, int M, int C, int nslab,
+                                                           int transposed) {
+    using SL = Slab<KS>;
+    const long total = (long)nslab * M * SL::AP;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int e = (int)(idx % SL::AP);
+        const long sm = idx / SL::AP;
+        const int m = (int)(sm % M);
+        const int slab = (int)(sm / M);
+        const int h = e / SL::HP, t = e - h * SL::HP;
+        const int k = 2 * t + h;
+        float v = 0.f;
+        if (t < SL::T && k < SL::ROWS) {
+            const int cl = k / SL::KK, tap = k - cl * SL::KK;
+            const int c = slab * SL::CPS + cl;
+            if (c < C) v = transposed ? w[((long)c * M + m) * SL::KK + tap] : w[((long)m * C + c) * SL::KK + tap];
+        }
+        ap[idx] = v;
+    }
+}
+
 template <int KS, int S, int MODE, int WM, int WN, int TM, int TN>
 int launch_cfg(ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
@@ -267,7 +312,7 @@ int launch_cfg(ConvArgs& a, hipStream_t stream) {
 // Tile configurations: id -> (WM, WN, TM, TN) -> BM x BN
 //   0: 2,2,2,2 -> 128x128     1: 2,2,1,2 -> 64x128     2: 1,4,3,1 -> 96x128
 //   3: 2,2,1,1 -> 64x64       4: 1,4,1,1 -> 32x128     5: 1,4,5,1 -> 160x128
-//   6: alias of 3            7: 2,2,2,1 -> 128x64
+//   6: 1,4,2,1 -> 64x128 (4 waves along pixels)        7: 2,2,2,1 -> 128x64
 template <int KS, int S, int MODE>
 int launch_tile(ConvArgs& a, int cfg, hipStream_t stream) {
     switch (cfg) {
@@ -277,7 +322,7 @@ int launch_tile(ConvArgs& a, int cfg, hipStream_t stream) {
         case 3: return launch_cfg<KS, S, MODE, 2, 2, 1, 1>(a, stream);
         case 4: return launch_cfg<KS, S, MODE, 1, 4, 1, 1>(a, stream);
         case 5: return launch_cfg<KS, S, MODE, 1, 4, 5, 1>(a, stream);
-        case 6: return launch_cfg<KS, S, MODE, 2, 2, 1, 1>(a, stream);  // (retired 128x32: alias of 3)
+        case 6: return launch_cfg<KS, S, MODE, 1, 4, 2, 1>(a, stream);
         case 7: return launch_cfg<KS, S, MODE, 2, 2, 2, 1>(a, stream);
     }
     ssn_set_error("conv_igemm: unknown tile config %d", cfg);
@@ -285,9 +330,10 @@ int launch_tile(ConvArgs& a, int cfg, hipStream_t stream) {
 }
 
 const int kTileBM[8] = {128, 64, 96, 64, 32, 160, 64, 128};
-const int kTileBN[8] = {128, 128, 128, 64, 128, 128, 64, 64};
+const int kTileBN[8] = {128, 128, 128, 64, 128, 128, 128, 64};
+const double kTileEff[8] = {1.0, 1.05, 1.0, 1.12, 1.2, 1.0, 1.05, 1.05};
 
-// Pick the tile that minimises (padded MACs) x (wave-quantisation of the grid over 256 CUs).
+// Heuristic used when no autotuned entry exists: padded MACs x grid quantisation x per-tile overhead.
 int pick_tile(int M, long P) {
     double best = 1e300;
     int best_cfg = 0;
@@ -296,12 +342,9 @@ int pick_tile(int M, long P) {
         const long pt = (P + kTileBN[c] - 1) / kTileBN[c];
         const double padded = (double)mt * kTileBM[c] * (double)pt * kTileBN[c];
         const double blocks = (double)mt * pt;
-        // two workgroups per CU resident: a "round" is 512 blocks
-        const double rounds = blocks / 512.0;
+        const double rounds = blocks / 768.0;  // ~3 workgroups per CU resident
         const double quant = (rounds < 1.0) ? 1.0 / (rounds > 0.05 ? rounds : 0.05) : ((long)rounds + 1) / rounds;
-        // small tiles re-gather more: mild penalty for BM < 64
-        const double reuse = (kTileBM[c] < 64) ? 1.15 : (kTileBN[c] < 64 ? 1.1 : 1.0);
-        const double cost = padded * quant * reuse;
+        const double cost = padded * quant * kTileEff[c];
         if (cost < best) {
             best = cost;
             best_cfg = c;
@@ -310,22 +353,59 @@ int pick_tile(int M, long P) {
     return best_cfg;
 }
 
+int slab_count(int C, int ksize) {
+    const int cps = ksize == 1 ? Slab<1>::CPS : (ksize == 3 ? Slab<3>::CPS : Slab<7>::CPS);
+    return (C + cps - 1) / cps;
+}
+int packed_row(int ksize) { return ksize == 1 ? Slab<1>::AP : (ksize == 3 ? Slab<3>::AP : Slab<7>::AP); }
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
 // C ABI (declared in include/ssn_hip.h)
 // ------------------------------------------------------------------------------------------
-extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w, const float* scale, const float* shift,
+
+// floats needed for the packed form of a [Cout][Cin][k][k] weight.  transposed=0: forward operand
+// (M = Cout, channels = Cin); transposed=1: dgrad operand (M = Cin, channels = Cout).
+extern "C" long ssn_conv_packed_floats(int Cout, int Cin, int ksize, int transposed) {
+    const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
+    return (long)slab_count(C, ksize) * M * packed_row(ksize);
+}
+
+extern "C" int ssn_conv_pack_weights(const float* w, float* packed, int Cout, int Cin, int ksize, int transposed,
+                                     hipStream_t stream) {
+    SSN_CHECK_ARG(w && packed, "conv pack: null pointer");
+    SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 7, "conv pack: ksize %d unsupported", ksize);
+    const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
+    const int nslab = slab_count(C, ksize);
+    const long total = (long)nslab * M * packed_row(ksize);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    // the source is always the torch-layout weight [Cout][Cin][KK]; transposed selects which index is "m"
+    if (ksize == 1)
+        hipLaunchKernelGGL(pack_weights_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, w, packed, M, C, nslab,
+                           transposed);
+    else if (ksize == 3)
+        hipLaunchKernelGGL(pack_weights_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, stream, w, packed, M, C, nslab,
+                           transposed);
+    else
+        hipLaunchKernelGGL(pack_weights_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, stream, w, packed, M, C, nslab,
+                           transposed);
+    SSN_CHECK_LAUNCH("conv_pack_weights");
+    return SSN_OK;
+}
+
+extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                                     float* y, int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho,
                                     int Wo, long y_img_stride, int ksize, int stride, int pad, int relu,
                                     int tile_cfg, hipStream_t stream) {
-    SSN_CHECK_ARG(x && w && y, "conv fwd: null pointer");
+    SSN_CHECK_ARG(x && w_packed && y, "conv fwd: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 7, "conv fwd: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv fwd: stride %d unsupported", stride);
     SSN_CHECK_ARG((long)N * Ho * Wo < (1l << 31), "conv fwd: too many pixels");
     ConvArgs a;
     a.x = x;
-    a.a = w;
+    a.ap = w_packed;
     a.y = y;
     a.scale = scale;
     a.shift = shift;
@@ -338,14 +418,15 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w, const float*
     a.Ho = Ho;
     a.Wo = Wo;
     a.y_img_stride = y_img_stride;
-    a.K = Cin * ksize * ksize;
     a.P = N * Ho * Wo;
     a.pad = pad;
     a.relu = relu;
     a.accumulate = 0;
+    a.nslab = slab_count(Cin, ksize);
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
-    const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4, ab = (long)Cout * a.K * 4;
+    const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
+    const long ab = ssn_conv_packed_floats(Cout, Cin, ksize, 0) * 4;
     SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31), "conv fwd: operand larger than 2 GiB (buffer addressing)");
     a.x_bytes = (uint32_t)xb;
     a.a_bytes = (uint32_t)ab;
@@ -358,16 +439,17 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w, const float*
     return SSN_ERR_ARG;
 }
 
-// dx[n][ci][hi][wi] (+)= sum_{co,r,s} wt[ci][(co,r,s)] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]
-extern "C" int ssn_conv_dgrad(const float* dy, const float* wt, float* dx, int N, int Cout, int Ho, int Wo,
+// dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]
+// wt_packed = ssn_conv_pack_weights(w, ..., transposed = 1)
+extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                               long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize,
                               int stride, int pad, int accumulate, int tile_cfg, hipStream_t stream) {
-    SSN_CHECK_ARG(dy && wt && dx, "conv dgrad: null pointer");
+    SSN_CHECK_ARG(dy && wt_packed && dx, "conv dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv dgrad: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv dgrad: stride %d unsupported", stride);
     ConvArgs a;
     a.x = dy;
-    a.a = wt;
+    a.ap = wt_packed;
     a.y = dx;
     a.scale = nullptr;
     a.shift = nullptr;
@@ -380,14 +462,15 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt, float* dx, int N
     a.Ho = H;
     a.Wo = W;
     a.y_img_stride = dx_img_stride;
-    a.K = Cout * ksize * ksize;
     a.P = N * H * W;
     a.pad = pad;
     a.relu = 0;
     a.accumulate = accumulate;
+    a.nslab = slab_count(Cout, ksize);
     a.div_hw = make_fastdiv((uint32_t)(H * W));
     a.div_w = make_fastdiv((uint32_t)W);
-    const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4, ab = (long)Cin * a.K * 4;
+    const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4;
+    const long ab = ssn_conv_packed_floats(Cout, Cin, ksize, 1) * 4;
     SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31), "conv dgrad: operand larger than 2 GiB (buffer addressing)");
     a.x_bytes = (uint32_t)xb;
     a.a_bytes = (uint32_t)ab;

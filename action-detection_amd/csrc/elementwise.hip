@@ -46,18 +46,6 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_kernel(float* dy, const float
     }
 }
 
-// wt[ci][co*KK + t] = w[co][ci*KK + t]   (operand A of the dgrad implicit GEMM)
-__global__ __launch_bounds__(256) void weight_transpose_kernel(const float* w, float* wt, int Cout, int Cin, int KK) {
-    const long total = (long)Cout * Cin * KK;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int t = (int)(idx % KK);
-        const long r = idx / KK;
-        const int ci = (int)(r % Cin);
-        const int co = (int)(r / Cin);
-        wt[((long)ci * Cout + co) * KK + t] = w[idx];
-    }
-}
-
 // Counter-based RNG for dropout: Philox-4x32-10 keyed by (seed), counter = element index / 4.
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
                                              uint32_t k1) {
@@ -175,15 +163,6 @@ extern "C" int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, in
                        dy_img_stride, y_img_stride, total, make_fastdiv((uint32_t)(C * HW)),
                        make_fastdiv((uint32_t)HW));
     SSN_CHECK_LAUNCH("relu_bn_bwd");
-    return SSN_OK;
-}
-
-extern "C" int ssn_weight_transpose(const float* w, float* wt, int Cout, int Cin, int ksize, hipStream_t stream) {
-    SSN_CHECK_ARG(w && wt, "weight_transpose: null pointer");
-    const long total = (long)Cout * Cin * ksize * ksize;
-    hipLaunchKernelGGL(weight_transpose_kernel, dim3(grid_for(total)), dim3(256), 0, stream, w, wt, Cout, Cin,
-                       ksize * ksize);
-    SSN_CHECK_LAUNCH("weight_transpose");
     return SSN_OK;
 }
 

@@ -72,14 +72,34 @@ def bn_fold(conv_bias, gamma, beta, mean, var, eps, scale, shift):
              _p(shift), gamma.numel(), _stream(lib, gamma))
 
 
-def conv_fwd(x, w, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
-    """x, y: ChanSlice.  w: [Cout, Cin, k, k]."""
-    lib = _check(x, w, scale, shift, y)
+def packed_floats(cout, cin, ksize, transposed):
+    return int(_lib.get_lib().cdll.ssn_conv_packed_floats(cout, cin, ksize, int(transposed)))
+
+
+def pack_weights(w, transposed, out=None):
+    """Re-lay a torch-layout weight [Cout, Cin, k, k] into the slab/lane-half order the conv kernels read.
+
+    transposed=False -> forward operand, True -> dgrad operand.
+    """
+    lib = _check(w, out)
+    cout, cin, k, _ = w.shape
+    n = packed_floats(cout, cin, k, transposed)
+    if out is None:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    assert out.numel() >= n
+    lib.call("ssn_conv_pack_weights", _p(w), _p(out), cout, cin, k, int(transposed), _stream(lib, w))
+    return out
+
+
+def conv_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
+    """x, y: ChanSlice.  w_packed: pack_weights(w, transposed=False)."""
+    lib = _check(x, w_packed, scale, shift, y)
     h, wd = x.hw
     ho, wo = y.hw
-    assert w.shape[0] == y.c and w.shape[1] == x.c, (w.shape, x.c, y.c)
-    lib.call("ssn_conv_bn_relu_fwd", _p(x), _p(w), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd, x.img_stride,
-             y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg, _stream(lib, w))
+    assert w_packed.numel() >= packed_floats(y.c, x.c, ksize, False)
+    lib.call("ssn_conv_bn_relu_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
+             x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg,
+             _stream(lib, w_packed))
 
 
 def relu_bn_bwd(dy, y, scale):
@@ -90,14 +110,10 @@ def relu_bn_bwd(dy, y, scale):
              _stream(lib, scale))
 
 
-def weight_transpose(w, wt):
-    lib = _check(w, wt)
-    lib.call("ssn_weight_transpose", _p(w), _p(wt), w.shape[0], w.shape[1], w.shape[2], _stream(lib, w))
-
-
 def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1):
-    """dy: ChanSlice (grad of conv output), dx: ChanSlice (grad of conv input), wt: transposed weights."""
+    """dy: ChanSlice (grad of conv output), dx: ChanSlice (grad of conv input), wt: pack_weights(w, True)."""
     lib = _check(dy, wt, dx)
+    assert wt.numel() >= packed_floats(dy.c, dx.c, ksize, True)
     ho, wo = dy.hw
     h, w = dx.hw
     lib.call("ssn_conv_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,

@@ -35,12 +35,20 @@ const char* ssn_last_error(void);
 int ssn_abi_version(void);
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
- * Replaces cuDNN conv fwd + cudnnBatchNorm(eval) + ReLU of every "conv / bn / relu" triple of
+ * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
+ * descriptors): w is the torch-layout [Cout][Cin][k][k] weight; `packed` receives
+ * ssn_conv_packed_floats() floats.  transposed=0 -> operand of the forward conv, 1 -> of dgrad. */
+long ssn_conv_packed_floats(int Cout, int Cin, int ksize, int transposed);
+int ssn_conv_pack_weights(const float* w, float* packed, int Cout, int Cin, int ksize, int transposed,
+                          hipStream_t stream);
+
+/* Replaces cuDNN conv fwd + cudnnBatchNorm(eval) + ReLU of every "conv / bn / relu" triple of
  * model_zoo.BNInception, reached from ssn_models.py:266 (train) and :298 (test).
  * y[n][co][ho][wo] = relu?( scale[co] * sum_{ci,r,s} w[co][ci][r][s] * x[n][ci][ho*S-pad+r][wo*S-pad+s]
  *                           + shift[co] )        scale/shift may be NULL (plain convolution).
- * ksize in {1,3,7}, stride in {1,2}.  tile_cfg < 0 selects the tile heuristically. */
-int ssn_conv_bn_relu_fwd(const float* x, const float* w, const float* scale, const float* shift, float* y,
+ * ksize in {1,3,7}, stride in {1,2}.  tile_cfg < 0 selects the tile heuristically.
+ * w_packed = ssn_conv_pack_weights(w, transposed=0). */
+int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                          int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                          long y_img_stride, int ksize, int stride, int pad, int relu, int tile_cfg,
                          hipStream_t stream);
@@ -55,12 +63,11 @@ int ssn_bn_fold(const float* conv_bias, const float* gamma, const float* beta, c
 int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C, int HW, long dy_img_stride,
                     long y_img_stride, hipStream_t stream);
 
-/* cuDNN dgrad replacement.  wt is the weight re-laid-out as [Cin][Cout*k*k] (ssn_weight_transpose).
- * dx[n][ci][hi][wi] (+)= sum_{co,r,s} wt[ci][(co,r,s)] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]. */
-int ssn_conv_dgrad(const float* dy, const float* wt, float* dx, int N, int Cout, int Ho, int Wo,
+/* cuDNN dgrad replacement.  wt_packed = ssn_conv_pack_weights(w, transposed=1).
+ * dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]. */
+int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                    long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int stride,
                    int pad, int accumulate, int tile_cfg, hipStream_t stream);
-int ssn_weight_transpose(const float* w, float* wt, int Cout, int Cin, int ksize, hipStream_t stream);
 
 /* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
  * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */

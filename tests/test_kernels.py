@@ -51,7 +51,7 @@ def test_conv_bn_relu_fwd(backend):
         c0, ctot = 16, cout + 48      # write into a channel slice of a wider (concat) tensor
         y = torch.full((n, ctot, ho, ho), 7.0)
         yd = backend.put(y)
-        K.conv_fwd(K.full(backend.put(x)), backend.put(w), backend.put(scale), backend.put(shift),
+        K.conv_fwd(K.full(backend.put(x)), K.pack_weights(backend.put(w), False), backend.put(scale), backend.put(shift),
                    K.ChanSlice(yd, c0, cout), k, s, p, True, tile)
         got = yd.cpu()
         assert rel_err(got[:, c0:c0 + cout], ref) < 2e-5, (n, cin, h, cout, k, s, tile)
@@ -71,8 +71,7 @@ def test_conv_dgrad_and_wgrad(backend):
         ho = y.shape[2]
         gd, xd, wd = backend.put(gy), backend.put(x.detach()), backend.put(w.detach())
         if k != 7:
-            wt = backend.put(torch.empty(cin, cout * k * k))
-            K.weight_transpose(wd, wt)
+            wt = K.pack_weights(wd, True)
             dx = backend.put(torch.full(x.shape, 0.5))
             K.conv_dgrad(K.full(gd), wt, K.full(dx), k, s, p, True, tile)
             assert rel_err(dx.cpu() - 0.5, x.grad) < 5e-5, ("dgrad", n, cin, h, cout, k, s)

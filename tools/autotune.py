@@ -51,19 +51,19 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     y = torch.empty(n, cout, ho, ho, device=dev)
     g = torch.randn(n, cout, ho, ho, device=dev)
     scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-    wt = torch.empty(cin, cout * k * k, device=dev)
-    K.weight_transpose(w, wt)
+    wt = K.pack_weights(w, True)
+    wp = K.pack_weights(w, False)
     dx = torch.empty_like(x)
     dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
     flops = 2.0 * n * ho * ho * cout * cin * k * k
     res = {}
-    for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 7]), ("wgrad", [0, 1, 2, 3, 4])):
+    for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]), ("wgrad", [0, 1, 2, 3, 4])):
         if kind == "dgrad" and k == 7:
             continue
         best = (1e9, -1)
         for cfg in cfgs:
             if kind == "fwd":
-                fn = lambda: K.conv_fwd(K.full(x), w, scale, shift, K.full(y), k, s, p, True, cfg)
+                fn = lambda: K.conv_fwd(K.full(x), wp, scale, shift, K.full(y), k, s, p, True, cfg)
             elif kind == "dgrad":
                 fn = lambda: K.conv_dgrad(K.full(g), wt, K.full(dx), k, s, p, False, cfg)
             else:
