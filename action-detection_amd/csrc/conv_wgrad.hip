@@ -30,12 +30,24 @@ struct WgradArgs {
     int pad;
     int splits, chunks_per_split;  // chunk = 32 pixels
     int n_mtiles, n_ktiles;
+    uint32_t g_bytes, x_bytes;     // extents for the buffer descriptors
     FastDiv div_hw, div_w, div_tiles, div_kt;
 };
 
 constexpr int BP = 32;      // pixels per LDS slab
 constexpr int PITCH = 36;   // floats; rows of 144 B keep ds_read_b128 column reads conflict-free
+constexpr uint32_t OOB = 0x80000000u;  // out-of-range marker (extents < 2^31, row constants < 2^31)
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// Loop structure: a workgroup owns a fixed [BM x BN] tile of dW and walks its pixel range in chunks of
+// 32.  Everything that depends on the ROW a thread loads (output channel for G; (c, r, s) for the im2col
+// of X) is loop-invariant and computed once: a byte-offset constant per row and the tap index.  Per
+// chunk a thread decodes its ONE pixel (2 magic divisions), builds a KS*KS-bit border-validity mask, and
+// then every element costs one add (+ a bit test for X) before a branch-free buffer load -- invalid
+// elements get an out-of-range offset and read as 0.
 template <int KS, int S, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int BM = WM * TM * 32;
@@ -68,26 +80,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const int HW = p.H * p.W;
     const int howo = p.Ho * p.Wo;
 
-    // per-thread constant decode of the kk rows this thread gathers
-    int b_off[NBR];
-    int b_rs[NBR];
+    // ---- loop-invariant row constants ----
+    uint32_t a_const[NA];   // byte offset of row m inside an image of G, or OOB
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + rgrp + 8 * i;
+        a_const[i] = (m < p.M) ? (uint32_t)(m * howo) * 4u : OOB;
+    }
+    uint32_t b_const[NBR];  // byte offset of (c, r, s) relative to the pixel's window origin, or OOB
+    int b_tap[NBR];         // r * KS + s
 #pragma unroll
     for (int i = 0; i < NBR; ++i) {
         const int kk = kk0 + rgrp + 8 * i;
-        int c, r, s;
+        int c, tap;
         if (KS == 1) {
             c = kk;
-            r = 0;
-            s = 0;
+            tap = 0;
         } else {
             c = kk / KK;
-            const int rem = kk - c * KK;
-            r = rem / KS;
-            s = rem - r * KS;
+            tap = kk - c * KK;
         }
-        b_off[i] = (kk < p.K) ? (c * HW + r * p.W + s) : -1;
-        b_rs[i] = (r << 8) | s;
+        const int r = tap / KS, s = tap - r * KS;
+        b_const[i] = (kk < p.K) ? (uint32_t)(c * HW + r * p.W + s) * 4u : OOB;
+        b_tap[i] = tap;
     }
+    const __amdgpu_buffer_rsrc_t grsrc = make_rsrc(p.g, p.g_bytes);
+    const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.x_bytes);
 
     float areg[NA], breg[NBR];
 
@@ -97,30 +115,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         uint32_t n, hw, ho, wo;
         fd_divmod((uint32_t)(valid ? pp : 0), p.div_hw, n, hw);
         fd_divmod(hw, p.div_w, ho, wo);
-        const float* gp = p.g + (long)n * p.g_img_stride + hw;
+        // G: one add per element
+        const uint32_t abase = valid ? (uint32_t)((long)n * p.g_img_stride * 4) + hw * 4u : OOB;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int m = m0 + rgrp + 8 * i;
-            areg[i] = (valid && m < p.M) ? gp[(long)m * howo] : 0.f;
-        }
+        for (int i = 0; i < NA; ++i)
+            areg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, abase + a_const[i], 0, 0));
+        // X: window origin + border-validity mask over the KS*KS taps (bit r*KS+s)
         const int h0 = (int)ho * S - p.pad;
         const int w0 = (int)wo * S - p.pad;
-        const float* xp = p.x + (long)n * p.x_img_stride + h0 * p.W + w0;
+        const uint32_t bbase = (uint32_t)((long)n * p.x_img_stride * 4) + (uint32_t)(h0 * p.W + w0) * 4u;
+        uint64_t mask = 0;
+        if (valid) {
+            uint32_t rows = 0, cols = 0;
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+                rows |= ((unsigned)(h0 + r) < (unsigned)p.H) ? (1u << r) : 0u;
+                cols |= ((unsigned)(w0 + r) < (unsigned)p.W) ? (1u << r) : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < KS; ++r)
+                if (rows & (1u << r)) mask |= (uint64_t)cols << (r * KS);
+        }
 #pragma unroll
         for (int i = 0; i < NBR; ++i) {
-            const int r = b_rs[i] >> 8, s = b_rs[i] & 255;
-            const bool ok = valid && b_off[i] >= 0 && ((unsigned)(h0 + r) < (unsigned)p.H) &&
-                            ((unsigned)(w0 + s) < (unsigned)p.W);
-            breg[i] = ok ? xp[b_off[i]] : 0.f;
+            const bool ok = (mask >> b_tap[i]) & 1;
+            const uint32_t off = ok ? bbase + b_const[i] : OOB;
+            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, off, 0, 0));
         }
     };
     auto store_slab = [&](int buf) {
-        float* As = As0 + buf * BM * PITCH;
-        float* Bs = Bs0 + buf * BN * PITCH;
+        float* As = As0 + buf * BM * PITCH + rgrp * PITCH + pix;
+        float* Bs = Bs0 + buf * BN * PITCH + rgrp * PITCH + pix;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[(rgrp + 8 * i) * PITCH + pix] = areg[i];
+        for (int i = 0; i < NA; ++i) As[8 * i * PITCH] = areg[i];
 #pragma unroll
-        for (int i = 0; i < NBR; ++i) Bs[(rgrp + 8 * i) * PITCH + pix] = breg[i];
+        for (int i = 0; i < NBR; ++i) Bs[8 * i * PITCH] = breg[i];
     };
 
     f32x16 acc[TM][TN];
@@ -205,7 +234,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     const long total = (long)M * ldp;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += part[(long)z * total + idx];
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {   // four independent loads in flight, fixed summation order
+            const float v0 = part[(long)z * total + idx], v1 = part[(long)(z + 1) * total + idx];
+            const float v2 = part[(long)(z + 2) * total + idx], v3 = part[(long)(z + 3) * total + idx];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; z < splits; ++z) s += part[(long)z * total + idx];
         const int m = (int)(idx / ldp);
         const int kk = (int)(idx - (long)m * ldp);
         if (kk < K)
@@ -231,9 +266,10 @@ int launch_wgrad(WgradArgs& a, hipStream_t stream) {
 }
 
 // tile configs: 0: 2,2,1,1 -> 64(co) x 64(kk)   1: 1,4,1,1 -> 32 x 128   2: 2,2,2,2 -> 128 x 128
-//               3: 2,2,1,2 -> 64 x 128          4: 1,4,3,1 -> 96 x 128
-const int kWgBM[5] = {64, 32, 128, 64, 96};
-const int kWgBN[5] = {64, 128, 128, 128, 128};
+//               3: 2,2,1,2 -> 64 x 128          4: 1,4,3,1 -> 96 x 128   5: 1,4,2,1 -> 64 x 128 (waves along kk)
+//               6: 2,2,2,1 -> 128 x 64
+const int kWgBM[7] = {64, 32, 128, 64, 96, 64, 128};
+const int kWgBN[7] = {64, 128, 128, 128, 128, 128, 64};
 
 template <int KS, int S>
 int launch_wgrad_tile(WgradArgs& a, int cfg, hipStream_t stream) {
@@ -243,6 +279,8 @@ int launch_wgrad_tile(WgradArgs& a, int cfg, hipStream_t stream) {
         case 2: return launch_wgrad<KS, S, 2, 2, 2, 2>(a, stream);
         case 3: return launch_wgrad<KS, S, 2, 2, 1, 2>(a, stream);
         case 4: return launch_wgrad<KS, S, 1, 4, 3, 1>(a, stream);
+        case 5: return launch_wgrad<KS, S, 1, 4, 2, 1>(a, stream);
+        case 6: return launch_wgrad<KS, S, 2, 2, 2, 1>(a, stream);
     }
     ssn_set_error("conv_wgrad: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -251,7 +289,7 @@ int launch_wgrad_tile(WgradArgs& a, int cfg, hipStream_t stream) {
 int pick_wgrad_tile(int M, int K) {
     double best = 1e300;
     int bc = 0;
-    for (int c = 0; c < 5; ++c) {
+    for (int c = 0; c < 7; ++c) {
         const double padded = (double)((M + kWgBM[c] - 1) / kWgBM[c]) * kWgBM[c] *
                               (double)((K + kWgBN[c] - 1) / kWgBN[c]) * kWgBN[c];
         const double reuse = (kWgBM[c] * kWgBN[c] >= 128 * 64) ? 1.0 : 1.12;
@@ -309,6 +347,11 @@ extern "C" int ssn_conv_wgrad(const float* g, const float* x, float* dw, float* 
     a.pad = pad;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
+    const long gb = ((long)(N - 1) * g_img_stride + (long)Cout * Ho * Wo) * 4;
+    const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
+    SSN_CHECK_ARG(gb < (1l << 31) && xb < (1l << 31), "conv wgrad: operand larger than 2 GiB (buffer addressing)");
+    a.g_bytes = (uint32_t)gb;
+    a.x_bytes = (uint32_t)xb;
     const int cfg = tile_cfg >= 0 ? tile_cfg : pick_wgrad_tile(Cout, a.K);
     plan_wgrad(Cout, a.K, a.P, cfg, &a.splits, &a.chunks_per_split);
     const long need = (long)a.splits * Cout * a.ldp * (long)sizeof(float);

@@ -92,7 +92,7 @@ def test_wgrad_tiles(backend):
     y = F.conv2d(x, w, None, s, p)
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
-    for cfg in range(5):
+    for cfg in range(7):
         ws = backend.put(torch.empty(K.wgrad_workspace_bytes(n, cin, cout, h, h, k, cfg) // 4))
         dw = backend.put(torch.empty(w.shape))
         K.conv_wgrad(K.full(backend.put(gy)), K.full(backend.put(x)), dw, None, k, s, p, ws, cfg)

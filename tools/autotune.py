@@ -57,7 +57,7 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
     flops = 2.0 * n * ho * ho * cout * cin * k * k
     res = {}
-    for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]), ("wgrad", [0, 1, 2, 3, 4])):
+    for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]), ("wgrad", [0, 1, 2, 3, 4, 5, 6])):
         if kind == "dgrad" and k == 7:
             continue
         best = (1e9, -1)
