@@ -10,7 +10,7 @@ timeout 600 python bench.py ${BENCH_ARGS:---steps 10 --warmup 3} > gpurun_out/be
 echo "bench rc=$?" >> gpurun_out/bench.log; tail -3 gpurun_out/bench.log
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   rm -rf gpurun_out/prof; cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof" -o run -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-baseline-videos 0 > "$R/gpurun_out/prof.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o run -- python "$R/bench.py" --steps 5 --warmup 2 --cpu-baseline-videos 0 > "$R/gpurun_out/prof.log" 2>&1
   echo "rocprof rc=$?" >> "$R/gpurun_out/prof.log"; cd "$R"
   find gpurun_out/prof -name "*stats*.csv" | head; tail -3 gpurun_out/prof.log
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f"
