@@ -38,7 +38,7 @@ _SIGS = {
     "ssn_pool_bwd": "ipppiiiiliiliiiip",
     "ssn_global_avgpool_fwd": "ppiiilp",
     "ssn_global_avgpool_bwd": "ppiiilip",
-    "ssn_dropout_fwd": "ppplfup",
+    "ssn_dropout_fwd": "ppplfupp",
     "ssn_dropout_bwd": "ppplfp",
     "ssn_stpp_fwd": "ppppiipp",
     "ssn_stpp_bwd": "ppppiipp",

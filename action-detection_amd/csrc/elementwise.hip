@@ -76,7 +76,8 @@ __device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint32_t ou
 // y = x * mask / (1-p); mask bit saved as uint8 (1 = kept).  nn.Dropout semantics
 // (/root/reference/ssn_models.py:74); the reference RNG stream itself is not reproducible.
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* x, float* y, uint8_t* mask, long total,
-                                                          float p, uint64_t seed) {
+                                                          float p, uint64_t seed, const long* counter) {
+    if (counter) seed ^= (uint64_t)counter[0] * 0x9E3779B97F4A7C15ull;
     const float inv = 1.f / (1.f - p);
     const long nquad = (total + 3) / 4;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long)gridDim.x * 256) {
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* x, float*
         }
     }
 }
+__global__ void counter_inc_kernel(long* counter) { counter[0] += 1; }
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, long total,
                                                           float p) {
     const float inv = 1.f / (1.f - p);
@@ -167,10 +169,11 @@ extern "C" int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, in
 }
 
 extern "C" int ssn_dropout_fwd(const float* x, float* y, unsigned char* mask, long total, float p,
-                               unsigned long long seed, hipStream_t stream) {
+                               unsigned long long seed, long* counter, hipStream_t stream) {
     SSN_CHECK_ARG(x && y && mask && p >= 0.f && p < 1.f, "dropout_fwd: bad arguments");
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for((total + 3) / 4)), dim3(256), 0, stream, x, y,
-                       (uint8_t*)mask, total, p, (uint64_t)seed);
+                       (uint8_t*)mask, total, p, (uint64_t)seed, (const long*)counter);
+    if (counter) hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, stream, counter);
     SSN_CHECK_LAUNCH("dropout_fwd");
     return SSN_OK;
 }

@@ -40,11 +40,11 @@ class DropoutFn(torch.autograd.Function):
     """nn.Dropout that replaces the backbone's fc (/root/reference/ssn_models.py:74)."""
 
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed, counter=None):
         x = x.contiguous()
         y = _new(x, x.shape)
         mask = _new(x, x.shape, torch.uint8)
-        K.dropout_fwd(x, y, mask, p, seed)
+        K.dropout_fwd(x, y, mask, p, seed, counter)
         ctx.save_for_backward(mask)
         ctx.p = p
         return y
@@ -55,7 +55,7 @@ class DropoutFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = _new(dy, dy.shape)
         K.dropout_bwd(dy, mask, dx, ctx.p)
-        return dx, None, None
+        return dx, None, None, None
 
 
 class StppFn(torch.autograd.Function):

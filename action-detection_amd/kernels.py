@@ -163,9 +163,11 @@ def gap_bwd(dy, dx, accumulate=False):
              _stream(lib, dy))
 
 
-def dropout_fwd(x, y, mask, p, seed):
-    lib = _check(x, y, mask)
-    lib.call("ssn_dropout_fwd", _p(x), _p(y), _p(mask), x.numel(), float(p), int(seed), _stream(lib, x))
+def dropout_fwd(x, y, mask, p, seed, counter=None):
+    """counter: optional int64[1] device tensor; it is mixed into the Philox key and incremented by the call."""
+    lib = _check(x, y, mask, counter)
+    lib.call("ssn_dropout_fwd", _p(x), _p(y), _p(mask), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+             _p(counter), _stream(lib, x))
 
 
 def dropout_bwd(dy, mask, dx, p):

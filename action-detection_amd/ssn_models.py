@@ -32,13 +32,22 @@ class HipLinear(nn.Linear):
 
 
 class HipDropout(nn.Dropout):
-    """nn.Dropout on the ssn_dropout_* kernels (own Philox stream seeded from torch's CPU RNG)."""
+    """nn.Dropout on the ssn_dropout_* kernels.
+
+    Philox stream keyed by (seed drawn once from torch's CPU RNG) + a per-call counter that lives in
+    device memory and is advanced by the kernel launch itself, so a hipGraph replay of a captured step
+    still draws a fresh mask every time.
+    """
 
     def forward(self, input):
         if not self.training or self.p == 0:
             return input
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
-        return FN.DropoutFn.apply(input, float(self.p), seed)
+        st = getattr(self, "_rng_state", None)
+        if st is None or st[1].device != input.device:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            st = (seed, torch.zeros(1, dtype=torch.int64, device=input.device))
+            self._rng_state = st
+        return FN.DropoutFn.apply(input, float(self.p), st[0], st[1])
 
 
 class SSN(torch.nn.Module):
@@ -239,11 +248,10 @@ class SSN(torch.nn.Module):
         raw_act_fc = self.activity_fc(activity_ft)
         raw_comp_fc = self.completeness_fc(completeness_ft)
 
-        # the reference's three nonzero() calls (ssn_models.py:275-282) -> one host read of prop_type
-        type_host = prop_type.reshape(-1).cpu()
+        # the reference's three nonzero() calls (ssn_models.py:275-282) -> one host read of prop_type,
+        # cached while the same prop_type tensor is fed again (so a step can be captured in a hipGraph)
         dev = raw_act_fc.device
-        act_indexer = torch.nonzero((type_host == 0) | (type_host == 2)).reshape(-1).to(dev)
-        comp_indexer = torch.nonzero((type_host == 0) | (type_host == 1)).reshape(-1).to(dev)
+        act_indexer, comp_indexer, reg_indexer = self._row_indexers(prop_type, dev)
         target = target.reshape(-1).to(dev)
 
         def sel(t, idx):
@@ -251,7 +259,6 @@ class SSN(torch.nn.Module):
 
         if self.with_regression:
             reg_target = reg_target.reshape(-1, 2).to(dev)
-            reg_indexer = torch.nonzero(type_host == 0).reshape(-1).to(dev)
             raw_regress_fc = self.regressor_fc(completeness_ft).reshape(-1, self.completeness_fc.out_features, 2)
             return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), sel(target, act_indexer),
                     FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), sel(target, comp_indexer),
@@ -260,6 +267,18 @@ class SSN(torch.nn.Module):
         else:
             return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), sel(target, act_indexer),
                     FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), sel(target, comp_indexer))
+
+    def _row_indexers(self, prop_type, dev):
+        key = (prop_type.data_ptr(), prop_type._version, tuple(prop_type.shape), str(dev))
+        cache = getattr(self, "_indexer_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        type_host = prop_type.reshape(-1).cpu()
+        idx = (torch.nonzero((type_host == 0) | (type_host == 2)).reshape(-1).to(dev),
+               torch.nonzero((type_host == 0) | (type_host == 1)).reshape(-1).to(dev),
+               torch.nonzero(type_host == 0).reshape(-1).to(dev))
+        self._indexer_cache = (key, idx)
+        return idx
 
     def test_forward(self, input):
         base_out = self._backbone(input)

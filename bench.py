@@ -12,7 +12,8 @@ of 224x224 (weak scaling: per-GPU work is fixed as N grows).
 
 Rank 0 prints ONE JSON line.  `roofline` is the MFMA roofline of the dominant kernel family (the
 f32-MFMA implicit-GEMM convolution, `conv_igemm_kernel`, forward + dgrad launches), measured live
-with HIP events around every launch during the timed steps; `cpu_baseline` times the CPU oracle
+with HIP events around every launch of the same K steps (re-run eagerly right after the timed
+region, because events cannot be recorded inside a hipGraph replay); `cpu_baseline` times the CPU oracle
 (oracle/ssn_oracle.py, torch fp32 on the host cores) on a bounded sample of the same workload.
 """
 import argparse
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-baseline-videos", type=int, default=2,
                     help="videos in the CPU-oracle sample (0 disables the cpu_baseline leg)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP event timing")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly from Python instead of replaying one captured hipGraph per step")
     return ap.parse_args()
 
 
@@ -91,23 +94,59 @@ def main():
         opt.zero_grad(set_to_none=True)
         return loss
 
-    for _ in range(args.warmup):
-        step()
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    prof = None if args.no_kernel_events else []
-    model.base_model.profiler = prof
+    # ---- one hipGraph per step: the ~560 launches of a step are captured once and replayed, so the GPU is
+    # not paced by the Python launch loop.  Falls back to eager launches if capture is not possible.
+    launch = "eager"
+    run_step = step
+    static = {}
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):           # allocator / cache warm-up outside the capture
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static["loss"] = step()
+
+            def run_step():
+                graph.replay()
+                return static["loss"]
+            launch = "hipGraph replay (1 graph = 1 step)"
+        except Exception as e:  # noqa: BLE001 -- report and keep going eagerly
+            launch = "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:120])
+            run_step = step
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step()
+
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run_step()
     fence()
     elapsed = time.perf_counter() - t0
-    model.base_model.profiler = None
+
+    # ---- per-launch HIP events for the roofline: the same K steps once more, launched eagerly (events cannot
+    # be recorded inside a graph replay; the kernels and their arguments are identical)
+    prof = None
+    if not args.no_kernel_events and rank == 0:
+        prof = []
+        model.base_model.profiler = prof
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        model.base_model.profiler = None
+    fence()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -132,7 +171,7 @@ def main():
                                "fwd + losses + bwd + SGD, THUMOS14 shape (C=%d, stpp [1,1,1], dropout 0.8)"
                                % (args.modality, v, args.num_class),
                    "global_batch_proposals": 8 * v * world, "images_per_gpu": 72 * v,
-                   "parallelism": "dp%d" % world},
+                   "parallelism": "dp%d" % world, "launch": launch},
         "final_loss": float(loss.item()),
     }
 

@@ -91,9 +91,11 @@ int ssn_global_avgpool_fwd(const float* x, float* y, int N, int C, int HW, long 
 int ssn_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, long dx_img_stride, int accumulate,
                            hipStream_t stream);
 
-/* nn.Dropout standing in for the backbone's `fc` (ssn_models.py:71-74). mask: uint8 per element. */
+/* nn.Dropout standing in for the backbone's `fc` (ssn_models.py:71-74). mask: uint8 per element.
+ * counter (optional, int64[1] in device memory) is mixed into the Philox key and incremented by the
+ * call, so a hipGraph replay draws a fresh mask each time. */
 int ssn_dropout_fwd(const float* x, float* y, unsigned char* mask, long total, float p, unsigned long long seed,
-                    hipStream_t stream);
+                    long* counter, hipStream_t stream);
 int ssn_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long total, float p,
                     hipStream_t stream);
 

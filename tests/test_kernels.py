@@ -169,6 +169,10 @@ def test_global_avgpool_and_dropout(backend):
     assert torch.equal(mask.cpu(), mask2.cpu())
     K.dropout_fwd(backend.put(v), out2, mask2, 0.8, 99)
     assert not torch.equal(mask.cpu(), mask2.cpu())
+    ctr = backend.put(torch.zeros(1, dtype=torch.int64))      # device-side call counter (graph replays)
+    K.dropout_fwd(backend.put(v), out, mask, 0.8, 1234, ctr)
+    K.dropout_fwd(backend.put(v), out2, mask2, 0.8, 1234, ctr)
+    assert int(ctr.item()) == 2 and not torch.equal(mask.cpu(), mask2.cpu())
     dv = backend.put(torch.empty_like(v))
     K.dropout_bwd(backend.put(v), mask, dv, 0.8)
     assert rel_err(dv, out) < 1e-6
