@@ -31,11 +31,11 @@ _SIGS = {
     "ssn_conv_bn_relu_fwd": "pppppiiiiliiiliiiiip",
     "ssn_bn_fold": "pppppfppip",
     "ssn_relu_bn_bwd": "pppiiillp",
-    "ssn_conv_dgrad": "pppiiiiliiiliiiiip",
+    "ssn_conv_dgrad": "pppiiiiliiiliiiiplpip",
     "ssn_conv_pack_weights": "ppiiiip",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
-    "ssn_pool_bwd": "ipppiiiiliiliiiip",
+    "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
     "ssn_global_avgpool_fwd": "ppiiilp",
     "ssn_global_avgpool_bwd": "ppiiilip",
     "ssn_dropout_fwd": "ppplfupp",

@@ -158,12 +158,19 @@ class BNInception(nn.Module):
                 acts[name] = torch.empty((n, c, h, w), device=dev, dtype=torch.float32)
             return acts[name]
 
+        tscale = {}   # per tensor: folded-BN scale of every channel (-1: channel is not a conv+ReLU output)
+
+        def scale_slice(name, c0, c):
+            if name not in tscale:
+                tscale[name] = torch.full((shapes[name][0],), -1.0, device=dev, dtype=torch.float32)
+            return tscale[name][c0:c0 + c]
+
         feat = None
         for i, op in enumerate(ops):
             if op[0] == "conv":
                 _, lid, src, dst, c0, cin, cout, k, s, p = op
                 conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
-                scale = torch.empty(cout, device=dev, dtype=torch.float32)
+                scale = scale_slice(dst, c0, cout)
                 shift = torch.empty(cout, device=dev, dtype=torch.float32)
                 K.bn_fold(conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                           bn.running_var, bn.eps, scale, shift)
@@ -192,7 +199,7 @@ class BNInception(nn.Module):
                 # inference: drop activations as soon as their last consumer has been launched
                 for name in [nm for nm, last in last_use.items() if last == i and nm != "data"]:
                     acts.pop(name, None)
-        saved = (ops, shapes, acts, argmax, folds) if keep else None
+        saved = (ops, shapes, acts, argmax, folds, tscale) if keep else None
         return feat, saved
 
     # ------------------------------------------------------------------ backward executor
@@ -202,7 +209,7 @@ class BNInception(nn.Module):
         return self._ws
 
     def _run_backward(self, dfeat, saved):
-        ops, shapes, acts, argmax, folds = saved
+        ops, shapes, acts, argmax, folds, tscale = saved
         n, dev = dfeat.shape[0], dfeat.device
         layout, total = self.flat_grad_layout()
         lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
@@ -225,8 +232,25 @@ class BNInception(nn.Module):
                     tuned_tile("wgrad", n, cin, cout, k, s, shapes[src][1])))
         ws = self._workspace(ws_bytes, dev)
 
+        # The backward of ReLU + frozen BN (dy <- dy * (y > 0) * scale) is fused into the store of whichever
+        # launch writes a gradient tensor LAST (conv dgrad or max-pool backward); only tensors whose last
+        # writer cannot do it (the global-pool backward) take the separate ssn_relu_bn_bwd pass.
+        last_writer = {}
+        for idx in range(len(ops) - 1, -1, -1):
+            op = ops[idx]
+            src = op[3] if op[0] == "pool" else op[2]
+            last_writer[src] = idx          # reverse walk: the smallest op index writes last
+        masked = set()
+
+        def mask_args(idx, src, fusable):
+            if fusable and last_writer.get(src) == idx and src in tscale and src != "data":
+                masked.add(src)
+                return full(acts[src]), tscale[src]
+            return None, None
+
         pending_end = total
-        for op in reversed(ops):
+        for idx in range(len(ops) - 1, -1, -1):
+            op = ops[idx]
             if op[0] == "gap":
                 _, lid, src, dst = op
                 K.gap_bwd(dfeat, full(gbuf(src)), accumulate=src in inited)
@@ -234,14 +258,16 @@ class BNInception(nn.Module):
             elif op[0] == "pool":
                 _, lid, kind, src, dst, c0, k, s, p, _ceil = op
                 c = shapes[src][0]
+                my, ms = mask_args(idx, src, True)
                 K.pool_bwd(kind, ChanSlice(grads[dst], c0, c), argmax.get(lid), full(gbuf(src)), k, s, p,
-                           accumulate=src in inited)
+                           accumulate=src in inited, mask_y=my, mask_scale=ms)
                 inited.add(src)
             else:
                 _, lid, src, dst, c0, cin, cout, k, s, p = op
                 conv = getattr(self, lid)
                 g = ChanSlice(grads[dst], c0, cout)
-                K.relu_bn_bwd(g, ChanSlice(acts[dst], c0, cout), folds[lid])
+                if dst not in masked:
+                    K.relu_bn_bwd(g, ChanSlice(acts[dst], c0, cout), folds[lid])
                 wo, wn, bo, bn = lay[lid]
                 dw = flat[wo:wo + wn].view_as(conv.weight)
                 db = flat[bo:bo + bn]
@@ -254,9 +280,11 @@ class BNInception(nn.Module):
                 if src != "data":
                     wt = K.pack_weights(conv.weight.detach(), True)
                     acc_flag = src in inited
+                    my, ms = mask_args(idx, src, True)
                     self._timed("conv_dgrad", lid, flops,
                                 lambda: K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=acc_flag,
-                                                     tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin)))
+                                                     tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin),
+                                                     mask_y=my, mask_scale=ms))
                     inited.add(src)
                 if self.grad_ready_hook is not None and (lid.endswith("_1x1") or lid == self._conv_ids[0]
                                                          or lid == "inception_3c_3x3_reduce"

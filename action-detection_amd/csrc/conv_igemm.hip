@@ -61,6 +61,9 @@ struct ConvArgs {
     int P;               // N*Ho*Wo
     int pad;
     int relu, accumulate;
+    const float* mask_y;      // dgrad only: activation of the tensor whose gradient is being finalised
+    const float* mask_scale;  // its per-channel folded-BN scale (< 0: channel is not a ReLU output, use |scale|)
+    long mask_img_stride;
     int n_ptiles, n_mtiles, nslab;
     uint32_t x_bytes, a_bytes;  // extents of the gather source / packed weights (buffer descriptors)
     FastDiv div_hw, div_w, div_mt;
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         uint32_t n, hw;
         fd_divmod((uint32_t)pp, p.div_hw, n, hw);
         float* yb = p.y + (long)n * p.y_img_stride + hw;
+        const float* mb = p.mask_y ? p.mask_y + (long)n * p.mask_img_stride + hw : nullptr;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -265,6 +269,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 if (p.relu) v = fmaxf(v, 0.f);
                 float* dst = yb + (long)m * howo;
                 if (p.accumulate) v += *dst;
+                if (mb) {
+                    // last writer of this gradient tensor: fuse the backward of the producer's ReLU + frozen BN
+                    // (what ssn_relu_bn_bwd would do in a separate pass)
+                    const float sc = p.mask_scale[m];
+                    v = (sc < 0.f) ? v * -sc : (mb[(long)m * howo] > 0.f ? v * sc : 0.f);
+                }
                 *dst = v;
             }
         }
@@ -422,6 +432,9 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
     a.pad = pad;
     a.relu = relu;
     a.accumulate = 0;
+    a.mask_y = nullptr;
+    a.mask_scale = nullptr;
+    a.mask_img_stride = 0;
     a.nslab = slab_count(Cin, ksize);
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
@@ -441,9 +454,13 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
 
 // dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]
 // wt_packed = ssn_conv_pack_weights(w, ..., transposed = 1)
+// mask_y / mask_scale (optional): when this launch is the LAST writer of dx, apply the backward of the ReLU +
+// frozen BN that produced the tensor dx is the gradient of: dx <- dx * (mask_y > 0) * mask_scale[ci]
+// (mask_scale[ci] < 0 marks a channel that is not a ReLU output: dx <- dx * |mask_scale|).
 extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                               long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize,
-                              int stride, int pad, int accumulate, int tile_cfg, hipStream_t stream) {
+                              int stride, int pad, int accumulate, const float* mask_y, long mask_img_stride,
+                              const float* mask_scale, int tile_cfg, hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv dgrad: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv dgrad: stride %d unsupported", stride);
@@ -466,6 +483,9 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx
     a.pad = pad;
     a.relu = 0;
     a.accumulate = accumulate;
+    a.mask_y = mask_scale ? mask_y : nullptr;
+    a.mask_scale = mask_y ? mask_scale : nullptr;
+    a.mask_img_stride = mask_img_stride;
     a.nslab = slab_count(Cout, ksize);
     a.div_hw = make_fastdiv((uint32_t)(H * W));
     a.div_w = make_fastdiv((uint32_t)W);

@@ -11,6 +11,14 @@
 
 namespace {
 
+// All taps of a window are fetched with branch-free raw buffer loads: an out-of-window / out-of-tensor tap
+// gets an out-of-range offset and reads as 0, so the 9 (fwd) or up-to-9 (bwd) loads of an element are all
+// in flight together instead of being serialised behind exec-mask branches.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pool_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+constexpr uint32_t POOL_OOB = 0x80000000u;
+
 struct PoolArgs {
     const float* x;
     float* y;
@@ -19,66 +27,58 @@ struct PoolArgs {
     long x_img_stride, y_img_stride;
     int k, stride, pad;
     long total;
+    uint32_t x_bytes;
     FastDiv div_chw, div_hw, div_w;
 };
 
-// KC/SC/PC > 0: compile-time window (the two shapes BN-Inception uses: 3/2/0 and 3/1/1) so the tap
-// loops unroll; KC == 0: runtime fallback.
+// KC/SC/PC: compile-time window (BN-Inception uses 3/2/0 and 3/1/1); other shapes instantiate on demand.
 template <bool MAX, int KC, int SC, int PC>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
     const int howo = p.Ho * p.Wo;
-    const int K_ = KC ? KC : p.k, S_ = KC ? SC : p.stride, P_ = KC ? PC : p.pad;
+    const __amdgpu_buffer_rsrc_t xr = pool_rsrc(p.x, p.x_bytes);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw, ho, wo;
         fd_divmod((uint32_t)i, p.div_chw, n, rem);
         fd_divmod(rem, p.div_hw, c, hw);
         fd_divmod(hw, p.div_w, ho, wo);
-        const float* xp = p.x + (long)n * p.x_img_stride + (long)c * p.H * p.W;
-        const int h0 = (int)ho * S_ - P_, w0 = (int)wo * S_ - P_;
+        const uint32_t base = (uint32_t)(((long)n * p.x_img_stride + (long)c * p.H * p.W) * 4);
+        const int h0 = (int)ho * SC - PC, w0 = (int)wo * SC - PC;
+        float v[KC * KC];
+        bool ok[KC * KC];
+#pragma unroll
+        for (int r = 0; r < KC; ++r)
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const int hi = h0 + r, wi = w0 + s;
+                const bool in = ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+                ok[r * KC + s] = in;
+                const uint32_t off = in ? base + (uint32_t)(hi * p.W + wi) * 4u : POOL_OOB;
+                v[r * KC + s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+            }
         float out;
         if (MAX) {
+            // torch rule: start at the first in-window element, move on (v > best) or NaN
             float best = -INFINITY;
             int bi = 0;
             bool first = true;
 #pragma unroll
-            for (int r = 0; r < K_; ++r) {
-                const int hi = h0 + r;
-                if ((unsigned)hi >= (unsigned)p.H) continue;
-#pragma unroll
-                for (int s = 0; s < K_; ++s) {
-                    const int wi = w0 + s;
-                    if ((unsigned)wi >= (unsigned)p.W) continue;
-                    const float v = xp[hi * p.W + wi];
-                    // torch rule: start at the first in-bounds element, move on (v > best) or NaN
-                    if (first) {
-                        bi = r * K_ + s;
-                        first = false;
-                    }
-                    if (v > best || v != v) {
-                        best = v;
-                        bi = r * K_ + s;
-                    }
-                }
+            for (int t = 0; t < KC * KC; ++t) {
+                const bool take = ok[t] && (first || v[t] > best || v[t] != v[t]);
+                bi = (ok[t] && first) ? t : bi;
+                first = first && !ok[t];
+                bi = take ? t : bi;
+                best = take ? v[t] : best;
             }
             out = best;
             if (p.idx) p.idx[(long)n * p.C * howo + rem] = (uint8_t)bi;
         } else {
             float s_ = 0.f;
 #pragma unroll
-            for (int r = 0; r < K_; ++r) {
-                const int hi = h0 + r;
-                if ((unsigned)hi >= (unsigned)p.H) continue;
-#pragma unroll
-                for (int s = 0; s < K_; ++s) {
-                    const int wi = w0 + s;
-                    if ((unsigned)wi >= (unsigned)p.W) continue;
-                    s_ += xp[hi * p.W + wi];
-                }
-            }
+            for (int t = 0; t < KC * KC; ++t) s_ += v[t];
             // count_include_pad=True: divisor = window clipped to the PADDED extent (torch avg_pool2d)
-            int he = h0 + K_, we = w0 + K_;
-            if (he > p.H + P_) he = p.H + P_;
-            if (we > p.W + P_) we = p.W + P_;
+            int he = h0 + KC, we = w0 + KC;
+            if (he > p.H + PC) he = p.H + PC;
+            if (we > p.W + PC) we = p.W + PC;
             out = s_ / (float)((he - h0) * (we - w0));
         }
         p.y[(long)n * p.y_img_stride + rem] = out;
@@ -92,56 +92,75 @@ struct PoolBwdArgs {
     int N, C, H, W, Ho, Wo;
     long dy_img_stride, dx_img_stride;
     int k, stride, pad, accumulate;
+    const float* mask_y;      // optional fused ReLU+BN backward of the tensor dx is the gradient of
+    const float* mask_scale;
+    long mask_img_stride;
     long total;  // N*C*H*W
+    uint32_t dy_bytes, idx_bytes;
     FastDiv div_chw, div_hw, div_w;
 };
 
 template <bool MAX, int KC, int SC, int PC>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
     const int howo = p.Ho * p.Wo;
-    const int K_ = KC ? KC : p.k, S_ = KC ? SC : p.stride, P_ = KC ? PC : p.pad;
-    constexpr int NWIN = KC ? (KC + SC - 1) / SC : 0;  // max windows per axis covering one input pixel
+    constexpr int NWIN = (KC + SC - 1) / SC;  // max windows per axis covering one input pixel
+    const __amdgpu_buffer_rsrc_t dyr = pool_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t ixr = pool_rsrc(MAX ? (const void*)p.idx : (const void*)p.dy, MAX ? p.idx_bytes : 4u);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw, hi, wi;
         fd_divmod((uint32_t)i, p.div_chw, n, rem);
         fd_divmod(rem, p.div_hw, c, hw);
         fd_divmod(hw, p.div_w, hi, wi);
-        const float* dyp = p.dy + (long)n * p.dy_img_stride + (long)c * howo;
-        const uint8_t* ip = MAX ? p.idx + ((long)n * p.C + c) * howo : nullptr;
+        const uint32_t dybase = (uint32_t)(((long)n * p.dy_img_stride + (long)c * howo) * 4);
+        const uint32_t ixbase = (uint32_t)(((long)n * p.C + c) * howo);
         // output windows that contain (hi, wi): ho in [ceil((hi+pad-k+1)/s), floor((hi+pad)/s)]
-        const int hp = (int)hi + P_, wp = (int)wi + P_;
-        int ho_lo = hp - K_ + 1;
-        ho_lo = ho_lo <= 0 ? 0 : (ho_lo + S_ - 1) / S_;
-        int wo_lo = wp - K_ + 1;
-        wo_lo = wo_lo <= 0 ? 0 : (wo_lo + S_ - 1) / S_;
-        int ho_hi = hp / S_, wo_hi = wp / S_;
+        const int hp = (int)hi + PC, wp = (int)wi + PC;
+        int ho_lo = hp - KC + 1;
+        ho_lo = ho_lo <= 0 ? 0 : (ho_lo + SC - 1) / SC;
+        int wo_lo = wp - KC + 1;
+        wo_lo = wo_lo <= 0 ? 0 : (wo_lo + SC - 1) / SC;
+        int ho_hi = hp / SC, wo_hi = wp / SC;
         if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
         if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
-        float g = 0.f;
-        auto visit = [&](int ho, int wo) {
-            const int r = hp - ho * S_, s = wp - wo * S_;
-            if (MAX) {
-                if (ip[ho * p.Wo + wo] == (uint8_t)(r * K_ + s)) g += dyp[ho * p.Wo + wo];
-            } else {
-                const int h0 = ho * S_ - P_, w0 = wo * S_ - P_;
-                int he = h0 + K_, we = w0 + K_;
-                if (he > p.H + P_) he = p.H + P_;
-                if (we > p.W + P_) we = p.W + P_;
-                g += dyp[ho * p.Wo + wo] / (float)((he - h0) * (we - w0));
+        float gv[NWIN * NWIN];
+        unsigned iv[NWIN * NWIN];
+#pragma unroll
+        for (int a = 0; a < NWIN; ++a)
+#pragma unroll
+            for (int b = 0; b < NWIN; ++b) {
+                const int ho = ho_lo + a, wo = wo_lo + b;
+                const bool in = (ho <= ho_hi) && (wo <= wo_hi);
+                const uint32_t e = (uint32_t)(ho * p.Wo + wo);
+                gv[a * NWIN + b] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(dyr, in ? dybase + e * 4u : POOL_OOB, 0, 0));
+                if (MAX)
+                    iv[a * NWIN + b] = __builtin_amdgcn_raw_buffer_load_b8(ixr, in ? ixbase + e : POOL_OOB, 0, 0);
             }
-        };
-        if (KC) {
+        float g = 0.f;
 #pragma unroll
-            for (int a = 0; a < NWIN; ++a)
+        for (int a = 0; a < NWIN; ++a)
 #pragma unroll
-                for (int b = 0; b < NWIN; ++b)
-                    if (ho_lo + a <= ho_hi && wo_lo + b <= wo_hi) visit(ho_lo + a, wo_lo + b);
-        } else {
-            for (int ho = ho_lo; ho <= ho_hi; ++ho)
-                for (int wo = wo_lo; wo <= wo_hi; ++wo) visit(ho, wo);
-        }
+            for (int b = 0; b < NWIN; ++b) {
+                const int ho = ho_lo + a, wo = wo_lo + b;
+                const bool in = (ho <= ho_hi) && (wo <= wo_hi);
+                const int r = hp - ho * SC, s = wp - wo * SC;
+                if (MAX) {
+                    g += (in && iv[a * NWIN + b] == (unsigned)(r * KC + s)) ? gv[a * NWIN + b] : 0.f;
+                } else {
+                    const int h0 = ho * SC - PC, w0 = wo * SC - PC;
+                    int he = h0 + KC, we = w0 + KC;
+                    if (he > p.H + PC) he = p.H + PC;
+                    if (we > p.W + PC) we = p.W + PC;
+                    g += in ? gv[a * NWIN + b] / (float)((he - h0) * (we - w0)) : 0.f;
+                }
+            }
         float* dst = p.dx + (long)n * p.dx_img_stride + rem;
-        *dst = p.accumulate ? *dst + g : g;
+        if (p.accumulate) g += *dst;
+        if (p.mask_y) {
+            const float sc = p.mask_scale[c];
+            g = (sc < 0.f) ? g * -sc : (p.mask_y[(long)n * p.mask_img_stride + rem] > 0.f ? g * sc : 0.f);
+        }
+        *dst = g;
     }
 }
 
@@ -185,7 +204,6 @@ extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char*
                             long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
                             hipStream_t stream) {
     SSN_CHECK_ARG(x && y, "pool_fwd: null pointer");
-    SSN_CHECK_ARG(ksize * ksize <= 255, "pool_fwd: window too large");
     PoolArgs a;
     a.x = x;
     a.y = y;
@@ -203,6 +221,9 @@ extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char*
     a.pad = pad;
     a.total = (long)N * C * Ho * Wo;
     SSN_CHECK_ARG(a.total < (1l << 31), "pool_fwd: tensor too large");
+    const long xb = ((long)(N - 1) * x_img_stride + (long)C * H * W) * 4;
+    SSN_CHECK_ARG(xb < (1l << 31), "pool_fwd: operand larger than 2 GiB (buffer addressing)");
+    a.x_bytes = (uint32_t)xb;
     a.div_chw = make_fastdiv((uint32_t)(C * Ho * Wo));
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
@@ -213,17 +234,21 @@ extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char*
         hipLaunchKernelGGL((pool_fwd_kernel<true, 3, 1, 1>), grid, dim3(256), 0, stream, a);
     else if (ksize == 3 && stride == 1 && pad == 1)
         hipLaunchKernelGGL((pool_fwd_kernel<false, 3, 1, 1>), grid, dim3(256), 0, stream, a);
-    else if (is_max)
-        hipLaunchKernelGGL((pool_fwd_kernel<true, 0, 0, 0>), grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((pool_fwd_kernel<false, 0, 0, 0>), grid, dim3(256), 0, stream, a);
+    else if (ksize == 3 && stride == 2 && pad == 0)
+        hipLaunchKernelGGL((pool_fwd_kernel<false, 3, 2, 0>), grid, dim3(256), 0, stream, a);
+    else {
+        ssn_set_error("pool_fwd: window (k=%d, s=%d, p=%d) is not instantiated (BN-Inception uses 3/2/0 and 3/1/1)",
+                      ksize, stride, pad);
+        return SSN_ERR_ARG;
+    }
     SSN_CHECK_LAUNCH("pool_fwd");
     return SSN_OK;
 }
 
 extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H,
                             int W, long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride,
-                            int pad, int accumulate, hipStream_t stream) {
+                            int pad, int accumulate, const float* mask_y, long mask_img_stride,
+                            const float* mask_scale, hipStream_t stream) {
     SSN_CHECK_ARG(dy && dx && (!is_max || argmax), "pool_bwd: null pointer");
     PoolBwdArgs a;
     a.dy = dy;
@@ -241,8 +266,15 @@ extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* ar
     a.stride = stride;
     a.pad = pad;
     a.accumulate = accumulate;
+    a.mask_y = mask_scale ? mask_y : nullptr;
+    a.mask_scale = mask_y ? mask_scale : nullptr;
+    a.mask_img_stride = mask_img_stride;
     a.total = (long)N * C * H * W;
     SSN_CHECK_ARG(a.total < (1l << 31), "pool_bwd: tensor too large");
+    const long db = ((long)(N - 1) * dy_img_stride + (long)C * Ho * Wo) * 4;
+    SSN_CHECK_ARG(db < (1l << 31), "pool_bwd: operand larger than 2 GiB (buffer addressing)");
+    a.dy_bytes = (uint32_t)db;
+    a.idx_bytes = (uint32_t)((long)N * C * Ho * Wo);
     a.div_chw = make_fastdiv((uint32_t)(C * H * W));
     a.div_hw = make_fastdiv((uint32_t)(H * W));
     a.div_w = make_fastdiv((uint32_t)W);
@@ -253,10 +285,13 @@ extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* ar
         hipLaunchKernelGGL((pool_bwd_kernel<true, 3, 1, 1>), grid, dim3(256), 0, stream, a);
     else if (ksize == 3 && stride == 1 && pad == 1)
         hipLaunchKernelGGL((pool_bwd_kernel<false, 3, 1, 1>), grid, dim3(256), 0, stream, a);
-    else if (is_max)
-        hipLaunchKernelGGL((pool_bwd_kernel<true, 0, 0, 0>), grid, dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((pool_bwd_kernel<false, 0, 0, 0>), grid, dim3(256), 0, stream, a);
+    else if (ksize == 3 && stride == 2 && pad == 0)
+        hipLaunchKernelGGL((pool_bwd_kernel<false, 3, 2, 0>), grid, dim3(256), 0, stream, a);
+    else {
+        ssn_set_error("pool_bwd: window (k=%d, s=%d, p=%d) is not instantiated (BN-Inception uses 3/2/0 and 3/1/1)",
+                      ksize, stride, pad);
+        return SSN_ERR_ARG;
+    }
     SSN_CHECK_LAUNCH("pool_bwd");
     return SSN_OK;
 }

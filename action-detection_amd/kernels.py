@@ -110,14 +110,18 @@ def relu_bn_bwd(dy, y, scale):
              _stream(lib, scale))
 
 
-def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1):
-    """dy: ChanSlice (grad of conv output), dx: ChanSlice (grad of conv input), wt: pack_weights(w, True)."""
-    lib = _check(dy, wt, dx)
+def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
+    """dy: ChanSlice (grad of conv output), dx: ChanSlice (grad of conv input), wt: pack_weights(w, True).
+
+    mask_y (ChanSlice like dx) + mask_scale [dx.c]: fuse the ReLU+frozen-BN backward of dx's tensor into the store.
+    """
+    lib = _check(dy, wt, dx, mask_y, mask_scale)
     assert wt.numel() >= packed_floats(dy.c, dx.c, ksize, True)
     ho, wo = dy.hw
     h, w = dx.hw
     lib.call("ssn_conv_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
-             dx.img_stride, ksize, stride, pad, int(accumulate), tile_cfg, _stream(lib, wt))
+             dx.img_stride, ksize, stride, pad, int(accumulate), _p(mask_y),
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), tile_cfg, _stream(lib, wt))
 
 
 def wgrad_workspace_bytes(n, cin, cout, ho, wo, ksize, tile_cfg=-1):
@@ -142,12 +146,13 @@ def pool_fwd(kind, x, y, argmax, ksize, stride, pad):
              y.img_stride, ksize, stride, pad, _stream(lib, x))
 
 
-def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate):
-    lib = _check(dy, dx, argmax)
+def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, mask_scale=None):
+    lib = _check(dy, dx, argmax, mask_y, mask_scale)
     h, w = dx.hw
     ho, wo = dy.hw
     lib.call("ssn_pool_bwd", int(kind == "max"), _p(dy), _p(argmax), _p(dx), dx.n, dx.c, h, w, dx.img_stride, ho,
-             wo, dy.img_stride, ksize, stride, pad, int(accumulate), _stream(lib, dx))
+             wo, dy.img_stride, ksize, stride, pad, int(accumulate), _p(mask_y),
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _stream(lib, dx))
 
 
 def gap_fwd(x, y):

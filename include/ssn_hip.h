@@ -64,10 +64,14 @@ int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C,
                     long y_img_stride, hipStream_t stream);
 
 /* cuDNN dgrad replacement.  wt_packed = ssn_conv_pack_weights(w, transposed=1).
- * dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]. */
+ * dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S].
+ * mask_y / mask_scale (optional, both or neither): when this call is the last writer of dx, the
+ * backward of the ReLU + frozen BN that produced the tensor dx belongs to is fused into the store:
+ * dx <- dx * (mask_y > 0) * mask_scale[ci]   (mask_scale[ci] < 0: not a ReLU output, dx <- dx * |scale|). */
 int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                    long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int stride,
-                   int pad, int accumulate, int tile_cfg, hipStream_t stream);
+                   int pad, int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
+                   int tile_cfg, hipStream_t stream);
 
 /* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
  * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */
@@ -86,7 +90,8 @@ int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, in
                  hipStream_t stream);
 int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H, int W,
                  long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride, int pad,
-                 int accumulate, hipStream_t stream);
+                 int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
+                 hipStream_t stream);
 int ssn_global_avgpool_fwd(const float* x, float* y, int N, int C, int HW, long x_img_stride, hipStream_t stream);
 int ssn_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, long dx_img_stride, int accumulate,
                            hipStream_t stream);

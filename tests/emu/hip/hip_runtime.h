@@ -306,6 +306,11 @@ static inline unsigned int __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_
     if (o + 4 <= r.bytes) memcpy(&v, r.base + o, 4);
     return v;
 }
+static inline unsigned char __builtin_amdgcn_raw_buffer_load_b8(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
+                                                               int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    return (o + 1 <= r.bytes) ? (unsigned char)r.base[o] : (unsigned char)0;
+}
 static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
                                                               int) {
     const uint64_t o = (uint64_t)voff + soff;

@@ -243,3 +243,36 @@ def test_sgd_and_norm(backend):
     K.scale_(x, backend.put(torch.tensor([0.25])))
     K.scale_(x, None, 2.0)
     assert rel_err(x, gr * 0.5) < 1e-7
+
+
+def test_fused_relu_bn_backward_epilogues(backend):
+    """dgrad / max-pool backward as LAST writer: dx <- (dx_old + contribution) * (y > 0) * scale, |scale| where < 0."""
+    g = torch.Generator().manual_seed(10)
+    n, cin, h, cout, k, s, p = (4, 32, 14, 48, 3, 1, 1) if backend.is_gpu else (2, 6, 7, 40, 3, 1, 1)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    gy = torch.randn(n, cout, h, h, generator=g)
+    y_in = torch.relu(torch.randn(n, cin, h, h, generator=g))
+    scale = torch.rand(cin, generator=g) + 0.5
+    scale[::3] = -1.0                                         # pass-through channels
+    old = torch.randn(n, cin, h, h, generator=g)
+    contrib = torch.nn.grad.conv2d_input((n, cin, h, h), w, gy, s, p)
+    tot = old + contrib
+    ref = torch.where(scale.view(1, -1, 1, 1) < 0, tot * (-scale).view(1, -1, 1, 1),
+                      torch.where(y_in > 0, tot * scale.view(1, -1, 1, 1), torch.zeros_like(tot)))
+    dx = backend.put(old.clone())
+    K.conv_dgrad(K.full(backend.put(gy)), K.pack_weights(backend.put(w), True), K.full(dx), k, s, p, True,
+                 mask_y=K.full(backend.put(y_in)), mask_scale=backend.put(scale))
+    assert rel_err(dx, ref) < 5e-5
+    # max-pool backward with the same fusion
+    x = torch.relu(torch.randn(n, cin, 2 * h, 2 * h, generator=g)).requires_grad_()
+    yp = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+    gp = torch.randn(yp.shape, generator=g)
+    yp.backward(gp)
+    am = backend.put(torch.zeros(yp.shape, dtype=torch.uint8))
+    K.pool_fwd("max", K.full(backend.put(x.detach())), K.full(backend.put(torch.empty(yp.shape))), am, 3, 2, 0)
+    ref = torch.where(scale.view(1, -1, 1, 1) < 0, x.grad * (-scale).view(1, -1, 1, 1),
+                      torch.where(x.detach() > 0, x.grad * scale.view(1, -1, 1, 1), torch.zeros_like(x.grad)))
+    dxp = backend.put(torch.empty(x.shape))
+    K.pool_bwd("max", K.full(backend.put(gp)), am, K.full(dxp), 3, 2, 0, False,
+               mask_y=K.full(backend.put(x.detach())), mask_scale=backend.put(scale))
+    assert rel_err(dxp, ref) < 1e-6
