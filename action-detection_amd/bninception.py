@@ -87,6 +87,8 @@ class BNInception(nn.Module):
         self.fc = nn.Linear(FEATURE_DIM, num_classes)
         self.grad_ready_hook = None   # object with range_ready(flat, start, end) / finish() (parallel.GradReducer)
         self._ws = None
+        self._side = {}               # device -> side HIP stream for the weight-gradient chain
+        self.overlap_wgrad = True     # run wgrad launches on a second stream, concurrently with the dgrad chain
         self.profiler = None          # list; when set, every conv launch is bracketed by HIP events
 
     def _timed(self, family, lid, flops, fn):
@@ -248,6 +250,19 @@ class BNInception(nn.Module):
                 return full(acts[src]), tscale[src]
             return None, None
 
+        # Two HIP streams: the data-gradient chain (dgrad / pool backward, each layer depends on the previous
+        # one) stays on the caller's stream; every weight gradient only needs its layer's finished output
+        # gradient and goes to a side stream, so the two kernel families fill each other's tails and
+        # low-occupancy phases.  All wgrads share one stream (and therefore the split-K workspace) in order.
+        use_side = self.overlap_wgrad and dfeat.is_cuda
+        main = torch.cuda.current_stream(dev) if use_side else None
+        side = None
+        if use_side:
+            side = self._side.get(dev)
+            if side is None:
+                side = self._side[dev] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+
         pending_end = total
         for idx in range(len(ops) - 1, -1, -1):
             op = ops[idx]
@@ -275,8 +290,16 @@ class BNInception(nn.Module):
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
                 hin = shapes[src][1]
                 wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
-                self._timed("conv_wgrad", lid, flops,
-                            lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws, wcfg))
+                if use_side:
+                    ready = torch.cuda.Event()
+                    ready.record(main)            # the output gradient of this layer is final here
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        self._timed("conv_wgrad", lid, flops,
+                                    lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws, wcfg))
+                else:
+                    self._timed("conv_wgrad", lid, flops,
+                                lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws, wcfg))
                 if src != "data":
                     wt = K.pack_weights(conv.weight.detach(), True)
                     acc_flag = src in inited
@@ -290,8 +313,12 @@ class BNInception(nn.Module):
                                                          or lid == "inception_3c_3x3_reduce"
                                                          or lid == "inception_4e_3x3_reduce"):
                     # the first conv of a block (forward order) closes that block's contiguous range
+                    if use_side:
+                        main.wait_stream(side)    # the block's wgrads must have landed before the all-reduce
                     self.grad_ready_hook.range_ready(flat, wo, pending_end)
                     pending_end = wo
+        if use_side:
+            main.wait_stream(side)
         if self.grad_ready_hook is not None:
             if pending_end > 0:
                 self.grad_ready_hook.range_ready(flat, 0, pending_end)

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     // ---- loop-invariant gather offsets of this thread's pixel column ----
     const int gcol = tid % BN;
-    const int gk0 = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int gk0 = wave_uniform(tid / BN);
     uint32_t voff[NB];
     {
         const int gp = p0 + gcol;

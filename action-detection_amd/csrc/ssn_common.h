@@ -75,6 +75,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Promote a value that is known to be wave-uniform to an SGPR.  (Wrapped in a typed function: in hipcc's host
+// pass the raw builtin has no type, which silently poisons every expression it touches.)
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// LDS-DMA helpers (buffer_load ... lds): the destination is a wave-uniform LDS address + lane * size.
+#ifndef SSN_LDS_PTR
+#define SSN_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#endif
+#ifndef SSN_WAIT_VMCNT
+#define SSN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -23,6 +23,7 @@
 #include <functional>
 #include <vector>
 
+#define __HIP_DEVICE_COMPILE__ 1   /* the emulator executes device code */
 #define __global__
 #define __device__
 #define __host__
@@ -318,5 +319,18 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rs
     if (o + 16 <= r.bytes) memcpy(&v, r.base + o, 16);
     return v;
 }
+// LDS-DMA: every lane deposits `size` bytes at (wave-uniform lds base) + lane * size
+#define SSN_LDS_PTR(p) ((void*)(p))
+#define SSN_WAIT_VMCNT(n) ((void)0)
+static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds, int size, uint32_t voff,
+                                                            uint32_t soff, int imm, int) {
+    const uint64_t o = (uint64_t)voff + soff + (uint32_t)imm;
+    char* dst = (char*)lds + (size_t)emu::g_cur->lane * size;
+    if (o + size <= r.bytes)
+        memcpy(dst, r.base + o, size);
+    else
+        memset(dst, 0, size);
+}
+static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
