@@ -10,7 +10,7 @@ OBJS=()
 for f in "$SRC"/*.hip "$HERE/emu_globals.cpp"; do
   o="$HERE/.obj_$(basename "$f").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ "$SRC/ssn_common.h" -nt "$o" ]; then
-    "$CXX" -x c++ -std=c++17 -O1 -fPIC -Wno-unused-value -I "$HERE" -I "$SRC" -c "$f" -o "$o" &
+    "$CXX" -x c++ -std=c++17 -O1 -fPIC -w -I "$HERE" -I "$SRC" -c "$f" -o "$o" &
   fi
   OBJS+=("$o")
 done
