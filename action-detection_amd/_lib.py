@@ -61,7 +61,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
-                                "ssn_conv_pick_tile", "ssn_conv_packed_floats"])
+                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_debug_flags"])
 
 
 class SsnLibrary:

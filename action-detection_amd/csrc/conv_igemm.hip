@@ -65,6 +65,7 @@ struct ConvArgs {
     const float* mask_scale;  // its per-channel folded-BN scale (< 0: channel is not a ReLU output, use |scale|)
     long mask_img_stride;
     int n_ptiles, n_mtiles, nslab;
+    int dbg;             // ablation switches for tools/ablate_conv.py (0 in production)
     uint32_t x_bytes, a_bytes;  // extents of the gather source / packed weights (buffer descriptors)
     FastDiv div_hw, div_w, div_mt;
 };
@@ -216,36 +217,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         const int buf = t & 1;
         xso += x_step;
         aso += a_step;
-        if (t + 2 < p.nslab)
-            load_full(xso, aso);
-        else if (t + 1 < p.nslab)
-            load_slab(xso, aso, c_tail);
+        if (!(p.dbg & 1)) {
+            if (t + 2 < p.nslab)
+                load_full(xso, aso);
+            else if (t + 1 < p.nslab)
+                load_slab(xso, aso, c_tail);
+        }
 
         const float* As = As0 + buf * BM * APITCH + (wm * TM * 32 + li) * APITCH + lh * HP;
         const float* Bs = Bs0 + buf * BROWS * BN + lh * BN + wn * TN * 32 + li;
+        // Fragment groups of 4 MFMA steps, software-pipelined: the LDS reads of group q+1 are issued before the
+        // MFMAs of group q, so a wave does not sit on LDS latency between every pair of matrix instructions.
+        constexpr int NQ = HP / 4;
+        f32x4 af[2][TM];
+        float bf[2][4][TN];
+        auto load_group = [&](int q, int slot) {
 #pragma unroll
-        for (int q = 0; q < HP / 4; ++q) {
-            f32x4 af[TM];
+            for (int i = 0; i < TM; ++i)
+                af[slot][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * APITCH + 4 * q);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * APITCH + 4 * q);
+            for (int s = 0; s < 4; ++s)
+                if (4 * q + s < T) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int step = 4 * q + s;
-                if (step < T) {
-                    float bf[TN];
+                    for (int j = 0; j < TN; ++j) bf[slot][s][j] = Bs[(2 * (4 * q + s)) * BN + j * 32];
+                }
+        };
+        load_group(0, 0);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * step) * BN + j * 32];
+        for (int q = 0; q < NQ; ++q) {
+            const int cur = q & 1;
+            if (q + 1 < NQ) load_group(q + 1, cur ^ 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (4 * q + s < T) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][s][j], acc[i][j],
+                                                                            0, 0, 0);
                 }
-            }
         }
 
-        if (t + 1 < p.nslab) store_slab(buf ^ 1);
-        __syncthreads();
+        if (t + 1 < p.nslab && !(p.dbg & 2)) store_slab(buf ^ 1);
+        if (!(p.dbg & 4)) __syncthreads();
     }
 
     // ---- epilogue: folded BN affine + ReLU (fwd) or accumulate (dgrad), NCHW stores ----
@@ -339,6 +354,7 @@ int launch_tile(ConvArgs& a, int cfg, hipStream_t stream) {
     return SSN_ERR_ARG;
 }
 
+int g_conv_debug = 0;
 const int kTileBM[8] = {128, 64, 96, 64, 32, 160, 64, 128};
 const int kTileBN[8] = {128, 128, 128, 64, 128, 128, 128, 64};
 const double kTileEff[8] = {1.0, 1.05, 1.0, 1.12, 1.2, 1.0, 1.05, 1.05};
@@ -436,6 +452,7 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
     a.mask_scale = nullptr;
     a.mask_img_stride = 0;
     a.nslab = slab_count(Cin, ksize);
+    a.dbg = g_conv_debug;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
     const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
@@ -487,6 +504,7 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx
     a.mask_scale = mask_y ? mask_scale : nullptr;
     a.mask_img_stride = mask_img_stride;
     a.nslab = slab_count(Cout, ksize);
+    a.dbg = g_conv_debug;
     a.div_hw = make_fastdiv((uint32_t)(H * W));
     a.div_w = make_fastdiv((uint32_t)W);
     const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4;
@@ -503,3 +521,11 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx
 }
 
 extern "C" int ssn_conv_pick_tile(int M, long P) { return pick_tile(M, P); }
+
+// Tooling only (tools/ablate_conv.py): bit 0 skip global loads, 1 skip LDS stores, 2 skip barriers, 3 skip MFMAs.
+// Results are garbage with any bit set; production code never calls this.
+extern "C" int ssn_conv_debug_flags(int flags) {
+    const int old = g_conv_debug;
+    g_conv_debug = flags;
+    return old;
+}

@@ -15,6 +15,8 @@ To reproduce the reference's numbers exactly, the completeness loss must use the
 denominator (``CompletenessLoss(..., global_rows=)``); cross-entropy and smooth-L1 are means
 over equal per-rank counts, so averaging per-rank gradients is exact.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -38,6 +40,9 @@ class GradReducer:
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        # SSN_FORCE_ALLREDUCE=1 issues the collectives even on a 1-rank group (lets a single-GPU box exercise
+        # the RCCL + hipGraph-capture path the multi-GPU runs take)
+        self.force = os.environ.get("SSN_FORCE_ALLREDUCE") == "1"
         self.min_bucket = min_bucket_elems
         self._handles = []
         self._flat = None
@@ -61,7 +66,7 @@ class GradReducer:
     def _launch(self):
         s, e = self._pend
         self._pend = None
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self._handles.append(dist.all_reduce(self._flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
         self.launched.append((s, e))
@@ -73,7 +78,7 @@ class GradReducer:
         for h in self._handles:
             h.wait()
         self._handles = []
-        if self._flat is not None and self.world > 1:
+        if self._flat is not None and (self.world > 1 or self.force):
             _scale_inplace(self._flat, 1.0 / self.world)
         self._flat = None
 
@@ -88,7 +93,7 @@ class GradReducer:
 
     def reduce_heads(self):
         """Average the head gradients (call after loss.backward())."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         ps = self.head_parameters()
         if not ps:

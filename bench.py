@@ -58,8 +58,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SSN_FORCE_ALLREDUCE") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import action_detection_amd as pkg
@@ -78,7 +80,7 @@ def main():
     model.to(dev).train()
     policies = model.get_optim_policies()
     opt = SSNSGD(policies, lr=0.001, momentum=0.9, weight_decay=5e-4)
-    reducer = GradReducer(model) if world > 1 else None
+    reducer = GradReducer(model) if use_dist else None
     act_crit, comp_crit, reg_crit = ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss()
     batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank)]
     global_comp_rows = 7 * v * world
@@ -95,7 +97,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -142,9 +144,12 @@ def main():
     if not args.no_kernel_events and rank == 0:
         prof = []
         model.base_model.profiler = prof
+        overlap = model.base_model.overlap_wgrad
+        model.base_model.overlap_wgrad = False   # one kernel at a time, so an event pair times exactly one launch
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        model.base_model.overlap_wgrad = overlap
         model.base_model.profiler = None
     fence()
     if world > 1:
@@ -244,7 +249,7 @@ def main():
             result["parity_max_rel_logits_vs_cpu_oracle"] = rel
         print(json.dumps(result))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

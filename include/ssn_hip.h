@@ -80,6 +80,8 @@ int ssn_conv_wgrad(const float* g, const float* x, float* dw, float* db, int N, 
                    long x_img_stride, int Cout, int Ho, int Wo, long g_img_stride, int ksize, int stride, int pad,
                    void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream);
 int ssn_conv_pick_tile(int M, long P);
+/* tooling only: ablation switches for the conv kernel (tools/ablate_conv.py); 0 = normal operation */
+int ssn_conv_debug_flags(int flags);
 
 /* ------------------------------------------------------------------ backbone: pooling
  * Max / average pools of BN-Inception (ceil_mode output sizes computed by the caller, avg with
