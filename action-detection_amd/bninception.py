@@ -112,13 +112,38 @@ class BNInception(nn.Module):
         return ps
 
     def flat_grad_layout(self):
-        """[(layer id, weight offset, weight numel, bias offset, bias numel)], total -- forward order."""
+        """[(layer id, weight offset, weight numel, bias offset, bias numel)], total.
+
+        Forward layer order, except that the two 1x1 "reduce" convolutions of a block (which the executor
+        runs as ONE fused launch) sit as [w_3x3_reduce | w_double_3x3_reduce | b_3x3_reduce | b_double_...], so
+        the fused wgrad writes both weight gradients (and both bias gradients) as one contiguous matrix.
+        """
         off, lay = 0, []
-        for lid in self._conv_ids:
+        ids = list(self._conv_ids)
+        i = 0
+        while i < len(ids):
+            lid = ids[i]
+            mate = lid.replace("_3x3_reduce", "_double_3x3_reduce")
+            if lid.endswith("_3x3_reduce") and "double" not in lid and mate in ids and lid.startswith("inception_"):
+                a, b = getattr(self, lid), getattr(self, mate)
+                wa, wb, ba, bb = a.weight.numel(), b.weight.numel(), a.bias.numel(), b.bias.numel()
+                lay.append((lid, off, wa, off + wa + wb, ba))
+                lay.append((mate, off + wa, wb, off + wa + wb + ba, bb))
+                off += wa + wb + ba + bb
+                # the conv between them in forward order (<block>_3x3) follows the pair
+                mid = ids[i + 1]
+                assert ids[i + 2] == mate, (lid, ids[i + 1], ids[i + 2])
+                conv = getattr(self, mid)
+                wn, bn = conv.weight.numel(), conv.bias.numel()
+                lay.append((mid, off, wn, off + wn, bn))
+                off += wn + bn
+                i += 3
+                continue
             conv = getattr(self, lid)
             wn, bn = conv.weight.numel(), conv.bias.numel()
             lay.append((lid, off, wn, off + wn, bn))
             off += wn + bn
+            i += 1
         return lay, off
 
     def features(self, x):
@@ -134,7 +159,7 @@ class BNInception(nn.Module):
     def forward(self, x):
         return self.fc(self.features(x))
 
-    # ------------------------------------------------------------------ forward executor
+    # ------------------------------------------------------------------ execution plan
     def _manifest(self, x):
         cin = getattr(self, self._conv_ids[0]).in_channels  # may differ after flow surgery
         if x.shape[1] != cin:
@@ -143,16 +168,64 @@ class BNInception(nn.Module):
             raise ValueError("square inputs only")
         return build_manifest(cin, x.shape[2])
 
-    def _run_forward(self, x, keep):
+    def _plan(self, x):
+        """Manifest -> launch plan.
+
+        Plan ops are dicts.  The two 1x1 reduce convolutions of an Inception block read the same input;
+        they are planned as ONE convolution with concatenated output channels writing a shared
+        "<block>_reduce" tensor, whose channel slices the following 3x3 convolutions read.  That halves the
+        launches on the block input in all three passes and, in dgrad, replaces two read-modify-write
+        sweeps over the input gradient by one with twice the K.
+        """
         ops, shapes = self._manifest(x)
+        shapes = dict(shapes)
+        plan = []
+        alias = {}      # manifest tensor name -> (plan tensor name, channel offset)
+        skip = set()
+        for i, op in enumerate(ops):
+            if i in skip:
+                continue
+            if op[0] == "conv":
+                _, lid, src, dst, c0, cin, cout, k, s, p = op
+                psrc, sc0 = alias.get(src, (src, 0))
+                mate_id = lid.replace("_3x3_reduce", "_double_3x3_reduce")
+                mate = None
+                if lid.startswith("inception_") and lid.endswith("_3x3_reduce") and "double" not in lid:
+                    for j in range(i + 1, min(i + 4, len(ops))):
+                        if ops[j][0] == "conv" and ops[j][1] == mate_id and ops[j][2] == src:
+                            mate = (j, ops[j])
+                if mate is not None:
+                    j, mop = mate
+                    skip.add(j)
+                    red = lid[:-len("3x3_reduce")] + "reduce"
+                    ca, cb = cout, mop[6]
+                    shapes[red] = (ca + cb, shapes[dst][1], shapes[dst][2])
+                    alias[dst] = (red, 0)
+                    alias[mop[3]] = (red, ca)
+                    plan.append(dict(kind="conv", lids=[lid, mate_id], src=psrc, src_c0=sc0, cin=cin, dst=red,
+                                     dst_c0=0, cout=ca + cb, couts=[ca, cb], k=k, s=s, p=p))
+                else:
+                    plan.append(dict(kind="conv", lids=[lid], src=psrc, src_c0=sc0, cin=cin, dst=dst, dst_c0=c0,
+                                     cout=cout, couts=[cout], k=k, s=s, p=p))
+            elif op[0] == "pool":
+                _, lid, kind, src, dst, c0, k, s, p, _ceil = op
+                assert src not in alias
+                plan.append(dict(kind="pool", lid=lid, pool=kind, src=src, dst=dst, dst_c0=c0, c=shapes[src][0],
+                                 k=k, s=s, p=p))
+            else:
+                _, lid, src, dst = op
+                plan.append(dict(kind="gap", lid=lid, src=src, dst=dst))
+        return plan, shapes
+
+    # ------------------------------------------------------------------ forward executor
+    def _run_forward(self, x, keep):
+        plan, shapes = self._plan(x)
         n, dev = x.shape[0], x.device
         acts = {"data": x}
-        argmax = {}
-        folds = {}
+        argmax, tscale, wcat = {}, {}, {}
         last_use = {}
-        for i, op in enumerate(ops):
-            src = op[2] if op[0] != "pool" else op[3]
-            last_use[src] = i
+        for i, op in enumerate(plan):
+            last_use[op["src"]] = i
 
         def get(name):
             if name not in acts:
@@ -160,48 +233,55 @@ class BNInception(nn.Module):
                 acts[name] = torch.empty((n, c, h, w), device=dev, dtype=torch.float32)
             return acts[name]
 
-        tscale = {}   # per tensor: folded-BN scale of every channel (-1: channel is not a conv+ReLU output)
-
         def scale_slice(name, c0, c):
+            # per tensor: folded-BN scale of every channel (-1: channel is not a conv+ReLU output)
             if name not in tscale:
                 tscale[name] = torch.full((shapes[name][0],), -1.0, device=dev, dtype=torch.float32)
             return tscale[name][c0:c0 + c]
 
         feat = None
-        for i, op in enumerate(ops):
-            if op[0] == "conv":
-                _, lid, src, dst, c0, cin, cout, k, s, p = op
-                conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
-                scale = scale_slice(dst, c0, cout)
+        for i, op in enumerate(plan):
+            if op["kind"] == "conv":
+                cout, cin, k, s, p = op["cout"], op["cin"], op["k"], op["s"], op["p"]
                 shift = torch.empty(cout, device=dev, dtype=torch.float32)
-                K.bn_fold(conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                          bn.running_var, bn.eps, scale, shift)
-                ho = shapes[dst][1]
+                off = 0
+                ws = []
+                for lid, c in zip(op["lids"], op["couts"]):
+                    conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
+                    K.bn_fold(conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                              bn.running_var, bn.eps, scale_slice(op["dst"], op["dst_c0"] + off, c),
+                              shift[off:off + c])
+                    ws.append(conv.weight.detach())
+                    off += c
+                w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)   # fused pair: concatenated output channels
+                if keep and len(ws) > 1:
+                    wcat[op["lids"][0]] = w
+                scale = scale_slice(op["dst"], op["dst_c0"], cout)
+                ho = shapes[op["dst"]][1]
+                hin = shapes[op["src"]][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
-                self._timed("conv_fwd", lid, flops,
-                            lambda: K.conv_fwd(full(acts[src]), K.pack_weights(conv.weight.detach(), False), scale, shift,
-                                               ChanSlice(get(dst), c0, cout), k, s, p, True,
-                                               tuned_tile("fwd", n, cin, cout, k, s, shapes[src][1])))
-                folds[lid] = scale
-            elif op[0] == "pool":
-                _, lid, kind, src, dst, c0, k, s, p, _ceil = op
-                c = shapes[src][0]
-                out = ChanSlice(get(dst), c0, c)
+                src_slice = ChanSlice(acts[op["src"]], op["src_c0"], cin)
+                dst_slice = ChanSlice(get(op["dst"]), op["dst_c0"], cout)
+                self._timed("conv_fwd", op["lids"][0], flops,
+                            lambda: K.conv_fwd(src_slice, K.pack_weights(w, False), scale, shift, dst_slice, k, s, p,
+                                               True, tuned_tile("fwd", n, cin, cout, k, s, hin)))
+            elif op["kind"] == "pool":
+                c = op["c"]
+                out = ChanSlice(get(op["dst"]), op["dst_c0"], c)
                 am = None
-                if kind == "max" and keep:
-                    _, ho, wo = shapes[dst]
+                if op["pool"] == "max" and keep:
+                    _, ho, wo = shapes[op["dst"]]
                     am = torch.empty((n, c, ho, wo), device=dev, dtype=torch.uint8)
-                    argmax[lid] = am
-                K.pool_fwd(kind, full(acts[src]), out, am, k, s, p)
+                    argmax[op["lid"]] = am
+                K.pool_fwd(op["pool"], full(acts[op["src"]]), out, am, op["k"], op["s"], op["p"])
             else:
-                _, lid, src, dst = op
-                feat = torch.empty((n, shapes[src][0]), device=dev, dtype=torch.float32)
-                K.gap_fwd(full(acts[src]), feat)
+                feat = torch.empty((n, shapes[op["src"]][0]), device=dev, dtype=torch.float32)
+                K.gap_fwd(full(acts[op["src"]]), feat)
             if not keep:
                 # inference: drop activations as soon as their last consumer has been launched
                 for name in [nm for nm, last in last_use.items() if last == i and nm != "data"]:
                     acts.pop(name, None)
-        saved = (ops, shapes, acts, argmax, folds, tscale) if keep else None
+        saved = (plan, shapes, acts, argmax, tscale, wcat) if keep else None
         return feat, saved
 
     # ------------------------------------------------------------------ backward executor
@@ -211,13 +291,13 @@ class BNInception(nn.Module):
         return self._ws
 
     def _run_backward(self, dfeat, saved):
-        ops, shapes, acts, argmax, folds, tscale = saved
+        plan, shapes, acts, argmax, tscale, wcat = saved
         n, dev = dfeat.shape[0], dfeat.device
         layout, total = self.flat_grad_layout()
         lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
         flat = torch.empty(total, device=dev, dtype=torch.float32)
         grads = {}
-        inited = set()
+        inited = set()      # (tensor, c0) gradient slices that already hold a contribution
 
         def gbuf(name):
             if name not in grads:
@@ -226,29 +306,34 @@ class BNInception(nn.Module):
             return grads[name]
 
         ws_bytes = 0
-        for op in ops:
-            if op[0] == "conv":
-                _, lid, src, dst, c0, cin, cout, k, s, p = op
+        for op in plan:
+            if op["kind"] == "conv":
                 ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(
-                    n, cin, cout, shapes[dst][1], shapes[dst][2], k,
-                    tuned_tile("wgrad", n, cin, cout, k, s, shapes[src][1])))
+                    n, op["cin"], op["cout"], shapes[op["dst"]][1], shapes[op["dst"]][2], op["k"],
+                    tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
         ws = self._workspace(ws_bytes, dev)
 
         # The backward of ReLU + frozen BN (dy <- dy * (y > 0) * scale) is fused into the store of whichever
-        # launch writes a gradient tensor LAST (conv dgrad or max-pool backward); only tensors whose last
-        # writer cannot do it (the global-pool backward) take the separate ssn_relu_bn_bwd pass.
+        # launch writes a gradient slice LAST (conv dgrad or pool backward); only slices whose last writer
+        # cannot do it (the global-pool backward) take the separate ssn_relu_bn_bwd pass.
+        def src_key(op):
+            return (op["src"], op.get("src_c0", 0))
         last_writer = {}
-        for idx in range(len(ops) - 1, -1, -1):
-            op = ops[idx]
-            src = op[3] if op[0] == "pool" else op[2]
-            last_writer[src] = idx          # reverse walk: the smallest op index writes last
-        masked = set()
+        for idx in range(len(plan) - 1, -1, -1):
+            last_writer[src_key(plan[idx])] = idx      # reverse walk: the smallest op index writes last
+        masked = {}     # tensor -> disjoint channel intervals whose ReLU/BN backward is already applied
 
-        def mask_args(idx, src, fusable):
-            if fusable and last_writer.get(src) == idx and src in tscale and src != "data":
-                masked.add(src)
-                return full(acts[src]), tscale[src]
+        def mask_args(idx, op, width):
+            key = src_key(op)
+            if last_writer.get(key) == idx and key[0] in tscale and key[0] != "data":
+                masked.setdefault(key[0], []).append((key[1], key[1] + width))
+                return ChanSlice(acts[key[0]], key[1], width), tscale[key[0]][key[1]:key[1] + width]
             return None, None
+
+        def is_masked(name, c0, c):
+            covered = sum(max(0, min(hi, c0 + c) - max(lo, c0)) for lo, hi in masked.get(name, []))
+            assert covered in (0, c), "partially finalised gradient slice %s[%d:%d]" % (name, c0, c0 + c)
+            return covered == c
 
         # Two HIP streams: the data-gradient chain (dgrad / pool backward, each layer depends on the previous
         # one) stays on the caller's stream; every weight gradient only needs its layer's finished output
@@ -263,55 +348,67 @@ class BNInception(nn.Module):
                 side = self._side[dev] = torch.cuda.Stream(device=dev)
             side.wait_stream(main)
 
+        first_conv = self._conv_ids[0]
         pending_end = total
-        for idx in range(len(ops) - 1, -1, -1):
-            op = ops[idx]
-            if op[0] == "gap":
-                _, lid, src, dst = op
-                K.gap_bwd(dfeat, full(gbuf(src)), accumulate=src in inited)
-                inited.add(src)
-            elif op[0] == "pool":
-                _, lid, kind, src, dst, c0, k, s, p, _ceil = op
-                c = shapes[src][0]
-                my, ms = mask_args(idx, src, True)
-                K.pool_bwd(kind, ChanSlice(grads[dst], c0, c), argmax.get(lid), full(gbuf(src)), k, s, p,
-                           accumulate=src in inited, mask_y=my, mask_scale=ms)
-                inited.add(src)
+        for idx in range(len(plan) - 1, -1, -1):
+            op = plan[idx]
+            if op["kind"] == "gap":
+                key = (op["src"], 0)
+                K.gap_bwd(dfeat, full(gbuf(op["src"])), accumulate=key in inited)
+                inited.add(key)
+            elif op["kind"] == "pool":
+                c = op["c"]
+                key = (op["src"], 0)
+                my, ms = mask_args(idx, op, c)
+                K.pool_bwd(op["pool"], ChanSlice(grads[op["dst"]], op["dst_c0"], c), argmax.get(op["lid"]),
+                           full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=key in inited,
+                           mask_y=my, mask_scale=ms)
+                inited.add(key)
             else:
-                _, lid, src, dst, c0, cin, cout, k, s, p = op
-                conv = getattr(self, lid)
-                g = ChanSlice(grads[dst], c0, cout)
-                if dst not in masked:
-                    K.relu_bn_bwd(g, ChanSlice(acts[dst], c0, cout), folds[lid])
-                wo, wn, bo, bn = lay[lid]
-                dw = flat[wo:wo + wn].view_as(conv.weight)
+                cout, cin, k, s, p = op["cout"], op["cin"], op["k"], op["s"], op["p"]
+                lids = op["lids"]
+                g = ChanSlice(grads[op["dst"]], op["dst_c0"], cout)
+                if not is_masked(op["dst"], op["dst_c0"], cout):
+                    K.relu_bn_bwd(g, ChanSlice(acts[op["dst"]], op["dst_c0"], cout),
+                                  tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + cout])
+                wo, wn, bo, bn = lay[lids[0]]
+                if len(lids) == 2:      # fused pair: [wA | wB] and [bA | bB] are contiguous in the flat layout
+                    wo2, wn2, bo2, bn2 = lay[lids[1]]
+                    assert wo2 == wo + wn and bo2 == bo + bn
+                    wn, bn = wn + wn2, bn + bn2
+                    w = wcat[lids[0]]
+                else:
+                    w = getattr(self, lids[0]).weight.detach()
+                dw = flat[wo:wo + wn].view(cout, cin, k, k)
                 db = flat[bo:bo + bn]
-                ho = shapes[dst][1]
+                ho = shapes[op["dst"]][1]
+                hin = shapes[op["src"]][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
-                hin = shapes[src][1]
+                xin = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
                 if use_side:
                     ready = torch.cuda.Event()
                     ready.record(main)            # the output gradient of this layer is final here
                     side.wait_event(ready)
                     with torch.cuda.stream(side):
-                        self._timed("conv_wgrad", lid, flops,
-                                    lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws, wcfg))
+                        self._timed("conv_wgrad", lids[0], flops,
+                                    lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg))
                 else:
-                    self._timed("conv_wgrad", lid, flops,
-                                lambda: K.conv_wgrad(g, full(acts[src]), dw, db, k, s, p, ws, wcfg))
-                if src != "data":
-                    wt = K.pack_weights(conv.weight.detach(), True)
-                    acc_flag = src in inited
-                    my, ms = mask_args(idx, src, True)
-                    self._timed("conv_dgrad", lid, flops,
-                                lambda: K.conv_dgrad(g, wt, full(gbuf(src)), k, s, p, accumulate=acc_flag,
+                    self._timed("conv_wgrad", lids[0], flops, lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg))
+                if op["src"] != "data":
+                    wt = K.pack_weights(w, True)
+                    key = src_key(op)
+                    acc_flag = key in inited
+                    my, ms = mask_args(idx, op, cin)
+                    dx = ChanSlice(gbuf(op["src"]), op["src_c0"], cin)
+                    self._timed("conv_dgrad", lids[0], flops,
+                                lambda: K.conv_dgrad(g, wt, dx, k, s, p, accumulate=acc_flag,
                                                      tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin),
                                                      mask_y=my, mask_scale=ms))
-                    inited.add(src)
-                if self.grad_ready_hook is not None and (lid.endswith("_1x1") or lid == self._conv_ids[0]
-                                                         or lid == "inception_3c_3x3_reduce"
-                                                         or lid == "inception_4e_3x3_reduce"):
+                    inited.add(key)
+                closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
+                                or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
+                if self.grad_ready_hook is not None and closes_block:
                     # the first conv of a block (forward order) closes that block's contiguous range
                     if use_side:
                         main.wait_stream(side)    # the block's wgrads must have landed before the all-reduce

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import action_detection_amd as pkg  # noqa: E402
 from action_detection_amd import kernels as K  # noqa: E402
-from action_detection_amd.bninception_spec import build_manifest  # noqa: E402
+from action_detection_amd.bninception import BNInception  # noqa: E402
 
 pkg.build()
 dev = torch.device("cuda:0")
@@ -22,11 +22,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
 out_path = os.path.join(ROOT, "action-detection_amd", "tuned_tiles.json")
 shapes = {}
 for cin0 in (3, 10):
-    ops, t = build_manifest(cin0, 224)
-    for op in ops:
-        if op[0] == "conv":
-            _, lid, src, dst, c0, cin, cout, k, s, p = op
-            shapes[(cin, cout, k, s, p, t[src][1], t[dst][1])] = lid
+    # the executor's launch plan (fused reduce convolutions included), not the raw manifest
+    plan, t = BNInception(in_channels=cin0)._plan(torch.zeros(1, cin0, 224, 224))
+    for op in plan:
+        if op["kind"] == "conv":
+            shapes[(op["cin"], op["cout"], op["k"], op["s"], op["p"], t[op["src"]][1], t[op["dst"]][1])] = \
+                "+".join(op["lids"])
 
 
 def timeit(fn, reps=3):

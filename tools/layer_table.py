@@ -16,12 +16,11 @@ m = SSN(20, 2, 5, 2, "RGB", dropout=0.8, stpp_cfg=(1, 1, 1))
 init_backbone_synthetic(m.base_model)
 m.to(dev).train()
 x = make_batch(v, "RGB", 20, seed=0)[0].to(dev).reshape(-1, 3, 224, 224)
-ops, shapes = build_manifest(3, 224)
+plan, shapes = m.base_model._plan(x[:1])
 info = {}
-for op in ops:
-    if op[0] == "conv":
-        _, lid, src, dst, c0, cin, cout, k, s, p = op
-        info[lid] = (cin, cout, k, s, shapes[src][1], shapes[dst][1])
+for op in plan:
+    if op["kind"] == "conv":
+        info[op["lids"][0]] = (op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1], shapes[op["dst"]][1])
 def run():
     f = m.base_model.features(x)
     f.sum().backward()
