@@ -194,10 +194,23 @@ def main():
             gemm_ms = sum(fam[k][1] for k in ("conv_fwd", "conv_dgrad") if k in fam)
             gemm_n = sum(fam[k][2] for k in ("conv_fwd", "conv_dgrad") if k in fam)
             achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+            # HBM bytes per launch of the same kernel family from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
+            # raw; see profiles/README.md for the read-side calibration caveat); null if the summary is absent
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+                    pm = json.load(f)
+                fam_p = [pm[k] for k in ("conv_igemm_kernel_fwd", "conv_igemm_kernel_dgrad")]
+                nl = sum(x["launches"] for x in fam_p)
+                traffic = round(sum((x["fetch_bytes_per_launch_raw"] + x["write_bytes_per_launch"]) * x["launches"]
+                                    for x in fam_p) / nl)
+            except (OSError, KeyError, ValueError):
+                pass
             result["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm_kernel (f32 MFMA implicit GEMM; fwd + dgrad launches)",
                 "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes/launch, rocprofv3 PMC FETCH_SIZE+WRITE_SIZE (profiles/r1_pmc_summary.json)",
                 "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2), "launches": gemm_n,
                 "algorithmic_gflop_per_launch": round(gemm_fl / gemm_n / 1e9, 4),
             }
