@@ -31,7 +31,7 @@ _SIGS = {
     "ssn_conv_bn_relu_fwd": "pppppiiiiliiiliiiiip",
     "ssn_bn_fold": "pppppfppip",
     "ssn_relu_bn_bwd": "pppiiillp",
-    "ssn_conv_dgrad": "pppiiiiliiiliiiiplpip",
+    "ssn_conv_dgrad": "pppiiiiliiiliiiiplpiip",
     "ssn_conv_pack_weights": "ppiiiip",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
@@ -61,7 +61,8 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
-                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_debug_flags"])
+                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_debug_flags",
+                                "ssn_conv_dgrad_layout"])
 
 
 class SsnLibrary:

@@ -396,7 +396,9 @@ class BNInception(nn.Module):
                 else:
                     self._timed("conv_wgrad", lids[0], flops, lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg))
                 if op["src"] != "data":
-                    wt = K.pack_weights(w, True)
+                    hsrc = shapes[op["src"]][1]
+                    layout = K.dgrad_layout(k, s, p, hsrc, hsrc)
+                    wt = K.pack_weights(w, layout)
                     key = src_key(op)
                     acc_flag = key in inited
                     my, ms = mask_args(idx, op, cin)
@@ -404,7 +406,7 @@ class BNInception(nn.Module):
                     self._timed("conv_dgrad", lids[0], flops,
                                 lambda: K.conv_dgrad(g, wt, dx, k, s, p, accumulate=acc_flag,
                                                      tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin),
-                                                     mask_y=my, mask_scale=ms))
+                                                     mask_y=my, mask_scale=ms, wt_layout=layout))
                     inited.add(key)
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))

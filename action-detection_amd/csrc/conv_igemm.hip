@@ -66,6 +66,8 @@ struct ConvArgs {
     long mask_img_stride;
     int n_ptiles, n_mtiles, nslab;
     int dbg;             // ablation switches for tools/ablate_conv.py (0 in production)
+    int par;             // stride-2 dgrad: parity-major pixel order + tap-major slab rows (see below)
+    FastDiv div_nq, div_q, div_wh;  // N*(H/2)*(W/2), (H/2)*(W/2), W/2 of the enumerated grid (parity-major decode)
     uint32_t x_bytes, a_bytes;  // extents of the gather source / packed weights (buffer descriptors)
     FastDiv div_hw, div_w, div_mt;
 };
@@ -78,6 +80,36 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 // Out-of-range marker: extents are < 2^31 (checked on the host) and the per-slab scalar offset is added
 // by the hardware in 32 bits, so 0x80000000 + soffset stays >= num_records for every slab.
 constexpr uint32_t OOB = 0x80000000u;
+
+// ---- stride-2 dgrad without the 4x zero-feed ------------------------------------------------------------
+// For a 3x3 / stride-2 / pad-1 convolution an input pixel (hi, wi) only receives taps with r = hi+1 (mod 2),
+// s = wi+1 (mod 2): 1, 2, 2 or 4 of the 9 taps depending on its parity class (hi&1, wi&1).  In PAR mode the
+// pixels are enumerated class by class (n, class, hi/2, wi/2) so that a tile is (almost) single-class, and the
+// slab rows are tap-major with the taps grouped by class -- slot order 4 | 3 5 | 1 7 | 0 2 6 8 -- so the live
+// MFMA steps of class 00 / 01 / 10 / 11 are the contiguous ranges [0,1) / [1,3) / [3,5) / [5,9): a tile runs
+// only the steps of the classes it touches instead of all nine.
+__device__ __forceinline__ int par_tap(int slot) { return (int)((0x862071534ull >> (4 * slot)) & 15); }
+__device__ __forceinline__ int par_lo(int cls) { return (0x5310 >> (4 * cls)) & 15; }
+__device__ __forceinline__ int par_hi(int cls) { return (0x9531 >> (4 * cls)) & 15; }
+
+// flattened pixel index -> image, row, column of the enumerated grid.  Parity mode enumerates the whole batch
+// class by class: p = ((cls * N + n) * H/2 + u) * W/2 + v  with (hi, wi) = (2u + cls/2, 2v + cls%2), so only the
+// three tiles that contain a class boundary mix classes.
+__device__ __forceinline__ void decode_pixel(const ConvArgs& p, bool par, uint32_t pp, uint32_t& n, uint32_t& h,
+                                             uint32_t& w) {
+    if (par) {
+        uint32_t cls, rem, r2, u, v;
+        fd_divmod(pp, p.div_nq, cls, rem);
+        fd_divmod(rem, p.div_q, n, r2);
+        fd_divmod(r2, p.div_wh, u, v);
+        h = 2 * u + (cls >> 1);
+        w = 2 * v + (cls & 1);
+    } else {
+        uint32_t rem;
+        fd_divmod(pp, p.div_hw, n, rem);
+        fd_divmod(rem, p.div_w, h, w);
+    }
+}
 
 template <int KS, int S, int MODE, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
@@ -93,6 +125,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     constexpr int NA = (A_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BN >= 64 && BN <= 256 && (256 % BN) == 0, "a wave must gather whole rows: BN in {64,128,256}");
+    constexpr bool PAR = (MODE == MODE_DGRAD) && (S == 2) && (KS == 3);   // parity mode is possible at all
 
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM * APITCH + BROWS * BN)];
     float* As0 = lds;
@@ -111,6 +144,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int m0 = (int)mtile * BM;
     const int p0 = (int)ptile * BN;
 
+    // ---- live MFMA steps of this tile (all of them unless parity mode narrows the range) ----
+    int t_lo = 0, t_hi = SL::T;
+    if (PAR && p.par) {
+        const uint32_t first = (uint32_t)p0;
+        uint32_t last = (uint32_t)(p0 + BN - 1);
+        if (last > (uint32_t)(p.P - 1)) last = (uint32_t)(p.P - 1);
+        // classes are visited in order, so the union of the step ranges of the touched classes is contiguous
+        t_lo = par_lo((int)fd_div(first, p.div_nq));
+        t_hi = par_hi((int)fd_div(last, p.div_nq));
+    }
+
     // ---- loop-invariant gather offsets of this thread's pixel column ----
     const int gcol = tid % BN;
     const int gk0 = wave_uniform(tid / BN);
@@ -118,16 +162,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     {
         const int gp = p0 + gcol;
         const bool gvalid = gp < p.P;
-        uint32_t n, hw, ho, wo;
-        fd_divmod((uint32_t)(gvalid ? gp : 0), p.div_hw, n, hw);
-        fd_divmod(hw, p.div_w, ho, wo);
+        uint32_t n, ho, wo;
+        decode_pixel(p, PAR && p.par, (uint32_t)(gvalid ? gp : 0), n, ho, wo);
         const uint32_t gbase = (uint32_t)((long)n * p.x_img_stride * 4);
         const int HW = p.H * p.W;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int row = gk0 + KSTEP * i;   // wave-uniform
-            const int cl = row / SL::KK;
-            const int tap = row - cl * SL::KK;
+            int cl = row / SL::KK;
+            int tap = row - cl * SL::KK;
+            if (PAR && p.par && row < SL::ROWS) {   // tap-major rows, taps grouped by parity class
+                cl = row % SL::CPS;
+                tap = par_tap(row / SL::CPS);
+            }
             const int r = tap / KS, s = tap - r * KS;
             int hi, wi;
             bool ok = gvalid && (row < SL::ROWS);
@@ -170,7 +217,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     auto load_slab = [&](uint32_t xso, uint32_t aso, int c_left) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int cl = (gk0 + KSTEP * i) / SL::KK;
+            const int row = gk0 + KSTEP * i;
+            const int cl = (PAR && p.par) ? row % SL::CPS : row / SL::KK;
             const uint32_t vo = (cl < c_left) ? voff[i] : OOB;
             breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo, xso, 0));
         }
@@ -249,7 +297,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             if (q + 1 < NQ) load_group(q + 1, cur ^ 1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                if (4 * q + s < T) {
+                if (4 * q + s < T && (!PAR || (4 * q + s >= t_lo && 4 * q + s < t_hi))) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -270,7 +318,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         const int pp = p0 + (wn * TN + j) * 32 + li;
         if (pp >= p.P) continue;
         uint32_t n, hw;
-        fd_divmod((uint32_t)pp, p.div_hw, n, hw);
+        if (PAR && p.par) {
+            uint32_t eh, ew;
+            decode_pixel(p, true, (uint32_t)pp, n, eh, ew);
+            hw = eh * (uint32_t)p.Wo + ew;
+        } else {
+            fd_divmod((uint32_t)pp, p.div_hw, n, hw);
+        }
         float* yb = p.y + (long)n * p.y_img_stride + hw;
         const float* mb = p.mask_y ? p.mask_y + (long)n * p.mask_img_stride + hw : nullptr;
 #pragma unroll
@@ -299,6 +353,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 // Ap[slab][m][h*HP + t] = A[m][c = slab*CPS + cl][tap], (cl, tap) = decode(k = 2t + h); zero padded.
 //   transposed == 0 (forward operand):  A[m][c][tap] = w[m][c][tap]          (w is [M][C][KK])
 //   transposed == 1 (dgrad operand):    A[m][c][tap] = w[c][m][tap]          (w is [C][M][KK])
+//   transposed == 2 (3x3 only): as 1, with the parity-mode row order of the stride-2 dgrad (see par_tap)
 template <int KS>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float* ap, int M, int C, int nslab,
                                                            int transposed) {
@@ -313,7 +368,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float
         const int k = 2 * t + h;
         float v = 0.f;
         if (t < SL::T && k < SL::ROWS) {
-            const int cl = k / SL::KK, tap = k - cl * SL::KK;
+            int cl = k / SL::KK, tap = k - cl * SL::KK;
+            if (transposed == 2) {   // stride-2 dgrad operand: tap-major rows, taps grouped by parity class
+                cl = k % SL::CPS;
+                tap = par_tap(k / SL::CPS);
+            }
             const int c = slab * SL::CPS + cl;
             if (c < C) v = transposed ? w[((long)c * M + m) * SL::KK + tap] : w[((long)m * C + c) * SL::KK + tap];
         }
@@ -402,6 +461,8 @@ extern "C" int ssn_conv_pack_weights(const float* w, float* packed, int Cout, in
                                      hipStream_t stream) {
     SSN_CHECK_ARG(w && packed, "conv pack: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 7, "conv pack: ksize %d unsupported", ksize);
+    SSN_CHECK_ARG(transposed == 0 || transposed == 1 || (transposed == 2 && ksize == 3), "conv pack: bad layout %d",
+                  transposed);
     const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
     const int nslab = slab_count(C, ksize);
     const long total = (long)nslab * M * packed_row(ksize);
@@ -453,6 +514,10 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
     a.mask_img_stride = 0;
     a.nslab = slab_count(Cin, ksize);
     a.dbg = g_conv_debug;
+    a.par = 0;
+    a.div_nq = make_fastdiv(1);
+    a.div_q = make_fastdiv(1);
+    a.div_wh = make_fastdiv(1);
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
     const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
@@ -469,6 +534,12 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
     return SSN_ERR_ARG;
 }
 
+// Which packed-weight layout ssn_conv_dgrad wants for this conv: 2 (parity mode) for 3x3 / stride-2 / pad-1 with an
+// even input size, else 1.  Pass the result to ssn_conv_pack_weights(transposed=...) and to ssn_conv_dgrad.
+extern "C" int ssn_conv_dgrad_layout(int ksize, int stride, int pad, int H, int W) {
+    return (ksize == 3 && stride == 2 && pad == 1 && (H % 2) == 0 && (W % 2) == 0) ? 2 : 1;
+}
+
 // dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S]
 // wt_packed = ssn_conv_pack_weights(w, ..., transposed = 1)
 // mask_y / mask_scale (optional): when this launch is the LAST writer of dx, apply the backward of the ReLU +
@@ -477,7 +548,7 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
 extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                               long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize,
                               int stride, int pad, int accumulate, const float* mask_y, long mask_img_stride,
-                              const float* mask_scale, int tile_cfg, hipStream_t stream) {
+                              const float* mask_scale, int wt_layout, int tile_cfg, hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv dgrad: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv dgrad: stride %d unsupported", stride);
@@ -505,6 +576,13 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx
     a.mask_img_stride = mask_img_stride;
     a.nslab = slab_count(Cout, ksize);
     a.dbg = g_conv_debug;
+    a.par = (wt_layout == 2);
+    SSN_CHECK_ARG(wt_layout == 1 || wt_layout == 2, "conv dgrad: wt_layout must be 1 or 2");
+    SSN_CHECK_ARG(!a.par || ssn_conv_dgrad_layout(ksize, stride, pad, H, W) == 2,
+                  "conv dgrad: parity layout needs a 3x3 / stride-2 / pad-1 conv with even input size");
+    a.div_nq = make_fastdiv(a.par ? (uint32_t)(N * (H / 2) * (W / 2)) : 1u);
+    a.div_q = make_fastdiv(a.par ? (uint32_t)((H / 2) * (W / 2)) : 1u);
+    a.div_wh = make_fastdiv(a.par ? (uint32_t)(W / 2) : 1u);
     a.div_hw = make_fastdiv((uint32_t)(H * W));
     a.div_w = make_fastdiv((uint32_t)W);
     const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4;

@@ -73,13 +73,19 @@ def bn_fold(conv_bias, gamma, beta, mean, var, eps, scale, shift):
 
 
 def packed_floats(cout, cin, ksize, transposed):
-    return int(_lib.get_lib().cdll.ssn_conv_packed_floats(cout, cin, ksize, int(transposed)))
+    return int(_lib.get_lib().cdll.ssn_conv_packed_floats(cout, cin, ksize, int(bool(transposed))))
+
+
+def dgrad_layout(ksize, stride, pad, h, w):
+    """Packed-weight layout ssn_conv_dgrad wants for this conv (2 = parity-ordered stride-2 path, else 1)."""
+    return int(_lib.get_lib().cdll.ssn_conv_dgrad_layout(ksize, stride, pad, h, w))
 
 
 def pack_weights(w, transposed, out=None):
     """Re-lay a torch-layout weight [Cout, Cin, k, k] into the slab/lane-half order the conv kernels read.
 
-    transposed=False -> forward operand, True -> dgrad operand.
+    transposed=False/0 -> forward operand, True/1 -> dgrad operand, 2 -> parity-ordered stride-2 dgrad operand
+    (use dgrad_layout() to choose between 1 and 2).
     """
     lib = _check(w, out)
     cout, cin, k, _ = w.shape
@@ -110,7 +116,7 @@ def relu_bn_bwd(dy, y, scale):
              _stream(lib, scale))
 
 
-def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
+def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None, wt_layout=1):
     """dy: ChanSlice (grad of conv output), dx: ChanSlice (grad of conv input), wt: pack_weights(w, True).
 
     mask_y (ChanSlice like dx) + mask_scale [dx.c]: fuse the ReLU+frozen-BN backward of dx's tensor into the store.
@@ -121,7 +127,8 @@ def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1, mask_y=N
     h, w = dx.hw
     lib.call("ssn_conv_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, ksize, stride, pad, int(accumulate), _p(mask_y),
-             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), tile_cfg, _stream(lib, wt))
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), int(wt_layout), tile_cfg,
+             _stream(lib, wt))
 
 
 def wgrad_workspace_bytes(n, cin, cout, ho, wo, ksize, tile_cfg=-1):

@@ -37,7 +37,8 @@ int ssn_abi_version(void);
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
  * descriptors): w is the torch-layout [Cout][Cin][k][k] weight; `packed` receives
- * ssn_conv_packed_floats() floats.  transposed=0 -> operand of the forward conv, 1 -> of dgrad. */
+ * ssn_conv_packed_floats() floats.  transposed=0 -> operand of the forward conv, 1 -> of dgrad,
+ * 2 -> of the parity-ordered stride-2 dgrad (see ssn_conv_dgrad_layout). */
 long ssn_conv_packed_floats(int Cout, int Cin, int ksize, int transposed);
 int ssn_conv_pack_weights(const float* w, float* packed, int Cout, int Cin, int ksize, int transposed,
                           hipStream_t stream);
@@ -67,11 +68,14 @@ int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C,
  * dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S].
  * mask_y / mask_scale (optional, both or neither): when this call is the last writer of dx, the
  * backward of the ReLU + frozen BN that produced the tensor dx belongs to is fused into the store:
- * dx <- dx * (mask_y > 0) * mask_scale[ci]   (mask_scale[ci] < 0: not a ReLU output, dx <- dx * |scale|). */
+ * dx <- dx * (mask_y > 0) * mask_scale[ci]   (mask_scale[ci] < 0: not a ReLU output, dx <- dx * |scale|).
+ * wt_layout = ssn_conv_dgrad_layout(...): 2 selects the parity-ordered stride-2 path (3x3/s2/p1, even input),
+ * whose weights must have been packed with transposed = 2; otherwise 1. */
+int ssn_conv_dgrad_layout(int ksize, int stride, int pad, int H, int W);
 int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                    long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int stride,
                    int pad, int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                   int tile_cfg, hipStream_t stream);
+                   int wt_layout, int tile_cfg, hipStream_t stream);
 
 /* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
  * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */

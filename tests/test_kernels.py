@@ -71,12 +71,13 @@ def test_conv_dgrad_and_wgrad(backend):
         ho = y.shape[2]
         gd, xd, wd = backend.put(gy), backend.put(x.detach()), backend.put(w.detach())
         if k != 7:
-            wt = K.pack_weights(wd, True)
-            dx = backend.put(torch.full(x.shape, 0.5))
-            K.conv_dgrad(K.full(gd), wt, K.full(dx), k, s, p, True, tile)
-            assert rel_err(dx.cpu() - 0.5, x.grad) < 5e-5, ("dgrad", n, cin, h, cout, k, s)
-            K.conv_dgrad(K.full(gd), wt, K.full(dx), k, s, p, False, tile)
-            assert rel_err(dx, x.grad) < 5e-5
+            for layout in sorted({1, K.dgrad_layout(k, s, p, h, h)}):   # plain and (where it applies) parity mode
+                wt = K.pack_weights(wd, layout)
+                dx = backend.put(torch.full(x.shape, 0.5))
+                K.conv_dgrad(K.full(gd), wt, K.full(dx), k, s, p, True, tile, wt_layout=layout)
+                assert rel_err(dx.cpu() - 0.5, x.grad) < 5e-5, ("dgrad", n, cin, h, cout, k, s, layout)
+                K.conv_dgrad(K.full(gd), wt, K.full(dx), k, s, p, False, tile, wt_layout=layout)
+                assert rel_err(dx, x.grad) < 5e-5
         ws = backend.put(torch.empty(K.wgrad_workspace_bytes(n, cin, cout, ho, ho, k) // 4))
         dw, db = backend.put(torch.empty(w.shape)), backend.put(torch.empty(cout))
         K.conv_wgrad(K.full(gd), K.full(xd), dw, db, k, s, p, ws)

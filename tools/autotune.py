@@ -52,7 +52,8 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     y = torch.empty(n, cout, ho, ho, device=dev)
     g = torch.randn(n, cout, ho, ho, device=dev)
     scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-    wt = K.pack_weights(w, True)
+    lay = K.dgrad_layout(k, s, p, hi, hi)
+    wt = K.pack_weights(w, lay)
     wp = K.pack_weights(w, False)
     dx = torch.empty_like(x)
     dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
@@ -66,7 +67,7 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
             if kind == "fwd":
                 fn = lambda: K.conv_fwd(K.full(x), wp, scale, shift, K.full(y), k, s, p, True, cfg)
             elif kind == "dgrad":
-                fn = lambda: K.conv_dgrad(K.full(g), wt, K.full(dx), k, s, p, False, cfg)
+                fn = lambda: K.conv_dgrad(K.full(g), wt, K.full(dx), k, s, p, False, cfg, wt_layout=lay)
             else:
                 ws = torch.empty(K.wgrad_workspace_bytes(n, cin, cout, ho, ho, k, cfg) // 4, device=dev)
                 fn = lambda: K.conv_wgrad(K.full(g), K.full(x), dw, db, k, s, p, ws, cfg)
