@@ -33,6 +33,7 @@ _SIGS = {
     "ssn_relu_bn_bwd": "pppiiillp",
     "ssn_conv_dgrad": "pppiiiiliiiliiiiplpiip",
     "ssn_conv_pack_weights": "ppiiiip",
+    "ssn_conv_pack_weights_multi": "ippppppppp",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
     "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
@@ -54,6 +55,8 @@ _SIGS = {
     "ssn_cw_smoothl1_fwd": "pppppiip",
     "ssn_cw_smoothl1_bwd": "ppppiip",
     "ssn_sgd_step": "ppplffffip",
+    "ssn_sgd_step_multi": "ippppppffip",
+    "ssn_bn_fold_multi": "ipppppppppp",
     "ssn_sumsq": "plpipp",
     "ssn_scale": "plpfp",
 }

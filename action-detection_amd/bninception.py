@@ -239,23 +239,38 @@ class BNInception(nn.Module):
                 tscale[name] = torch.full((shapes[name][0],), -1.0, device=dev, dtype=torch.float32)
             return tscale[name][c0:c0 + c]
 
+        # frozen-BN folding of all 69 layers in two launches (scale into the per-tensor vectors, shift into one
+        # flat buffer the conv epilogues read slices of)
+        shift_flat = torch.empty(sum(op["cout"] for op in plan if op["kind"] == "conv"), device=dev,
+                                 dtype=torch.float32)
+        fold = ([], [], [], [], [], [], [], [])
+        shift_of = {}
+        soff = 0
+        for op in plan:
+            if op["kind"] != "conv":
+                continue
+            shift_of[op["lids"][0]] = shift_flat[soff:soff + op["cout"]]
+            off = 0
+            for lid, c in zip(op["lids"], op["couts"]):
+                conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
+                for lst, v in zip(fold, (conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                         bn.running_var, bn.eps, scale_slice(op["dst"], op["dst_c0"] + off, c),
+                                         shift_flat[soff + off:soff + off + c])):
+                    lst.append(v)
+                off += c
+            soff += op["cout"]
+        K.bn_fold_multi(*fold)
+        # all forward weight operands in two launches (fused pairs read both sources directly: no concatenation)
+        conv_ops = [op for op in plan if op["kind"] == "conv"]
+        packed_fwd = dict(zip((op["lids"][0] for op in conv_ops), K.pack_weights_multi(
+            [([getattr(self, lid).weight.detach() for lid in op["lids"]], 0) for op in conv_ops])))
+
         feat = None
         for i, op in enumerate(plan):
             if op["kind"] == "conv":
                 cout, cin, k, s, p = op["cout"], op["cin"], op["k"], op["s"], op["p"]
-                shift = torch.empty(cout, device=dev, dtype=torch.float32)
-                off = 0
-                ws = []
-                for lid, c in zip(op["lids"], op["couts"]):
-                    conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
-                    K.bn_fold(conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                              bn.running_var, bn.eps, scale_slice(op["dst"], op["dst_c0"] + off, c),
-                              shift[off:off + c])
-                    ws.append(conv.weight.detach())
-                    off += c
-                w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)   # fused pair: concatenated output channels
-                if keep and len(ws) > 1:
-                    wcat[op["lids"][0]] = w
+                shift = shift_of[op["lids"][0]]
+                wp = packed_fwd[op["lids"][0]]
                 scale = scale_slice(op["dst"], op["dst_c0"], cout)
                 ho = shapes[op["dst"]][1]
                 hin = shapes[op["src"]][1]
@@ -263,7 +278,7 @@ class BNInception(nn.Module):
                 src_slice = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 dst_slice = ChanSlice(get(op["dst"]), op["dst_c0"], cout)
                 self._timed("conv_fwd", op["lids"][0], flops,
-                            lambda: K.conv_fwd(src_slice, K.pack_weights(w, False), scale, shift, dst_slice, k, s, p,
+                            lambda: K.conv_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
                                                True, tuned_tile("fwd", n, cin, cout, k, s, hin)))
             elif op["kind"] == "pool":
                 c = op["c"]
@@ -312,6 +327,13 @@ class BNInception(nn.Module):
                     n, op["cin"], op["cout"], shapes[op["dst"]][1], shapes[op["dst"]][2], op["k"],
                     tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
         ws = self._workspace(ws_bytes, dev)
+        # all dgrad weight operands in two launches
+        dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
+        dg_layout = {op["lids"][0]: K.dgrad_layout(op["k"], op["s"], op["p"], shapes[op["src"]][1],
+                                                   shapes[op["src"]][2]) for op in dg_ops}
+        packed_dg = dict(zip((op["lids"][0] for op in dg_ops), K.pack_weights_multi(
+            [([getattr(self, lid).weight.detach() for lid in op["lids"]], dg_layout[op["lids"][0]])
+             for op in dg_ops])))
 
         # The backward of ReLU + frozen BN (dy <- dy * (y > 0) * scale) is fused into the store of whichever
         # launch writes a gradient slice LAST (conv dgrad or pool backward); only slices whose last writer
@@ -376,9 +398,6 @@ class BNInception(nn.Module):
                     wo2, wn2, bo2, bn2 = lay[lids[1]]
                     assert wo2 == wo + wn and bo2 == bo + bn
                     wn, bn = wn + wn2, bn + bn2
-                    w = wcat[lids[0]]
-                else:
-                    w = getattr(self, lids[0]).weight.detach()
                 dw = flat[wo:wo + wn].view(cout, cin, k, k)
                 db = flat[bo:bo + bn]
                 ho = shapes[op["dst"]][1]
@@ -396,9 +415,8 @@ class BNInception(nn.Module):
                 else:
                     self._timed("conv_wgrad", lids[0], flops, lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg))
                 if op["src"] != "data":
-                    hsrc = shapes[op["src"]][1]
-                    layout = K.dgrad_layout(k, s, p, hsrc, hsrc)
-                    wt = K.pack_weights(w, layout)
+                    layout = dg_layout[lids[0]]
+                    wt = packed_dg[lids[0]]
                     key = src_key(op)
                     acc_flag = key in inited
                     my, ms = mask_args(idx, op, cin)

@@ -380,6 +380,66 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* w, float
     }
 }
 
+// ---- table-driven packing of many layers in one launch (the per-layer pack launches are ~4 us each, ~120
+// per training step).  An entry may name two sources: the fused pair of 1x1 reduce convolutions is packed as
+// one operand whose output-channel index co < split comes from w0 and the rest from w1.
+constexpr int PK_MAX = 40;
+constexpr int PK_CHUNK = 8192;
+struct PackTable {
+    const float* w0[PK_MAX];
+    const float* w1[PK_MAX];
+    float* out[PK_MAX];
+    int cout[PK_MAX], cin[PK_MAX], ks[PK_MAX], mode[PK_MAX], split[PK_MAX];
+    int blk0[PK_MAX + 1];
+    int count;
+};
+template <int KS>
+__device__ __forceinline__ void pack_entry(const PackTable& t, int ti, long base) {
+    using SL = Slab<KS>;
+    const int mode = t.mode[ti];
+    const int Cout = t.cout[ti], Cin = t.cin[ti];
+    const int M = mode ? Cin : Cout, C = mode ? Cout : Cin;
+    const int nslab = (C + SL::CPS - 1) / SL::CPS;
+    const long total = (long)nslab * M * SL::AP;
+    long end = base + PK_CHUNK;
+    if (end > total) end = total;
+    for (long idx = base + threadIdx.x; idx < end; idx += 256) {
+        const int e = (int)(idx % SL::AP);
+        const long sm = idx / SL::AP;
+        const int m = (int)(sm % M);
+        const int slab = (int)(sm / M);
+        const int h = e / SL::HP, tt = e - h * SL::HP;
+        const int k = 2 * tt + h;
+        float v = 0.f;
+        if (tt < SL::T && k < SL::ROWS) {
+            int cl = k / SL::KK, tap = k - cl * SL::KK;
+            if (mode == 2) {
+                cl = k % SL::CPS;
+                tap = par_tap(k / SL::CPS);
+            }
+            const int c = slab * SL::CPS + cl;
+            if (c < C) {
+                const int co = mode ? c : m, ci = mode ? m : c;
+                const float* src = co < t.split[ti] ? t.w0[ti] : t.w1[ti];
+                const int cor = co < t.split[ti] ? co : co - t.split[ti];
+                v = src[((long)cor * Cin + ci) * SL::KK + tap];
+            }
+        }
+        t.out[ti][idx] = v;
+    }
+}
+__global__ __launch_bounds__(256) void pack_multi_kernel(PackTable t) {
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;
+    const long base = (long)((int)blockIdx.x - t.blk0[ti]) * PK_CHUNK;
+    if (t.ks[ti] == 1)
+        pack_entry<1>(t, ti, base);
+    else if (t.ks[ti] == 3)
+        pack_entry<3>(t, ti, base);
+    else
+        pack_entry<7>(t, ti, base);
+}
+
 template <int KS, int S, int MODE, int WM, int WN, int TM, int TN>
 int launch_cfg(ConvArgs& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
@@ -479,6 +539,44 @@ extern "C" int ssn_conv_pack_weights(const float* w, float* packed, int Cout, in
         hipLaunchKernelGGL(pack_weights_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, stream, w, packed, M, C, nslab,
                            transposed);
     SSN_CHECK_LAUNCH("conv_pack_weights");
+    return SSN_OK;
+}
+
+// Pack `count` layers in ceil(count / 40) launches.  All arguments are HOST arrays with one entry per layer:
+// w0 / w1 device pointers of the torch-layout weights ([cout][cin][k][k]; w1 = second source of a fused pair
+// holding output channels >= split, or NULL with split = cout), out = device destination of
+// ssn_conv_packed_floats() floats, mode as `transposed` of ssn_conv_pack_weights.
+extern "C" int ssn_conv_pack_weights_multi(int count, const float* const* w0, const float* const* w1,
+                                           float* const* out, const int* cout, const int* cin, const int* ksize,
+                                           const int* mode, const int* split, hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (w0 && w1 && out && cout && cin && ksize && mode && split)),
+                  "conv pack multi: bad arguments");
+    for (int base = 0; base < count; base += PK_MAX) {
+        PackTable t;
+        t.count = count - base < PK_MAX ? count - base : PK_MAX;
+        int blocks = 0;
+        for (int i = 0; i < t.count; ++i) {
+            const int j = base + i;
+            SSN_CHECK_ARG(ksize[j] == 1 || ksize[j] == 3 || ksize[j] == 7, "conv pack multi: ksize %d", ksize[j]);
+            SSN_CHECK_ARG(mode[j] >= 0 && mode[j] <= 2 && (mode[j] != 2 || ksize[j] == 3), "conv pack multi: mode");
+            SSN_CHECK_ARG(w0[j] && out[j] && (w1[j] || split[j] >= cout[j]), "conv pack multi: null pointer");
+            t.w0[i] = w0[j];
+            t.w1[i] = w1[j];
+            t.out[i] = out[j];
+            t.cout[i] = cout[j];
+            t.cin[i] = cin[j];
+            t.ks[i] = ksize[j];
+            t.mode[i] = mode[j];
+            t.split[i] = split[j];
+            t.blk0[i] = blocks;
+            const long total = ssn_conv_packed_floats(cout[j], cin[j], ksize[j], mode[j] ? 1 : 0);
+            blocks += (int)((total + PK_CHUNK - 1) / PK_CHUNK);
+        }
+        t.blk0[t.count] = blocks;
+        if (blocks)
+            hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    }
+    SSN_CHECK_LAUNCH("conv_pack_weights_multi");
     return SSN_OK;
 }
 

@@ -116,6 +116,60 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* w, const float* grad, f
     }
 }
 
+// ---- multi-tensor variants: one launch covers up to MT_MAX small tensors (the per-layer launches of
+// bn_fold / sgd are ~4 us each, 200+ per step).  The tensor table travels by value in the kernel arguments, so
+// nothing has to be staged in device memory and the launch is hipGraph-capturable.
+constexpr int MT_MAX = 48;
+struct SgdTable {
+    float* w[MT_MAX];
+    const float* g[MT_MAX];
+    float* buf[MT_MAX];
+    int blk0[MT_MAX + 1];   // first block of tensor t (prefix sums; CHUNK elements per block)
+    long n[MT_MAX];
+    float lr[MT_MAX], wd[MT_MAX];
+    int count;
+};
+constexpr int MT_CHUNK = 4096;
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdTable t, float momentum, float grad_scale, int first_step) {
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;   // block-uniform linear search
+    const long base = (long)((int)blockIdx.x - t.blk0[ti]) * MT_CHUNK;
+    float* w = t.w[ti];
+    const float* g = t.g[ti];
+    float* buf = t.buf[ti];
+    const float lr = t.lr[ti], wd = t.wd[ti];
+    long end = base + MT_CHUNK;
+    if (end > t.n[ti]) end = t.n[ti];
+    for (long i = base + threadIdx.x; i < end; i += 256) {
+        const float gg = g[i] * grad_scale + wd * w[i];
+        const float b = first_step ? gg : momentum * buf[i] + gg;
+        buf[i] = b;
+        w[i] = w[i] - lr * b;
+    }
+}
+
+struct FoldTable {
+    const float* bias[MT_MAX];
+    const float* gamma[MT_MAX];
+    const float* beta[MT_MAX];
+    const float* mean[MT_MAX];
+    const float* var[MT_MAX];
+    float* scale[MT_MAX];
+    float* shift[MT_MAX];
+    int c[MT_MAX];
+    float eps[MT_MAX];
+    int count;
+};
+// one block per layer
+__global__ __launch_bounds__(256) void bn_fold_multi_kernel(FoldTable t) {
+    const int ti = blockIdx.x;
+    for (int c = threadIdx.x; c < t.c[ti]; c += 256) {
+        const float s = t.gamma[ti][c] / sqrtf(t.var[ti][c] + t.eps[ti]);
+        t.scale[ti][c] = s;
+        t.shift[ti][c] = ((t.bias[ti] ? t.bias[ti][c] : 0.f) - t.mean[ti][c]) * s + t.beta[ti][c];
+    }
+}
+
 // sum of squares of a flat segment -> one partial per block (deterministic second stage on host side
 // of the ABI: ssn_sumsq reduces partials in a single-block kernel).
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* x, long n, float* partial) {
@@ -193,6 +247,63 @@ extern "C" int ssn_sgd_step(float* w, const float* grad, float* momentum_buf, lo
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, stream, w, grad, momentum_buf, n, lr,
                        momentum, weight_decay, grad_scale, first_step);
     SSN_CHECK_LAUNCH("sgd_step");
+    return SSN_OK;
+}
+
+// Multi-tensor SGD: the same update as ssn_sgd_step for `count` tensors with per-tensor lr / weight decay
+// (host arrays of device pointers); ceil(count / 48) launches.
+extern "C" int ssn_sgd_step_multi(int count, float* const* w, const float* const* grad, float* const* momentum_buf,
+                                  const long* n, const float* lr, const float* weight_decay, float momentum,
+                                  float grad_scale, int first_step, hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (w && grad && momentum_buf && n && lr && weight_decay)),
+                  "sgd_step_multi: bad arguments");
+    for (int base = 0; base < count; base += MT_MAX) {
+        SgdTable t;
+        t.count = count - base < MT_MAX ? count - base : MT_MAX;
+        int blocks = 0;
+        for (int i = 0; i < t.count; ++i) {
+            t.w[i] = w[base + i];
+            t.g[i] = grad[base + i];
+            t.buf[i] = momentum_buf[base + i];
+            t.n[i] = n[base + i];
+            t.lr[i] = lr[base + i];
+            t.wd[i] = weight_decay[base + i];
+            t.blk0[i] = blocks;
+            blocks += (int)((n[base + i] + MT_CHUNK - 1) / MT_CHUNK);
+        }
+        t.blk0[t.count] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, momentum, grad_scale,
+                           first_step);
+    }
+    SSN_CHECK_LAUNCH("sgd_step_multi");
+    return SSN_OK;
+}
+
+// Multi-tensor ssn_bn_fold: `count` layers in ceil(count / 48) launches (host arrays of device pointers).
+extern "C" int ssn_bn_fold_multi(int count, const float* const* conv_bias, const float* const* gamma,
+                                 const float* const* beta, const float* const* mean, const float* const* var,
+                                 const float* eps, float* const* scale, float* const* shift, const int* channels,
+                                 hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (gamma && beta && mean && var && eps && scale && shift && channels)),
+                  "bn_fold_multi: bad arguments");
+    for (int base = 0; base < count; base += MT_MAX) {
+        FoldTable t;
+        t.count = count - base < MT_MAX ? count - base : MT_MAX;
+        for (int i = 0; i < t.count; ++i) {
+            t.bias[i] = conv_bias ? conv_bias[base + i] : nullptr;
+            t.gamma[i] = gamma[base + i];
+            t.beta[i] = beta[base + i];
+            t.mean[i] = mean[base + i];
+            t.var[i] = var[base + i];
+            t.scale[i] = scale[base + i];
+            t.shift[i] = shift[base + i];
+            t.c[i] = channels[base + i];
+            t.eps[i] = eps[base + i];
+        }
+        hipLaunchKernelGGL(bn_fold_multi_kernel, dim3((unsigned)t.count), dim3(256), 0, stream, t);
+    }
+    SSN_CHECK_LAUNCH("bn_fold_multi");
     return SSN_OK;
 }
 

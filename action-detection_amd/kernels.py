@@ -97,6 +97,38 @@ def pack_weights(w, transposed, out=None):
     return out
 
 
+def pack_weights_multi(entries):
+    """entries: list of (weights, mode) with weights = [w] or [wA, wB] (fused pair, concatenated output channels).
+
+    Returns one packed tensor per entry (views of a single flat buffer); ceil(len / 40) launches in total.
+    """
+    if not entries:
+        return []
+    n = len(entries)
+    lib = _check(*[w for ws, _ in entries for w in ws])
+    first = entries[0][0][0]
+    couts = [sum(w.shape[0] for w in ws) for ws, _ in entries]
+    cins = [ws[0].shape[1] for ws, _ in entries]
+    kss = [ws[0].shape[2] for ws, _ in entries]
+    sizes = [packed_floats(co, ci, k, m) for co, ci, k, (_, m) in zip(couts, cins, kss, entries)]
+    flat = torch.empty(sum(sizes), device=first.device, dtype=torch.float32)
+    outs, off = [], 0
+    for sz in sizes:
+        outs.append(flat[off:off + sz])
+        off += sz
+    w0 = _ptr_array([ws[0] for ws, _ in entries])
+    w1 = _ptr_array([ws[1] if len(ws) > 1 else None for ws, _ in entries])
+    po = _ptr_array(outs)
+    ia = lambda vals: (ctypes.c_int * n)(*[int(v) for v in vals])   # noqa: E731
+    a_cout, a_cin, a_ks = ia(couts), ia(cins), ia(kss)
+    a_mode = ia([m for _, m in entries])
+    a_split = ia([ws[0].shape[0] if len(ws) > 1 else co for (ws, _), co in zip(entries, couts)])
+    lib.call("ssn_conv_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(po),
+             ctypes.addressof(a_cout), ctypes.addressof(a_cin), ctypes.addressof(a_ks), ctypes.addressof(a_mode),
+             ctypes.addressof(a_split), _stream(lib, first))
+    return outs
+
+
 def conv_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
     """x, y: ChanSlice.  w_packed: pack_weights(w, transposed=False)."""
     lib = _check(x, w_packed, scale, shift, y)
@@ -283,6 +315,42 @@ def sgd_step(w, grad, buf, lr, momentum, weight_decay, grad_scale=1.0, first_ste
     lib = _check(w, grad, buf)
     lib.call("ssn_sgd_step", _p(w), _p(grad), _p(buf), w.numel(), float(lr), float(momentum), float(weight_decay),
              float(grad_scale), int(first_step), _stream(lib, w))
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale=1.0, first_step=False):
+    """One fused launch (per 48 tensors) of the SGD update for many parameter tensors."""
+    if not ws:
+        return
+    lib = _check(*ws, *grads, *bufs)
+    n = len(ws)
+    sizes = (ctypes.c_long * n)(*[w.numel() for w in ws])
+    lr = (ctypes.c_float * n)(*[float(v) for v in lrs])
+    wd = (ctypes.c_float * n)(*[float(v) for v in wds])
+    pw, pg, pb = _ptr_array(ws), _ptr_array(grads), _ptr_array(bufs)   # keep the arrays alive across the call
+    lib.call("ssn_sgd_step_multi", n, ctypes.addressof(pw), ctypes.addressof(pg), ctypes.addressof(pb),
+             ctypes.addressof(sizes), ctypes.addressof(lr), ctypes.addressof(wd), float(momentum), float(grad_scale),
+             int(first_step), _stream(lib, ws[0]))
+
+
+def bn_fold_multi(biases, gammas, betas, means, variances, eps, scales, shifts):
+    """ssn_bn_fold for many layers in one launch per 48 layers."""
+    if not gammas:
+        return
+    lib = _check(*gammas, *scales, *shifts)
+    n = len(gammas)
+    e = (ctypes.c_float * n)(*[float(v) for v in eps])
+    c = (ctypes.c_int * n)(*[g.numel() for g in gammas])
+    arrs = [_ptr_array(x) for x in (biases, gammas, betas, means, variances, scales, shifts)]   # kept alive
+    lib.call("ssn_bn_fold_multi", n, ctypes.addressof(arrs[0]), ctypes.addressof(arrs[1]), ctypes.addressof(arrs[2]),
+             ctypes.addressof(arrs[3]), ctypes.addressof(arrs[4]), ctypes.addressof(e), ctypes.addressof(arrs[5]),
+             ctypes.addressof(arrs[6]), ctypes.addressof(c), _stream(lib, gammas[0]))
 
 
 def sumsq(x, out, accumulate, workspace):

@@ -35,6 +35,8 @@ class SSNSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
+        """All parameter tensors in ceil(#tensors / 48) fused launches (ssn_sgd_step_multi)."""
+        batches = {}   # (momentum, first_step) -> lists
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
@@ -44,6 +46,12 @@ class SSNSGD(torch.optim.Optimizer):
                 if first:
                     st["momentum_buffer"] = torch.empty_like(p)
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                K.sgd_step(p.data, grad, st["momentum_buffer"], g["lr"], g["momentum"], g["weight_decay"],
-                           grad_scale, first)
+                b = batches.setdefault((g["momentum"], first), ([], [], [], [], []))
+                b[0].append(p.data)
+                b[1].append(grad)
+                b[2].append(st["momentum_buffer"])
+                b[3].append(g["lr"])
+                b[4].append(g["weight_decay"])
+        for (momentum, first), (ws, grads, bufs, lrs, wds) in batches.items():
+            K.sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale, first)
         return None

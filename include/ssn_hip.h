@@ -43,6 +43,13 @@ long ssn_conv_packed_floats(int Cout, int Cin, int ksize, int transposed);
 int ssn_conv_pack_weights(const float* w, float* packed, int Cout, int Cin, int ksize, int transposed,
                           hipStream_t stream);
 
+/* The same for `count` layers in ceil(count/40) launches; every argument is a HOST array with one entry per
+ * layer.  w1/split describe the optional second source of a fused pair (output channels >= split come from w1);
+ * pass w1 = NULL and split = cout otherwise. */
+int ssn_conv_pack_weights_multi(int count, const float* const* w0, const float* const* w1, float* const* out,
+                                const int* cout, const int* cin, const int* ksize, const int* mode, const int* split,
+                                hipStream_t stream);
+
 /* Replaces cuDNN conv fwd + cudnnBatchNorm(eval) + ReLU of every "conv / bn / relu" triple of
  * model_zoo.BNInception, reached from ssn_models.py:266 (train) and :298 (test).
  * y[n][co][ho][wo] = relu?( scale[co] * sum_{ci,r,s} w[co][ci][r][s] * x[n][ci][ho*S-pad+r][wo*S-pad+s]
@@ -58,6 +65,12 @@ int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const float* sca
  * scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta. */
 int ssn_bn_fold(const float* conv_bias, const float* gamma, const float* beta, const float* mean,
                 const float* var, float eps, float* scale, float* shift, int C, hipStream_t stream);
+
+/* ssn_bn_fold for `count` layers in ceil(count/48) launches; every argument is a HOST array with one entry
+ * per layer (device pointers, eps, channel count). */
+int ssn_bn_fold_multi(int count, const float* const* conv_bias, const float* const* gamma, const float* const* beta,
+                      const float* const* mean, const float* const* var, const float* eps, float* const* scale,
+                      float* const* shift, const int* channels, hipStream_t stream);
 
 /* Backward of ReLU + frozen BN, in place on dy:  dy <- dy * (y > 0) * scale[c]
  * (autograd of the same triples, entered from ssn_train.py:236 loss.backward()). */
@@ -169,6 +182,11 @@ int ssn_cw_smoothl1_bwd(const long* labels, const float* diff, const float* gout
  * per-group lr_mult / decay_mult of ssn_models.py:240-251 are folded into lr / weight_decay. */
 int ssn_sgd_step(float* w, const float* grad, float* momentum_buf, long n, float lr, float momentum,
                  float weight_decay, float grad_scale, int first_step, hipStream_t stream);
+/* The same update for `count` tensors in ceil(count/48) launches; w / grad / momentum_buf / n / lr / weight_decay
+ * are HOST arrays (of device pointers resp. scalars), one entry per tensor. */
+int ssn_sgd_step_multi(int count, float* const* w, const float* const* grad, float* const* momentum_buf,
+                       const long* n, const float* lr, const float* weight_decay, float momentum, float grad_scale,
+                       int first_step, hipStream_t stream);
 /* clip_grad_norm support (ssn_train.py:245-249): out[0] (+)= sum(x^2); workspace >= 1024 floats. */
 int ssn_sumsq(const float* x, long n, float* out, int accumulate, float* workspace, hipStream_t stream);
 int ssn_scale(float* x, long n, const float* coef_dev, float coef, hipStream_t stream);

@@ -277,3 +277,44 @@ def test_fused_relu_bn_backward_epilogues(backend):
     K.pool_bwd("max", K.full(backend.put(gp)), am, K.full(dxp), 3, 2, 0, False,
                mask_y=K.full(backend.put(x.detach())), mask_scale=backend.put(scale))
     assert rel_err(dxp, ref) < 1e-6
+
+
+def test_multi_tensor_sgd_and_bn_fold(backend):
+    """The table-driven multi-tensor launches equal their per-tensor counterparts (incl. > 48 tensors)."""
+    g = torch.Generator().manual_seed(11)
+    n_t = 53
+    ws = [torch.randn(int(torch.randint(1, 9000, (1,), generator=g)), generator=g) for _ in range(n_t)]
+    gs = [torch.randn(w.shape, generator=g) for w in ws]
+    lrs = [0.01 * (1 + i % 2) for i in range(n_t)]
+    wds = [5e-4 * (i % 2) for i in range(n_t)]
+    wa, ba = [backend.put(w.clone()) for w in ws], [backend.put(torch.zeros_like(w)) for w in ws]
+    wb, bb = [backend.put(w.clone()) for w in ws], [backend.put(torch.zeros_like(w)) for w in ws]
+    gd = [backend.put(x) for x in gs]
+    for it in range(2):
+        K.sgd_step_multi(wa, gd, ba, lrs, wds, 0.9, 1.0, it == 0)
+        for w, x, b, lr, wd in zip(wb, gd, bb, lrs, wds):
+            K.sgd_step(w, x, b, lr, 0.9, wd, 1.0, it == 0)
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(wa, wb))
+    cs = [8, 33, 64]
+    prm = [[torch.rand(c, generator=g) + 0.5 for c in cs] for _ in range(5)]   # bias gamma beta mean var
+    sa, ha = [backend.put(torch.empty(c)) for c in cs], [backend.put(torch.empty(c)) for c in cs]
+    sb, hb = [backend.put(torch.empty(c)) for c in cs], [backend.put(torch.empty(c)) for c in cs]
+    dev = [[backend.put(t) for t in row] for row in prm]
+    K.bn_fold_multi(dev[0], dev[1], dev[2], dev[3], dev[4], [1e-5] * 3, sa, ha)
+    for i in range(3):
+        K.bn_fold(dev[0][i], dev[1][i], dev[2][i], dev[3][i], dev[4][i], 1e-5, sb[i], hb[i])
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(sa + ha, sb + hb))
+
+
+def test_pack_weights_multi(backend):
+    """Table-driven packing == per-layer packing, incl. a fused pair (two sources) and the parity layout."""
+    g = torch.Generator().manual_seed(12)
+    mk = lambda *s: backend.put(torch.randn(*s, generator=g))   # noqa: E731
+    wa, wb, w3, w7 = mk(24, 16, 1, 1), mk(40, 16, 1, 1), mk(10, 6, 3, 3), mk(8, 3, 7, 7)
+    entries = [([wa, wb], 0), ([wa, wb], 1), ([w3], 0), ([w3], 1), ([w3], 2), ([w7], 0), ([wa], 1)]
+    got = K.pack_weights_multi(entries)
+    cat = torch.cat([wa, wb], 0).contiguous()
+    want = [K.pack_weights(cat, 0), K.pack_weights(cat, 1), K.pack_weights(w3, 0), K.pack_weights(w3, 1),
+            K.pack_weights(w3, 2), K.pack_weights(w7, 0), K.pack_weights(wa, 1)]
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b.cpu())
