@@ -12,6 +12,8 @@
 // index.  The pixel range is split over `splits` workgroups (split-K); each writes its partial
 // [Cout][K(+1)] slab, and ssn_conv_wgrad's second kernel sums the slabs in a fixed order, so the
 // result is deterministic (no float atomics).
+#include <type_traits>
+
 #include "ssn_common.h"
 
 namespace {
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         const int h0 = (int)ho * S - p.pad;
         const int w0 = (int)wo * S - p.pad;
         const uint32_t bbase = (uint32_t)((long)n * p.x_img_stride * 4) + (uint32_t)(h0 * p.W + w0) * 4u;
-        uint64_t mask = 0;
+        using mask_t = typename std::conditional<(KK <= 32), uint32_t, uint64_t>::type;
+        mask_t mask = 0;
         if (valid) {
             uint32_t rows = 0, cols = 0;
 #pragma unroll
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             }
 #pragma unroll
             for (int r = 0; r < KS; ++r)
-                if (rows & (1u << r)) mask |= (uint64_t)cols << (r * KS);
+                if (rows & (1u << r)) mask |= (mask_t)cols << (r * KS);
         }
 #pragma unroll
         for (int i = 0; i < NBR; ++i) {
@@ -180,16 +183,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         if (t + 1 < nch) load_slab(c_begin + t + 1);
         const float* As = As0 + buf * BM * PITCH + (wm * TM * 32 + li) * PITCH + 4 * lh;
         const float* Bs = Bs0 + buf * BN * PITCH + (wn * TN * 32 + li) * PITCH + 4 * lh;
+        // fragment groups (8 pixels = 4 MFMA steps) software-pipelined one group ahead of the MFMAs
+        f32x4 af[2][TM], bf[2][TN];
+        auto load_group = [&](int u, int slot) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * PITCH + 8 * u);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * PITCH + 8 * u);
+        };
+        load_group(0, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * PITCH + 8 * u);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * PITCH + 8 * u);
+            const int cur = u & 1;
+            if (u + 1 < 4) load_group(u + 1, cur ^ 1);
             if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) rowsum[i] += (af[i].x + af[i].y) + (af[i].z + af[i].w);
+                for (int i = 0; i < TM; ++i)
+                    rowsum[i] += (af[cur][i].x + af[cur][i].y) + (af[cur][i].z + af[cur][i].w);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < nch) store_slab(buf ^ 1);
         __syncthreads();
