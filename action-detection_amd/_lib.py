@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "elementwise.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_wgrad.hip", "elementwise.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -35,6 +35,9 @@ _SIGS = {
     "ssn_conv_pack_weights": "ppiiiip",
     "ssn_conv_pack_weights_multi": "ippppppppp",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
+    "ssn_conv_x6_pack_weights_multi": "ippppppppp",
+    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiip",
+    "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
     "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
     "ssn_global_avgpool_fwd": "ppiiilp",
@@ -64,7 +67,8 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
-                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_debug_flags",
+                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
+                                "ssn_conv_debug_flags",
                                 "ssn_conv_dgrad_layout"])
 
 
@@ -82,6 +86,8 @@ class SsnLibrary:
         self.cdll.ssn_conv_wgrad_workspace_bytes.argtypes = [ctypes.c_int] * 7
         self.cdll.ssn_conv_packed_floats.restype = ctypes.c_long
         self.cdll.ssn_conv_packed_floats.argtypes = [ctypes.c_int] * 4
+        self.cdll.ssn_conv_x6_packed_floats.restype = ctypes.c_long
+        self.cdll.ssn_conv_x6_packed_floats.argtypes = [ctypes.c_int] * 4
         self.cdll.ssn_conv_pick_tile.restype = ctypes.c_int
         self.cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
         self._fn = {}

@@ -72,8 +72,9 @@ def bn_fold(conv_bias, gamma, beta, mean, var, eps, scale, shift):
              _p(shift), gamma.numel(), _stream(lib, gamma))
 
 
-def packed_floats(cout, cin, ksize, transposed):
-    return int(_lib.get_lib().cdll.ssn_conv_packed_floats(cout, cin, ksize, int(bool(transposed))))
+def packed_floats(cout, cin, ksize, transposed, x6=False):
+    fn = _lib.get_lib().cdll.ssn_conv_x6_packed_floats if x6 else _lib.get_lib().cdll.ssn_conv_packed_floats
+    return int(fn(cout, cin, ksize, int(bool(transposed))))
 
 
 def dgrad_layout(ksize, stride, pad, h, w):
@@ -97,10 +98,11 @@ def pack_weights(w, transposed, out=None):
     return out
 
 
-def pack_weights_multi(entries):
+def pack_weights_multi(entries, x6=False):
     """entries: list of (weights, mode) with weights = [w] or [wA, wB] (fused pair, concatenated output channels).
 
     Returns one packed tensor per entry (views of a single flat buffer); ceil(len / 40) launches in total.
+    x6=True: split every weight into three bf16 planes for the conv_x6 kernels (modes 0/1, ksize 1/3 only).
     """
     if not entries:
         return []
@@ -110,7 +112,7 @@ def pack_weights_multi(entries):
     couts = [sum(w.shape[0] for w in ws) for ws, _ in entries]
     cins = [ws[0].shape[1] for ws, _ in entries]
     kss = [ws[0].shape[2] for ws, _ in entries]
-    sizes = [packed_floats(co, ci, k, m) for co, ci, k, (_, m) in zip(couts, cins, kss, entries)]
+    sizes = [packed_floats(co, ci, k, m, x6) for co, ci, k, (_, m) in zip(couts, cins, kss, entries)]
     flat = torch.empty(sum(sizes), device=first.device, dtype=torch.float32)
     outs, off = [], 0
     for sz in sizes:
@@ -123,7 +125,7 @@ def pack_weights_multi(entries):
     a_cout, a_cin, a_ks = ia(couts), ia(cins), ia(kss)
     a_mode = ia([m for _, m in entries])
     a_split = ia([ws[0].shape[0] if len(ws) > 1 else co for (ws, _), co in zip(entries, couts)])
-    lib.call("ssn_conv_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(po),
+    lib.call("ssn_conv_x6_pack_weights_multi" if x6 else "ssn_conv_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(po),
              ctypes.addressof(a_cout), ctypes.addressof(a_cin), ctypes.addressof(a_ks), ctypes.addressof(a_mode),
              ctypes.addressof(a_split), _stream(lib, first))
     return outs
@@ -138,6 +140,28 @@ def conv_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_c
     lib.call("ssn_conv_bn_relu_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
              x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg,
              _stream(lib, w_packed))
+
+
+def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
+    """conv_fwd on the bf16 matrix cores (3-way split, fp32-class accuracy).  w_packed: pack_weights_multi(x6=True)."""
+    lib = _check(x, w_packed, scale, shift, y)
+    h, wd = x.hw
+    ho, wo = y.hw
+    assert w_packed.numel() >= packed_floats(y.c, x.c, ksize, False, True)
+    lib.call("ssn_conv_x6_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
+             x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg,
+             _stream(lib, w_packed))
+
+
+def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
+    """Stride-1 conv_dgrad on the bf16 matrix cores.  wt: pack_weights_multi([... mode 1], x6=True)."""
+    lib = _check(dy, wt, dx, mask_y, mask_scale)
+    assert wt.numel() >= packed_floats(dy.c, dx.c, ksize, True, True)
+    ho, wo = dy.hw
+    h, w = dx.hw
+    lib.call("ssn_conv_x6_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
+             dx.img_stride, ksize, pad, int(accumulate), _p(mask_y),
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), tile_cfg, _stream(lib, wt))
 
 
 def relu_bn_bwd(dy, y, scale):

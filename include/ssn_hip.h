@@ -90,6 +90,28 @@ int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, in
                    int pad, int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
                    int wt_layout, int tile_cfg, hipStream_t stream);
 
+/* ---- "x6" variants: the same convolutions computed on the bf16 matrix cores with fp32-class accuracy.
+ * Every fp32 operand is split exactly into three bf16 terms (8+8+8 significand bits) and the product is
+ * accumulated in fp32 from the six partial products a_i*b_j with i+j <= 4 (csrc/conv_x6.hip); the dropped
+ * terms are <= 2^-24 |ab|, i.e. the result is as accurate as an fp32 FMA chain (the 1e-4 budget of the path is
+ * untouched) at 6/16 of the f32-MFMA matrix time.  ksize in {1,3}; forward stride in {1,2}; dgrad stride 1.
+ * Weights: ssn_conv_x6_pack_weights_multi (mode 0 forward / 1 dgrad operand; same w1/split convention as
+ * ssn_conv_pack_weights_multi), ssn_conv_x6_packed_floats() floats per layer.  Same call sites as
+ * ssn_conv_bn_relu_fwd / ssn_conv_dgrad (ssn_models.py:266,298; loss.backward at ssn_train.py:223). */
+long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int transposed);
+void ssn_conv_x6_debug_trace(unsigned long long* per_block_8_words); /* tooling only; NULL = off */
+void ssn_conv_x6_debug_flags(int flags);   /* tooling only (tools/ablate_x6.py); 0 = normal operation */
+int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1, float* const* out,
+                                   const int* cout, const int* cin, const int* ksize, const int* mode,
+                                   const int* split, hipStream_t stream);
+int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
+                    int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo, long y_img_stride,
+                    int ksize, int stride, int pad, int relu, int tile_cfg, hipStream_t stream);
+int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
+                      long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
+                      int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
+                      int tile_cfg, hipStream_t stream);
+
 /* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
  * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */
 long ssn_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int ksize, int tile_cfg);

@@ -35,6 +35,9 @@ struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
+struct uint2 {
+    unsigned int x, y;
+};
 struct float4 {
     float x, y, z, w;
 };
@@ -66,7 +69,7 @@ struct Fiber {
 
 struct WaveX {
     // double-buffered exchange area: 4 dwords per lane
-    uint32_t buf[2][64][4];
+    uint32_t buf[2][64][8];
 };
 
 struct BlockState {
@@ -158,8 +161,8 @@ inline void block_barrier() {
     yield_to_sched();
 }
 
-// deposit up to 4 dwords, wait for the whole wave, return pointer to the wave's slot array
-inline uint32_t (*wave_exchange(const uint32_t* v, int n))[4] {
+// deposit up to 8 dwords, wait for the whole wave, return pointer to the wave's slot array
+inline uint32_t (*wave_exchange(const uint32_t* v, int n))[8] {
     Fiber* f = g_cur;
     WaveX& w = g_blk->waves[f->wave];
     const int slot = (int)(f->wave_seq & 1);
@@ -235,6 +238,34 @@ inline f32x4_t mfma_16x16x4(float a, float b, f32x4_t c) {
     return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l & 31][k = 8 (l >> 5) + 0..7] (8 bf16 in 4 dwords, k even in
+// the low half) and likewise B[k][j = l & 31]; the C/D layout is that of the 32x32x2 f32 instruction.
+template <class V>
+inline f32x16_t mfma_32x32x16_bf16(V a, V b, f32x16_t c) {
+    static_assert(sizeof(V) == 16, "8 x bf16 operands");
+    uint32_t u[8];
+    memcpy(&u[0], &a, 16);
+    memcpy(&u[4], &b, 16);
+    auto* buf = wave_exchange(u, 8);
+    const int lane = g_cur->lane;
+    const int col = lane & 31, hi = lane >> 5;
+    auto elem = [&](int src_lane, int base, int kk) {
+        const uint32_t d = buf[src_lane][base + (kk >> 1)];
+        const uint32_t bits = (kk & 1) ? (d & 0xFFFF0000u) : (d << 16);
+        float f;
+        memcpy(&f, &bits, 4);
+        return f;
+    };
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc = fmaf(elem((k >> 3) * 32 + row, 0, k & 7), elem((k >> 3) * 32 + col, 4, k & 7), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
 template <class K, class... Args>
 inline void launch(K kernel, dim3 grid, dim3 block, Args... args) {
     BlockState b;
@@ -290,6 +321,20 @@ static inline int atomicAdd(int* p, int v) {
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
+// v_perm_b32: selector bytes 0-3 pick bytes of the SECOND operand, 4-7 bytes of the first
+static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    const uint64_t both = ((uint64_t)s0 << 32) | s1;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t q = (sel >> (8 * i)) & 0xFF;
+        const uint32_t byte = q < 8 ? (uint32_t)((both >> (8 * q)) & 0xFF) : (q == 12 ? 0u : 0xFFu);
+        out |= byte << (8 * i);
+    }
+    return out;
+}
+#define __builtin_amdgcn_s_getreg(x) 0
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only used on wave-uniform values */
 struct __amdgpu_buffer_rsrc_t {
     const char* base;

@@ -318,3 +318,99 @@ def test_pack_weights_multi(backend):
             K.pack_weights(w3, 2), K.pack_weights(w7, 0), K.pack_weights(wa, 1)]
     for a, b in zip(got, want):
         assert torch.equal(a.cpu(), b.cpu())
+
+
+X6_CASES_SMALL = [
+    # N, Cin, H, Cout, k, s, p, tile     (Cin deliberately not always a multiple of 16: tail-group masking)
+    (2, 16, 7, 96, 1, 1, 0, 2), (2, 24, 9, 40, 3, 1, 1, 3), (1, 32, 8, 130, 1, 1, 0, 0), (2, 16, 10, 33, 3, 2, 1, 4),
+    (1, 16, 9, 160, 3, 1, 1, 5), (1, 40, 6, 64, 1, 1, 0, 6), (1, 16, 6, 100, 3, 1, 1, 7), (2, 20, 6, 70, 3, 1, 1, 1),
+    (2, 16, 6, 48, 1, 1, 0, -1),
+]
+X6_CASES_GPU = [
+    (9, 64, 56, 192, 3, 1, 1, -1), (18, 192, 28, 64, 1, 1, 0, -1), (18, 128, 28, 160, 3, 2, 1, -1),
+    (18, 576, 14, 224, 1, 1, 0, -1), (18, 160, 14, 192, 3, 1, 1, -1), (36, 1056, 7, 352, 1, 1, 0, -1),
+    (36, 224, 7, 224, 3, 1, 1, -1), (4, 72, 14, 96, 3, 1, 1, -1),
+    (5, 96, 28, 96, 3, 1, 1, 0), (5, 96, 28, 96, 3, 1, 1, 1), (5, 96, 28, 96, 3, 1, 1, 2), (5, 96, 28, 96, 3, 1, 1, 3),
+    (5, 96, 28, 96, 3, 1, 1, 4), (5, 96, 28, 160, 3, 1, 1, 5), (5, 96, 28, 96, 1, 1, 0, 6), (5, 96, 28, 96, 1, 1, 0, 7),
+]
+
+
+def test_conv_x6_fwd_and_dgrad(backend):
+    """bf16-split ("x6") convolution kernels against fp64 torch: the split is exact and only three partial products
+    below 2^-24 |ab| are dropped, so the SAME tolerances as the f32-MFMA kernels apply (2e-5 / 5e-5 relative)."""
+    g = torch.Generator().manual_seed(20)
+    for (n, cin, h, cout, k, s, p, tile) in (X6_CASES_GPU if backend.is_gpu else X6_CASES_SMALL):
+        x = torch.randn(n, cin, h, h, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g) * 0.1
+        ref = F.relu(F.conv2d(x.double(), w.double(), None, s, p) * scale.double().view(1, -1, 1, 1)
+                     + shift.double().view(1, -1, 1, 1))
+        ho = ref.shape[2]
+        wd = backend.put(w)
+        wp, wt = K.pack_weights_multi([([wd], 0), ([wd], 1)], x6=True)
+        c0, ctot = 16, cout + 48
+        yd = backend.put(torch.full((n, ctot, ho, ho), 7.0))
+        K.conv_x6_fwd(K.full(backend.put(x)), wp, backend.put(scale), backend.put(shift), K.ChanSlice(yd, c0, cout),
+                      k, s, p, True, tile)
+        got = yd.cpu()
+        assert rel_err(got[:, c0:c0 + cout], ref) < 2e-5, ("fwd", n, cin, h, cout, k, s, tile)
+        assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all(), "wrote outside its slice"
+        if s != 1:
+            continue
+        gy = torch.randn(n, cout, ho, ho, generator=g)
+        gref = torch.nn.grad.conv2d_input((n, cin, h, h), w.double(), gy.double(), s, p)
+        dx = backend.put(torch.full((n, cin, h, h), 0.5))
+        K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), k, p, True, tile)
+        assert rel_err(dx.cpu() - 0.5, gref) < 5e-5, ("dgrad", n, cin, h, cout, k, tile)
+        K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), k, p, False, tile)
+        assert rel_err(dx, gref) < 5e-5
+
+
+def test_conv_x6_is_fp32_accurate(backend):
+    """The x6 kernel must be in the accuracy class of the exact-f32 MFMA kernel (measured against fp64), orders of
+    magnitude away from a plain bf16 product."""
+    g = torch.Generator().manual_seed(21)
+    n, cin, h, cout = (4, 256, 14, 128) if backend.is_gpu else (1, 64, 6, 32)
+    x = torch.randn(n, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    ref64 = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xd, wd = backend.put(x), backend.put(w)
+    y32 = backend.put(torch.empty(n, cout, h, h))
+    K.conv_fwd(K.full(xd), K.pack_weights(wd, False), None, None, K.full(y32), 3, 1, 1, False)
+    err32 = (y32.cpu().double() - ref64).abs().max().item()
+    (wp,) = K.pack_weights_multi([([wd], 0)], x6=True)
+    y = backend.put(torch.empty(n, cout, h, h))
+    K.conv_x6_fwd(K.full(xd), wp, None, None, K.full(y), 3, 1, 1, False)
+    err6 = (y.cpu().double() - ref64).abs().max().item()
+    bf = lambda t: t.bfloat16().double()   # noqa: E731
+    err_bf16 = (F.conv2d(bf(x), bf(w), None, 1, 1) - ref64).abs().max().item()
+    assert err6 < 2 * err32 + 1e-6, (err6, err32)
+    assert err6 < err_bf16 / 100, (err6, err_bf16)
+
+
+def test_conv_x6_fused_pair_and_mask(backend):
+    """x6 pack with two sources (fused reduce pair) and the dgrad last-writer ReLU/BN epilogue."""
+    g = torch.Generator().manual_seed(22)
+    n, cin, h = (4, 64, 14) if backend.is_gpu else (1, 16, 6)
+    wa = torch.randn(24, cin, 1, 1, generator=g) * 0.1
+    wb = torch.randn(40, cin, 1, 1, generator=g) * 0.1
+    wcat = torch.cat([wa, wb])
+    x = torch.randn(n, cin, h, h, generator=g)
+    wp, wt = K.pack_weights_multi([([backend.put(wa), backend.put(wb)], 0), ([backend.put(wa), backend.put(wb)], 1)],
+                                  x6=True)
+    y = backend.put(torch.empty(n, 64, h, h))
+    K.conv_x6_fwd(K.full(backend.put(x)), wp, None, None, K.full(y), 1, 1, 0, False)
+    assert rel_err(y, F.conv2d(x, wcat)) < 2e-5
+    gy = torch.randn(n, 64, h, h, generator=g)
+    y_in = torch.relu(torch.randn(n, cin, h, h, generator=g))
+    scale = torch.rand(cin, generator=g) + 0.5
+    scale[::3] = -1.0
+    old = torch.randn(n, cin, h, h, generator=g)
+    tot = old + torch.nn.grad.conv2d_input((n, cin, h, h), wcat, gy, 1, 0)
+    ref = torch.where(scale.view(1, -1, 1, 1) < 0, tot * (-scale).view(1, -1, 1, 1),
+                      torch.where(y_in > 0, tot * scale.view(1, -1, 1, 1), torch.zeros_like(tot)))
+    dx = backend.put(old.clone())
+    K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), 1, 0, True, mask_y=K.full(backend.put(y_in)),
+                    mask_scale=backend.put(scale))
+    assert rel_err(dx, ref) < 5e-5

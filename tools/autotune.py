@@ -19,6 +19,8 @@ from action_detection_amd.bninception import BNInception  # noqa: E402
 pkg.build()
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
+# optional second argument: comma list of kinds to (re)tune; the other kinds keep their entries
+only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None
 out_path = os.path.join(ROOT, "action-detection_amd", "tuned_tiles.json")
 shapes = {}
 for cin0 in (3, 10):
@@ -44,7 +46,7 @@ def timeit(fn, reps=3):
     return best
 
 
-table = {}
+table = json.load(open(out_path))["tiles"] if (only and os.path.exists(out_path)) else {}
 report = []
 for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     x = torch.randn(n, cin, hi, hi, device=dev)
@@ -55,17 +57,26 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     lay = K.dgrad_layout(k, s, p, hi, hi)
     wt = K.pack_weights(w, lay)
     wp = K.pack_weights(w, False)
+    wp6, wt6 = K.pack_weights_multi([([w], 0), ([w], 1)], x6=True) if k != 7 else (None, None)
     dx = torch.empty_like(x)
     dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
     flops = 2.0 * n * ho * ho * cout * cin * k * k
     res = {}
-    for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]), ("wgrad", [0, 1, 2, 3, 4, 5, 6])):
-        if kind == "dgrad" and k == 7:
+    for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]),
+                       ("wgrad", [0, 1, 2, 3, 4, 5, 6]), ("fwd6", [0, 1, 2, 3, 4, 5, 6, 7]),
+                       ("dgrad6", [0, 1, 2, 3, 4, 5, 6, 7])):
+        if only and kind not in only:
+            continue
+        if (kind in ("dgrad", "fwd6") and k == 7) or (kind == "dgrad6" and (k == 7 or s != 1)):
             continue
         best = (1e9, -1)
         for cfg in cfgs:
             if kind == "fwd":
                 fn = lambda: K.conv_fwd(K.full(x), wp, scale, shift, K.full(y), k, s, p, True, cfg)
+            elif kind == "fwd6":
+                fn = lambda: K.conv_x6_fwd(K.full(x), wp6, scale, shift, K.full(y), k, s, p, True, cfg)
+            elif kind == "dgrad6":
+                fn = lambda: K.conv_x6_dgrad(K.full(g), wt6, K.full(dx), k, p, False, cfg)
             elif kind == "dgrad":
                 fn = lambda: K.conv_dgrad(K.full(g), wt, K.full(dx), k, s, p, False, cfg, wt_layout=lay)
             else:
