@@ -36,8 +36,8 @@ _SIGS = {
     "ssn_conv_pack_weights_multi": "ippppppppp",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
     "ssn_conv_x6_pack_weights_multi": "ippppppppp",
-    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiip",
-    "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpip",
+    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiip",
+    "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
     "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
     "ssn_global_avgpool_fwd": "ppiiilp",

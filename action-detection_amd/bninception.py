@@ -34,12 +34,12 @@ def _load_tuned():
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get("tiles", {}), int(d.get("n_images", 0))
+        return d.get("tiles", {}), int(d.get("n_images", 0)), d.get("ms", {})
     except (OSError, ValueError):
-        return {}, 0
+        return {}, 0, {}
 
 
-_TUNED, _TUNED_N = _load_tuned()
+_TUNED, _TUNED_N, _TUNED_MS = _load_tuned()
 
 
 def tuned_tile(kind, n, cin, cout, k, s, hin):
@@ -47,6 +47,13 @@ def tuned_tile(kind, n, cin, cout, k, s, hin):
     if not _TUNED or n * 2 < _TUNED_N:
         return -1
     return _TUNED.get("%s|%d|%d|%d|%d|%d" % (kind, cin, cout, k, s, hin), -1)
+
+
+def x6_wins(kind, cin, cout, k, s, hin):
+    """bf16-split ("x6") kernel or the exact-f32 MFMA kernel for this layer?  x6 unless the f32 one measured faster."""
+    key = "|%d|%d|%d|%d|%d" % (cin, cout, k, s, hin)
+    t6, t32 = _TUNED_MS.get(kind + "6" + key), _TUNED_MS.get(kind + key)
+    return t6 is None or t32 is None or t6 <= t32
 
 
 class _BackboneFn(torch.autograd.Function):
@@ -90,6 +97,9 @@ class BNInception(nn.Module):
         self._side = {}               # device -> side HIP stream for the weight-gradient chain
         self.overlap_wgrad = True     # run wgrad launches on a second stream, concurrently with the dgrad chain
         self.profiler = None          # list; when set, every conv launch is bracketed by HIP events
+        # "bf16x6": 1x1/3x3 convolutions (forward, stride-1 dgrad) multiply on the bf16 matrix cores with every fp32
+        # operand split exactly into three bf16 terms (fp32-class accuracy, csrc/conv_x6.hip); "f32": exact-f32 MFMA
+        self.conv_precision = "bf16x6"
 
     def _timed(self, family, lid, flops, fn):
         """Run one conv launch; with a profiler attached, bracket it with events on the current stream."""
@@ -230,7 +240,8 @@ class BNInception(nn.Module):
         def get(name):
             if name not in acts:
                 c, h, w = shapes[name]
-                acts[name] = torch.empty((n, c, h, w), device=dev, dtype=torch.float32)
+                # readable floats in front of every activation: lets the x6 kernels use 16-byte loads
+                acts[name] = K.guarded_empty((n, c, h, w), dev)
             return acts[name]
 
         def scale_slice(name, c0, c):
@@ -262,8 +273,14 @@ class BNInception(nn.Module):
         K.bn_fold_multi(*fold)
         # all forward weight operands in two launches (fused pairs read both sources directly: no concatenation)
         conv_ops = [op for op in plan if op["kind"] == "conv"]
-        packed_fwd = dict(zip((op["lids"][0] for op in conv_ops), K.pack_weights_multi(
-            [([getattr(self, lid).weight.detach() for lid in op["lids"]], 0) for op in conv_ops])))
+        for op in conv_ops:      # which matrix path each layer takes (bf16 3-way split, or exact f32 MFMA)
+            op["x6"] = (self.conv_precision == "bf16x6" and op["k"] in (1, 3)
+                        and x6_wins("fwd", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1]))
+        packed_fwd = {}
+        for x6 in (False, True):
+            ops = [op for op in conv_ops if op["x6"] == x6]
+            packed_fwd.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
+                [([getattr(self, lid).weight.detach() for lid in op["lids"]], 0) for op in ops], x6=x6)))
 
         feat = None
         for i, op in enumerate(plan):
@@ -277,9 +294,14 @@ class BNInception(nn.Module):
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
                 src_slice = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 dst_slice = ChanSlice(get(op["dst"]), op["dst_c0"], cout)
-                self._timed("conv_fwd", op["lids"][0], flops,
-                            lambda: K.conv_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
-                                               True, tuned_tile("fwd", n, cin, cout, k, s, hin)))
+                if op["x6"]:
+                    self._timed("conv_fwd", op["lids"][0], flops,
+                                lambda: K.conv_x6_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
+                                                      True, tuned_tile("fwd6", n, cin, cout, k, s, hin)))
+                else:
+                    self._timed("conv_fwd", op["lids"][0], flops,
+                                lambda: K.conv_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
+                                                   True, tuned_tile("fwd", n, cin, cout, k, s, hin)))
             elif op["kind"] == "pool":
                 c = op["c"]
                 out = ChanSlice(get(op["dst"]), op["dst_c0"], c)
@@ -317,7 +339,7 @@ class BNInception(nn.Module):
         def gbuf(name):
             if name not in grads:
                 c, h, w = shapes[name]
-                grads[name] = torch.empty((n, c, h, w), device=dev, dtype=torch.float32)
+                grads[name] = K.guarded_empty((n, c, h, w), dev)
             return grads[name]
 
         ws_bytes = 0
@@ -331,9 +353,15 @@ class BNInception(nn.Module):
         dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
         dg_layout = {op["lids"][0]: K.dgrad_layout(op["k"], op["s"], op["p"], shapes[op["src"]][1],
                                                    shapes[op["src"]][2]) for op in dg_ops}
-        packed_dg = dict(zip((op["lids"][0] for op in dg_ops), K.pack_weights_multi(
-            [([getattr(self, lid).weight.detach() for lid in op["lids"]], dg_layout[op["lids"][0]])
-             for op in dg_ops])))
+        dg_x6 = {op["lids"][0]: (self.conv_precision == "bf16x6" and op["k"] in (1, 3) and op["s"] == 1
+                                 and x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1]))
+                 for op in dg_ops}
+        packed_dg = {}
+        for x6 in (False, True):
+            ops = [op for op in dg_ops if dg_x6[op["lids"][0]] == x6]
+            packed_dg.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
+                [([getattr(self, lid).weight.detach() for lid in op["lids"]], 1 if x6 else dg_layout[op["lids"][0]])
+                 for op in ops], x6=x6)))
 
         # The backward of ReLU + frozen BN (dy <- dy * (y > 0) * scale) is fused into the store of whichever
         # launch writes a gradient slice LAST (conv dgrad or pool backward); only slices whose last writer
@@ -421,10 +449,16 @@ class BNInception(nn.Module):
                     acc_flag = key in inited
                     my, ms = mask_args(idx, op, cin)
                     dx = ChanSlice(gbuf(op["src"]), op["src_c0"], cin)
-                    self._timed("conv_dgrad", lids[0], flops,
-                                lambda: K.conv_dgrad(g, wt, dx, k, s, p, accumulate=acc_flag,
-                                                     tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin),
-                                                     mask_y=my, mask_scale=ms, wt_layout=layout))
+                    if dg_x6[lids[0]]:
+                        self._timed("conv_dgrad", lids[0], flops,
+                                    lambda: K.conv_x6_dgrad(g, wt, dx, k, p, acc_flag,
+                                                            tuned_tile("dgrad6", n, cin, cout, k, s, hin),
+                                                            mask_y=my, mask_scale=ms))
+                    else:
+                        self._timed("conv_dgrad", lids[0], flops,
+                                    lambda: K.conv_dgrad(g, wt, dx, k, s, p, accumulate=acc_flag,
+                                                         tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin),
+                                                         mask_y=my, mask_scale=ms, wt_layout=layout))
                     inited.add(key)
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))

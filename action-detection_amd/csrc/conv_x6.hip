@@ -11,16 +11,23 @@
 //   The three dropped products are <= 2^-24 |ab|; measured error against float64 equals that of the f32
 //   MFMA (tools/proto/run_bf16x6.py: 2.4e-7 vs 3.0e-7 of sum|ab|), at 6/16 of its matrix-pipe time.
 //
-// Structure (what keeps the loop matrix-bound now that an MFMA is 32 cycles):
-//  * K runs in slabs of 16 rows = one bf16 MFMA.  1x1: 16 channels.  3x3: 16 channels x ONE tap, taps
-//    innermost -- all rows of a slab share the tap, so a thread needs one border-checked gather offset per
-//    tap (9 registers, computed once) and the channel part of the address is a scalar:
-//    `buffer_load_dword v, tapoff[tap], rsrc, soffset`.  No per-element address arithmetic in the loop.
-//  * Weights are split and packed once per step (ssn_conv_pack_weights_x6*) into exactly the LDS image
-//    (row = [3 planes][16 bf16], 112-byte pitch): the A tile is a contiguous block copied with b128 loads.
-//  * Activations are split on the fly while staging the gathered slab to LDS: ~5.5 VALU per element
-//    (and/sub for the residuals, one v_perm per bf16 pair), written as one ds_write_b128 per plane.
-//  * LDS rows are k-contiguous for both operands, so every MFMA operand is one conflict-free ds_read_b128.
+// Structure (what keeps the loop matrix-bound now that a slab is only ~0.4-0.8k matrix cycles per wave):
+//  * K runs in slabs of 16 rows = one bf16 MFMA.  1x1: 16 channels.  3x3: 16 channels x ONE tap, taps innermost:
+//    all rows of a slab share the tap, so a lane needs one gather offset per slab (base + scalar tap delta, a
+//    9-bit validity mask) and the channel part of the address is a scalar soffset.
+//  * Operands reach LDS by LDS-DMA (`buffer_load ... lds`), two slabs ahead in a 3-stage ring: no VGPR staging,
+//    no VALU, no ds_write; the global round trip (~1.5-2k cycles under load) is hidden behind two slabs of MFMAs.
+//      - weights: split and packed once per step (ssn_conv_x6_pack_weights_multi) into exactly the LDS image
+//        (row = 8 chunks of 16 B: 3 planes x 2 k-halves + pad, chunk-swizzled), copied 1 KiB per instruction;
+//      - activations: RAW fp32, 16 k-rows x BN pixels (the DMA deposits lane-consecutive dwords = pixel-major
+//        rows); a wave splits them into bf16 planes while building its B fragments (8 ds_read_b32 + ~44 VALU per
+//        32-pixel fragment and slab).
+//  * NG = 2 ("ping-pong") workgroups have 8 waves = two groups that share the A tile and own half of the pixel
+//    columns each.  Two s_barriers per slab hold the groups half a slab apart: while one group issues its MFMAs the
+//    other reads LDS and splits, so each SIMD's matrix pipe always has one wave feeding it (free-running co-resident
+//    workgroups drift into lock-step instead: both wait, then both compete -- measured 60 % pipe utilisation).
+//  * Epilogue: per-channel vectors via LDS, branch-free buffer addressing (out-of-range rows/pixels fall off the
+//    buffer), read-modify-write operands fetched one accumulator tile ahead.
 #include "ssn_common.h"
 
 namespace {
@@ -30,12 +37,12 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PITCH_DW = 28;   // dwords per operand row in LDS and in the packed weights (96 B data + 16 B pad)
+constexpr int APITCH = 32;    // dwords per packed weight row: 8 chunks of 16 B (6 data + 2 pad), chunk-swizzled
 constexpr uint32_t OOB = 0x80000000u;
 
 struct X6Args {
     const float* x;       // gather source (channel-slice base), fp32 NCHW
-    const uint32_t* ap;   // packed split weights [nslab][M][PITCH_DW]
+    const uint32_t* ap;   // packed split weights [nslab][M][APITCH]
     float* y;
     const float* scale;
     const float* shift;
@@ -51,10 +58,10 @@ struct X6Args {
     const float* mask_scale;
     long mask_img_stride;
     int n_ptiles, n_mtiles, ngroups;   // ngroups = ceil(C / 16)
-    uint32_t x_bytes, a_bytes;
+    uint32_t x_bytes, a_bytes, y_bytes, mask_bytes;
+    int x_guard;   // readable bytes in front of x (>= 256 enables the 16-byte activation loads)
     unsigned long long* trace;   // tooling only: per-block phase timestamps (tools/trace_x6.py), normally null
-    int desync;   // first-round start stagger between co-resident workgroups, in units of 1024 cycles (0 = off)
-    int dbg;   // tooling only (tools/ablate_x6.py): 1 no global loads, 2 no LDS stores/split, 4 no barrier
+    int dbg;      // tooling only (tools/ablate_x6.py)
     FastDiv div_hw, div_w, div_mt;
 };
 
@@ -70,24 +77,61 @@ __device__ __forceinline__ float residual(float x) {
     return x - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
 }
 
-template <int KS, int S, int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_x6_kernel(X6Args p) {
-    constexpr int BM = WM * TM * 32;
-    constexpr int BN = WN * TN * 32;
-    constexpr int TPP = 256 / BN;            // threads per pixel column
-    constexpr int RPT = 16 / TPP;            // slab rows (channels) per thread: 4, 8 or 16
-    constexpr int KK = KS * KS;
-    constexpr int A_CH = BM * PITCH_DW / 4;  // 16-byte chunks of one weight tile
-    constexpr int NA = (A_CH + 255) / 256;
-    constexpr int STAGE = (BM + BN) * PITCH_DW;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(BN == 64 || BN == 128 || BN == 256, "BN in {64,128,256}");
+// The 16-byte LDS-DMA form only exists for gfx950; hipcc's HOST pass (no target features) rejects it and then
+// silently drops the kernel's launch stub, so it is compiled for the device pass only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define X6_DMA_B128(rsrc_, dst_, voff_, soff_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_, SSN_LDS_PTR(dst_), 16, voff_, soff_, 0, 0)
+#else
+#define X6_DMA_B128(rsrc_, dst_, voff_, soff_) ((void)(dst_), (void)(voff_), (void)(soff_))
+#endif
 
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+// tooling build only (tools/build_trace_lib.sh): per-phase cycle accumulators of wave 0 and wave 4
+#ifdef X6_PHASE_TRACE
+#define X6_PH_DECL unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, phc_ = __builtin_readcyclecounter()
+#define X6_PH(k)                                                  \
+    do {                                                          \
+        const unsigned long long n_ = __builtin_readcyclecounter(); \
+        ph_[k] += n_ - phc_;                                      \
+        phc_ = n_;                                                \
+    } while (0)
+#else
+#define X6_PH_DECL
+#define X6_PH(k)
+#endif
+
+template <int KS, int S, int MODE, bool WIDE, int NG, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
+    constexpr int NW = 4 * NG;              // waves per workgroup
+    constexpr int NT = 64 * NW;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BNG = WN * TN * 32;       // pixel columns of one wave group
+    constexpr int BN = NG * BNG;
+    constexpr int KK = KS * KS;
+    constexpr int A_PIECES = BM / 8;        // 1 KiB pieces of the BM x 128 B weight tile
+    constexpr int NA = (A_PIECES + NW - 1) / NW;
+    constexpr int A_STAGE = NA * NW * 256;  // dwords; padded so that every wave copies exactly NA pieces
+    constexpr int B_STAGE = 16 * BN;        // dwords
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int NSTAGE = 3;
+    constexpr int SEGS = BN / 64;           // 64-pixel segments per k-row
+    // activation DMA instructions per wave and slab: 4 B per lane (256 B pieces = one k-row of 64 pixels), or,
+    // WIDE, 16 B per lane (1 KiB pieces = 256 consecutive (k-row, pixel) slots, 4 pixels per lane)
+    constexpr int NB = WIDE ? BN / 16 / NW : 16 * SEGS / NW;
+    constexpr int KSTEP = NW / SEGS;
+    constexpr int RPP = 256 / BN > 0 ? 256 / BN : 1;   // WIDE: k-rows per piece
+    constexpr uint32_t GUARD = WIDE ? 256u : 0u;       // WIDE: readable bytes in front of x (contract)
+    static_assert(!WIDE || (S == 1 && BN <= 256 && BN / 16 >= NW), "WIDE: stride 1, 64*NW/4 <= BN <= 256");
+    constexpr int NLOAD = NA + NB;
+    static_assert(WM * WN == 4, "4 waves per group");
+    static_assert(NW % SEGS == 0 && (16 * SEGS) % NW == 0, "unsupported tile width");
+
+    __shared__ __attribute__((aligned(1024))) uint32_t lds[NSTAGE * STAGE];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int grp = wave >> 2, gw = wave & 3;
+    const int wm = gw / WN, wn = gw % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     const uint32_t nblk = (uint32_t)p.n_ptiles * (uint32_t)p.n_mtiles;
@@ -98,103 +142,116 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(X6Args p) {
     const int p0 = (int)ptile * BN;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if (p.trace) tr0 = __builtin_readcyclecounter();
-    // Workgroups of equal work started together stay in lock-step for the whole launch, so every CU would run its
-    // store-bound epilogues at the same moment with the matrix pipe idle.  Delay the second (third) workgroup that
-    // lands on each CU once, in the first round; the phase shift then persists.
-    if (p.desync > 0 && blockIdx.x >= 256u && blockIdx.x < 768u) {
-        const int n = (int)(blockIdx.x >> 8) * p.desync;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-    }
 
-    // ---- per-thread gather state: one border-checked byte offset per tap ----
-    const int gcol = tid % BN;
-    const int gq = wave_uniform(tid / BN);    // which RPT-row group of the slab this thread stages
-    uint32_t tapoff[KK];
-    {
-        const int gp = p0 + gcol;
+    // ---- B gather state ----
+    //  narrow: this lane fetches pixel (seg * 64 + lane) of k-rows krow0 + i * KSTEP; taps that fall outside the
+    //          image are turned into out-of-range offsets (-> zeros) per slab.
+    //  WIDE:   this lane fetches the 4 consecutive pixels wpx.. of k-row (piece * RPP + wkl).  Address arithmetic is
+    //          linear in the pixel index for stride 1, so no per-pixel border handling is possible at the load:
+    //          whatever lies next to the image in memory is fetched (x must be preceded by GUARD readable bytes),
+    //          and the padding positions are zeroed when the fragments are read (fmask).
+    const int seg = wave % SEGS;
+    const int krow0 = wave / SEGS;
+    const int wkl = WIDE ? (4 * lane) / BN : 0;
+    const int wpx = WIDE ? (4 * lane) % BN : seg * 64 + lane;
+    uint32_t gbase;                        // byte offset of the tap-(0,0) input element (may wrap below zero)
+    uint32_t gmask = 0;                    // bit t: tap t reads inside the image (WIDE: bit 0 = pixel exists)
+    const uint32_t hw_bytes = (uint32_t)(p.H * p.W) * 4u;
+    auto tap_mask = [&](int gp, uint32_t& n, int& h0, int& w0) {
         const bool gvalid = gp < p.P;
-        uint32_t n, hw, ho, wo;
+        uint32_t hw, ho, wo, m = 0;
         fd_divmod((uint32_t)(gvalid ? gp : 0), p.div_hw, n, hw);
         fd_divmod(hw, p.div_w, ho, wo);
-        const uint32_t gbase = (uint32_t)((long)n * p.x_img_stride * 4);
+        h0 = (MODE == MODE_FWD) ? (int)ho * S - p.pad : (int)ho + p.pad;
+        w0 = (MODE == MODE_FWD) ? (int)wo * S - p.pad : (int)wo + p.pad;
 #pragma unroll
         for (int t = 0; t < KK; ++t) {
             const int r = t / KS, s = t - r * KS;
-            int hi, wi;
-            if (MODE == MODE_FWD) {
-                hi = (int)ho * S - p.pad + r;
-                wi = (int)wo * S - p.pad + s;
-            } else {
-                hi = (int)ho + p.pad - r;
-                wi = (int)wo + p.pad - s;
-            }
-            const bool ok = gvalid && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
-            tapoff[t] = ok ? gbase + (uint32_t)(hi * p.W + wi) * 4u : OOB;
+            const int hi = (MODE == MODE_FWD) ? h0 + r : h0 - r;
+            const int wi = (MODE == MODE_FWD) ? w0 + s : w0 - s;
+            if (gvalid && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W)) m |= 1u << t;
         }
+        return m;
+    };
+    {
+        uint32_t n;
+        int h0, w0;
+        const uint32_t m = tap_mask(p0 + wpx, n, h0, w0);
+        gmask = WIDE ? (uint32_t)(p0 + wpx < p.P) : m;
+        gbase = (uint32_t)((long)n * p.x_img_stride * 4) + (uint32_t)((h0 * p.W + w0) * 4) + (uint32_t)wkl * hw_bytes +
+                GUARD;
     }
-    const uint32_t hw_bytes = (uint32_t)(p.H * p.W) * 4u;
-    const uint32_t row0_off = (uint32_t)(gq * RPT) * hw_bytes;   // first channel row of this thread inside a group
+    // WIDE: validity of the taps at the pixels of this lane's B fragments
+    uint32_t fmask[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        uint32_t n;
+        int h0, w0;
+        fmask[j] = (WIDE && KK > 1) ? tap_mask(p0 + grp * BNG + (wn * TN + j) * 32 + li, n, h0, w0) : 0u;
+    }
 
-    // ---- weight tile: one contiguous block of the packed operand per slab ----
+    // ---- A copy: wave w moves 1 KiB pieces (q * NW + w) of the tile ----
     uint32_t aoff[NA];
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-        const int f = tid + 256 * q;
-        const int row = (f * 4) / PITCH_DW;
-        const bool ok = (f < A_CH) && (m0 + row < p.M);
-        aoff[q] = ok ? (uint32_t)(m0 * PITCH_DW) * 4u + (uint32_t)f * 16u : OOB;
+        const int f = (q * NW + wave) * 64 + lane;   // 16-byte chunk of the tile
+        aoff[q] = (f < BM * 8 && m0 + f / 8 < p.M) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : OOB;
     }
-    const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - GUARD, p.x_bytes + GUARD);
     const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.ap, p.a_bytes);
-    const uint32_t a_step = (uint32_t)(p.M * PITCH_DW) * 4u;
+    const uint32_t a_step = (uint32_t)(p.M * APITCH) * 4u;
+    const int nslab = p.ngroups * KK;
     const int c_last = p.C - (p.ngroups - 1) * 16;   // channels in the last group (16 when exact)
 
-    float breg[RPT];
-    u32x4 areg[NA];
-    // slab (g, tap): taps innermost; `tap` is a compile-time constant at every call site (unrolled tap loop), so
-    // tapoff[] stays in registers
-    auto load_slab = [&](int g, int tap) {
-        const uint32_t vo = tapoff[tap];
-        const uint32_t so = (uint32_t)g * 16u * hw_bytes + row0_off;
-        const bool tail = (g == p.ngroups - 1) && (c_last != 16);
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            uint32_t v = vo;
-            if (tail && (gq * RPT + i >= c_last)) v = OOB;   // channels past the end (never in BN-Inception)
-            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, v, so + (uint32_t)i * hw_bytes, 0));
+    // DMA of slab (ig, itap) into a ring stage, as NLOAD separate pieces (NB activation rows, then NA weight pieces)
+    // so that they can be dealt out between the MFMAs: the texture path takes 64 B/clk per CU, and a wave that
+    // issues its whole share in one burst (together with the 7 other waves) stalls ~800 cycles at the issue.
+    int ig = 0, itap = 0;
+    uint32_t d_vo, d_so, d_aso;
+    uint32_t *d_b, *d_a;
+    bool d_tail;
+    auto issue_begin = [&](int st) {
+        if (KK == 1) {
+            d_vo = (gmask & 1u) ? gbase : OOB;
+        } else {
+            const int r = (itap * 11) >> 5, s = itap - 3 * r;   // itap / 3, itap % 3 for itap < 9
+            const int d = (r * p.W + s) * 4;
+            const uint32_t ok = WIDE ? (gmask & 1u) : ((gmask >> itap) & 1u);
+            d_vo = ok ? (MODE == MODE_FWD ? gbase + (uint32_t)d : gbase - (uint32_t)d) : OOB;
         }
-        const uint32_t aso = (uint32_t)(g * KK + tap) * a_step;
-#pragma unroll
-        for (int q = 0; q < NA; ++q) areg[q] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[q], aso, 0);
+        d_tail = (ig == p.ngroups - 1) && (c_last != 16);
+        if (WIDE) {
+            d_so = (uint32_t)(ig * 16 + wave * RPP) * hw_bytes;
+            d_b = lds + st * STAGE + A_STAGE + wave * 256;
+        } else {
+            d_so = (uint32_t)(ig * 16 + krow0) * hw_bytes;
+            d_b = lds + st * STAGE + A_STAGE + krow0 * BN + seg * 64;
+        }
+        d_aso = (uint32_t)(ig * KK + itap) * a_step;
+        d_a = lds + st * STAGE + wave * 256;
+        if (++itap == KK) {
+            itap = 0;
+            ++ig;
+        }
     };
-    // split the staged fp32 rows into 3 bf16 planes and write them (k-contiguous) next to the weights
-    auto store_slab = [&](int buf) {
-        uint32_t* As = lds + buf * STAGE;
-        uint32_t* Bs = As + BM * PITCH_DW + gcol * PITCH_DW + gq * (RPT / 2);
-#pragma unroll
-        for (int q = 0; q < NA; ++q)
-            if (tid + 256 * q < A_CH) *reinterpret_cast<u32x4*>(As + (tid + 256 * q) * 4) = areg[q];
-        uint32_t pl[3][RPT / 2];
-#pragma unroll
-        for (int i = 0; i < RPT / 2; ++i) {
-            const float x0 = breg[2 * i], x1 = breg[2 * i + 1];
-            const float r0 = residual(x0), r1 = residual(x1);
-            const float s0 = residual(r0), s1 = residual(r1);
-            pl[0][i] = pack_hi16(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, x1));
-            pl[1][i] = pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
-            pl[2][i] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+    auto issue_piece = [&](int k) {   // k is a compile-time constant at every call site
+        if (k < NB && WIDE) {
+            uint32_t v = d_vo;
+            if (d_tail && ((k * NW + wave) * RPP + wkl >= c_last)) v = OOB;
+            X6_DMA_B128(xrsrc, d_b + k * NW * 256, v, d_so + (uint32_t)(k * NW * RPP) * hw_bytes);
+        } else if (k < NB) {
+            uint32_t v = d_vo;
+            if (d_tail && (krow0 + k * KSTEP >= c_last)) v = OOB;   // channels past the end (never in BN-Inception)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SSN_LDS_PTR(d_b + k * KSTEP * BN), 4, v,
+                                                     d_so + (uint32_t)(k * KSTEP) * hw_bytes, 0, 0);
+        } else {
+            X6_DMA_B128(arsrc, d_a + (k - NB) * NW * 256, aoff[k - NB], d_aso);
         }
+    };
+    auto issue = [&](int st) {
+        issue_begin(st);
 #pragma unroll
-        for (int pn = 0; pn < 3; ++pn) {
-            if (RPT == 4) {
-                *reinterpret_cast<uint2*>(Bs + pn * 8) = uint2{pl[pn][0], pl[pn][1]};
-            } else {
-#pragma unroll
-                for (int v = 0; v < RPT / 8; ++v)
-                    *reinterpret_cast<u32x4*>(Bs + pn * 8 + 4 * v) =
-                        u32x4{pl[pn][4 * v], pl[pn][4 * v + 1], pl[pn][4 * v + 2], pl[pn][4 * v + 3]};
-            }
-        }
+        for (int k = 0; k < NLOAD; ++k) issue_piece(k);
     };
 
     f32x16 acc[TM][TN];
@@ -205,84 +262,213 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(X6Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_slab(0, 0);
-    store_slab(0);
-    __syncthreads();
+    issue(0);
+    if (nslab > 1) issue(1);
     if (p.trace) tr1 = __builtin_readcyclecounter();
 
-    int buf = 0;
-    for (int g = 0; g < p.ngroups; ++g) {
+    // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 1) & 7)
+    const int swz = (li >> 1) & 7;
+    int achunk[3];
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-            const bool more = (tap + 1 < KK) || (g + 1 < p.ngroups);
-            if (!(p.dbg & 1)) {
-                if (tap + 1 < KK)
-                    load_slab(g, tap + 1);
-                else if (g + 1 < p.ngroups)
-                    load_slab(g + 1, 0);
-            }
+    for (int pn = 0; pn < 3; ++pn) achunk[pn] = ((2 * pn + lh) ^ swz) * 4;
+    const int arow = (wm * TM * 32 + li) * APITCH;
+    const int bcol = A_STAGE + (8 * lh) * BN + grp * BNG + wn * TN * 32 + li;
 
-            const uint32_t* As = lds + buf * STAGE + (wm * TM * 32 + li) * PITCH_DW + lh * 4;
-            const uint32_t* Bs = lds + buf * STAGE + BM * PITCH_DW + (wn * TN * 32 + li) * PITCH_DW + lh * 4;
-            bf16x8 af[3][TM], bf[3][TN];
+    bf16x8 af[3][TM], bf[3][TN];
+    // LDS -> operand registers for one slab (B: raw fp32 -> three bf16 planes)
+    int ctap = 0;   // tap of the slab being consumed (WIDE 3x3 only)
+    auto front = [&](int stage) {
+        const uint32_t* Ls = lds + stage * STAGE;
 #pragma unroll
-            for (int pn = 0; pn < 3; ++pn) {
+        for (int j = 0; j < TN; ++j) {
+            float raw[8];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + i * 32 * PITCH_DW + pn * 8));
+            for (int e = 0; e < 8; ++e) raw[e] = __builtin_bit_cast(float, Ls[bcol + e * BN + j * 32]);
+            if (WIDE && KK > 1) {
+                const bool inside = (fmask[j] >> ctap) & 1u;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bf[pn][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + j * 32 * PITCH_DW + pn * 8));
+                for (int e = 0; e < 8; ++e) raw[e] = inside ? raw[e] : 0.f;
             }
-            // six partial products, smallest magnitude first
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            uint32_t pl[3][4];
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = raw[2 * e], x1 = raw[2 * e + 1];
+                const float r0 = residual(x0), r1 = residual(x1);
+                const float s0 = residual(r0), s1 = residual(r1);
+                pl[0][e] = pack_hi16(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, x1));
+                pl[1][e] = pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
+                pl[2][e] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+            }
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], bf[PB[c]][j], acc[i][j], 0, 0, 0);
-
-            if (more && !(p.dbg & 2)) store_slab(buf ^ 1);
-            if (!(p.dbg & 4)) __syncthreads();
-            buf ^= 1;
+            for (int pn = 0; pn < 3; ++pn)
+                bf[pn][j] = __builtin_bit_cast(bf16x8, u32x4{pl[pn][0], pl[pn][1], pl[pn][2], pl[pn][3]});
         }
-    }
+#pragma unroll
+        for (int pn = 0; pn < 3; ++pn)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[pn][i] = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const u32x4*>(Ls + arow + i * 32 * APITCH + achunk[pn]));
+        if (WIDE && KK > 1) ctap = (ctap + 1 == KK) ? 0 : ctap + 1;
+    };
+    // six partial products per accumulator tile, smallest magnitude first; with dma_stage >= 0 the DMA pieces of
+    // the slab two ahead are dealt out between the MFMAs
+    auto mfma = [&](int dma_stage) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NM = 6 * TM * TN;
+        constexpr int EVERY = NM / NLOAD > 0 ? NM / NLOAD : 1;
+        const bool dma = dma_stage >= 0;
+        if (dma) issue_begin(dma_stage);
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], bf[PB[c]][j], acc[i][j], 0, 0, 0);
+                    const int idx = (c * TM + i) * TN + j;
+                    if ((idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) {
+                        if (dma) issue_piece((idx + 1) / EVERY - 1);
+                    }
+                }
+        if (dma) {
+#pragma unroll
+            for (int k = NM / EVERY; k < NLOAD; ++k) issue_piece(k);
+        }
+    };
 
+    int stage = 0;
+    X6_PH_DECL;
+    for (int t = 0; t < nslab; ++t) {
+        // slab t has landed once at most the NLOAD loads of slab t+1 are still in flight
+        if (t + 1 < nslab && !(p.dbg & 1))
+            SSN_WAIT_VMCNT(NLOAD);
+        else
+            SSN_WAIT_VMCNT(0);
+        X6_PH(0);
+        __builtin_amdgcn_s_barrier();   // (a) every wave's share of slab t is visible, (b) slab t-1 is consumed
+        __builtin_amdgcn_sched_barrier(0);
+        X6_PH(1);
+        const int dst = (t + 2 < nslab && !(p.dbg & 1)) ? (stage == 0 ? 2 : stage - 1) : -1;   // ring slot of slab t-1, for slab t+2
+        if (NG == 1) {
+            front(stage);
+            X6_PH(3);
+            mfma(dst);
+            X6_PH(5);
+        } else if (grp == 0) {
+            front(stage);
+            X6_PH(3);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            X6_PH(4);
+            mfma(dst);
+            X6_PH(5);
+        } else {
+            if (t > 0)
+                mfma(dst);                    // slab t-1, operands split during the previous half-phase
+            else if (dst >= 0)
+                issue(dst);
+            X6_PH(3);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            X6_PH(4);
+            front(stage);
+            X6_PH(5);
+        }
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    }
+    if (NG == 2 && grp == 1) mfma(-1);
     if (p.trace) tr2 = __builtin_readcyclecounter();
-    // ---- epilogue (identical to conv_igemm.hip): BN affine + ReLU, or accumulate + fused ReLU/BN backward ----
-    const int howo = p.Ho * p.Wo;
+
+    // ---- epilogue: BN affine + ReLU (forward), or accumulate + fused ReLU/BN backward (dgrad) ----
+    __syncthreads();
+    float* ch = reinterpret_cast<float*>(lds);   // [0,BM) scale  [BM,2BM) shift  [2BM,3BM) mask scale
+    for (int r = tid; r < BM; r += NT) {
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        ch[r] = (ok && p.scale) ? p.scale[m] : 1.f;
+        ch[BM + r] = (ok && p.scale) ? p.shift[m] : 0.f;
+        ch[2 * BM + r] = (ok && p.mask_scale) ? p.mask_scale[m] : -1.f;
+    }
+    __syncthreads();
+    // Everything below is branch-free buffer addressing: lanes whose pixel or row is outside the tensor carry an
+    // out-of-range offset (loads return 0, stores are dropped), so the compiler can count outstanding operations
+    // exactly instead of draining the queue (s_waitcnt vmcnt(0)) at every divergent join.
+    const uint32_t howo4 = (uint32_t)(p.Ho * p.Wo) * 4u;
+    const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(p.y, p.y_bytes);
+    uint32_t yoff[TN], moff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int pp = p0 + (wn * TN + j) * 32 + li;
-        if (pp >= p.P) continue;
+        const int pp = p0 + grp * BNG + (wn * TN + j) * 32 + li;
         uint32_t n, hw;
-        fd_divmod((uint32_t)pp, p.div_hw, n, hw);
-        float* yb = p.y + (long)n * p.y_img_stride + hw;
-        const float* mb = p.mask_y ? p.mask_y + (long)n * p.mask_img_stride + hw : nullptr;
+        fd_divmod((uint32_t)(pp < p.P ? pp : 0), p.div_hw, n, hw);
+        const uint32_t row0 = (uint32_t)(m0 + 4 * lh) * howo4 + hw * 4u;
+        yoff[j] = pp < p.P ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : OOB;
+        moff[j] = pp < p.P ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : OOB;
+    }
+    const int mlim = p.M - m0 - 4 * lh;   // rows srow (without the lane-half term) below this are inside the tensor
+    auto srow = [&](int i, int r) { return (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2); };
+    if (!p.accumulate && !p.mask_y) {
+        // pure stores: nothing in this path waits on memory
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (p.scale) v = v * p.scale[m] + p.shift[m];
-                if (p.relu) v = fmaxf(v, 0.f);
-                float* dst = yb + (long)m * howo;
-                if (p.accumulate) v += *dst;
-                if (mb) {
-                    const float sc = p.mask_scale[m];
-                    v = (sc < 0.f) ? v * -sc : (mb[(long)m * howo] > 0.f ? v * sc : 0.f);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sr = srow(i, r);
+                    float v = acc[i][j][r] * ch[sr + 4 * lh] + ch[BM + sr + 4 * lh];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
+                                                          sr < mlim ? yoff[j] : OOB, (uint32_t)sr * howo4, 0);
                 }
-                *dst = v;
+    } else {
+        // read-modify-write: the operands of tile g+1 are requested before tile g is stored
+        const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.y, p.accumulate ? p.y_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t mrsrc = make_rsrc(p.mask_y ? p.mask_y : p.y, p.mask_y ? p.mask_bytes : 0u);
+        constexpr int G = TM * TN * 2;   // half accumulator tiles (8 values per lane)
+        float old[2][8], mk[2][8];
+        auto fetch = [&](int g, int b) {
+            const int j = (g >> 1) / TM, i = (g >> 1) % TM;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int sr = srow(i, (g & 1) * 8 + q);
+                old[b][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                          orsrc, sr < mlim ? yoff[j] : OOB, (uint32_t)sr * howo4, 0));
+                mk[b][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                         mrsrc, sr < mlim ? moff[j] : OOB, (uint32_t)sr * howo4, 0));
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) fetch(g + 1, (g + 1) & 1);
+            const int j = (g >> 1) / TM, i = (g >> 1) % TM, b = g & 1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = (g & 1) * 8 + q;
+                const int sr = srow(i, r);
+                float v = acc[i][j][r] * ch[sr + 4 * lh] + ch[BM + sr + 4 * lh];
+                if (p.relu) v = fmaxf(v, 0.f);
+                v += old[b][q];
+                const float sc = ch[2 * BM + sr + 4 * lh];
+                v = (sc < 0.f) ? v * -sc : (mk[b][q] > 0.f ? v * sc : 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
+                                                      sr < mlim ? yoff[j] : OOB, (uint32_t)sr * howo4, 0);
             }
         }
     }
+#ifdef X6_PHASE_TRACE
+    if (p.trace && lane == 0 && (wave & 3) == 0) {
+        unsigned long long* t = p.trace + (size_t)blockIdx.x * 32 + 8 + 8 * (wave >> 2);
+        for (int k = 0; k < 6; ++k) t[k] = ph_[k];
+    }
+#endif
     if (p.trace && tid == 0) {
-        unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+        unsigned long long* t = p.trace + (size_t)blockIdx.x * 32;
         t[0] = tr0;
         t[1] = tr1;
         t[2] = tr2;
@@ -291,9 +477,12 @@ __global__ __launch_bounds__(256) void conv_x6_kernel(X6Args p) {
         t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
     }
 }
+#undef X6_DMA_B128
 
-// ---- weight split + pack: out[slab][m][plane*8 + kpair] (PITCH_DW dwords per row, zero padded) ----
-// slab = g (1x1) or g * 9 + tap (3x3); row k of a slab = channel 16 g + k.
+// ---- weight split + pack: out[slab][m][8 chunks x 4 dwords] ----
+// slab = g (1x1) or g * 9 + tap (3x3); row k of a slab = channel 16 g + k.  Logical 16-byte chunk c = 2 * plane +
+// khalf holds bf16 k = 8 * khalf + 0..7 of that plane (c = 6, 7: zero padding); it is stored at chunk position
+// c ^ ((m >> 1) & 7), which makes the straight LDS copy conflict-free for the ds_read_b128 fragment reads.
 //   mode 0 (forward operand): A[m][c][tap] = w[m][c][tap];  mode 1 (dgrad operand): A[m][c][tap] = w[c][m][tap]
 // Two sources (fused pair): output channel co < split comes from w0, the rest from w1.
 constexpr int XP_MAX = 40;
@@ -338,47 +527,72 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
         }
         const float r0 = residual(v[0]), r1 = residual(v[1]);
         const float s0 = residual(r0), s1 = residual(r1);
-        uint32_t* row = t.out[ti] + ((long)slab * M + m) * PITCH_DW;
-        row[kp] = pack_hi16(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]));
-        row[8 + kp] = pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
-        row[16 + kp] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
-        if (kp < 4) row[24 + kp] = 0u;   // row padding
+        uint32_t* row = t.out[ti] + ((long)slab * M + m) * APITCH;
+        const int swz = (m >> 1) & 7;
+        const int khalf = kp >> 2, w = kp & 3;
+        row[((0 + khalf) ^ swz) * 4 + w] = pack_hi16(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]));
+        row[((2 + khalf) ^ swz) * 4 + w] = pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
+        row[((4 + khalf) ^ swz) * 4 + w] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+        row[((6 + khalf) ^ swz) * 4 + w] = 0u;   // padding chunks
     }
 }
 
-template <int KS, int S, int MODE, int WM, int WN, int TM, int TN>
+int g_x6_dbg = 0;   // tooling: bit 4 (16) disables the 16-byte activation loads
+unsigned long long* g_x6_trace = nullptr;
+
+template <int KS, int S, int MODE, int NG, int WM, int WN, int TM, int TN>
 int launch_cfg(X6Args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
-    constexpr int BN = WN * TN * 32;
+    constexpr int BN = NG * WN * TN * 32;
     a.n_ptiles = (a.P + BN - 1) / BN;
     a.n_mtiles = (a.M + BM - 1) / BM;
     a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
     const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
-    hipLaunchKernelGGL((conv_x6_kernel<KS, S, MODE, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
+    // 16-byte activation loads: stride 1, images a multiple of 4 pixels (a lane's 4 pixels never straddle two images),
+    // a tile width the 1 KiB pieces divide, and the caller's guarantee that the bytes in front of x are readable
+    constexpr bool wide_ok = (S == 1) && BN <= 256 && BN / 16 >= 4 * NG;
+    if constexpr (wide_ok) {
+        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && !(g_x6_dbg & 16)) {
+            hipLaunchKernelGGL((conv_x6_kernel<KS, S, MODE, true, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0,
+                               stream, a);
+            SSN_CHECK_LAUNCH("conv_x6 (wide)");
+            return SSN_OK;
+        }
+    }
+    hipLaunchKernelGGL((conv_x6_kernel<KS, S, MODE, false, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0, stream,
+                       a);
     SSN_CHECK_LAUNCH("conv_x6");
     return SSN_OK;
 }
 
-// tile ids as in conv_igemm.hip: 0 128x128, 1 64x128, 2 96x128, 3 64x64, 4 32x128, 5 160x128, 6 64x128 (1x4), 7 128x64
+// Tile ids (rows x pixels).  0-7: 4-wave workgroups:
+//   0 128x128, 1 64x128, 2 96x128, 3 64x64, 4 32x128, 5 128x128 (1x4 waves), 6 64x128 (1x4 waves), 7 128x64
+// 8-15: 8-wave ping-pong workgroups (two groups side by side along the pixel axis):
+//   8 128x256, 9 64x256, 10 96x256, 11 64x128, 12 160x256, 13 128x128, 14 64x256 (1x4 waves), 15 128x256 (1x4 waves)
 template <int KS, int S, int MODE>
 int launch_tile(X6Args& a, int cfg, hipStream_t stream) {
     switch (cfg) {
-        case 0: return launch_cfg<KS, S, MODE, 2, 2, 2, 2>(a, stream);
-        case 1: return launch_cfg<KS, S, MODE, 2, 2, 1, 2>(a, stream);
-        case 2: return launch_cfg<KS, S, MODE, 1, 4, 3, 1>(a, stream);
-        case 3: return launch_cfg<KS, S, MODE, 2, 2, 1, 1>(a, stream);
-        case 4: return launch_cfg<KS, S, MODE, 1, 4, 1, 1>(a, stream);
-        case 5: return launch_cfg<KS, S, MODE, 1, 4, 5, 1>(a, stream);
-        case 6: return launch_cfg<KS, S, MODE, 1, 4, 2, 1>(a, stream);
-        case 7: return launch_cfg<KS, S, MODE, 2, 2, 2, 1>(a, stream);
+        case 0: return launch_cfg<KS, S, MODE, 1, 2, 2, 2, 2>(a, stream);
+        case 1: return launch_cfg<KS, S, MODE, 1, 2, 2, 1, 2>(a, stream);
+        case 2: return launch_cfg<KS, S, MODE, 1, 1, 4, 3, 1>(a, stream);
+        case 3: return launch_cfg<KS, S, MODE, 1, 2, 2, 1, 1>(a, stream);
+        case 4: return launch_cfg<KS, S, MODE, 1, 1, 4, 1, 1>(a, stream);
+        case 5: return launch_cfg<KS, S, MODE, 1, 1, 4, 4, 1>(a, stream);
+        case 6: return launch_cfg<KS, S, MODE, 1, 1, 4, 2, 1>(a, stream);
+        case 7: return launch_cfg<KS, S, MODE, 1, 2, 2, 2, 1>(a, stream);
+        case 8: return launch_cfg<KS, S, MODE, 2, 2, 2, 2, 2>(a, stream);
+        case 9: return launch_cfg<KS, S, MODE, 2, 2, 2, 1, 2>(a, stream);
+        case 10: return launch_cfg<KS, S, MODE, 2, 1, 4, 3, 1>(a, stream);
+        case 11: return launch_cfg<KS, S, MODE, 2, 2, 2, 1, 1>(a, stream);
+        case 12: return launch_cfg<KS, S, MODE, 2, 1, 4, 5, 1>(a, stream);
+        case 13: return launch_cfg<KS, S, MODE, 2, 2, 2, 2, 1>(a, stream);
+        case 14: return launch_cfg<KS, S, MODE, 2, 1, 4, 2, 1>(a, stream);
+        case 15: return launch_cfg<KS, S, MODE, 2, 1, 4, 4, 1>(a, stream);
     }
     ssn_set_error("conv_x6: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
 }
 
-int g_x6_dbg = 0;
-int g_x6_desync = 0;
-unsigned long long* g_x6_trace = nullptr;
 
 int default_tile(int M, long P) {
     if (M % 128 == 0 || M > 256) return 0;
@@ -388,7 +602,7 @@ int default_tile(int M, long P) {
 
 long x6_packed_dwords(int Cout, int Cin, int ksize, int transposed) {
     const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
-    return (long)((C + 15) / 16) * ksize * ksize * M * PITCH_DW;
+    return (long)((C + 15) / 16) * ksize * ksize * M * APITCH;
 }
 
 int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, int C, int H, int W, long xs, int M,
@@ -411,16 +625,22 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
     const long xb = ((long)(N - 1) * xs + (long)C * H * W) * 4;
-    const long ab = (long)a.ngroups * ksize * ksize * M * PITCH_DW * 4;
+    const long ab = (long)a.ngroups * ksize * ksize * M * APITCH * 4;
     if (!(xb < (1l << 31) && ab < (1l << 31) && (long)N * Ho * Wo < (1l << 31))) {
         ssn_set_error("%s: operand larger than 2 GiB (buffer addressing)", what);
         return SSN_ERR_ARG;
     }
     a.dbg = g_x6_dbg;
-    a.desync = g_x6_desync;
     a.trace = g_x6_trace;
     a.x_bytes = (uint32_t)xb;
     a.a_bytes = (uint32_t)ab;
+    const long yb = ((long)(N - 1) * ys + (long)M * Ho * Wo) * 4;
+    if (!(yb < (1l << 31))) {
+        ssn_set_error("%s: output larger than 2 GiB (buffer addressing)", what);
+        return SSN_ERR_ARG;
+    }
+    a.y_bytes = (uint32_t)yb;
+    a.mask_bytes = 0;
     return SSN_OK;
 }
 
@@ -428,8 +648,7 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" void ssn_conv_x6_debug_flags(int flags) {
-    g_x6_dbg = flags & 0xFF;
-    g_x6_desync = flags >> 8;
+    g_x6_dbg = flags;
 }
 extern "C" void ssn_conv_x6_debug_trace(unsigned long long* buf) { g_x6_trace = buf; }
 
@@ -461,7 +680,7 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
             t.mode[i] = mode[j];
             t.split[i] = split[j];
             t.blk0[i] = blocks;
-            const long triples = x6_packed_dwords(cout[j], cin[j], ksize[j], mode[j]) / PITCH_DW * 8;
+            const long triples = x6_packed_dwords(cout[j], cin[j], ksize[j], mode[j]) / APITCH * 8;
             blocks += (int)((triples + XP_CHUNK - 1) / XP_CHUNK);
         }
         t.blk0[t.count] = blocks;
@@ -473,8 +692,8 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
 
 extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                                float* y, int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
-                               long y_img_stride, int ksize, int stride, int pad, int relu, int tile_cfg,
-                               hipStream_t stream) {
+                               long y_img_stride, int ksize, int stride, int pad, int relu, int x_guard_bytes,
+                               int tile_cfg, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv x6 fwd: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 fwd: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv x6 fwd: stride %d unsupported", stride);
@@ -482,6 +701,7 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
     int rc = fill_args(a, x, (const uint32_t*)w_packed, y, N, Cin, H, W, x_img_stride, Cout, Ho, Wo, y_img_stride,
                        ksize, pad, "conv x6 fwd");
     if (rc != SSN_OK) return rc;
+    a.x_guard = x_guard_bytes;
     a.scale = scale;
     a.shift = shift;
     a.relu = relu;
@@ -501,13 +721,14 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
 extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                                  long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                                 int tile_cfg, hipStream_t stream) {
+                                 int dy_guard_bytes, int tile_cfg, hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 dgrad: ksize %d unsupported", ksize);
     X6Args a;
     int rc = fill_args(a, dy, (const uint32_t*)wt_packed, dx, N, Cout, Ho, Wo, dy_img_stride, Cin, H, W,
                        dx_img_stride, ksize, pad, "conv x6 dgrad");
     if (rc != SSN_OK) return rc;
+    a.x_guard = dy_guard_bytes;
     a.scale = nullptr;
     a.shift = nullptr;
     a.relu = 0;
@@ -515,6 +736,11 @@ extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float*
     a.mask_y = mask_scale ? mask_y : nullptr;
     a.mask_scale = mask_y ? mask_scale : nullptr;
     a.mask_img_stride = mask_img_stride;
+    if (a.mask_y) {
+        const long mb = ((long)(N - 1) * mask_img_stride + (long)Cin * H * W) * 4;
+        SSN_CHECK_ARG(mb < (1l << 31), "conv x6 dgrad: mask tensor larger than 2 GiB (buffer addressing)");
+        a.mask_bytes = (uint32_t)mb;
+    }
     const int cfg = tile_cfg >= 0 ? tile_cfg : default_tile(Cin, a.P);
     if (ksize == 1) return launch_tile<1, 1, MODE_DGRAD>(a, cfg, stream);
     return launch_tile<3, 1, MODE_DGRAD>(a, cfg, stream);

@@ -142,6 +142,21 @@ def conv_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_c
              _stream(lib, w_packed))
 
 
+def guard_bytes(cs):
+    """Readable bytes in front of a ChanSlice: the channels below it, plus the pad of tensors from `guarded_empty`."""
+    base = cs.t.untyped_storage().data_ptr()
+    return int(min(cs.ptr - base, 1 << 20)) if base else 0
+
+
+def guarded_empty(shape, device, guard_floats=64):
+    """torch.empty with `guard_floats` readable floats in front of element 0 (see ssn_conv_x6_fwd: x_guard_bytes)."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    flat = torch.empty(n + guard_floats, device=device, dtype=torch.float32)
+    return flat[guard_floats:].view(*shape)
+
+
 def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
     """conv_fwd on the bf16 matrix cores (3-way split, fp32-class accuracy).  w_packed: pack_weights_multi(x6=True)."""
     lib = _check(x, w_packed, scale, shift, y)
@@ -149,7 +164,7 @@ def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, til
     ho, wo = y.hw
     assert w_packed.numel() >= packed_floats(y.c, x.c, ksize, False, True)
     lib.call("ssn_conv_x6_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
-             x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg,
+             x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), guard_bytes(x), tile_cfg,
              _stream(lib, w_packed))
 
 
@@ -161,7 +176,8 @@ def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, 
     h, w = dx.hw
     lib.call("ssn_conv_x6_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, ksize, pad, int(accumulate), _p(mask_y),
-             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), tile_cfg, _stream(lib, wt))
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), guard_bytes(dy), tile_cfg,
+             _stream(lib, wt))
 
 
 def relu_bn_bwd(dy, y, scale):

@@ -96,7 +96,11 @@ int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, in
  * terms are <= 2^-24 |ab|, i.e. the result is as accurate as an fp32 FMA chain (the 1e-4 budget of the path is
  * untouched) at 6/16 of the f32-MFMA matrix time.  ksize in {1,3}; forward stride in {1,2}; dgrad stride 1.
  * Weights: ssn_conv_x6_pack_weights_multi (mode 0 forward / 1 dgrad operand; same w1/split convention as
- * ssn_conv_pack_weights_multi), ssn_conv_x6_packed_floats() floats per layer.  Same call sites as
+ * ssn_conv_pack_weights_multi), ssn_conv_x6_packed_floats() floats per layer.
+ * x_guard_bytes / dy_guard_bytes: how many bytes directly in FRONT of the gathered tensor the caller guarantees to
+ * be readable device memory (e.g. the channels below a channel slice, or an allocation pad).  With >= 256 the
+ * stride-1 kernels fetch activations 16 bytes per lane (4 consecutive pixels; border positions are zeroed later),
+ * which reaches a few bytes before the first element; with 0 they use 4-byte loads and never leave the tensor.  Same call sites as
  * ssn_conv_bn_relu_fwd / ssn_conv_dgrad (ssn_models.py:266,298; loss.backward at ssn_train.py:223). */
 long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int transposed);
 void ssn_conv_x6_debug_trace(unsigned long long* per_block_8_words); /* tooling only; NULL = off */
@@ -106,11 +110,11 @@ int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const floa
                                    const int* split, hipStream_t stream);
 int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
                     int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo, long y_img_stride,
-                    int ksize, int stride, int pad, int relu, int tile_cfg, hipStream_t stream);
+                    int ksize, int stride, int pad, int relu, int x_guard_bytes, int tile_cfg, hipStream_t stream);
 int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                       long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                       int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                      int tile_cfg, hipStream_t stream);
+                      int dy_guard_bytes, int tile_cfg, hipStream_t stream);
 
 /* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
  * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */

@@ -359,10 +359,18 @@ static inline unsigned char __builtin_amdgcn_raw_buffer_load_b8(__amdgpu_buffer_
 }
 static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
                                                               int) {
+    // multi-dword raw loads are range-checked dword by dword
     const uint64_t o = (uint64_t)voff + soff;
-    emu_u32x4 v = {0, 0, 0, 0};
-    if (o + 16 <= r.bytes) memcpy(&v, r.base + o, 16);
-    return v;
+    unsigned int w[4] = {0, 0, 0, 0};
+    for (int d = 0; d < 4; ++d)
+        if (o + 4 * d + 4 <= r.bytes) memcpy(&w[d], r.base + o + 4 * d, 4);
+    return emu_u32x4{w[0], w[1], w[2], w[3]};
+}
+// raw buffer store: offsets at or beyond num_records are dropped
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned int v, __amdgpu_buffer_rsrc_t r, uint32_t voff,
+                                                         uint32_t soff, int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    if (o + 4 <= r.bytes) memcpy(const_cast<char*>(r.base) + o, &v, 4);
 }
 // LDS-DMA: every lane deposits `size` bytes at (wave-uniform lds base) + lane * size
 #define SSN_LDS_PTR(p) ((void*)(p))
@@ -371,10 +379,12 @@ static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc
                                                             uint32_t soff, int imm, int) {
     const uint64_t o = (uint64_t)voff + soff + (uint32_t)imm;
     char* dst = (char*)lds + (size_t)emu::g_cur->lane * size;
-    if (o + size <= r.bytes)
-        memcpy(dst, r.base + o, size);
-    else
-        memset(dst, 0, size);
+    for (int d = 0; d < size; d += 4) {       // range check dword by dword
+        if (o + d + 4 <= r.bytes)
+            memcpy(dst + d, r.base + o + d, 4);
+        else
+            memset(dst + d, 0, 4);
+    }
 }
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

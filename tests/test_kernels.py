@@ -322,9 +322,13 @@ def test_pack_weights_multi(backend):
 
 X6_CASES_SMALL = [
     # N, Cin, H, Cout, k, s, p, tile     (Cin deliberately not always a multiple of 16: tail-group masking)
-    (2, 16, 7, 96, 1, 1, 0, 2), (2, 24, 9, 40, 3, 1, 1, 3), (1, 32, 8, 130, 1, 1, 0, 0), (2, 16, 10, 33, 3, 2, 1, 4),
+    (2, 16, 6, 96, 1, 1, 0, 2), (2, 24, 10, 40, 3, 1, 1, 3), (1, 32, 8, 130, 1, 1, 0, 0), (2, 16, 10, 33, 3, 2, 1, 4),
     (1, 16, 9, 160, 3, 1, 1, 5), (1, 40, 6, 64, 1, 1, 0, 6), (1, 16, 6, 100, 3, 1, 1, 7), (2, 20, 6, 70, 3, 1, 1, 1),
+    (1, 16, 14, 40, 3, 1, 1, 0),
     (2, 16, 6, 48, 1, 1, 0, -1),
+    # 8-wave ping-pong workgroups (tile ids 8-15)
+    (2, 32, 10, 130, 3, 1, 1, 8), (3, 16, 7, 40, 1, 1, 0, 9), (2, 24, 8, 100, 3, 1, 1, 10), (2, 16, 10, 33, 3, 2, 1, 11),
+    (1, 16, 12, 170, 3, 1, 1, 12), (2, 40, 6, 64, 1, 1, 0, 13), (3, 16, 6, 70, 3, 1, 1, 14), (2, 16, 8, 128, 1, 1, 0, 15),
 ]
 X6_CASES_GPU = [
     (9, 64, 56, 192, 3, 1, 1, -1), (18, 192, 28, 64, 1, 1, 0, -1), (18, 128, 28, 160, 3, 2, 1, -1),
@@ -332,6 +336,8 @@ X6_CASES_GPU = [
     (36, 224, 7, 224, 3, 1, 1, -1), (4, 72, 14, 96, 3, 1, 1, -1),
     (5, 96, 28, 96, 3, 1, 1, 0), (5, 96, 28, 96, 3, 1, 1, 1), (5, 96, 28, 96, 3, 1, 1, 2), (5, 96, 28, 96, 3, 1, 1, 3),
     (5, 96, 28, 96, 3, 1, 1, 4), (5, 96, 28, 160, 3, 1, 1, 5), (5, 96, 28, 96, 1, 1, 0, 6), (5, 96, 28, 96, 1, 1, 0, 7),
+    (5, 96, 28, 96, 3, 1, 1, 8), (5, 96, 28, 96, 3, 1, 1, 9), (5, 96, 28, 96, 3, 1, 1, 10), (5, 96, 28, 96, 3, 2, 1, 11),
+    (5, 96, 28, 160, 3, 1, 1, 12), (5, 96, 28, 96, 1, 1, 0, 13), (5, 96, 28, 96, 1, 1, 0, 14), (5, 96, 28, 130, 3, 1, 1, 15),
 ]
 
 
@@ -350,21 +356,29 @@ def test_conv_x6_fwd_and_dgrad(backend):
         wd = backend.put(w)
         wp, wt = K.pack_weights_multi([([wd], 0), ([wd], 1)], x6=True)
         c0, ctot = 16, cout + 48
-        yd = backend.put(torch.full((n, ctot, ho, ho), 7.0))
-        K.conv_x6_fwd(K.full(backend.put(x)), wp, backend.put(scale), backend.put(shift), K.ChanSlice(yd, c0, cout),
-                      k, s, p, True, tile)
-        got = yd.cpu()
-        assert rel_err(got[:, c0:c0 + cout], ref) < 2e-5, ("fwd", n, cin, h, cout, k, s, tile)
-        assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all(), "wrote outside its slice"
-        if s != 1:
-            continue
         gy = torch.randn(n, cout, ho, ho, generator=g)
-        gref = torch.nn.grad.conv2d_input((n, cin, h, h), w.double(), gy.double(), s, p)
-        dx = backend.put(torch.full((n, cin, h, h), 0.5))
-        K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), k, p, True, tile)
-        assert rel_err(dx.cpu() - 0.5, gref) < 5e-5, ("dgrad", n, cin, h, cout, k, tile)
-        K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), k, p, False, tile)
-        assert rel_err(dx, gref) < 5e-5
+        gref = torch.nn.grad.conv2d_input((n, cin, h, h), w.double(), gy.double(), s, p) if s == 1 else None
+        # guarded = readable floats in front of the gathered tensor -> 16-byte activation loads where they apply
+        for guarded in (False, True):
+            def put(t):
+                if not guarded:
+                    return backend.put(t)
+                d = K.guarded_empty(t.shape, backend.put(torch.zeros(1)).device)
+                d.copy_(t)
+                return d
+            yd = backend.put(torch.full((n, ctot, ho, ho), 7.0))
+            K.conv_x6_fwd(K.full(put(x)), wp, backend.put(scale), backend.put(shift), K.ChanSlice(yd, c0, cout),
+                          k, s, p, True, tile)
+            got = yd.cpu()
+            assert rel_err(got[:, c0:c0 + cout], ref) < 2e-5, ("fwd", n, cin, h, cout, k, s, tile, guarded)
+            assert (got[:, :c0] == 7.0).all() and (got[:, c0 + cout:] == 7.0).all(), "wrote outside its slice"
+            if s != 1:
+                continue
+            dx = backend.put(torch.full((n, cin, h, h), 0.5))
+            K.conv_x6_dgrad(K.full(put(gy)), wt, K.full(dx), k, p, True, tile)
+            assert rel_err(dx.cpu() - 0.5, gref) < 5e-5, ("dgrad", n, cin, h, cout, k, tile, guarded)
+            K.conv_x6_dgrad(K.full(put(gy)), wt, K.full(dx), k, p, False, tile)
+            assert rel_err(dx, gref) < 5e-5
 
 
 def test_conv_x6_is_fp32_accurate(backend):
