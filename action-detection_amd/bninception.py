@@ -343,11 +343,22 @@ class BNInception(nn.Module):
             return grads[name]
 
         ws_bytes = 0
+        wg_x6 = {}
         for op in plan:
             if op["kind"] == "conv":
-                ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(
-                    n, op["cin"], op["cout"], shapes[op["dst"]][1], shapes[op["dst"]][2], op["k"],
-                    tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
+                hin, win = shapes[op["src"]][1], shapes[op["src"]][2]
+                x6 = (self.conv_precision == "bf16x6" and op["src"] != "data"
+                      and K.wgrad_x6_supported(op["k"], op["s"], op["p"], hin, win)
+                      and x6_wins("wgrad", op["cin"], op["cout"], op["k"], op["s"], hin))
+                wg_x6[op["lids"][0]] = x6
+                if x6:
+                    ws_bytes = max(ws_bytes, K.wgrad_x6_workspace_bytes(
+                        n, op["cin"], op["cout"], hin, win, op["k"],
+                        tuned_tile("wgrad6", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
+                else:
+                    ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(
+                        n, op["cin"], op["cout"], shapes[op["dst"]][1], shapes[op["dst"]][2], op["k"],
+                        tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
         ws = self._workspace(ws_bytes, dev)
         # all dgrad weight operands in two launches
         dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
@@ -432,16 +443,20 @@ class BNInception(nn.Module):
                 hin = shapes[op["src"]][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
                 xin = ChanSlice(acts[op["src"]], op["src_c0"], cin)
-                wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
+                if wg_x6[lids[0]]:
+                    wcfg = tuned_tile("wgrad6", n, cin, cout, k, s, hin)
+                    run_wgrad = lambda: K.conv_wgrad_x6(g, xin, dw, db, k, p, ws, wcfg)   # noqa: E731
+                else:
+                    wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
+                    run_wgrad = lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg)   # noqa: E731
                 if use_side:
                     ready = torch.cuda.Event()
                     ready.record(main)            # the output gradient of this layer is final here
                     side.wait_event(ready)
                     with torch.cuda.stream(side):
-                        self._timed("conv_wgrad", lids[0], flops,
-                                    lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg))
+                        self._timed("conv_wgrad", lids[0], flops, run_wgrad)
                 else:
-                    self._timed("conv_wgrad", lids[0], flops, lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg))
+                    self._timed("conv_wgrad", lids[0], flops, run_wgrad)
                 if op["src"] != "data":
                     layout = dg_layout[lids[0]]
                     wt = packed_dg[lids[0]]

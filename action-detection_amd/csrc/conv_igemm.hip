@@ -30,6 +30,7 @@
 //    the current one.
 //
 // Tiling: 256 threads = 4 waves as WM x WN; each wave owns TM x TN MFMA tiles of 32x32.
+#include "conv_epilogue.h"
 #include "ssn_common.h"
 
 namespace {
@@ -69,6 +70,7 @@ struct ConvArgs {
     int par;             // stride-2 dgrad: parity-major pixel order + tap-major slab rows (see below)
     FastDiv div_nq, div_q, div_wh;  // N*(H/2)*(W/2), (H/2)*(W/2), W/2 of the enumerated grid (parity-major decode)
     uint32_t x_bytes, a_bytes;  // extents of the gather source / packed weights (buffer descriptors)
+    uint32_t y_bytes, mask_bytes;   // extents of the output / mask tensors (epilogue buffer descriptors)
     FastDiv div_hw, div_w, div_mt;
 };
 
@@ -311,43 +313,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         if (!(p.dbg & 4)) __syncthreads();
     }
 
-    // ---- epilogue: folded BN affine + ReLU (fwd) or accumulate (dgrad), NCHW stores ----
-    const int howo = p.Ho * p.Wo;
+    // ---- epilogue: folded BN affine + ReLU (fwd) or accumulate + fused ReLU/BN backward (dgrad); conv_epilogue.h ----
+    __syncthreads();
+    float* ch = lds;
+    epi_stage_channels<BM, 256>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid);
+    __syncthreads();
+    EpiArgs e;
+    e.y = p.y;
+    e.mask_y = p.mask_y;
+    e.y_bytes = p.y_bytes;
+    e.mask_bytes = p.mask_bytes;
+    e.howo4 = (uint32_t)(p.Ho * p.Wo) * 4u;
+    e.M = p.M;
+    e.relu = p.relu;
+    e.accumulate = p.accumulate;
+    uint32_t yoff[TN], moff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pp = p0 + (wn * TN + j) * 32 + li;
-        if (pp >= p.P) continue;
+        const bool pv = pp < p.P;
         uint32_t n, hw;
         if (PAR && p.par) {
             uint32_t eh, ew;
-            decode_pixel(p, true, (uint32_t)pp, n, eh, ew);
+            decode_pixel(p, true, (uint32_t)(pv ? pp : 0), n, eh, ew);
             hw = eh * (uint32_t)p.Wo + ew;
         } else {
-            fd_divmod((uint32_t)pp, p.div_hw, n, hw);
+            fd_divmod((uint32_t)(pv ? pp : 0), p.div_hw, n, hw);
         }
-        float* yb = p.y + (long)n * p.y_img_stride + hw;
-        const float* mb = p.mask_y ? p.mask_y + (long)n * p.mask_img_stride + hw : nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (p.scale) v = v * p.scale[m] + p.shift[m];
-                if (p.relu) v = fmaxf(v, 0.f);
-                float* dst = yb + (long)m * howo;
-                if (p.accumulate) v += *dst;
-                if (mb) {
-                    // last writer of this gradient tensor: fuse the backward of the producer's ReLU + frozen BN
-                    // (what ssn_relu_bn_bwd would do in a separate pass)
-                    const float sc = p.mask_scale[m];
-                    v = (sc < 0.f) ? v * -sc : (mb[(long)m * howo] > 0.f ? v * sc : 0.f);
-                }
-                *dst = v;
-            }
-        }
+        const uint32_t row0 = (uint32_t)(m0 + 4 * lh) * e.howo4 + hw * 4u;
+        yoff[j] = pv ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : EPI_OOB;
+        moff[j] = pv ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : EPI_OOB;
     }
+    conv_epilogue<TM, TN, BM>(acc, ch, e, yoff, moff, wm * TM * 32, lh, m0);
 }
 
 // Ap[slab][m][h*HP + t] = A[m][c = slab*CPS + cl][tap], (cl, tap) = decode(k = 2t + h); zero padded.
@@ -620,9 +617,13 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
     a.div_w = make_fastdiv((uint32_t)Wo);
     const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
     const long ab = ssn_conv_packed_floats(Cout, Cin, ksize, 0) * 4;
-    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31), "conv fwd: operand larger than 2 GiB (buffer addressing)");
+    const long yb = ((long)(N - 1) * y_img_stride + (long)Cout * Ho * Wo) * 4;
+    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31) && yb < (1l << 31),
+                  "conv fwd: operand larger than 2 GiB (buffer addressing)");
     a.x_bytes = (uint32_t)xb;
     a.a_bytes = (uint32_t)ab;
+    a.y_bytes = (uint32_t)yb;
+    a.mask_bytes = 0;
     const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, a.P);
     if (ksize == 1 && stride == 1) return launch_tile<1, 1, MODE_FWD>(a, cfg, stream);
     if (ksize == 3 && stride == 1) return launch_tile<3, 1, MODE_FWD>(a, cfg, stream);
@@ -685,9 +686,14 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx
     a.div_w = make_fastdiv((uint32_t)W);
     const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4;
     const long ab = ssn_conv_packed_floats(Cout, Cin, ksize, 1) * 4;
-    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31), "conv dgrad: operand larger than 2 GiB (buffer addressing)");
+    const long yb = ((long)(N - 1) * dx_img_stride + (long)Cin * H * W) * 4;
+    const long mb = a.mask_y ? ((long)(N - 1) * mask_img_stride + (long)Cin * H * W) * 4 : 0;
+    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31) && yb < (1l << 31) && mb < (1l << 31),
+                  "conv dgrad: operand larger than 2 GiB (buffer addressing)");
     a.x_bytes = (uint32_t)xb;
     a.a_bytes = (uint32_t)ab;
+    a.y_bytes = (uint32_t)yb;
+    a.mask_bytes = (uint32_t)mb;
     const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cin, a.P);
     if (ksize == 1 && stride == 1) return launch_tile<1, 1, MODE_DGRAD>(a, cfg, stream);
     if (ksize == 3 && stride == 1) return launch_tile<3, 1, MODE_DGRAD>(a, cfg, stream);

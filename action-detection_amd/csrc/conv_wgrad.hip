@@ -325,6 +325,17 @@ void plan_wgrad(int M, int K, long P, int cfg, int* splits, int* chunks_per_spli
 
 }  // namespace
 
+// dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] (fixed order); shared with conv_wgrad_x6.hip
+extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream) {
+    const long total = (long)M * (K + 1);
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, part, dw, db, M, K, K + 1,
+                       splits);
+    SSN_CHECK_LAUNCH("wgrad_reduce");
+    return SSN_OK;
+}
+
 extern "C" long ssn_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int ksize, int tile_cfg) {
     const int K = Cin * ksize * ksize;
     const int cfg = tile_cfg >= 0 ? tile_cfg : pick_wgrad_tile(Cout, K);
@@ -383,11 +394,5 @@ extern "C" int ssn_conv_wgrad(const float* g, const float* x, float* dw, float* 
         return SSN_ERR_ARG;
     }
     if (rc != SSN_OK) return rc;
-    const long total = (long)Cout * a.ldp;
-    long blocks = (total + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)a.part, dw,
-                       db, Cout, a.K, a.ldp, a.splits);
-    SSN_CHECK_LAUNCH("wgrad_reduce");
-    return SSN_OK;
+    return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
 }

@@ -1,0 +1,416 @@
+// Weight (and bias) gradient of the stride-1 1x1 / 3x3 backbone convolutions on the bf16 matrix cores with
+// fp32-class accuracy ("x6" scheme of conv_x6.hip: every fp32 operand split exactly into three bf16 terms, six
+// partial products per k16 step accumulated in fp32), gfx950.
+//
+// Same contract as conv_wgrad.hip (the cuDNN wgrad behind loss.backward(), /root/reference/ssn_train.py:236):
+//   dW[co][kk] = sum_p G[co][p] * X[kk][p]        kk = (ci, r, s),  p = (n, ho, wo)
+//   db[co]     = sum_p G[co][p]                   (summed in fp32 from the unsplit values)
+// split-K over the pixel range, partial slabs reduced in a fixed order by the shared reduce kernel (deterministic).
+//
+// What is different from the f32 kernel, and why:
+//  * The reduction index (pixels) is the contiguous axis of BOTH operands in NCHW, so every global access is a
+//    16-byte load of 4 consecutive pixels.  The texture path accepts one wave instruction per ~16 cycles whatever
+//    its width; the dword-per-pixel loads of the f32 kernel keep it as busy as the (64-cycle) f32 MFMAs, and would
+//    starve a 32-cycle bf16 MFMA.  Address arithmetic is linear in the pixel index for stride 1, so a 4-pixel group
+//    is one load even when it runs over the end of an image row; the taps that fall on padding are zeroed in
+//    registers afterwards (two compares per pixel and row).  Loads of the shifted taps reach up to (W+1) floats in
+//    front of x: the caller guarantees 256 readable bytes there (x_guard_bytes, see include/ssn_hip.h).
+//  * Both operands are activations, so both are split on the fly: once per element, by the thread that stages it
+//    (22 VALU per 4 pixels), written to LDS as three bf16 planes per row ([row][plane][16 k], 112-byte pitch) so
+//    that every MFMA operand is one conflict-free ds_read_b128.
+//  * Loads run two chunks (2 x 16 pixels) ahead of the MFMAs in two alternating register sets: one chunk of MFMAs
+//    (~0.8k cycles per wave) does not cover a global round trip.
+#include "ssn_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct WgX6Args {
+    const float* g;  // [N][..Cout..][H][W] channel-slice base (stride 1, same-size convolution)
+    const float* x;  // [N][..Cin..][H][W] channel-slice base
+    float* part;     // [splits][M][ldp]
+    int N, Cin, H, W;
+    long x_img_stride;
+    int M;
+    long g_img_stride;
+    int K;    // Cin*KS*KS
+    int ldp;  // K + 1 (last column = bias gradient)
+    int P;    // N*H*W
+    int pad;
+    int splits, chunks_per_split;  // chunk = 16 pixels
+    int n_mtiles, n_ktiles;
+    uint32_t g_bytes, x_bytes;
+    FastDiv div_hw, div_w, div_tiles, div_kt;
+};
+
+constexpr int CP = 16;          // pixels per chunk = one bf16 MFMA k-step
+constexpr int PITCH_DW = 28;    // LDS row: 3 planes x 32 B + 16 B pad
+constexpr uint32_t OOB = 0x80000000u;
+constexpr uint32_t GUARD = 256u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t wg_pack_hi16(uint32_t even, uint32_t odd) {
+    return __builtin_amdgcn_perm(odd, even, 0x07060302u);
+}
+__device__ __forceinline__ float wg_residual(float x) {
+    return x - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
+}
+// 4 consecutive k values -> 2 dwords per plane (k even in the low half)
+__device__ __forceinline__ void wg_split4(const float (&v)[4], uint32_t (&pl)[3][2]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float x0 = v[2 * e], x1 = v[2 * e + 1];
+        const float r0 = wg_residual(x0), r1 = wg_residual(x1);
+        const float s0 = wg_residual(r0), s1 = wg_residual(r1);
+        pl[0][e] = wg_pack_hi16(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, x1));
+        pl[1][e] = wg_pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
+        pl[2][e] = wg_pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+    }
+}
+
+template <int KS, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    constexpr int NAR = (BM + 63) / 64;   // G rows per thread (thread = one row x 4 pixels of a chunk)
+    constexpr int NBR = (BN + 63) / 64;   // X rows per thread
+    constexpr int KK = KS * KS;
+    constexpr int STAGE = (BM + BN) * PITCH_DW;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const uint32_t tiles = (uint32_t)p.n_mtiles * (uint32_t)p.n_ktiles;
+    const uint32_t nblk = tiles * (uint32_t)p.splits;
+    const uint32_t logical = xcd_remap(blockIdx.x, nblk);
+    uint32_t z, tile, mt, kt;
+    fd_divmod(logical, p.div_tiles, z, tile);
+    fd_divmod(tile, p.div_kt, mt, kt);
+    const int m0 = (int)mt * BM;
+    const int kk0 = (int)kt * BN;
+
+    const int pxg = tid & 3;       // which 4-pixel group of the chunk
+    const int row0 = tid >> 2;     // 0..63; this thread stages rows row0 + 64 i
+    const int HW = p.H * p.W;
+
+    // ---- loop-invariant row constants ----
+    uint32_t a_const[NAR];   // byte offset of row m inside an image of G, or OOB
+#pragma unroll
+    for (int i = 0; i < NAR; ++i) {
+        const int r = row0 + 64 * i, m = m0 + r;
+        a_const[i] = (r < BM && m < p.M) ? (uint32_t)(m * HW) * 4u : OOB;
+    }
+    uint32_t b_const[NBR];   // byte offset of (c, r, s) relative to the pixel (guard included), or OOB
+    int b_dh[NBR], b_dw[NBR];   // tap displacement (r - pad, s - pad)
+#pragma unroll
+    for (int i = 0; i < NBR; ++i) {
+        const int r = row0 + 64 * i, kk = kk0 + r;
+        int c = kk, tap = 0;
+        if (KS != 1) {
+            c = kk / KK;
+            tap = kk - c * KK;
+        }
+        const int tr = tap / KS, ts = tap - tr * KS;
+        b_dh[i] = tr - p.pad;
+        b_dw[i] = ts - p.pad;
+        b_const[i] = (r < BN && kk < p.K) ? (uint32_t)((c * HW + b_dh[i] * p.W + b_dw[i]) * 4 + (int)GUARD) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t grsrc = wg_rsrc(p.g, p.g_bytes);
+    const __amdgpu_buffer_rsrc_t xrsrc = wg_rsrc(reinterpret_cast<const char*>(p.x) - GUARD, p.x_bytes + GUARD);
+
+    struct Staged {
+        u32x4 a[NAR], b[NBR];
+        uint32_t ho, wo;   // first pixel of the group
+    };
+    auto load_chunk = [&](int chunk, Staged& s) {
+        const int pp = chunk * CP + pxg * 4;
+        const bool valid = pp < p.P;
+        uint32_t n, hw;
+        fd_divmod((uint32_t)(valid ? pp : 0), p.div_hw, n, hw);
+        fd_divmod(hw, p.div_w, s.ho, s.wo);
+        const uint32_t abase = (uint32_t)((long)n * p.g_img_stride * 4) + hw * 4u;
+        const uint32_t bbase = (uint32_t)((long)n * p.x_img_stride * 4) + hw * 4u;
+#pragma unroll
+        for (int i = 0; i < NAR; ++i)
+            s.a[i] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, (valid && a_const[i] != OOB) ? abase + a_const[i] : OOB,
+                                                           0, 0);
+#pragma unroll
+        for (int i = 0; i < NBR; ++i)
+            s.b[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (valid && b_const[i] != OOB) ? bbase + b_const[i] : OOB,
+                                                           0, 0);
+    };
+
+    float rowsum[NAR];
+#pragma unroll
+    for (int i = 0; i < NAR; ++i) rowsum[i] = 0.f;
+    const bool do_bias = (kt == 0);
+
+    // split the staged fp32 values into bf16 planes and write them to LDS buffer `buf`
+    auto store_chunk = [&](const Staged& s, int buf) {
+        uint32_t* As = lds + buf * STAGE + row0 * PITCH_DW + pxg * 2;
+        uint32_t* Bs = lds + buf * STAGE + BM * PITCH_DW + row0 * PITCH_DW + pxg * 2;
+#pragma unroll
+        for (int i = 0; i < NAR; ++i) {
+            if (row0 + 64 * i >= BM) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t u = s.a[i][e];   // (bit_cast straight from a vector element reads element 0)
+                v[e] = __builtin_bit_cast(float, u);
+            }
+            if (do_bias) rowsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            uint32_t pl[3][2];
+            wg_split4(v, pl);
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn)
+                *reinterpret_cast<uint2*>(As + 64 * i * PITCH_DW + pn * 8) = uint2{pl[pn][0], pl[pn][1]};
+        }
+        // pixel coordinates of the 4 pixels (a group may run over the end of an image row)
+        int hh[4], ww[4];
+        if (KS != 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int w = (int)s.wo + e, h = (int)s.ho;
+                if (w >= p.W) {
+                    w -= p.W;
+                    h += 1;
+                }
+                hh[e] = h;
+                ww[e] = w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NBR; ++i) {
+            if (row0 + 64 * i >= BN) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t u = s.b[i][e];
+                v[e] = __builtin_bit_cast(float, u);
+                if (KS != 1) {
+                    const bool ok = ((unsigned)(hh[e] + b_dh[i]) < (unsigned)p.H) && ((unsigned)(ww[e] + b_dw[i]) < (unsigned)p.W);
+                    v[e] = ok ? v[e] : 0.f;
+                }
+            }
+            uint32_t pl[3][2];
+            wg_split4(v, pl);
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn)
+                *reinterpret_cast<uint2*>(Bs + 64 * i * PITCH_DW + pn * 8) = uint2{pl[pn][0], pl[pn][1]};
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const uint32_t* As = lds + buf * STAGE + (wm * TM * 32 + li) * PITCH_DW + lh * 4;
+        const uint32_t* Bs = lds + buf * STAGE + BM * PITCH_DW + (wn * TN * 32 + li) * PITCH_DW + lh * 4;
+        bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+        for (int pn = 0; pn < 3; ++pn) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + i * 32 * PITCH_DW + pn * 8));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[pn][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + j * 32 * PITCH_DW + pn * 8));
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], bf[PB[c]][j], acc[i][j], 0, 0, 0);
+    };
+
+    const int total_chunks = (p.P + CP - 1) / CP;
+    const int c_begin = (int)z * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+    const int nch = c_end - c_begin;
+
+    // chunk t lives in register set t & 1 from two iterations before it is multiplied until one iteration before
+    Staged s0, s1;
+    if (nch > 0) {
+        load_chunk(c_begin, s0);
+        if (nch > 1) load_chunk(c_begin + 1, s1);
+        store_chunk(s0, 0);
+        if (nch > 2) load_chunk(c_begin + 2, s0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nch; t += 2) {
+        // even chunk t: LDS buffer 0; registers: s1 = chunk t+1, s0 = chunk t+2 (in flight)
+        compute(0);
+        if (t + 1 < nch) store_chunk(s1, 1);
+        if (t + 3 < nch) load_chunk(c_begin + t + 3, s1);
+        __syncthreads();
+        if (t + 1 >= nch) break;
+        // odd chunk t+1: LDS buffer 1; registers: s0 = chunk t+2, s1 = chunk t+3 (in flight)
+        compute(1);
+        if (t + 2 < nch) store_chunk(s0, 0);
+        if (t + 4 < nch) load_chunk(c_begin + t + 4, s0);
+        __syncthreads();
+    }
+
+    // ---- partial slab store: part[z][m][kk] (kk contiguous across lanes) ----
+    float* out = p.part + (long)z * p.M * p.ldp;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int kk = kk0 + (wn * TN + j) * 32 + li;
+        if (kk >= p.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) out[(long)m * p.ldp + kk] = acc[i][j][r];
+            }
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < NAR; ++i) {
+            float tot = rowsum[i];
+            tot += __shfl_xor(tot, 1, 64);   // the 4 pixel groups of a row sit in 4 adjacent lanes
+            tot += __shfl_xor(tot, 2, 64);
+            const int r = row0 + 64 * i, m = m0 + r;
+            if (pxg == 0 && r < BM && m < p.M) out[(long)m * p.ldp + p.K] = tot;
+        }
+    }
+}
+
+template <int KS, int WM, int WN, int TM, int TN>
+int launch_wgx6(WgX6Args& a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.n_ktiles = (a.K + BN - 1) / BN;
+    const unsigned tiles = (unsigned)a.n_mtiles * (unsigned)a.n_ktiles;
+    a.div_tiles = make_fastdiv(tiles);
+    a.div_kt = make_fastdiv((uint32_t)a.n_ktiles);
+    hipLaunchKernelGGL((wgrad_x6_kernel<KS, WM, WN, TM, TN>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("conv_wgrad_x6");
+    return SSN_OK;
+}
+
+// tile configs as in conv_wgrad.hip:
+//   0: 64(co) x 64(kk)   1: 32 x 128   2: 128 x 128   3: 64 x 128   4: 96 x 128   5: 64 x 128 (waves along kk)   6: 128 x 64
+const int kBM[7] = {64, 32, 128, 64, 96, 64, 128};
+const int kBN[7] = {64, 128, 128, 128, 128, 128, 64};
+
+template <int KS>
+int launch_wgx6_tile(WgX6Args& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_wgx6<KS, 2, 2, 1, 1>(a, stream);
+        case 1: return launch_wgx6<KS, 1, 4, 1, 1>(a, stream);
+        case 2: return launch_wgx6<KS, 2, 2, 2, 2>(a, stream);
+        case 3: return launch_wgx6<KS, 2, 2, 1, 2>(a, stream);
+        case 4: return launch_wgx6<KS, 1, 4, 3, 1>(a, stream);
+        case 5: return launch_wgx6<KS, 1, 4, 2, 1>(a, stream);
+        case 6: return launch_wgx6<KS, 2, 2, 2, 1>(a, stream);
+    }
+    ssn_set_error("conv_wgrad_x6: unknown tile config %d", cfg);
+    return SSN_ERR_ARG;
+}
+
+int pick_tile(int M, int K) {
+    double best = 1e300;
+    int bc = 0;
+    for (int c = 0; c < 7; ++c) {
+        const double padded = (double)((M + kBM[c] - 1) / kBM[c]) * kBM[c] * (double)((K + kBN[c] - 1) / kBN[c]) * kBN[c];
+        const double reuse = (kBM[c] * kBN[c] >= 128 * 64) ? 1.0 : 1.12;
+        if (padded * reuse < best) {
+            best = padded * reuse;
+            bc = c;
+        }
+    }
+    return bc;
+}
+
+void plan(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
+    const long tiles = (long)((M + kBM[cfg] - 1) / kBM[cfg]) * ((K + kBN[cfg] - 1) / kBN[cfg]);
+    const long chunks = (P + CP - 1) / CP;
+    long want = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
+    if (want < 1) want = 1;
+    long cps = (chunks + want - 1) / want;
+    if (cps < 32) cps = chunks < 32 ? chunks : 32;  // keep at least 512 pixels per workgroup
+    if (cps < 1) cps = 1;
+    *chunks_per_split = (int)cps;
+    *splits = (int)((chunks + cps - 1) / cps);
+}
+
+}  // namespace
+
+// reduce kernel shared with conv_wgrad.hip
+extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
+
+extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int H, int W, int ksize, int tile_cfg) {
+    const int K = Cin * ksize * ksize;
+    const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, K);
+    int splits, cps;
+    plan(Cout, K, (long)N * H * W, cfg, &splits, &cps);
+    return (long)splits * Cout * (K + 1) * (long)sizeof(float);
+}
+
+// Stride-1, same-size (2*pad == ksize-1) convolutions with H*W a multiple of 4; x_guard_bytes >= 256 (see header).
+extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                                 long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
+                                 void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream) {
+    SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
+    SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv wgrad x6: ksize %d unsupported", ksize);
+    SSN_CHECK_ARG(2 * pad == ksize - 1, "conv wgrad x6: only same-size stride-1 convolutions (pad %d, ksize %d)", pad, ksize);
+    SSN_CHECK_ARG((H * W) % 4 == 0, "conv wgrad x6: H*W = %d is not a multiple of 4", H * W);
+    SSN_CHECK_ARG((pad * W + pad) * 4 <= (int)GUARD, "conv wgrad x6: image rows of %d pixels are too wide for the guard", W);
+    SSN_CHECK_ARG(x_guard_bytes >= (int)GUARD, "conv wgrad x6: needs %u readable bytes in front of x (got %d)", GUARD,
+                  x_guard_bytes);
+    WgX6Args a;
+    a.g = g;
+    a.x = x;
+    a.part = (float*)workspace;
+    a.N = N;
+    a.Cin = Cin;
+    a.H = H;
+    a.W = W;
+    a.x_img_stride = x_img_stride;
+    a.M = Cout;
+    a.g_img_stride = g_img_stride;
+    a.K = Cin * ksize * ksize;
+    a.ldp = a.K + 1;
+    a.P = N * H * W;
+    a.pad = pad;
+    a.div_hw = make_fastdiv((uint32_t)(H * W));
+    a.div_w = make_fastdiv((uint32_t)W);
+    const long gb = ((long)(N - 1) * g_img_stride + (long)Cout * H * W) * 4;
+    const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
+    SSN_CHECK_ARG(gb < (1l << 31) && xb < (1l << 31) - 512, "conv wgrad x6: operand larger than 2 GiB (buffer addressing)");
+    a.g_bytes = (uint32_t)gb;
+    a.x_bytes = (uint32_t)xb;
+    const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, a.K);
+    plan(Cout, a.K, a.P, cfg, &a.splits, &a.chunks_per_split);
+    const long need = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
+    if (ws_bytes < need) {
+        ssn_set_error("conv wgrad x6: workspace %ld < %ld bytes", ws_bytes, need);
+        return SSN_ERR_WORKSPACE;
+    }
+    const int rc = ksize == 1 ? launch_wgx6_tile<1>(a, cfg, stream) : launch_wgx6_tile<3>(a, cfg, stream);
+    if (rc != SSN_OK) return rc;
+    return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
+}

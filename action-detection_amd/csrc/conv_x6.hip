@@ -28,6 +28,7 @@
 //    workgroups drift into lock-step instead: both wait, then both compete -- measured 60 % pipe utilisation).
 //  * Epilogue: per-channel vectors via LDS, branch-free buffer addressing (out-of-range rows/pixels fall off the
 //    buffer), read-modify-write operands fetched one accumulator tile ahead.
+#include "conv_epilogue.h"
 #include "ssn_common.h"
 
 namespace {
@@ -385,82 +386,29 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
 
     // ---- epilogue: BN affine + ReLU (forward), or accumulate + fused ReLU/BN backward (dgrad) ----
     __syncthreads();
-    float* ch = reinterpret_cast<float*>(lds);   // [0,BM) scale  [BM,2BM) shift  [2BM,3BM) mask scale
-    for (int r = tid; r < BM; r += NT) {
-        const int m = m0 + r;
-        const bool ok = m < p.M;
-        ch[r] = (ok && p.scale) ? p.scale[m] : 1.f;
-        ch[BM + r] = (ok && p.scale) ? p.shift[m] : 0.f;
-        ch[2 * BM + r] = (ok && p.mask_scale) ? p.mask_scale[m] : -1.f;
-    }
+    float* ch = reinterpret_cast<float*>(lds);
+    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid);
     __syncthreads();
-    // Everything below is branch-free buffer addressing: lanes whose pixel or row is outside the tensor carry an
-    // out-of-range offset (loads return 0, stores are dropped), so the compiler can count outstanding operations
-    // exactly instead of draining the queue (s_waitcnt vmcnt(0)) at every divergent join.
-    const uint32_t howo4 = (uint32_t)(p.Ho * p.Wo) * 4u;
-    const __amdgpu_buffer_rsrc_t yrsrc = make_rsrc(p.y, p.y_bytes);
+    EpiArgs e;
+    e.y = p.y;
+    e.mask_y = p.mask_y;
+    e.y_bytes = p.y_bytes;
+    e.mask_bytes = p.mask_bytes;
+    e.howo4 = (uint32_t)(p.Ho * p.Wo) * 4u;
+    e.M = p.M;
+    e.relu = p.relu;
+    e.accumulate = p.accumulate;
     uint32_t yoff[TN], moff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pp = p0 + grp * BNG + (wn * TN + j) * 32 + li;
         uint32_t n, hw;
         fd_divmod((uint32_t)(pp < p.P ? pp : 0), p.div_hw, n, hw);
-        const uint32_t row0 = (uint32_t)(m0 + 4 * lh) * howo4 + hw * 4u;
-        yoff[j] = pp < p.P ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : OOB;
-        moff[j] = pp < p.P ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : OOB;
+        const uint32_t row0 = (uint32_t)(m0 + 4 * lh) * e.howo4 + hw * 4u;
+        yoff[j] = pp < p.P ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : EPI_OOB;
+        moff[j] = pp < p.P ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : EPI_OOB;
     }
-    const int mlim = p.M - m0 - 4 * lh;   // rows srow (without the lane-half term) below this are inside the tensor
-    auto srow = [&](int i, int r) { return (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2); };
-    if (!p.accumulate && !p.mask_y) {
-        // pure stores: nothing in this path waits on memory
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int sr = srow(i, r);
-                    float v = acc[i][j][r] * ch[sr + 4 * lh] + ch[BM + sr + 4 * lh];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
-                                                          sr < mlim ? yoff[j] : OOB, (uint32_t)sr * howo4, 0);
-                }
-    } else {
-        // read-modify-write: the operands of tile g+1 are requested before tile g is stored
-        const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.y, p.accumulate ? p.y_bytes : 0u);
-        const __amdgpu_buffer_rsrc_t mrsrc = make_rsrc(p.mask_y ? p.mask_y : p.y, p.mask_y ? p.mask_bytes : 0u);
-        constexpr int G = TM * TN * 2;   // half accumulator tiles (8 values per lane)
-        float old[2][8], mk[2][8];
-        auto fetch = [&](int g, int b) {
-            const int j = (g >> 1) / TM, i = (g >> 1) % TM;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int sr = srow(i, (g & 1) * 8 + q);
-                old[b][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                          orsrc, sr < mlim ? yoff[j] : OOB, (uint32_t)sr * howo4, 0));
-                mk[b][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                         mrsrc, sr < mlim ? moff[j] : OOB, (uint32_t)sr * howo4, 0));
-            }
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (g + 1 < G) fetch(g + 1, (g + 1) & 1);
-            const int j = (g >> 1) / TM, i = (g >> 1) % TM, b = g & 1;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = (g & 1) * 8 + q;
-                const int sr = srow(i, r);
-                float v = acc[i][j][r] * ch[sr + 4 * lh] + ch[BM + sr + 4 * lh];
-                if (p.relu) v = fmaxf(v, 0.f);
-                v += old[b][q];
-                const float sc = ch[2 * BM + sr + 4 * lh];
-                v = (sc < 0.f) ? v * -sc : (mk[b][q] > 0.f ? v * sc : 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
-                                                      sr < mlim ? yoff[j] : OOB, (uint32_t)sr * howo4, 0);
-            }
-        }
-    }
+    conv_epilogue<TM, TN, BM>(acc, ch, e, yoff, moff, wm * TM * 32, lh, m0);
 #ifdef X6_PHASE_TRACE
     if (p.trace && lane == 0 && (wave & 3) == 0) {
         unsigned long long* t = p.trace + (size_t)blockIdx.x * 32 + 8 + 8 * (wave >> 2);
@@ -552,7 +500,8 @@ int launch_cfg(X6Args& a, hipStream_t stream) {
     // a tile width the 1 KiB pieces divide, and the caller's guarantee that the bytes in front of x are readable
     constexpr bool wide_ok = (S == 1) && BN <= 256 && BN / 16 >= 4 * NG;
     if constexpr (wide_ok) {
-        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && !(g_x6_dbg & 16)) {
+        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && (KS - 1) * (a.W + 1) * 4 <= 256 &&
+            !(g_x6_dbg & 16)) {
             hipLaunchKernelGGL((conv_x6_kernel<KS, S, MODE, true, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0,
                                stream, a);
             SSN_CHECK_LAUNCH("conv_x6 (wide)");

@@ -217,6 +217,25 @@ def conv_wgrad(g, x, dw, db, ksize, stride, pad, workspace, tile_cfg=-1):
              tile_cfg, _stream(lib, dw))
 
 
+def wgrad_x6_supported(ksize, stride, pad, h, w):
+    """Layers the x6 weight-gradient kernel takes (the others stay on the exact-f32 kernel)."""
+    return ksize in (1, 3) and stride == 1 and 2 * pad == ksize - 1 and (h * w) % 4 == 0 and (pad * w + pad) * 4 <= 256
+
+
+def wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg=-1):
+    return int(_lib.get_lib().cdll.ssn_conv_wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg))
+
+
+def conv_wgrad_x6(g, x, dw, db, ksize, pad, workspace, tile_cfg=-1):
+    """conv_wgrad on the bf16 matrix cores (stride 1, same size).  x needs >= 256 readable bytes in front of it."""
+    lib = _check(g, x, dw, db, workspace)
+    h, w = x.hw
+    assert g.hw == x.hw
+    lib.call("ssn_conv_wgrad_x6", _p(g), _p(x), _p(dw), _p(db), x.n, x.c, h, w, x.img_stride, g.c, g.img_stride,
+             ksize, pad, guard_bytes(x), _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg,
+             _stream(lib, dw))
+
+
 def pool_fwd(kind, x, y, argmax, ksize, stride, pad):
     lib = _check(x, y, argmax)
     h, w = x.hw

@@ -116,6 +116,16 @@ int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N,
                       int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
                       int dy_guard_bytes, int tile_cfg, hipStream_t stream);
 
+/* x6 weight gradient (csrc/conv_wgrad_x6.hip): stride-1 same-size 1x1 / 3x3 convolutions with H*W % 4 == 0, both
+ * operands split to bf16 on the fly, 16-byte loads along the pixel axis.  Same result contract as ssn_conv_wgrad
+ * (deterministic split-K).  x_guard_bytes >= 256 is REQUIRED (the shifted taps read up to W+1 floats before x). */
+long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int H, int W, int ksize, int tile_cfg);
+int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                      long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
+                      void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream);
+/* second pass of both wgrad kernels: dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] */
+int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
+
 /* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
  * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */
 long ssn_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int ksize, int tile_cfg);

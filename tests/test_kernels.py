@@ -428,3 +428,35 @@ def test_conv_x6_fused_pair_and_mask(backend):
     K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), 1, 0, True, mask_y=K.full(backend.put(y_in)),
                     mask_scale=backend.put(scale))
     assert rel_err(dx, ref) < 5e-5
+
+
+def test_conv_wgrad_x6(backend):
+    """bf16-split weight gradient (+ fp32 bias gradient) vs torch autograd in fp64; tolerance as the f32 kernel (5e-5)."""
+    g = torch.Generator().manual_seed(30)
+    cases = ([(6, 24, 14, 80, 3, -1), (4, 64, 28, 96, 1, -1), (3, 40, 56, 64, 3, 2), (5, 576, 14, 224, 1, -1),
+              (2, 20, 14, 33, 3, 0), (2, 16, 28, 100, 3, 1), (2, 64, 14, 130, 1, 3), (2, 16, 14, 96, 3, 4),
+              (2, 32, 14, 64, 1, 5), (2, 16, 14, 128, 3, 6)] if backend.is_gpu else
+             [(2, 6, 8, 40, 3, 0), (1, 16, 6, 33, 1, 1), (1, 8, 10, 130, 3, 2), (2, 4, 6, 70, 3, 3), (1, 20, 8, 96, 1, 4),
+              (1, 4, 14, 64, 3, 5), (2, 8, 6, 128, 1, 6), (3, 5, 4, 20, 3, -1)])
+    for (n, cin, h, cout, k, cfg) in cases:
+        p = (k - 1) // 2
+        x = torch.randn(n, cin, h, h, generator=g)
+        w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).double().requires_grad_()
+        b = torch.zeros(cout, dtype=torch.double, requires_grad=True)
+        y = F.conv2d(x.double(), w, b, 1, p)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy.double())
+        assert K.wgrad_x6_supported(k, 1, p, h, h)
+        dev = backend.put(torch.zeros(1)).device
+        xd = K.guarded_empty(x.shape, dev)
+        xd.copy_(x)
+        ws = backend.put(torch.empty(K.wgrad_x6_workspace_bytes(n, cin, cout, h, h, k, cfg) // 4))
+        dw, db = backend.put(torch.empty(cout, cin, k, k)), backend.put(torch.empty(cout))
+        K.conv_wgrad_x6(K.full(backend.put(gy)), K.full(xd), dw, db, k, p, ws, cfg)
+        assert rel_err(dw, w.grad) < 5e-5, ("wgrad x6", n, cin, h, cout, k, cfg)
+        assert rel_err(db, b.grad) < 5e-5
+        # channel slices of wider tensors (the guard is then the channels below the slice)
+        xw = backend.put(torch.randn(n, cin + 8, h, h, generator=g))
+        xw[:, 8:].copy_(backend.put(x))
+        K.conv_wgrad_x6(K.full(backend.put(gy)), K.ChanSlice(xw, 8, cin), dw, None, k, p, ws, cfg)
+        assert rel_err(dw, w.grad) < 5e-5, ("wgrad x6 slice", n, cin, h, cout, k, cfg)

@@ -65,10 +65,12 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     res = {}
     for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]),
                        ("wgrad", [0, 1, 2, 3, 4, 5, 6]), ("fwd6", list(range(16))),
-                       ("dgrad6", list(range(16)))):
+                       ("dgrad6", list(range(16))), ("wgrad6", [0, 1, 2, 3, 4, 5, 6])):
         if only and kind not in only:
             continue
         if (kind in ("dgrad", "fwd6") and k == 7) or (kind == "dgrad6" and (k == 7 or s != 1)):
+            continue
+        if kind == "wgrad6" and not K.wgrad_x6_supported(k, s, p, hi, hi):
             continue
         best = (1e9, -1)
         for cfg in cfgs:
@@ -78,6 +80,9 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
                 fn = lambda: K.conv_x6_fwd(K.full(x), wp6, scale, shift, K.full(y), k, s, p, True, cfg)
             elif kind == "dgrad6":
                 fn = lambda: K.conv_x6_dgrad(K.full(g), wt6, K.full(dx), k, p, False, cfg)
+            elif kind == "wgrad6":
+                ws = torch.empty(K.wgrad_x6_workspace_bytes(n, cin, cout, hi, hi, k, cfg) // 4, device=dev)
+                fn = lambda: K.conv_wgrad_x6(K.full(g), K.full(x), dw, db, k, p, ws, cfg)
             elif kind == "dgrad":
                 fn = lambda: K.conv_dgrad(K.full(g), wt, K.full(dx), k, s, p, False, cfg, wt_layout=lay)
             else:

@@ -1,0 +1,8 @@
+#!/bin/bash
+# wgrad x6: parity, autotune (wgrad + wgrad6, keeps the other kinds), GPU tier, bench
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_kernels.py -x -q -m gpu -k "wgrad or conv_bn or dgrad or fused" > gpurun_out/wg6_tests.log 2>&1; echo "rc=$?" >> gpurun_out/wg6_tests.log; tail -4 gpurun_out/wg6_tests.log
+timeout 900 python tools/autotune.py 288 wgrad,wgrad6 > gpurun_out/autotune_wg6.log 2>&1; echo "rc=$?" >> gpurun_out/autotune_wg6.log; tail -2 gpurun_out/autotune_wg6.log
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/gpu_tests.log; tail -4 gpurun_out/gpu_tests.log
+timeout 600 python bench.py --steps 10 --warmup 3 --cpu-baseline-videos 0 > gpurun_out/bench_quick.log 2>&1
+echo "bench rc=$?" >> gpurun_out/bench_quick.log; tail -2 gpurun_out/bench_quick.log | cut -c1-1800
