@@ -114,7 +114,7 @@ __device__ __forceinline__ void decode_pixel(const ConvArgs& p, bool par, uint32
 }
 
 template <int KS, int S, int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     using SL = Slab<KS>;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;

@@ -245,10 +245,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         float s = 0.f;
         int z = 0;
-        for (; z + 4 <= splits; z += 4) {   // four independent loads in flight, fixed summation order
-            const float v0 = part[(long)z * total + idx], v1 = part[(long)(z + 1) * total + idx];
-            const float v2 = part[(long)(z + 2) * total + idx], v3 = part[(long)(z + 3) * total + idx];
-            s = (((s + v0) + v1) + v2) + v3;
+        for (; z + 8 <= splits; z += 8) {   // eight independent loads in flight, fixed summation order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = part[(long)(z + q) * total + idx];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
         }
         for (; z < splits; ++z) s += part[(long)z * total + idx];
         const int m = (int)(idx / ldp);
@@ -311,16 +313,13 @@ int pick_wgrad_tile(int M, int K) {
     return bc;
 }
 
+// co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 144 B; VGPRs as compiled)
+const int kWgOcc[7] = {4, 3, 2, 2, 2, 2, 2};
+
 void plan_wgrad(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
     const long tiles = (long)((M + kWgBM[cfg] - 1) / kWgBM[cfg]) * ((K + kWgBN[cfg] - 1) / kWgBN[cfg]);
-    const long chunks = (P + BP - 1) / BP;
-    long want = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
-    if (want < 1) want = 1;
-    long cps = (chunks + want - 1) / want;
-    if (cps < 8) cps = chunks < 8 ? chunks : 8;  // keep at least 256 pixels per workgroup
-    if (cps < 1) cps = 1;
-    *chunks_per_split = (int)cps;
-    *splits = (int)((chunks + cps - 1) / cps);
+    // reduce pass: ~8 bytes per output element and split at ~2 TB/s, in units of a ~2.5 us (32-pixel, f32 MFMA) chunk
+    plan_split_k(tiles, (P + BP - 1) / BP, kWgOcc[cfg], 8, 6, 0.02 + (double)M * K * 1.6e-6, splits, chunks_per_split);
 }
 
 }  // namespace

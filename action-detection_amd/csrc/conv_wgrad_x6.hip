@@ -345,16 +345,13 @@ int pick_tile(int M, int K) {
     return bc;
 }
 
+// co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 112 B, VGPRs as compiled)
+const int kOcc[7] = {5, 4, 2, 3, 2, 3, 3};
+
 void plan(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
     const long tiles = (long)((M + kBM[cfg] - 1) / kBM[cfg]) * ((K + kBN[cfg] - 1) / kBN[cfg]);
-    const long chunks = (P + CP - 1) / CP;
-    long want = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
-    if (want < 1) want = 1;
-    long cps = (chunks + want - 1) / want;
-    if (cps < 32) cps = chunks < 32 ? chunks : 32;  // keep at least 512 pixels per workgroup
-    if (cps < 1) cps = 1;
-    *chunks_per_split = (int)cps;
-    *splits = (int)((chunks + cps - 1) / cps);
+    // reduce pass: ~8 bytes per output element and split at ~2 TB/s, in units of a ~0.6 us chunk
+    plan_split_k(tiles, (P + CP - 1) / CP, kOcc[cfg], 32, 24, 0.02 + (double)M * K * 6.7e-6, splits, chunks_per_split);
 }
 
 }  // namespace

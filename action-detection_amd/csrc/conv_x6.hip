@@ -500,7 +500,7 @@ int launch_cfg(X6Args& a, hipStream_t stream) {
     // a tile width the 1 KiB pieces divide, and the caller's guarantee that the bytes in front of x are readable
     constexpr bool wide_ok = (S == 1) && BN <= 256 && BN / 16 >= 4 * NG;
     if constexpr (wide_ok) {
-        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && (KS - 1) * (a.W + 1) * 4 <= 256 &&
+        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && (a.pad > KS - 1 - a.pad ? a.pad : KS - 1 - a.pad) * (a.W + 1) * 4 <= 256 &&
             !(g_x6_dbg & 16)) {
             hipLaunchKernelGGL((conv_x6_kernel<KS, S, MODE, true, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0,
                                stream, a);

@@ -63,6 +63,37 @@ __device__ __forceinline__ void fd_divmod(uint32_t n, const FastDiv& f, uint32_t
     r = n - q * f.d;
 }
 
+// ---- split-K planning (host): how many workgroups share one output tile of a weight-gradient GEMM ----
+// All workgroups of a launch do the same amount of work, so the launch takes `rounds` = ceil(blocks / slots)
+// block-times, slots = 256 CUs x co-resident workgroups; a block-time is the chunks of one split plus a fixed
+// prologue/epilogue cost (~`fixed_chunks` chunks).  Pick the split count that minimises rounds x block-time plus
+// `reduce_chunks_per_split` (the time, in chunk units, the reduce pass spends on each additional partial slab).
+static inline void plan_split_k(long tiles, long chunks, int occupancy, int min_chunks, int fixed_chunks,
+                                double reduce_chunks_per_split, int* splits, int* chunks_per_split) {
+    const long slots = 256L * (occupancy > 0 ? occupancy : 1);
+    long max_splits = chunks / (min_chunks > 0 ? min_chunks : 1);
+    if (max_splits < 1) max_splits = 1;
+    double best = 1e300;
+    long best_s = 1;
+    for (long m = 1; m <= 16; ++m) {
+        long s = (m * slots) / tiles;
+        if (s < 1) s = 1;
+        if (s > max_splits) s = max_splits;
+        const long cps = (chunks + s - 1) / s;
+        const long s_eff = (chunks + cps - 1) / cps;
+        const long rounds = (tiles * s_eff + slots - 1) / slots;
+        const double cost = (double)rounds * (double)(cps + fixed_chunks) + reduce_chunks_per_split * (double)s_eff;
+        if (cost < best) {
+            best = cost;
+            best_s = s_eff;
+        }
+        if (s == max_splits) break;
+    }
+    const long cps = (chunks + best_s - 1) / best_s;
+    *chunks_per_split = (int)cps;
+    *splits = (int)((chunks + cps - 1) / cps);
+}
+
 // ---- wave64 reductions ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
