@@ -366,6 +366,21 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rs
         if (o + 4 * d + 4 <= r.bytes) memcpy(&w[d], r.base + o + 4 * d, 4);
     return emu_u32x4{w[0], w[1], w[2], w[3]};
 }
+typedef unsigned int emu_u32x2 __attribute__((ext_vector_type(2)));
+static inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    unsigned int w[2] = {0, 0};
+    for (int d = 0; d < 2; ++d)
+        if (o + 4 * d + 4 <= r.bytes) memcpy(&w[d], r.base + o + 4 * d, 4);
+    return emu_u32x2{w[0], w[1]};
+}
+static inline unsigned short __builtin_amdgcn_raw_buffer_load_b16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
+                                                                  int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    unsigned short v = 0;
+    if (o + 2 <= r.bytes) memcpy(&v, r.base + o, 2);
+    return v;
+}
 // raw buffer store: offsets at or beyond num_records are dropped
 static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned int v, __amdgpu_buffer_rsrc_t r, uint32_t voff,
                                                          uint32_t soff, int) {

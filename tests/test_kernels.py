@@ -126,7 +126,7 @@ def test_pools(backend):
     """ceil_mode max/avg pools: forward exact; backward routes ties exactly like torch (post-ReLU zeros)."""
     g = torch.Generator().manual_seed(4)
     for kind, k, s, p in POOLS:
-        for h in ((112, 28, 7) if backend.is_gpu else (12, 7, 5)):
+        for h in ((112, 56, 28, 14, 7) if backend.is_gpu else (12, 16, 14, 7, 5)):
             n, c = 2, 6
             x = torch.relu(torch.randn(n, c, h, h, generator=g)).requires_grad_()   # many exact ties at 0
             if kind == "max":

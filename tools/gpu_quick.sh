@@ -1,7 +1,6 @@
 #!/bin/bash
-# quick GPU iteration: kernel parity tests + one bench line (no CPU baseline, no profile)
+# GPU tier + bench (no autotune)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_kernels.py -m gpu -q --tb=short --no-header -p no:cacheprovider -x > gpurun_out/pytest_quick.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/pytest_quick.log; tail -6 gpurun_out/pytest_quick.log
-timeout 600 python bench.py --steps 10 --warmup 3 --cpu-baseline-videos 0 ${BENCH_ARGS} > gpurun_out/bench_quick.log 2>&1
-echo "bench rc=$?" >> gpurun_out/bench_quick.log; tail -2 gpurun_out/bench_quick.log | cut -c1-2500
+timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/gpu_tests.log; tail -4 gpurun_out/gpu_tests.log
+timeout 600 python bench.py --steps 10 --warmup 3 --cpu-baseline-videos 0 > gpurun_out/bench_quick.log 2>&1
+echo "bench rc=$?" >> gpurun_out/bench_quick.log; tail -2 gpurun_out/bench_quick.log | cut -c1-1800
