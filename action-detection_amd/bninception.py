@@ -295,11 +295,11 @@ class BNInception(nn.Module):
                 src_slice = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 dst_slice = ChanSlice(get(op["dst"]), op["dst_c0"], cout)
                 if op["x6"]:
-                    self._timed("conv_fwd", op["lids"][0], flops,
+                    self._timed("conv_fwd_x6", op["lids"][0], flops,
                                 lambda: K.conv_x6_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
                                                       True, tuned_tile("fwd6", n, cin, cout, k, s, hin)))
                 else:
-                    self._timed("conv_fwd", op["lids"][0], flops,
+                    self._timed("conv_fwd_f32", op["lids"][0], flops,
                                 lambda: K.conv_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
                                                    True, tuned_tile("fwd", n, cin, cout, k, s, hin)))
             elif op["kind"] == "pool":
@@ -449,14 +449,15 @@ class BNInception(nn.Module):
                 else:
                     wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
                     run_wgrad = lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg)   # noqa: E731
+                wfam = "conv_wgrad_x6" if wg_x6[lids[0]] else "conv_wgrad_f32"
                 if use_side:
                     ready = torch.cuda.Event()
                     ready.record(main)            # the output gradient of this layer is final here
                     side.wait_event(ready)
                     with torch.cuda.stream(side):
-                        self._timed("conv_wgrad", lids[0], flops, run_wgrad)
+                        self._timed(wfam, lids[0], flops, run_wgrad)
                 else:
-                    self._timed("conv_wgrad", lids[0], flops, run_wgrad)
+                    self._timed(wfam, lids[0], flops, run_wgrad)
                 if op["src"] != "data":
                     layout = dg_layout[lids[0]]
                     wt = packed_dg[lids[0]]
@@ -465,12 +466,12 @@ class BNInception(nn.Module):
                     my, ms = mask_args(idx, op, cin)
                     dx = ChanSlice(gbuf(op["src"]), op["src_c0"], cin)
                     if dg_x6[lids[0]]:
-                        self._timed("conv_dgrad", lids[0], flops,
+                        self._timed("conv_dgrad_x6", lids[0], flops,
                                     lambda: K.conv_x6_dgrad(g, wt, dx, k, p, acc_flag,
                                                             tuned_tile("dgrad6", n, cin, cout, k, s, hin),
                                                             mask_y=my, mask_scale=ms))
                     else:
-                        self._timed("conv_dgrad", lids[0], flops,
+                        self._timed("conv_dgrad_f32", lids[0], flops,
                                     lambda: K.conv_dgrad(g, wt, dx, k, s, p, accumulate=acc_flag,
                                                          tile_cfg=tuned_tile("dgrad", n, cin, cout, k, s, hin),
                                                          mask_y=my, mask_scale=ms, wt_layout=layout))

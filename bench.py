@@ -11,9 +11,10 @@ Workload per GPU = BASELINE.json configs[1]: 4 videos x 8 proposals x 9 segments
 of 224x224 (weak scaling: per-GPU work is fixed as N grows).
 
 Rank 0 prints ONE JSON line.  `roofline` is the MFMA roofline of the dominant kernel family (the
-f32-MFMA implicit-GEMM convolution, `conv_igemm_kernel`, forward + dgrad launches), measured live
-with HIP events around every launch of the same K steps (re-run eagerly right after the timed
-region, because events cannot be recorded inside a hipGraph replay); `cpu_baseline` times the CPU oracle
+bf16-split implicit-GEMM convolution `conv_x6_kernel`, forward + stride-1 dgrad launches; with
+--precision f32 the exact-f32 `conv_igemm_kernel`), measured live with HIP events around every
+launch of the same K steps (re-run eagerly right after the timed region, because events cannot be
+recorded inside a hipGraph replay); `roofline_detail` lists every conv kernel family; `cpu_baseline` times the CPU oracle
 (oracle/ssn_oracle.py, torch fp32 on the host cores) on a bounded sample of the same workload.
 """
 import argparse
@@ -29,6 +30,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (no 2:1 sparsity)
+X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6  # algorithmic fp32 flops through the 3-way bf16 split (6 MFMA products)
+PMC_SUMMARY = "r1_pmc_summary_x6.json"
 FWD_GFLOP_PER_IMAGE = {"RGB": 4.063152128, "Flow": 4.613883904}  # 2 * conv MACs
 
 
@@ -42,6 +46,9 @@ def parse():
     ap.add_argument("--num-class", type=int, default=20)
     ap.add_argument("--cpu-baseline-videos", type=int, default=2,
                     help="videos in the CPU-oracle sample (0 disables the cpu_baseline leg)")
+    ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "f32"],
+                    help="matrix path of the 1x1/3x3 convolutions: exact 3-way bf16 split on the bf16 MFMA (fp32-class "
+                         "error, default) or the exact-f32 MFMA for every layer")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP event timing")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly from Python instead of replaying one captured hipGraph per step")
@@ -77,6 +84,7 @@ def main():
     model = SSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1))
     init_backbone_synthetic(model.base_model)  # same weights on every rank (same seed)
     init_heads_synthetic(model, std=0.001)
+    model.base_model.conv_precision = args.precision
     model.to(dev).train()
     policies = model.get_optim_policies()
     opt = SSNSGD(policies, lr=0.001, momentum=0.9, weight_decay=5e-4)
@@ -176,7 +184,10 @@ def main():
                                "fwd + losses + bwd + SGD, THUMOS14 shape (C=%d, stpp [1,1,1], dropout 0.8)"
                                % (args.modality, v, args.num_class),
                    "global_batch_proposals": 8 * v * world, "images_per_gpu": 72 * v,
-                   "parallelism": "dp%d" % world, "launch": launch},
+                   "parallelism": "dp%d" % world, "launch": launch,
+                   "conv_precision": ("fp32 in/out; 1x1/3x3 multiplies = 6 bf16-MFMA products of exact 3-way bf16 operand "
+                                      "splits (fp32-class error), 7x7 and stride-2 dgrad on the exact-f32 MFMA"
+                                      if args.precision == "bf16x6" else "exact-f32 MFMA everywhere")},
         "final_loss": float(loss.item()),
     }
 
@@ -190,40 +201,68 @@ def main():
                 f[0] += flops
                 f[1] += ms
                 f[2] += 1
-            gemm_fl = sum(fam[k][0] for k in ("conv_fwd", "conv_dgrad") if k in fam)
-            gemm_ms = sum(fam[k][1] for k in ("conv_fwd", "conv_dgrad") if k in fam)
-            gemm_n = sum(fam[k][2] for k in ("conv_fwd", "conv_dgrad") if k in fam)
-            achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
-            # HBM bytes per launch of the same kernel family from the committed PMC passes (FETCH_SIZE + WRITE_SIZE,
-            # raw; see profiles/README.md for the read-side calibration caveat); null if the summary is absent
+
+            def agg(keys):
+                fl = sum(fam[k][0] for k in keys if k in fam)
+                ms = sum(fam[k][1] for k in keys if k in fam)
+                n = sum(fam[k][2] for k in keys if k in fam)
+                return fl, ms, n
+            # dominant kernel: conv_x6_kernel (forward + stride-1 dgrad launches of the 1x1/3x3 layers).  Every fp32
+            # multiply is 6 bf16 MFMA products, so its matrix-pipe ceiling in ALGORITHMIC flops is bf16 dense / 6.
+            x6_fl, x6_ms, x6_n = agg(("conv_fwd_x6", "conv_dgrad_x6"))
+            if x6_n:
+                dom_name = ("conv_x6_kernel (implicit GEMM, fp32 operands split into 3 bf16 terms, 6 "
+                            "v_mfma_f32_32x32x16_bf16 per k16 step; fwd + stride-1 dgrad launches)")
+                dom_fl, dom_ms, dom_n, dom_peak = x6_fl, x6_ms, x6_n, X6_PEAK_TFLOPS
+                pmc_keys = ("conv_x6_kernel_fwd", "conv_x6_kernel_dgrad")
+            else:   # --precision f32: the exact-f32 MFMA kernel carries everything
+                dom_name = "conv_igemm_kernel (f32 MFMA implicit GEMM; fwd + dgrad launches)"
+                dom_fl, dom_ms, dom_n = agg(("conv_fwd_f32", "conv_dgrad_f32"))
+                dom_peak = F32_MFMA_PEAK_TFLOPS
+                pmc_keys = ("conv_igemm_kernel_fwd", "conv_igemm_kernel_dgrad")
+            achieved = dom_fl / (dom_ms * 1e-3) / 1e12
+            # HBM bytes per launch of the same kernel family from the committed PMC passes (FETCH_SIZE, WRITE_SIZE in
+            # separate passes, x1024, FETCH doubled for the 16 B/lane read streams as the guide prescribes for gfx950;
+            # tools/pmc_summary.py); null if the summary is absent
             traffic = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+                with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as f:
                     pm = json.load(f)
-                fam_p = [pm[k] for k in ("conv_igemm_kernel_fwd", "conv_igemm_kernel_dgrad")]
-                nl = sum(x["launches"] for x in fam_p)
-                traffic = round(sum((x["fetch_bytes_per_launch_raw"] + x["write_bytes_per_launch"]) * x["launches"]
-                                    for x in fam_p) / nl)
-            except (OSError, KeyError, ValueError):
+                fam_p = [pm[k] for k in pmc_keys]
+                nl = sum(x["launches_sampled"] for x in fam_p)
+                traffic = round(sum(x["hbm_bytes_per_launch"] * x["launches_sampled"] for x in fam_p) / nl)
+            except (OSError, KeyError, ValueError, ZeroDivisionError):
                 pass
             result["roofline"] = {
-                "bound": "mfma", "kernel": "conv_igemm_kernel (f32 MFMA implicit GEMM; fwd + dgrad launches)",
-                "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes/launch, rocprofv3 PMC FETCH_SIZE+WRITE_SIZE (profiles/r1_pmc_summary.json)",
-                "avg_launch_us": round(1e3 * gemm_ms / gemm_n, 2), "launches": gemm_n,
-                "algorithmic_gflop_per_launch": round(gemm_fl / gemm_n / 1e9, 4),
+                "bound": "mfma", "kernel": dom_name,
+                "achieved": round(achieved, 3), "peak": round(dom_peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / dom_peak, 4), "traffic": traffic,
+                "peak_note": ("algorithmic fp32 flops (2*MACs); peak = 2500 TF dense bf16 MFMA / 6 products per multiply"
+                              if x6_n else "exact-f32 MFMA peak"),
+                "frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                "issued_bf16_mfma_tflops": round(6 * achieved, 1) if x6_n else None,
+                "traffic_note": "HBM bytes/launch, rocprofv3 PMC (profiles/%s)" % PMC_SUMMARY,
+                "avg_launch_us": round(1e3 * dom_ms / dom_n, 2), "launches": dom_n,
+                "algorithmic_gflop_per_launch": round(dom_fl / dom_n / 1e9, 4),
             }
-            result["roofline_detail"] = {
-                k: {"tflops": round(f[0] / (f[1] * 1e-3) / 1e12, 3), "frac": round(f[0] / (f[1] * 1e-3) / 1e12
-                                                                                 / F32_MFMA_PEAK_TFLOPS, 4),
-                    "ms_per_step": round(f[1] / args.steps, 3), "launches_per_step": f[2] // args.steps}
-                for k, f in fam.items()}
-            conv_ms = sum(f[1] for f in fam.values()) / args.steps
-            result["roofline_detail"]["conv_ms_per_step"] = round(conv_ms, 3)
-            result["roofline_detail"]["whole_step_frac_of_f32_mfma_peak"] = round(
+            det = {}
+            for k, f in sorted(fam.items()):
+                tf = f[0] / (f[1] * 1e-3) / 1e12
+                own = X6_PEAK_TFLOPS if k.endswith("_x6") else F32_MFMA_PEAK_TFLOPS
+                det[k] = {"tflops": round(tf, 3), "frac_of_own_mfma_peak": round(tf / own, 4),
+                          "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                          "ms_per_step": round(f[1] / args.steps, 3), "launches_per_step": f[2] // args.steps}
+            for grp in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
+                fl, ms, n = agg((grp + "_x6", grp + "_f32"))
+                if n:
+                    det[grp + "_all"] = {"tflops": round(fl / (ms * 1e-3) / 1e12, 3),
+                                         "frac_of_f32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                                         "ms_per_step": round(ms / args.steps, 3)}
+            det["conv_ms_per_step"] = round(sum(f[1] for f in fam.values()) / args.steps, 3)
+            det["whole_step_frac_of_f32_mfma_peak"] = round(
                 (3 * FWD_GFLOP_PER_IMAGE[args.modality] * 72 * v * 1e9 / (elapsed / args.steps)) / 1e12
                 / F32_MFMA_PEAK_TFLOPS, 4)
+            result["roofline_detail"] = det
 
         # ---------------- CPU baseline: the oracle on the host cores, bounded sample ----------------
         if args.cpu_baseline_videos > 0:

@@ -35,7 +35,8 @@ for _ in range(reps):
 torch.cuda.synchronize()
 agg = {}
 for fam, lid, flops, s, e in prof:
-    a = agg.setdefault((lid, fam), [0.0, flops])
+    base, path = fam.rsplit("_", 1)          # conv_fwd_x6 -> (conv_fwd, x6)
+    a = agg.setdefault((lid, base), [0.0, flops, path])
     a[0] += s.elapsed_time(e) / reps
 lib = _lib.get_lib()
 n = x.shape[0]
@@ -48,8 +49,8 @@ for lid, (cin, cout, k, s, hi, ho) in info.items():
         a = agg.get((lid, fam))
         if a:
             tot[fam] += a[0]
-            row += ["%8.3f" % a[0], "%6.1f" % (a[1] / a[0] / 1e9)]
+            row += ["%8.3f" % a[0], "%5.0f%s" % (a[1] / a[0] / 1e9, "*" if a[2] == "x6" else " ")]
         else:
             row += ["       -", "     -"]
     print("%-34s %5d %5d %2d %2d %4d | %-4d %s %s | %s %s | %s %s" % ((lid, cin, cout, k, s, ho, tile) + tuple(row)))
-print("totals ms:", tot)
+print("totals ms:", tot, "(* = bf16-split x6 kernel, otherwise exact-f32 MFMA kernel)")

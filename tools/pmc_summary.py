@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Aggregate rocprofv3 --pmc passes (counter_collection CSVs) into one JSON per kernel family.
+
+    python tools/pmc_summary.py <dir with pmc*/ sub-directories> <out.json>
+
+Per family: launches, MFMA pipe busy fraction, wait fractions, VALU+SALU per MFMA, LDS bank-conflict fraction
+and HBM bytes per launch.  FETCH_SIZE / WRITE_SIZE are KiB (x1024); on gfx950 FETCH_SIZE reports half of the bytes
+of a wide (16 B/lane) coalesced read stream (/opt/skills/guides/MI355X_MICROARCH.md, section HBM), so families
+whose loads are 16 B/lane (`wide_reads`) get `hbm_bytes_per_launch` = 2*FETCH + WRITE, the others the raw sum
+(upper/lower values are both kept).
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+FAMILIES = [  # (family, regex on the kernel name, wide 16-byte reads?)
+    ("conv_x6_kernel_fwd", r"conv_x6_kernel<\d+,\s*\d+,\s*0,", True),
+    ("conv_x6_kernel_dgrad", r"conv_x6_kernel<\d+,\s*\d+,\s*1,", True),
+    ("wgrad_x6_kernel", r"wgrad_x6_kernel", True),
+    ("conv_igemm_kernel_fwd", r"conv_igemm_kernel<\d+,\s*\d+,\s*0,", False),
+    ("conv_igemm_kernel_dgrad", r"conv_igemm_kernel<\d+,\s*\d+,\s*[12],", False),
+    ("conv_wgrad_kernel", r"conv_wgrad_kernel", False),
+    ("wgrad_reduce_kernel", r"wgrad_reduce_kernel", True),
+    ("pool3_vec_kernel", r"pool3_vec_kernel", True),
+    ("pool_max2_bwd_vec_kernel", r"pool_max2_bwd_vec_kernel", True),
+    ("pool_fwd_kernel", r"pool_fwd_kernel", False),
+    ("pool_bwd_kernel", r"pool_bwd_kernel", False),
+    ("relu_bn_bwd_kernel", r"relu_bn_bwd_kernel", True),
+    ("sgd_multi_kernel", r"sgd_multi_kernel", True),
+]
+
+
+def family_of(name):
+    for fam, rx, _ in FAMILIES:
+        if re.search(rx, name):
+            return fam
+    return None
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    sums = {}      # family -> counter -> [sum, n]
+    for path in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                fam = family_of(row["Kernel_Name"])
+                if fam is None:
+                    continue
+                c = sums.setdefault(fam, {}).setdefault(row["Counter_Name"], [0.0, 0])
+                c[0] += float(row["Counter_Value"])
+                c[1] += 1
+    wide = {fam: w for fam, _, w in FAMILIES}
+    res = {}
+    for fam, cs in sums.items():
+        def tot(name):
+            return cs[name][0] if name in cs else None
+
+        def per(name):
+            return cs[name][0] / cs[name][1] if name in cs and cs[name][1] else None
+        n = max(v[1] for v in cs.values())
+        r = {"launches_sampled": n, "wide_reads": wide[fam]}
+        gui, busy = tot("GRBM_GUI_ACTIVE"), tot("SQ_VALU_MFMA_BUSY_CYCLES")
+        wc = tot("SQ_WAVE_CYCLES")
+        if busy is not None and gui:
+            # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (separate passes of the
+            # same command, hence per-launch averages)
+            r["mfma_pipe_busy_frac"] = round(per("SQ_VALU_MFMA_BUSY_CYCLES") / (per("GRBM_GUI_ACTIVE") / 8 * 1024), 4)
+        if wc:
+            for key, cname in (("wait_any_frac", "SQ_WAIT_ANY"), ("wait_inst_any_frac", "SQ_WAIT_INST_ANY"),
+                               ("active_inst_any_frac", "SQ_ACTIVE_INST_ANY")):
+                if tot(cname) is not None:
+                    r[key] = round(tot(cname) / wc, 4)
+        if gui and per("GRBM_GUI_ACTIVE"):
+            r["gpu_active_cycles_per_launch"] = round(per("GRBM_GUI_ACTIVE"))
+        lds_act, lds_conf = tot("SQ_LDS_IDX_ACTIVE"), tot("SQ_LDS_BANK_CONFLICT")
+        if lds_act:
+            r["lds_bank_conflict_frac"] = round(lds_conf / lds_act, 4)
+        f, w = per("FETCH_SIZE"), per("WRITE_SIZE")
+        if f is not None:
+            r["fetch_bytes_per_launch_raw"] = round(f * 1024)
+        if w is not None:
+            r["write_bytes_per_launch"] = round(w * 1024)
+        if f is not None and w is not None:
+            r["hbm_bytes_per_launch"] = round(((2 if wide[fam] else 1) * f + w) * 1024)
+        for cname in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
+                      "SQ_INSTS_MFMA"):
+            if per(cname) is not None:
+                r[cname.lower() + "_per_launch"] = round(per(cname))
+        res[fam] = r
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    print(json.dumps(res, indent=1, sort_keys=True)[:4000])
+
+
+if __name__ == "__main__":
+    main()
