@@ -30,6 +30,7 @@
 //    buffer), read-modify-write operands fetched one accumulator tile ahead.
 #include "conv_epilogue.h"
 #include "ssn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -127,7 +128,9 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
     static_assert(WM * WN == 4, "4 waves per group");
     static_assert(NW % SEGS == 0 && (16 * SEGS) % NW == 0, "unsupported tile width");
 
-    __shared__ __attribute__((aligned(1024))) uint32_t lds[NSTAGE * STAGE];
+    // WIDE 3x3: rows of zeros behind the ring; a lane whose tap falls on padding reads its fragment from there
+    constexpr int ZROWS = (WIDE && KK > 1) ? 7 * BN + 64 : 0;
+    __shared__ __attribute__((aligned(1024))) uint32_t lds[NSTAGE * STAGE + ZROWS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -207,32 +210,51 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
     // DMA of slab (ig, itap) into a ring stage, as NLOAD separate pieces (NB activation rows, then NA weight pieces)
     // so that they can be dealt out between the MFMAs: the texture path takes 64 B/clk per CU, and a wave that
     // issues its whole share in one burst (together with the 7 other waves) stalls ~800 cycles at the issue.
-    int ig = 0, itap = 0;
-    uint32_t d_vo, d_so, d_aso;
+    // Slabs past the end (the ring always runs two ahead) are issued too, with every offset out of range, so the
+    // K loop has no "is there still something to fetch" branches: such a piece deposits zeros in a ring slot that is
+    // never read again.
+    // Producer state = the slab that is fetched next, kept as running scalars (no multiplies in the loop): groups
+    // still to fetch, tap, tap displacement in bytes, channel-group offset of the source and slab offset of the weights.
+    int pf_left = (p.dbg & 1) ? 0 : p.ngroups;
+    int pf_tap = 0, pf_col = 0;
+    uint32_t pf_d = 0;                                                       // (r * W + s) * 4 of the tap
+    uint32_t pf_x = (uint32_t)(WIDE ? wave * RPP : krow0) * hw_bytes;        // + 16 channels per group
+    uint32_t pf_a = 0;                                                       // + a_step per slab
+    const uint32_t row_wrap = (uint32_t)(p.W - 3) * 4u, group_step = 16u * hw_bytes;
+    uint32_t d_vo, d_so, d_aso, d_dead;
     uint32_t *d_b, *d_a;
     bool d_tail;
-    auto issue_begin = [&](int st) {
+    auto issue_begin = [&](uint32_t st_off) {   // st_off = dword offset of the destination ring slot
+        const uint32_t live = pf_left > 0 ? 1u : 0u;
+        d_dead = live ? 0u : OOB;
+        uint32_t cand = gbase, ok = gmask & 1u;
+        if (KK > 1) {
+            cand = (MODE == MODE_FWD) ? gbase + pf_d : gbase - pf_d;
+            if (!WIDE) ok = (gmask >> pf_tap) & 1u;
+        }
+        d_vo = (ok & live) ? cand : OOB;
+        d_tail = (pf_left == 1) && (c_last != 16);
+        d_so = pf_x;
+        d_b = lds + st_off + A_STAGE + (WIDE ? wave * 256 : krow0 * BN + seg * 64);
+        d_aso = pf_a;
+        d_a = lds + st_off + wave * 256;
+        // advance to the next slab
+        pf_a += a_step;
         if (KK == 1) {
-            d_vo = (gmask & 1u) ? gbase : OOB;
+            pf_x += group_step;
+            --pf_left;
         } else {
-            const int r = (itap * 11) >> 5, s = itap - 3 * r;   // itap / 3, itap % 3 for itap < 9
-            const int d = (r * p.W + s) * 4;
-            const uint32_t ok = WIDE ? (gmask & 1u) : ((gmask >> itap) & 1u);
-            d_vo = ok ? (MODE == MODE_FWD ? gbase + (uint32_t)d : gbase - (uint32_t)d) : OOB;
-        }
-        d_tail = (ig == p.ngroups - 1) && (c_last != 16);
-        if (WIDE) {
-            d_so = (uint32_t)(ig * 16 + wave * RPP) * hw_bytes;
-            d_b = lds + st * STAGE + A_STAGE + wave * 256;
-        } else {
-            d_so = (uint32_t)(ig * 16 + krow0) * hw_bytes;
-            d_b = lds + st * STAGE + A_STAGE + krow0 * BN + seg * 64;
-        }
-        d_aso = (uint32_t)(ig * KK + itap) * a_step;
-        d_a = lds + st * STAGE + wave * 256;
-        if (++itap == KK) {
-            itap = 0;
-            ++ig;
+            pf_d += 4u;
+            if (++pf_col == KS) {
+                pf_col = 0;
+                pf_d += row_wrap;
+            }
+            if (++pf_tap == KK) {
+                pf_tap = 0;
+                pf_d = 0;
+                pf_x += group_step;
+                --pf_left;
+            }
         }
     };
     auto issue_piece = [&](int k) {   // k is a compile-time constant at every call site
@@ -246,11 +268,11 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SSN_LDS_PTR(d_b + k * KSTEP * BN), 4, v,
                                                      d_so + (uint32_t)(k * KSTEP) * hw_bytes, 0, 0);
         } else {
-            X6_DMA_B128(arsrc, d_a + (k - NB) * NW * 256, aoff[k - NB], d_aso);
+            X6_DMA_B128(arsrc, d_a + (k - NB) * NW * 256, aoff[k - NB] | d_dead, d_aso);
         }
     };
-    auto issue = [&](int st) {
-        issue_begin(st);
+    auto issue = [&](uint32_t st_off) {
+        issue_begin(st_off);
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) issue_piece(k);
     };
@@ -263,8 +285,12 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if (ZROWS) {
+        for (int i = tid; i < ZROWS; i += NT) lds[NSTAGE * STAGE + i] = 0u;
+        __syncthreads();
+    }
     issue(0);
-    if (nslab > 1) issue(1);
+    issue(STAGE);   // past the last slab the pieces turn into out-of-range (all-zero) copies: no branches in the loop
     if (p.trace) tr1 = __builtin_readcyclecounter();
 
     // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 1) & 7)
@@ -275,34 +301,41 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
     const int arow = (wm * TM * 32 + li) * APITCH;
     const int bcol = A_STAGE + (8 * lh) * BN + grp * BNG + wn * TN * 32 + li;
 
-    bf16x8 af[3][TM], bf[3][TN];
-    // LDS -> operand registers for one slab (B: raw fp32 -> three bf16 planes)
+    bf16x8 af[3][TM];
+    float raw[TN][8];        // the slab's fp32 activations of this lane's fragments
+    uint32_t pl[3][TN][4];   // their three bf16 planes, as k-pairs
+    // The split of pair e (k = 2e, 2e+1) of fragment j into its plane-1 and plane-2 dwords, as two half steps of
+    // 5 VALU (what fits in the shadow of one MFMA): first residual + plane 1, then second residual + plane 2.
+    float res[TN][8];
+    auto split_half = [&](int j, int e, int half) {
+        if (half == 0) {
+            res[j][2 * e] = residual(raw[j][2 * e]);
+            res[j][2 * e + 1] = residual(raw[j][2 * e + 1]);
+            pl[1][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, res[j][2 * e]), __builtin_bit_cast(uint32_t, res[j][2 * e + 1]));
+        } else {
+            const float s0 = residual(res[j][2 * e]), s1 = residual(res[j][2 * e + 1]);
+            pl[2][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+        }
+    };
+    auto split_step = [&](int j, int e) {
+        split_half(j, e, 0);
+        split_half(j, e, 1);
+    };
+    // LDS -> registers for one slab: raw activations + their top plane (one v_perm per k-pair), weight fragments.
+    // `all_planes`: also the two lower planes (the ping-pong groups split while the other group multiplies; a
+    // free-running wave does it in the shadow of its own MFMAs instead, see mfma).
     int ctap = 0;   // tap of the slab being consumed (WIDE 3x3 only)
-    auto front = [&](int stage) {
-        const uint32_t* Ls = lds + stage * STAGE;
+    auto front = [&](uint32_t st_off, bool all_planes) {
+        const uint32_t* Ls = lds + st_off;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            float raw[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[e] = __builtin_bit_cast(float, Ls[bcol + e * BN + j * 32]);
-            if (WIDE && KK > 1) {
+            const uint32_t* src = Ls + bcol + j * 32;
+            if (WIDE && KK > 1) {   // tap on padding: the whole fragment comes from the rows of zeros
                 const bool inside = (fmask[j] >> ctap) & 1u;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) raw[e] = inside ? raw[e] : 0.f;
-            }
-            uint32_t pl[3][4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = raw[2 * e], x1 = raw[2 * e + 1];
-                const float r0 = residual(x0), r1 = residual(x1);
-                const float s0 = residual(r0), s1 = residual(r1);
-                pl[0][e] = pack_hi16(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, x1));
-                pl[1][e] = pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
-                pl[2][e] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+                src = inside ? src : lds + NSTAGE * STAGE + li;
             }
 #pragma unroll
-            for (int pn = 0; pn < 3; ++pn)
-                bf[pn][j] = __builtin_bit_cast(bf16x8, u32x4{pl[pn][0], pl[pn][1], pl[pn][2], pl[pn][3]});
+            for (int e = 0; e < 8; ++e) raw[j][e] = __builtin_bit_cast(float, src[e * BN]);
         }
 #pragma unroll
         for (int pn = 0; pn < 3; ++pn)
@@ -310,28 +343,50 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
             for (int i = 0; i < TM; ++i)
                 af[pn][i] = __builtin_bit_cast(
                     bf16x8, *reinterpret_cast<const u32x4*>(Ls + arow + i * 32 * APITCH + achunk[pn]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pl[0][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, raw[j][2 * e]),
+                                        __builtin_bit_cast(uint32_t, raw[j][2 * e + 1]));
+                if (all_planes) split_step(j, e);
+            }
         if (WIDE && KK > 1) ctap = (ctap + 1 == KK) ? 0 : ctap + 1;
     };
-    // six partial products per accumulator tile, smallest magnitude first; with dma_stage >= 0 the DMA pieces of
-    // the slab two ahead are dealt out between the MFMAs
-    auto mfma = [&](int dma_stage) {
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    // Six partial products per accumulator tile.  The three that only need the TOP plane of the activations go first,
+    // then plane 1, then plane 2, and (`interleave`) the 8 * TN half steps that produce the two lower planes are dealt
+    // out behind those first MFMAs, fenced in place: the matrix pipe starts as soon as the LDS reads are back and the
+    // ~40 VALU per fragment run in its shadow.  (The running fp32 accumulator already holds the earlier slabs, so the
+    // order of the six products inside a slab is immaterial for rounding.)  With `dma` the pieces of the slab two
+    // ahead are dealt out between the MFMAs as well.
+    auto mfma = [&](auto dma_tag, auto il_tag, uint32_t dma_stage) {
+        constexpr bool dma = decltype(dma_tag)::value;
+        constexpr bool interleave = decltype(il_tag)::value;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
         constexpr int NM = 6 * TM * TN;
+        constexpr int NTOP = 3 * TM * TN;   // MFMAs that need plane 0 only
+        constexpr int NSTEP = 8 * TN;   // half steps
         constexpr int EVERY = NM / NLOAD > 0 ? NM / NLOAD : 1;
-        const bool dma = dma_stage >= 0;
         if (dma) issue_begin(dma_stage);
+        if (interleave) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 6; ++c)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], bf[PB[c]][j], acc[i][j], 0, 0, 0);
+                    const bf16x8 b = __builtin_bit_cast(
+                        bf16x8, u32x4{pl[PB[c]][j][0], pl[PB[c]][j][1], pl[PB[c]][j][2], pl[PB[c]][j][3]});
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], b, acc[i][j], 0, 0, 0);
                     const int idx = (c * TM + i) * TN + j;
-                    if ((idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) {
-                        if (dma) issue_piece((idx + 1) / EVERY - 1);
+                    if (interleave && idx < NTOP) {
+#pragma unroll
+                        for (int st = idx * NSTEP / NTOP; st < (idx + 1) * NSTEP / NTOP; ++st)
+                            split_half(st / 8, (st % 8) / 2, st % 2);
                     }
+                    if (dma && (idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) issue_piece((idx + 1) / EVERY - 1);
+                    if (interleave) __builtin_amdgcn_sched_barrier(0);
                 }
         if (dma) {
 #pragma unroll
@@ -339,49 +394,47 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
         }
     };
 
-    int stage = 0;
+    uint32_t stage = 0;   // dword offset of the ring slot holding slab t
     X6_PH_DECL;
     for (int t = 0; t < nslab; ++t) {
-        // slab t has landed once at most the NLOAD loads of slab t+1 are still in flight
-        if (t + 1 < nslab && !(p.dbg & 1))
-            SSN_WAIT_VMCNT(NLOAD);
-        else
-            SSN_WAIT_VMCNT(0);
+        // slab t has landed once at most the NLOAD pieces of slab t+1 (real or out-of-range) are still in flight
+        SSN_WAIT_VMCNT(NLOAD);
         X6_PH(0);
         __builtin_amdgcn_s_barrier();   // (a) every wave's share of slab t is visible, (b) slab t-1 is consumed
         __builtin_amdgcn_sched_barrier(0);
         X6_PH(1);
-        const int dst = (t + 2 < nslab && !(p.dbg & 1)) ? (stage == 0 ? 2 : stage - 1) : -1;   // ring slot of slab t-1, for slab t+2
+        const uint32_t dst = stage == 0 ? 2 * STAGE : stage - STAGE;   // ring slot of slab t-1, refilled with slab t+2
         if (NG == 1) {
-            front(stage);
+            front(stage, false);
             X6_PH(3);
-            mfma(dst);
+            mfma(std::true_type{}, std::true_type{}, dst);
             X6_PH(5);
         } else if (grp == 0) {
-            front(stage);
+            front(stage, true);
             X6_PH(3);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             X6_PH(4);
-            mfma(dst);
+            mfma(std::true_type{}, std::false_type{}, dst);
             X6_PH(5);
         } else {
             if (t > 0)
-                mfma(dst);                    // slab t-1, operands split during the previous half-phase
-            else if (dst >= 0)
+                mfma(std::true_type{}, std::false_type{}, dst);   // slab t-1, operands split during the previous half-phase
+            else
                 issue(dst);
             X6_PH(3);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             X6_PH(4);
-            front(stage);
+            front(stage, true);
             X6_PH(5);
         }
-        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        stage = stage == (NSTAGE - 1) * STAGE ? 0 : stage + STAGE;
     }
-    if (NG == 2 && grp == 1) mfma(-1);
+    if (NG == 2 && grp == 1) mfma(std::false_type{}, std::false_type{}, 0u);
+    SSN_WAIT_VMCNT(0);   // the out-of-range tail pieces still write (zeros) into the ring the epilogue is about to reuse
     if (p.trace) tr2 = __builtin_readcyclecounter();
 
     // ---- epilogue: BN affine + ReLU (forward), or accumulate + fused ReLU/BN backward (dgrad) ----

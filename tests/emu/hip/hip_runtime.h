@@ -404,3 +404,4 @@ static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc
 static inline void __builtin_amdgcn_s_barrier() { emu::block_barrier(); }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
