@@ -301,57 +301,81 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
     const int arow = (wm * TM * 32 + li) * APITCH;
     const int bcol = A_STAGE + (8 * lh) * BN + grp * BNG + wn * TN * 32 + li;
 
-    bf16x8 af[3][TM];
-    float raw[TN][8];        // the slab's fp32 activations of this lane's fragments
-    uint32_t pl[3][TN][4];   // their three bf16 planes, as k-pairs
+    // Operand registers of one slab: the raw fp32 activations of this lane's fragments and the weight fragments.  Two
+    // sets: a free-running (NG == 1) wave reads slab t+1 from LDS while it multiplies slab t.
+    struct Frags {
+        float raw[TN][8];
+        bf16x8 af[3][TM];
+    };
+    Frags fr0, fr1;
+    uint32_t pl[3][TN][4];   // the three bf16 planes of the slab being multiplied, as k-pairs
+    float res[TN][8];
     // The split of pair e (k = 2e, 2e+1) of fragment j into its plane-1 and plane-2 dwords, as two half steps of
     // 5 VALU (what fits in the shadow of one MFMA): first residual + plane 1, then second residual + plane 2.
-    float res[TN][8];
-    auto split_half = [&](int j, int e, int half) {
+    auto split_half = [&](const Frags& f, int j, int e, int half) {
         if (half == 0) {
-            res[j][2 * e] = residual(raw[j][2 * e]);
-            res[j][2 * e + 1] = residual(raw[j][2 * e + 1]);
+            res[j][2 * e] = residual(f.raw[j][2 * e]);
+            res[j][2 * e + 1] = residual(f.raw[j][2 * e + 1]);
             pl[1][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, res[j][2 * e]), __builtin_bit_cast(uint32_t, res[j][2 * e + 1]));
         } else {
             const float s0 = residual(res[j][2 * e]), s1 = residual(res[j][2 * e + 1]);
             pl[2][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
         }
     };
-    auto split_step = [&](int j, int e) {
-        split_half(j, e, 0);
-        split_half(j, e, 1);
-    };
-    // LDS -> registers for one slab: raw activations + their top plane (one v_perm per k-pair), weight fragments.
-    // `all_planes`: also the two lower planes (the ping-pong groups split while the other group multiplies; a
-    // free-running wave does it in the shadow of its own MFMAs instead, see mfma).
-    int ctap = 0;   // tap of the slab being consumed (WIDE 3x3 only)
-    auto front = [&](uint32_t st_off, bool all_planes) {
+    // LDS -> registers: raw activations (a tap on padding reads the rows of zeros instead) and weight fragments, as
+    // NREAD separate steps (a k-pair of one activation fragment = one ds_read2st64_b32, or one 16-byte weight read) so
+    // that a pipelined wave can deal them out between its MFMAs: eight waves that all burst 13+ reads right after the
+    // barrier queue up behind the LDS pipeline for ~200 cycles before anybody's first MFMA issues.
+    int ctap = 0;   // tap of the slab being read (WIDE 3x3 only)
+    constexpr int NREAD = 4 * TN + 3 * TM;
+    const uint32_t* rd_src[TN];
+    const uint32_t* rd_a;
+    auto read_begin = [&](uint32_t st_off) {
         const uint32_t* Ls = lds + st_off;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const uint32_t* src = Ls + bcol + j * 32;
-            if (WIDE && KK > 1) {   // tap on padding: the whole fragment comes from the rows of zeros
+            rd_src[j] = Ls + bcol + j * 32;
+            if (WIDE && KK > 1) {
                 const bool inside = (fmask[j] >> ctap) & 1u;
-                src = inside ? src : lds + NSTAGE * STAGE + li;
+                rd_src[j] = inside ? rd_src[j] : lds + NSTAGE * STAGE + li;
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[j][e] = __builtin_bit_cast(float, src[e * BN]);
         }
+        rd_a = Ls + arow;
+        if (WIDE && KK > 1) ctap = (ctap + 1 == KK) ? 0 : ctap + 1;
+    };
+    auto read_step = [&](Frags& f, int k) {   // k is a compile-time constant at every call site
+        if (k < 4 * TN) {
+            const int j = k / 4, e = k % 4;
+            f.raw[j][2 * e] = __builtin_bit_cast(float, rd_src[j][(2 * e) * BN]);
+            f.raw[j][2 * e + 1] = __builtin_bit_cast(float, rd_src[j][(2 * e + 1) * BN]);
+        } else {
+            const int q = k - 4 * TN, pn = q / TM, i = q % TM;
+            f.af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(rd_a + i * 32 * APITCH + achunk[pn]));
+        }
+    };
+    auto read_frags = [&](uint32_t st_off, Frags& f) {
+        read_begin(st_off);
 #pragma unroll
-        for (int pn = 0; pn < 3; ++pn)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[pn][i] = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const u32x4*>(Ls + arow + i * 32 * APITCH + achunk[pn]));
+        for (int k = 0; k < NREAD; ++k) read_step(f, k);
+    };
+    // top plane (one v_perm per k-pair); `all_planes`: also the two lower ones (the ping-pong groups split while the
+    // other group multiplies; a free-running wave does that in the shadow of its own MFMAs instead, see mfma)
+    auto top_plane = [&](const Frags& f, bool all_planes) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pl[0][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, raw[j][2 * e]),
-                                        __builtin_bit_cast(uint32_t, raw[j][2 * e + 1]));
-                if (all_planes) split_step(j, e);
+                pl[0][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, f.raw[j][2 * e]),
+                                        __builtin_bit_cast(uint32_t, f.raw[j][2 * e + 1]));
+                if (all_planes) {
+                    split_half(f, j, e, 0);
+                    split_half(f, j, e, 1);
+                }
             }
-        if (WIDE && KK > 1) ctap = (ctap + 1 == KK) ? 0 : ctap + 1;
+    };
+    auto front = [&](uint32_t st_off, bool all_planes) {
+        read_frags(st_off, fr0);
+        top_plane(fr0, all_planes);
     };
     // Six partial products per accumulator tile.  The three that only need the TOP plane of the activations go first,
     // then plane 1, then plane 2, and (`interleave`) the 8 * TN half steps that produce the two lower planes are dealt
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
     // ~40 VALU per fragment run in its shadow.  (The running fp32 accumulator already holds the earlier slabs, so the
     // order of the six products inside a slab is immaterial for rounding.)  With `dma` the pieces of the slab two
     // ahead are dealt out between the MFMAs as well.
-    auto mfma = [&](auto dma_tag, auto il_tag, uint32_t dma_stage) {
+    auto mfma = [&](auto dma_tag, auto il_tag, const Frags& f, uint32_t dma_stage, Frags& nxt) {
         constexpr bool dma = decltype(dma_tag)::value;
         constexpr bool interleave = decltype(il_tag)::value;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
@@ -378,12 +402,16 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
                 for (int j = 0; j < TN; ++j) {
                     const bf16x8 b = __builtin_bit_cast(
                         bf16x8, u32x4{pl[PB[c]][j][0], pl[PB[c]][j][1], pl[PB[c]][j][2], pl[PB[c]][j][3]});
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], b, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.af[PA[c]][i], b, acc[i][j], 0, 0, 0);
                     const int idx = (c * TM + i) * TN + j;
                     if (interleave && idx < NTOP) {
 #pragma unroll
                         for (int st = idx * NSTEP / NTOP; st < (idx + 1) * NSTEP / NTOP; ++st)
-                            split_half(st / 8, (st % 8) / 2, st % 2);
+                            split_half(f, st / 8, (st % 8) / 2, st % 2);
+                    }
+                    if (interleave) {   // the LDS reads of the next slab (into the other register set)
+#pragma unroll
+                        for (int k = idx * NREAD / NM; k < (idx + 1) * NREAD / NM; ++k) read_step(nxt, k);
                     }
                     if (dma && (idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) issue_piece((idx + 1) / EVERY - 1);
                     if (interleave) __builtin_amdgcn_sched_barrier(0);
@@ -394,46 +422,80 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
         }
     };
 
-    uint32_t stage = 0;   // dword offset of the ring slot holding slab t
+    // tooling (tools/prio_x6.py): dbg bit 5 = static priority for the waves in odd hardware wave slots, bit 6 = raised
+    // priority around every MFMA block
+    if ((p.dbg & 32) && wave_uniform((int)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u)))
+        __builtin_amdgcn_s_setprio(2);
     X6_PH_DECL;
-    for (int t = 0; t < nslab; ++t) {
-        // slab t has landed once at most the NLOAD pieces of slab t+1 (real or out-of-range) are still in flight
-        SSN_WAIT_VMCNT(NLOAD);
-        X6_PH(0);
-        __builtin_amdgcn_s_barrier();   // (a) every wave's share of slab t is visible, (b) slab t-1 is consumed
-        __builtin_amdgcn_sched_barrier(0);
-        X6_PH(1);
-        const uint32_t dst = stage == 0 ? 2 * STAGE : stage - STAGE;   // ring slot of slab t-1, refilled with slab t+2
-        if (NG == 1) {
-            front(stage, false);
-            X6_PH(3);
-            mfma(std::true_type{}, std::true_type{}, dst);
-            X6_PH(5);
-        } else if (grp == 0) {
-            front(stage, true);
-            X6_PH(3);
-            __builtin_amdgcn_sched_barrier(0);
+    if (NG == 1) {
+        // Free-running waves, software-pipelined through two register sets: in iteration t the wave multiplies slab t out
+        // of registers while its LDS reads of slab t+1 and the DMA of slab t+3 are in flight, so neither the LDS round
+        // trip nor the split sits in front of the matrix pipe.  Ring slots: t+1 (being read), t+2 (landing), and the
+        // slot of slab t, free since every wave finished reading it before the barrier, takes slab t+3.
+        issue(2 * STAGE);
+        SSN_WAIT_VMCNT(2 * NLOAD);
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, fr0);
+        uint32_t s_cur = 0, s_n1 = STAGE, s_n2 = 2 * STAGE;   // ring slots of slabs t, t+1, t+2
+        auto half = [&](const Frags& cur, Frags& nxt) {
+            SSN_WAIT_VMCNT(NLOAD);   // this wave's pieces of slab t+1 (slab t+2's may still be in flight)
+            SSN_WAIT_LGKM0();        // ... and its reads of slab t are back
+            X6_PH(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            X6_PH(4);
-            mfma(std::true_type{}, std::false_type{}, dst);
-            X6_PH(5);
-        } else {
-            if (t > 0)
-                mfma(std::true_type{}, std::false_type{}, dst);   // slab t-1, operands split during the previous half-phase
-            else
-                issue(dst);
+            X6_PH(1);
+            read_begin(s_n1);
+            top_plane(cur, false);
             X6_PH(3);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            X6_PH(4);
-            front(stage, true);
+            mfma(std::true_type{}, std::true_type{}, cur, s_cur, nxt);
             X6_PH(5);
+            const uint32_t o = s_cur;
+            s_cur = s_n1;
+            s_n1 = s_n2;
+            s_n2 = o;
+        };
+        // two slabs per trip (the register sets swap roles); an odd slab count runs one all-zero slab at the end
+        for (int t = 0; t < nslab; t += 2) {
+            half(fr0, fr1);
+            half(fr1, fr0);
         }
-        stage = stage == (NSTAGE - 1) * STAGE ? 0 : stage + STAGE;
+        SSN_WAIT_LGKM0();
+    } else {
+        uint32_t stage = 0;   // dword offset of the ring slot holding slab t
+        for (int t = 0; t < nslab; ++t) {
+            // slab t has landed once at most the NLOAD pieces of slab t+1 (real or out-of-range) are still in flight
+            SSN_WAIT_VMCNT(NLOAD);
+            X6_PH(0);
+            __builtin_amdgcn_s_barrier();   // (a) every wave's share of slab t is visible, (b) slab t-1 is consumed
+            __builtin_amdgcn_sched_barrier(0);
+            X6_PH(1);
+            const uint32_t dst = stage == 0 ? 2 * STAGE : stage - STAGE;   // ring slot of slab t-1, refilled with slab t+2
+            if (grp == 0) {
+                front(stage, true);
+                X6_PH(3);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                X6_PH(4);
+                mfma(std::true_type{}, std::false_type{}, fr0, dst, fr1);
+                X6_PH(5);
+            } else {
+                if (t > 0)
+                    mfma(std::true_type{}, std::false_type{}, fr0, dst, fr1);   // slab t-1, split during the previous half-phase
+                else
+                    issue(dst);
+                X6_PH(3);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                X6_PH(4);
+                front(stage, true);
+                X6_PH(5);
+            }
+            stage = stage == (NSTAGE - 1) * STAGE ? 0 : stage + STAGE;
+        }
+        if (grp == 1) mfma(std::false_type{}, std::false_type{}, fr0, 0u, fr1);
     }
-    if (NG == 2 && grp == 1) mfma(std::false_type{}, std::false_type{}, 0u);
     SSN_WAIT_VMCNT(0);   // the out-of-range tail pieces still write (zeros) into the ring the epilogue is about to reuse
     if (p.trace) tr2 = __builtin_readcyclecounter();
 

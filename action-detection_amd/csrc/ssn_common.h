@@ -117,6 +117,10 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 #ifndef SSN_WAIT_VMCNT
 #define SSN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #endif
+#ifndef SSN_WAIT_LGKM0
+// as a builtin (not inline asm), so that the compiler's own wait-count bookkeeping sees it: vmcnt 63, expcnt 7, lgkmcnt 0
+#define SSN_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -390,6 +390,7 @@ static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned int v, __amdgp
 // LDS-DMA: every lane deposits `size` bytes at (wave-uniform lds base) + lane * size
 #define SSN_LDS_PTR(p) ((void*)(p))
 #define SSN_WAIT_VMCNT(n) ((void)0)
+#define SSN_WAIT_LGKM0() ((void)0)
 static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds, int size, uint32_t voff,
                                                             uint32_t soff, int imm, int) {
     const uint64_t o = (uint64_t)voff + soff + (uint32_t)imm;
