@@ -131,9 +131,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
         u32x4 a[NAR], b[NBR];
         uint32_t ho, wo;   // first pixel of the group
     };
+    const int total_chunks = (p.P + CP - 1) / CP;
+    const int c_begin = (int)z * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > total_chunks) c_end = total_chunks;
+    const int nch = c_end - c_begin;
+    // chunks past the end of this workgroup's split load as zeros (every offset out of range): the pipeline below
+    // runs without "is there another chunk" branches and an odd chunk count ends with one all-zero chunk
     auto load_chunk = [&](int chunk, Staged& s) {
         const int pp = chunk * CP + pxg * 4;
-        const bool valid = pp < p.P;
+        const bool valid = pp < p.P && chunk < c_end;
         uint32_t n, hw;
         fd_divmod((uint32_t)(valid ? pp : 0), p.div_hw, n, hw);
         fd_divmod(hw, p.div_w, s.ho, s.wo);
@@ -153,29 +160,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
 #pragma unroll
     for (int i = 0; i < NAR; ++i) rowsum[i] = 0.f;
     const bool do_bias = (kt == 0);
+    // a wave stages 16 consecutive rows, so "this staging row exists" is wave-uniform (BM, BN are multiples of 32)
+    bool a_live[NAR], b_live[NBR];
+#pragma unroll
+    for (int i = 0; i < NAR; ++i) a_live[i] = wave_uniform((row0 & ~15) + 64 * i) < BM;
+#pragma unroll
+    for (int i = 0; i < NBR; ++i) b_live[i] = wave_uniform((row0 & ~15) + 64 * i) < BN;
 
-    // split the staged fp32 values into bf16 planes and write them to LDS buffer `buf`
-    auto store_chunk = [&](const Staged& s, int buf) {
-        uint32_t* As = lds + buf * STAGE + row0 * PITCH_DW + pxg * 2;
-        uint32_t* Bs = lds + buf * STAGE + BM * PITCH_DW + row0 * PITCH_DW + pxg * 2;
-#pragma unroll
-        for (int i = 0; i < NAR; ++i) {
-            if (row0 + 64 * i >= BM) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t u = s.a[i][e];   // (bit_cast straight from a vector element reads element 0)
-                v[e] = __builtin_bit_cast(float, u);
-            }
-            if (do_bias) rowsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
-            uint32_t pl[3][2];
-            wg_split4(v, pl);
-#pragma unroll
-            for (int pn = 0; pn < 3; ++pn)
-                *reinterpret_cast<uint2*>(As + 64 * i * PITCH_DW + pn * 8) = uint2{pl[pn][0], pl[pn][1]};
-        }
-        // pixel coordinates of the 4 pixels (a group may run over the end of an image row)
-        int hh[4], ww[4];
+    // Split of a staged chunk into bf16 planes + LDS store, cut into 2 * (NAR + NBR) steps of ~12-16 VALU (a k-pair of
+    // one staged row; the second step of a row also writes its three 8-byte plane pieces), so that the steps can be
+    // dealt out behind the MFMAs of the chunk that is being multiplied: the kernel is VALU-bound (~10 VALU per MFMA),
+    // and with the split running AFTER the MFMAs the two co-resident waves of a SIMD fall into lock-step -- both
+    // multiply, then both split -- which leaves the matrix pipe idle two thirds of the time.
+    constexpr int NROW = NAR + NBR, NSTEP = 2 * NROW;
+    int hh[4], ww[4];          // coordinates of the 4 pixels of the staged group (a group may run over a row end)
+    uint32_t plw[3][2];
+    auto stage_begin = [&](const Staged& s) {
         if (KS != 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -188,25 +188,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
                 ww[e] = w;
             }
         }
+    };
+    auto stage_step = [&](const Staged& s, int buf, int st) {   // st is a compile-time constant at every call site
+        const int row = st / 2, half = st % 2;
+        const bool is_a = row < NAR;
+        const int i = is_a ? row : row - NAR;
+        if (is_a ? !a_live[i] : !b_live[i]) return;
+        float v[2];
 #pragma unroll
-        for (int i = 0; i < NBR; ++i) {
-            if (row0 + 64 * i >= BN) continue;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t u = s.b[i][e];
-                v[e] = __builtin_bit_cast(float, u);
-                if (KS != 1) {
-                    const bool ok = ((unsigned)(hh[e] + b_dh[i]) < (unsigned)p.H) && ((unsigned)(ww[e] + b_dw[i]) < (unsigned)p.W);
-                    v[e] = ok ? v[e] : 0.f;
-                }
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t u = is_a ? s.a[i][2 * half + e] : s.b[i][2 * half + e];
+            v[e] = __builtin_bit_cast(float, u);
+            if (!is_a && KS != 1) {
+                const bool ok = ((unsigned)(hh[2 * half + e] + b_dh[i]) < (unsigned)p.H) &&
+                                ((unsigned)(ww[2 * half + e] + b_dw[i]) < (unsigned)p.W);
+                v[e] = ok ? v[e] : 0.f;
             }
-            uint32_t pl[3][2];
-            wg_split4(v, pl);
-#pragma unroll
-            for (int pn = 0; pn < 3; ++pn)
-                *reinterpret_cast<uint2*>(Bs + 64 * i * PITCH_DW + pn * 8) = uint2{pl[pn][0], pl[pn][1]};
         }
+        if (is_a && do_bias) rowsum[i] += v[0] + v[1];
+        const float r0 = wg_residual(v[0]), r1 = wg_residual(v[1]);
+        const float s0 = wg_residual(r0), s1 = wg_residual(r1);
+        plw[0][half] = wg_pack_hi16(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]));
+        plw[1][half] = wg_pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
+        plw[2][half] = wg_pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+        if (half == 1) {
+            uint32_t* dst = lds + buf * STAGE + (is_a ? 0 : BM * PITCH_DW) + (row0 + 64 * i) * PITCH_DW + pxg * 2;
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn) *reinterpret_cast<uint2*>(dst + pn * 8) = uint2{plw[pn][0], plw[pn][1]};
+        }
+    };
+    auto store_chunk = [&](const Staged& s, int buf) {
+        stage_begin(s);
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) stage_step(s, buf, st);
     };
 
     f32x16 acc[TM][TN];
@@ -217,7 +231,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    // multiply the chunk in LDS buffer `buf`; behind the MFMAs: split + store the staged chunk `st` into the other
+    // buffer, then fetch chunk `next_chunk` into the register set that has just been drained
+    auto compute = [&](int buf, Staged& st, int next_chunk) {
         const uint32_t* As = lds + buf * STAGE + (wm * TM * 32 + li) * PITCH_DW + lh * 4;
         const uint32_t* Bs = lds + buf * STAGE + BM * PITCH_DW + (wn * TN * 32 + li) * PITCH_DW + lh * 4;
         bf16x8 af[3][TM], bf[3][TN];
@@ -230,43 +246,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
             for (int j = 0; j < TN; ++j)
                 bf[pn][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + j * 32 * PITCH_DW + pn * 8));
         }
+        stage_begin(st);
+        __builtin_amdgcn_sched_barrier(0);
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int NM = 6 * TM * TN;
 #pragma unroll
         for (int c = 0; c < 6; ++c)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], bf[PB[c]][j], acc[i][j], 0, 0, 0);
+                    const int idx = (c * TM + i) * TN + j;
+#pragma unroll
+                    for (int k = idx * NSTEP / NM; k < (idx + 1) * NSTEP / NM; ++k) stage_step(st, buf ^ 1, k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        load_chunk(next_chunk, st);
     };
-
-    const int total_chunks = (p.P + CP - 1) / CP;
-    const int c_begin = (int)z * p.chunks_per_split;
-    int c_end = c_begin + p.chunks_per_split;
-    if (c_end > total_chunks) c_end = total_chunks;
-    const int nch = c_end - c_begin;
 
     // chunk t lives in register set t & 1 from two iterations before it is multiplied until one iteration before
     Staged s0, s1;
-    if (nch > 0) {
-        load_chunk(c_begin, s0);
-        if (nch > 1) load_chunk(c_begin + 1, s1);
-        store_chunk(s0, 0);
-        if (nch > 2) load_chunk(c_begin + 2, s0);
-    }
+    load_chunk(c_begin, s0);
+    load_chunk(c_begin + 1, s1);
+    store_chunk(s0, 0);
+    load_chunk(c_begin + 2, s0);
     __syncthreads();
     for (int t = 0; t < nch; t += 2) {
-        // even chunk t: LDS buffer 0; registers: s1 = chunk t+1, s0 = chunk t+2 (in flight)
-        compute(0);
-        if (t + 1 < nch) store_chunk(s1, 1);
-        if (t + 3 < nch) load_chunk(c_begin + t + 3, s1);
+        // even chunk t: LDS buffer 0; registers: s1 = chunk t+1 (-> buffer 1), then chunk t+3
+        compute(0, s1, c_begin + t + 3);
         __syncthreads();
-        if (t + 1 >= nch) break;
-        // odd chunk t+1: LDS buffer 1; registers: s0 = chunk t+2, s1 = chunk t+3 (in flight)
-        compute(1);
-        if (t + 2 < nch) store_chunk(s0, 0);
-        if (t + 4 < nch) load_chunk(c_begin + t + 4, s0);
+        // odd chunk t+1: LDS buffer 1; registers: s0 = chunk t+2 (-> buffer 0), then chunk t+4
+        compute(1, s0, c_begin + t + 4);
         __syncthreads();
     }
 
@@ -313,8 +325,10 @@ int launch_wgx6(WgX6Args& a, hipStream_t stream) {
 
 // tile configs as in conv_wgrad.hip:
 //   0: 64(co) x 64(kk)   1: 32 x 128   2: 128 x 128   3: 64 x 128   4: 96 x 128   5: 64 x 128 (waves along kk)   6: 128 x 64
-const int kBM[7] = {64, 32, 128, 64, 96, 64, 128};
-const int kBN[7] = {64, 128, 128, 128, 128, 128, 64};
+// and two larger ones (fewer elements to split per MFMA: the kernel is VALU-bound):   7: 96 x 256   8: 192 x 128
+constexpr int NCFG = 9;
+const int kBM[NCFG] = {64, 32, 128, 64, 96, 64, 128, 96, 192};
+const int kBN[NCFG] = {64, 128, 128, 128, 128, 128, 64, 256, 128};
 
 template <int KS>
 int launch_wgx6_tile(WgX6Args& a, int cfg, hipStream_t stream) {
@@ -326,6 +340,8 @@ int launch_wgx6_tile(WgX6Args& a, int cfg, hipStream_t stream) {
         case 4: return launch_wgx6<KS, 1, 4, 3, 1>(a, stream);
         case 5: return launch_wgx6<KS, 1, 4, 2, 1>(a, stream);
         case 6: return launch_wgx6<KS, 2, 2, 2, 1>(a, stream);
+        case 7: return launch_wgx6<KS, 1, 4, 3, 2>(a, stream);
+        case 8: return launch_wgx6<KS, 2, 2, 3, 2>(a, stream);
     }
     ssn_set_error("conv_wgrad_x6: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -334,7 +350,7 @@ int launch_wgx6_tile(WgX6Args& a, int cfg, hipStream_t stream) {
 int pick_tile(int M, int K) {
     double best = 1e300;
     int bc = 0;
-    for (int c = 0; c < 7; ++c) {
+    for (int c = 0; c < 7; ++c) {   // (the two large tiles are only taken when the autotuner picks them)
         const double padded = (double)((M + kBM[c] - 1) / kBM[c]) * kBM[c] * (double)((K + kBN[c] - 1) / kBN[c]) * kBN[c];
         const double reuse = (kBM[c] * kBN[c] >= 128 * 64) ? 1.0 : 1.12;
         if (padded * reuse < best) {
@@ -346,12 +362,17 @@ int pick_tile(int M, int K) {
 }
 
 // co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 112 B, VGPRs as compiled)
-const int kOcc[7] = {5, 4, 2, 3, 2, 3, 3};
+const int kOcc[NCFG] = {5, 4, 2, 3, 2, 3, 3, 2, 2};
 
 void plan(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
     const long tiles = (long)((M + kBM[cfg] - 1) / kBM[cfg]) * ((K + kBN[cfg] - 1) / kBN[cfg]);
     // reduce pass: ~8 bytes per output element and split at ~2 TB/s, in units of a ~0.6 us chunk
-    plan_split_k(tiles, (P + CP - 1) / CP, kOcc[cfg], 32, 24, 0.02 + (double)M * K * 6.7e-6, splits, chunks_per_split);
+    const long chunks = (P + CP - 1) / CP;
+    plan_split_k(tiles, chunks, kOcc[cfg], 32, 24, 0.02 + (double)M * K * 6.7e-6, splits, chunks_per_split);
+    if (*chunks_per_split & 1) {   // the kernel's pipeline runs two chunks per trip
+        ++*chunks_per_split;
+        *splits = (int)((chunks + *chunks_per_split - 1) / *chunks_per_split);
+    }
 }
 
 }  // namespace
@@ -361,7 +382,7 @@ extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, 
 
 extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int H, int W, int ksize, int tile_cfg) {
     const int K = Cin * ksize * ksize;
-    const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, K);
+    const int cfg = (tile_cfg >= 0 && tile_cfg < NCFG) ? tile_cfg : pick_tile(Cout, K);
     int splits, cps;
     plan(Cout, K, (long)N * H * W, cfg, &splits, &cps);
     return (long)splits * Cout * (K + 1) * (long)sizeof(float);
@@ -400,6 +421,7 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     SSN_CHECK_ARG(gb < (1l << 31) && xb < (1l << 31) - 512, "conv wgrad x6: operand larger than 2 GiB (buffer addressing)");
     a.g_bytes = (uint32_t)gb;
     a.x_bytes = (uint32_t)xb;
+    SSN_CHECK_ARG(tile_cfg < NCFG, "conv wgrad x6: unknown tile config %d", tile_cfg);
     const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, a.K);
     plan(Cout, a.K, a.P, cfg, &a.splits, &a.chunks_per_split);
     const long need = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
