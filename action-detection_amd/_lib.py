@@ -49,6 +49,8 @@ _SIGS = {
     "ssn_stpp_fwd": "ppppiipp",
     "ssn_stpp_bwd": "ppppiipp",
     "ssn_stpp_reorg": "piippppiiiiipppp",
+    "ssn_crop_mean": "ppiiip",
+    "ssn_reg_denorm": "plffffp",
     "ssn_linear_fwd": "ppppiiip",
     "ssn_linear_bwd": "ppppppiiiip",
     "ssn_row_gather": "pppiip",

@@ -95,7 +95,9 @@ class BNInception(nn.Module):
         self.grad_ready_hook = None   # object with range_ready(flat, start, end) / finish() (parallel.GradReducer)
         self._ws = None
         self._side = {}               # device -> side HIP stream for the weight-gradient chain
+        self._lanes = {}              # device -> two more streams for the forward branches of a block
         self.overlap_wgrad = True     # run wgrad launches on a second stream, concurrently with the dgrad chain
+        self.branch_streams = True    # forward: the branches of an Inception block run on three HIP streams
         self.profiler = None          # list; when set, every conv launch is bracketed by HIP events
         # "bf16x6": 1x1/3x3 convolutions (forward, stride-1 dgrad) multiply on the bf16 matrix cores with every fp32
         # operand split exactly into three bf16 terms (fp32-class accuracy, csrc/conv_x6.hip); "f32": exact-f32 MFMA
@@ -282,8 +284,52 @@ class BNInception(nn.Module):
             packed_fwd.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
                 [([getattr(self, lid).weight.detach() for lid in op["lids"]], 0) for op in ops], x6=x6)))
 
+        # Branch-level concurrency: most launches of the 14x14 / 7x7 stages fill the 256 CUs less than twice over
+        # (a 7x7 layer is 110-330 workgroups for 512 slots) and every launch ends with a partial round, so the three
+        # independent chains of an Inception block -- [1x1, reduce pair, 3x3], [double 3x3 a, b] and [pool, projection]
+        # -- go to three streams (fork at the block input, the double-3x3 chain additionally waits for the reduce pair,
+        # join at the block output).  Inside a captured step these become parallel branches of the hipGraph.
+        lanes = None
+        if self.branch_streams and x.is_cuda:
+            main = torch.cuda.current_stream(dev)
+            sides = self._lanes.get(dev)
+            if sides is None:
+                sides = self._lanes[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            lanes = (main,) + sides
+
+        def block_of(op):
+            lid = op["lids"][0] if op["kind"] == "conv" else op.get("lid", "")
+            return lid[:12] if lid.startswith("inception_") else None      # "inception_3a"
+
+        def lane_of(op):
+            lid = op["lids"][0] if op["kind"] == "conv" else op["lid"]
+            if "_double_3x3_1" in lid or "_double_3x3_2" in lid:
+                return 1
+            if lid.endswith("_pool") or lid.endswith("_pool_proj"):
+                return 2
+            return 0
+
         feat = None
+        cur_block = None
         for i, op in enumerate(plan):
+            lane_ctx = None
+            if lanes is not None:
+                blk = block_of(op)
+                if blk != cur_block:
+                    if cur_block is not None:         # join: the block output is complete
+                        lanes[0].wait_stream(lanes[1])
+                        lanes[0].wait_stream(lanes[2])
+                    if blk is not None:               # fork: the block input is complete
+                        lanes[1].wait_stream(lanes[0])
+                        lanes[2].wait_stream(lanes[0])
+                    cur_block = blk
+                if blk is not None:
+                    get(op["dst"])                    # allocate on the caller's stream, launch on the lane
+                    if op["kind"] == "pool" and op["pool"] == "max" and keep:
+                        _, ho, wo = shapes[op["dst"]]
+                        argmax[op["lid"]] = torch.empty((n, op["c"], ho, wo), device=dev, dtype=torch.uint8)
+                    lane_ctx = torch.cuda.stream(lanes[lane_of(op)])
+                    lane_ctx.__enter__()
             if op["kind"] == "conv":
                 cout, cin, k, s, p = op["cout"], op["cin"], op["k"], op["s"], op["p"]
                 shift = shift_of[op["lids"][0]]
@@ -305,8 +351,8 @@ class BNInception(nn.Module):
             elif op["kind"] == "pool":
                 c = op["c"]
                 out = ChanSlice(get(op["dst"]), op["dst_c0"], c)
-                am = None
-                if op["pool"] == "max" and keep:
+                am = argmax.get(op["lid"])
+                if am is None and op["pool"] == "max" and keep:
                     _, ho, wo = shapes[op["dst"]]
                     am = torch.empty((n, c, ho, wo), device=dev, dtype=torch.uint8)
                     argmax[op["lid"]] = am
@@ -314,7 +360,13 @@ class BNInception(nn.Module):
             else:
                 feat = torch.empty((n, shapes[op["src"]][0]), device=dev, dtype=torch.float32)
                 K.gap_fwd(full(acts[op["src"]]), feat)
-            if not keep:
+            if lane_ctx is not None:
+                lane_ctx.__exit__(None, None, None)
+                if op["kind"] == "conv" and len(op["lids"]) == 2:     # the reduce pair feeds the double-3x3 chain
+                    ev = torch.cuda.Event()
+                    ev.record(lanes[0])
+                    lanes[1].wait_event(ev)
+            if not keep and lanes is None:
                 # inference: drop activations as soon as their last consumer has been launched
                 for name in [nm for nm, last in last_use.items() if last == i and nm != "data"]:
                     acts.pop(name, None)

@@ -120,7 +120,63 @@ __global__ __launch_bounds__(256) void stpp_reorg_kernel(const float* scores, in
     }
 }
 
+// ---- dense testing (ssn_test.py:78-92) ----
+// x [num_crop][T][D] (crop-major rows, what GroupOverSample + view(num_crop, -1, D) give) -> y [T][D] = mean over
+// crops.  test_fc is linear, so the reference's fc-then-mean equals mean-then-fc: averaging the 1024-d features
+// first runs the folded FC on 10x fewer rows.
+template <bool VEC>
+__global__ __launch_bounds__(256) void crop_mean_kernel(const float* x, float* y, int num_crop, long TD, float inv) {
+    if (VEC) {   // T * D is a multiple of 4: every crop slab starts 16-byte aligned
+        const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (i >= TD) return;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < num_crop; ++c) acc += *reinterpret_cast<const f32x4*>(x + (long)c * TD + i);
+        *reinterpret_cast<f32x4*>(y + i) = acc * inv;
+    } else {
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= TD) return;
+        float acc = 0.f;
+        for (int c = 0; c < num_crop; ++c) acc += x[(long)c * TD + i];
+        y[i] = acc * inv;
+    }
+}
+// reg [P][C][2] in place: reg[..., k] = reg[..., k] * std[k] + mean[k]   (ssn_test.py:88-90)
+__global__ __launch_bounds__(256) void reg_denorm_kernel(float* reg, long n_pairs, float mean0, float std0, float mean1,
+                                                         float std1) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    float2 v = *reinterpret_cast<float2*>(reg + 2 * i);
+    v.x = v.x * std0 + mean0;
+    v.y = v.y * std1 + mean1;
+    *reinterpret_cast<float2*>(reg + 2 * i) = v;
+}
+
 }  // namespace
+
+extern "C" int ssn_crop_mean(const float* x, float* y, int num_crop, int T, int D, hipStream_t stream) {
+    SSN_CHECK_ARG(x && y && num_crop >= 1 && T >= 0 && D >= 1, "crop_mean: bad arguments");
+    const long TD = (long)T * D;
+    if (TD == 0) return SSN_OK;
+    const float inv = 1.0f / (float)num_crop;
+    if (TD % 4 == 0)
+        hipLaunchKernelGGL(crop_mean_kernel<true>, dim3((unsigned)((TD / 4 + 255) / 256)), dim3(256), 0, stream, x, y,
+                           num_crop, TD, inv);
+    else
+        hipLaunchKernelGGL(crop_mean_kernel<false>, dim3((unsigned)((TD + 255) / 256)), dim3(256), 0, stream, x, y,
+                           num_crop, TD, inv);
+    SSN_CHECK_LAUNCH("crop_mean");
+    return SSN_OK;
+}
+
+extern "C" int ssn_reg_denorm(float* reg, long n_pairs, float mean0, float std0, float mean1, float std1,
+                              hipStream_t stream) {
+    SSN_CHECK_ARG(reg && n_pairs >= 0, "reg_denorm: bad arguments");
+    if (n_pairs == 0) return SSN_OK;
+    hipLaunchKernelGGL(reg_denorm_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, reg, n_pairs,
+                       mean0, std0, mean1, std1);
+    SSN_CHECK_LAUNCH("reg_denorm");
+    return SSN_OK;
+}
 
 extern "C" int ssn_stpp_fwd(const float* ft, const float* scaling, float* act_ft, float* stpp_ft, int P, int D,
                             const SsnStppTable* table, hipStream_t stream) {

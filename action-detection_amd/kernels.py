@@ -310,6 +310,22 @@ def stpp_reorg(scores, ranges, act_range, scaling, part_scale_col, act_len, comp
              _p(out_act), _p(out_comp), _p(out_reg), _stream(lib, scores))
 
 
+def crop_mean(x, num_crop, out):
+    """x [num_crop * T, D] (crop-major) -> out [T, D] = mean over the crops (ssn_test.py:85)."""
+    lib = _check(x, out)
+    t = out.shape[0]
+    assert x.shape[0] == num_crop * t and x.shape[1] == out.shape[1]
+    lib.call("ssn_crop_mean", _p(x), _p(out), num_crop, t, out.shape[1], _stream(lib, x))
+
+
+def reg_denorm(reg, mean0, std0, mean1, std1):
+    """reg [..., 2] in place: reg[..., k] * std[k] + mean[k] (ssn_test.py:88-90)."""
+    lib = _check(reg)
+    assert reg.shape[-1] == 2 and reg.is_contiguous()
+    lib.call("ssn_reg_denorm", _p(reg), reg.numel() // 2, float(mean0), float(std0), float(mean1), float(std1),
+             _stream(lib, reg))
+
+
 def linear_fwd(x, w, b, out):
     lib = _check(x, w, b, out)
     lib.call("ssn_linear_fwd", _p(x), _p(w), _p(b), _p(out), x.shape[0], w.shape[0], w.shape[1], _stream(lib, x))

@@ -152,12 +152,13 @@ def main():
     if not args.no_kernel_events and rank == 0:
         prof = []
         model.base_model.profiler = prof
-        overlap = model.base_model.overlap_wgrad
+        overlap, lanes = model.base_model.overlap_wgrad, model.base_model.branch_streams
         model.base_model.overlap_wgrad = False   # one kernel at a time, so an event pair times exactly one launch
+        model.base_model.branch_streams = False
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        model.base_model.overlap_wgrad = overlap
+        model.base_model.overlap_wgrad, model.base_model.branch_streams = overlap, lanes
         model.base_model.profiler = None
     fence()
     if world > 1:

@@ -182,6 +182,12 @@ int ssn_stpp_reorg(const float* scores, int T, int D, const int* ranges, const i
                    const float* scaling, const int* part_scale_col, int P, int n_parts, int act_len, int comp_len,
                    int reg_len, float* out_act, float* out_comp, float* out_reg, hipStream_t stream);
 
+/* Dense testing (ssn_test.py:84-90): mean over the crops of the per-frame rows, `rst.view(num_crop, -1, D).mean(0)`
+ * (x [num_crop][T][D] -> y [T][D]); and the regression de-normalisation reg[..., k] = reg[..., k] * std[k] + mean[k]
+ * on reg [n_pairs][2], in place. */
+int ssn_crop_mean(const float* x, float* y, int num_crop, int T, int D, hipStream_t stream);
+int ssn_reg_denorm(float* reg, long n_pairs, float mean0, float std0, float mean1, float std1, hipStream_t stream);
+
 /* ------------------------------------------------------------------ heads
  * nn.Linear fwd/bwd for activity_fc / completeness_fc / regressor_fc / test_fc
  * (ssn_models.py:77-78,87,272-273,283,300; cuBLAS GEMMs in the reference). */

@@ -240,6 +240,32 @@ def stpp_reorganized(scores, proposal_ticks, scaling, act_len, comp_len, reg_len
     return act, comp, reg
 
 
+def dense_test_video(net, frames_gen, frame_cnt, prop_ticks, prop_scaling, num_class, num_crop=10, stats=None,
+                     stpp_cfg=(1, 1, 1)):
+    """The per-video body of the reference tester, /root/reference/ssn_test.py:66-92, on ``net`` = an OracleSSN in
+    test mode with prepare_test_fc() done: score every frame batch (:81-83), average the crops AFTER the folded FC
+    (:84-85), re-organised STPP (:87), regression de-normalisation with ``stats`` (:88-90)."""
+    length = (3 if net.modality == "RGB" else 2) * net.new_length
+    output_dim = net.test_fc.out_features
+    output = torch.zeros((frame_cnt, output_dim))
+    cnt = 0
+    with torch.no_grad():
+        for frames in frames_gen:
+            inp = frames.view(-1, length, frames.size(-2), frames.size(-1))
+            rst, _ = net(inp, None, None, None, None)
+            sc = rst.view(num_crop, -1, output_dim).mean(dim=0)
+            output[cnt:cnt + sc.size(0), :] = sc
+            cnt += sc.size(0)
+    act, comp, reg = stpp_reorganized(output.numpy(), prop_ticks, prop_scaling, num_class + 1, num_class,
+                                      num_class * 2, stpp_cfg=stpp_cfg, with_regression=net.with_regression)
+    if reg is not None:
+        reg = reg.reshape(-1, num_class, 2)
+        if stats is not None:
+            reg[:, :, 0] = reg[:, :, 0] * stats[1][0] + stats[0][0]
+            reg[:, :, 1] = reg[:, :, 1] * stats[1][1] + stats[0][1]
+    return act, comp, reg, output.numpy()
+
+
 # --------------------------------------------------------------------------------------
 # Losses -- /root/reference/ops/ssn_ops.py:173-258, /root/reference/ssn_train.py:133,210-214
 # --------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@ m = SSN(20, 2, 5, 2, "RGB", dropout=0.8, stpp_cfg=(1, 1, 1))
 init_backbone_synthetic(m.base_model)
 m.to(dev).train()
 m.base_model.overlap_wgrad = False   # one kernel at a time: clean per-launch timings
+m.base_model.branch_streams = False
 x = make_batch(v, "RGB", 20, seed=0)[0].to(dev).reshape(-1, 3, 224, 224)
 plan, shapes = m.base_model._plan(x[:1])
 info = {}
