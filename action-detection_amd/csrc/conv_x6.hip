@@ -28,519 +28,11 @@
 //    workgroups drift into lock-step instead: both wait, then both compete -- measured 60 % pipe utilisation).
 //  * Epilogue: per-channel vectors via LDS, branch-free buffer addressing (out-of-range rows/pixels fall off the
 //    buffer), read-modify-write operands fetched one accumulator tile ahead.
-#include "conv_epilogue.h"
-#include "ssn_common.h"
-#include <type_traits>
+#include "conv_x6_kernel.h"
 
 namespace {
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int APITCH = 32;    // dwords per packed weight row: 8 chunks of 16 B (6 data + 2 pad), chunk-swizzled
-constexpr uint32_t OOB = 0x80000000u;
-
-struct X6Args {
-    const float* x;       // gather source (channel-slice base), fp32 NCHW
-    const uint32_t* ap;   // packed split weights [nslab][M][APITCH]
-    float* y;
-    const float* scale;
-    const float* shift;
-    int N, C, H, W;       // gather-source dims
-    long x_img_stride;
-    int M;
-    int Ho, Wo;           // enumerated pixel grid
-    long y_img_stride;
-    int P;
-    int pad;
-    int relu, accumulate;
-    const float* mask_y;
-    const float* mask_scale;
-    long mask_img_stride;
-    int n_ptiles, n_mtiles, ngroups;   // ngroups = ceil(C / 16)
-    uint32_t x_bytes, a_bytes, y_bytes, mask_bytes;
-    int x_guard;   // readable bytes in front of x (>= 256 enables the 16-byte activation loads)
-    unsigned long long* trace;   // tooling only: per-block phase timestamps (tools/trace_x6.py), normally null
-    int dbg;      // tooling only (tools/ablate_x6.py)
-    FastDiv div_hw, div_w, div_mt;
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-
-// bf16 pair (k even -> low half, k odd -> high half) of the top 16 bits of two fp32 values
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t even, uint32_t odd) {
-    return __builtin_amdgcn_perm(odd, even, 0x07060302u);
-}
-__device__ __forceinline__ float residual(float x) {
-    return x - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
-}
-
-// The 16-byte LDS-DMA form only exists for gfx950; hipcc's HOST pass (no target features) rejects it and then
-// silently drops the kernel's launch stub, so it is compiled for the device pass only.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define X6_DMA_B128(rsrc_, dst_, voff_, soff_) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_, SSN_LDS_PTR(dst_), 16, voff_, soff_, 0, 0)
-#else
-#define X6_DMA_B128(rsrc_, dst_, voff_, soff_) ((void)(dst_), (void)(voff_), (void)(soff_))
-#endif
-
-// tooling build only (tools/build_trace_lib.sh): per-phase cycle accumulators of wave 0 and wave 4
-#ifdef X6_PHASE_TRACE
-#define X6_PH_DECL unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, phc_ = __builtin_readcyclecounter()
-#define X6_PH(k)                                                  \
-    do {                                                          \
-        const unsigned long long n_ = __builtin_readcyclecounter(); \
-        ph_[k] += n_ - phc_;                                      \
-        phc_ = n_;                                                \
-    } while (0)
-#else
-#define X6_PH_DECL
-#define X6_PH(k)
-#endif
-
-template <int KS, int S, int MODE, bool WIDE, int NG, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
-    constexpr int NW = 4 * NG;              // waves per workgroup
-    constexpr int NT = 64 * NW;
-    constexpr int BM = WM * TM * 32;
-    constexpr int BNG = WN * TN * 32;       // pixel columns of one wave group
-    constexpr int BN = NG * BNG;
-    constexpr int KK = KS * KS;
-    constexpr int A_PIECES = BM / 8;        // 1 KiB pieces of the BM x 128 B weight tile
-    constexpr int NA = (A_PIECES + NW - 1) / NW;
-    constexpr int A_STAGE = NA * NW * 256;  // dwords; padded so that every wave copies exactly NA pieces
-    constexpr int B_STAGE = 16 * BN;        // dwords
-    constexpr int STAGE = A_STAGE + B_STAGE;
-    constexpr int NSTAGE = 3;
-    constexpr int SEGS = BN / 64;           // 64-pixel segments per k-row
-    // activation DMA instructions per wave and slab: 4 B per lane (256 B pieces = one k-row of 64 pixels), or,
-    // WIDE, 16 B per lane (1 KiB pieces = 256 consecutive (k-row, pixel) slots, 4 pixels per lane)
-    constexpr int NB = WIDE ? BN / 16 / NW : 16 * SEGS / NW;
-    constexpr int KSTEP = NW / SEGS;
-    constexpr int RPP = 256 / BN > 0 ? 256 / BN : 1;   // WIDE: k-rows per piece
-    constexpr uint32_t GUARD = WIDE ? 256u : 0u;       // WIDE: readable bytes in front of x (contract)
-    static_assert(!WIDE || (S == 1 && BN <= 256 && BN / 16 >= NW), "WIDE: stride 1, 64*NW/4 <= BN <= 256");
-    constexpr int NLOAD = NA + NB;
-    static_assert(WM * WN == 4, "4 waves per group");
-    static_assert(NW % SEGS == 0 && (16 * SEGS) % NW == 0, "unsupported tile width");
-
-    // WIDE 3x3: rows of zeros behind the ring; a lane whose tap falls on padding reads its fragment from there
-    constexpr int ZROWS = (WIDE && KK > 1) ? 7 * BN + 64 : 0;
-    __shared__ __attribute__((aligned(1024))) uint32_t lds[NSTAGE * STAGE + ZROWS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-    const int grp = wave >> 2, gw = wave & 3;
-    const int wm = gw / WN, wn = gw % WN;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const uint32_t nblk = (uint32_t)p.n_ptiles * (uint32_t)p.n_mtiles;
-    const uint32_t logical = xcd_remap(blockIdx.x, nblk);
-    uint32_t ptile, mtile;
-    fd_divmod(logical, p.div_mt, ptile, mtile);
-    const int m0 = (int)mtile * BM;
-    const int p0 = (int)ptile * BN;
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-    if (p.trace) tr0 = __builtin_readcyclecounter();
-
-    // ---- B gather state ----
-    //  narrow: this lane fetches pixel (seg * 64 + lane) of k-rows krow0 + i * KSTEP; taps that fall outside the
-    //          image are turned into out-of-range offsets (-> zeros) per slab.
-    //  WIDE:   this lane fetches the 4 consecutive pixels wpx.. of k-row (piece * RPP + wkl).  Address arithmetic is
-    //          linear in the pixel index for stride 1, so no per-pixel border handling is possible at the load:
-    //          whatever lies next to the image in memory is fetched (x must be preceded by GUARD readable bytes),
-    //          and the padding positions are zeroed when the fragments are read (fmask).
-    const int seg = wave % SEGS;
-    const int krow0 = wave / SEGS;
-    const int wkl = WIDE ? (4 * lane) / BN : 0;
-    const int wpx = WIDE ? (4 * lane) % BN : seg * 64 + lane;
-    uint32_t gbase;                        // byte offset of the tap-(0,0) input element (may wrap below zero)
-    uint32_t gmask = 0;                    // bit t: tap t reads inside the image (WIDE: bit 0 = pixel exists)
-    const uint32_t hw_bytes = (uint32_t)(p.H * p.W) * 4u;
-    auto tap_mask = [&](int gp, uint32_t& n, int& h0, int& w0) {
-        const bool gvalid = gp < p.P;
-        uint32_t hw, ho, wo, m = 0;
-        fd_divmod((uint32_t)(gvalid ? gp : 0), p.div_hw, n, hw);
-        fd_divmod(hw, p.div_w, ho, wo);
-        h0 = (MODE == MODE_FWD) ? (int)ho * S - p.pad : (int)ho + p.pad;
-        w0 = (MODE == MODE_FWD) ? (int)wo * S - p.pad : (int)wo + p.pad;
-#pragma unroll
-        for (int t = 0; t < KK; ++t) {
-            const int r = t / KS, s = t - r * KS;
-            const int hi = (MODE == MODE_FWD) ? h0 + r : h0 - r;
-            const int wi = (MODE == MODE_FWD) ? w0 + s : w0 - s;
-            if (gvalid && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W)) m |= 1u << t;
-        }
-        return m;
-    };
-    {
-        uint32_t n;
-        int h0, w0;
-        const uint32_t m = tap_mask(p0 + wpx, n, h0, w0);
-        gmask = WIDE ? (uint32_t)(p0 + wpx < p.P) : m;
-        gbase = (uint32_t)((long)n * p.x_img_stride * 4) + (uint32_t)((h0 * p.W + w0) * 4) + (uint32_t)wkl * hw_bytes +
-                GUARD;
-    }
-    // WIDE: validity of the taps at the pixels of this lane's B fragments
-    uint32_t fmask[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        uint32_t n;
-        int h0, w0;
-        fmask[j] = (WIDE && KK > 1) ? tap_mask(p0 + grp * BNG + (wn * TN + j) * 32 + li, n, h0, w0) : 0u;
-    }
-
-    // ---- A copy: wave w moves 1 KiB pieces (q * NW + w) of the tile ----
-    uint32_t aoff[NA];
-#pragma unroll
-    for (int q = 0; q < NA; ++q) {
-        const int f = (q * NW + wave) * 64 + lane;   // 16-byte chunk of the tile
-        aoff[q] = (f < BM * 8 && m0 + f / 8 < p.M) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : OOB;
-    }
-    const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - GUARD, p.x_bytes + GUARD);
-    const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.ap, p.a_bytes);
-    const uint32_t a_step = (uint32_t)(p.M * APITCH) * 4u;
-    const int nslab = p.ngroups * KK;
-    const int c_last = p.C - (p.ngroups - 1) * 16;   // channels in the last group (16 when exact)
-
-    // DMA of slab (ig, itap) into a ring stage, as NLOAD separate pieces (NB activation rows, then NA weight pieces)
-    // so that they can be dealt out between the MFMAs: the texture path takes 64 B/clk per CU, and a wave that
-    // issues its whole share in one burst (together with the 7 other waves) stalls ~800 cycles at the issue.
-    // Slabs past the end (the ring always runs two ahead) are issued too, with every offset out of range, so the
-    // K loop has no "is there still something to fetch" branches: such a piece deposits zeros in a ring slot that is
-    // never read again.
-    // Producer state = the slab that is fetched next, kept as running scalars (no multiplies in the loop): groups
-    // still to fetch, tap, tap displacement in bytes, channel-group offset of the source and slab offset of the weights.
-    int pf_left = (p.dbg & 1) ? 0 : p.ngroups;
-    int pf_tap = 0, pf_col = 0;
-    uint32_t pf_d = 0;                                                       // (r * W + s) * 4 of the tap
-    uint32_t pf_x = (uint32_t)(WIDE ? wave * RPP : krow0) * hw_bytes;        // + 16 channels per group
-    uint32_t pf_a = 0;                                                       // + a_step per slab
-    const uint32_t row_wrap = (uint32_t)(p.W - 3) * 4u, group_step = 16u * hw_bytes;
-    uint32_t d_vo, d_so, d_aso, d_dead;
-    uint32_t *d_b, *d_a;
-    bool d_tail;
-    auto issue_begin = [&](uint32_t st_off) {   // st_off = dword offset of the destination ring slot
-        const uint32_t live = pf_left > 0 ? 1u : 0u;
-        d_dead = live ? 0u : OOB;
-        uint32_t cand = gbase, ok = gmask & 1u;
-        if (KK > 1) {
-            cand = (MODE == MODE_FWD) ? gbase + pf_d : gbase - pf_d;
-            if (!WIDE) ok = (gmask >> pf_tap) & 1u;
-        }
-        d_vo = (ok & live) ? cand : OOB;
-        d_tail = (pf_left == 1) && (c_last != 16);
-        d_so = pf_x;
-        d_b = lds + st_off + A_STAGE + (WIDE ? wave * 256 : krow0 * BN + seg * 64);
-        d_aso = pf_a;
-        d_a = lds + st_off + wave * 256;
-        // advance to the next slab
-        pf_a += a_step;
-        if (KK == 1) {
-            pf_x += group_step;
-            --pf_left;
-        } else {
-            pf_d += 4u;
-            if (++pf_col == KS) {
-                pf_col = 0;
-                pf_d += row_wrap;
-            }
-            if (++pf_tap == KK) {
-                pf_tap = 0;
-                pf_d = 0;
-                pf_x += group_step;
-                --pf_left;
-            }
-        }
-    };
-    auto issue_piece = [&](int k) {   // k is a compile-time constant at every call site
-        if (k < NB && WIDE) {
-            uint32_t v = d_vo;
-            if (d_tail && ((k * NW + wave) * RPP + wkl >= c_last)) v = OOB;
-            X6_DMA_B128(xrsrc, d_b + k * NW * 256, v, d_so + (uint32_t)(k * NW * RPP) * hw_bytes);
-        } else if (k < NB) {
-            uint32_t v = d_vo;
-            if (d_tail && (krow0 + k * KSTEP >= c_last)) v = OOB;   // channels past the end (never in BN-Inception)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SSN_LDS_PTR(d_b + k * KSTEP * BN), 4, v,
-                                                     d_so + (uint32_t)(k * KSTEP) * hw_bytes, 0, 0);
-        } else {
-            X6_DMA_B128(arsrc, d_a + (k - NB) * NW * 256, aoff[k - NB] | d_dead, d_aso);
-        }
-    };
-    auto issue = [&](uint32_t st_off) {
-        issue_begin(st_off);
-#pragma unroll
-        for (int k = 0; k < NLOAD; ++k) issue_piece(k);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (ZROWS) {
-        for (int i = tid; i < ZROWS; i += NT) lds[NSTAGE * STAGE + i] = 0u;
-        __syncthreads();
-    }
-    issue(0);
-    issue(STAGE);   // past the last slab the pieces turn into out-of-range (all-zero) copies: no branches in the loop
-    if (p.trace) tr1 = __builtin_readcyclecounter();
-
-    // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 1) & 7)
-    const int swz = (li >> 1) & 7;
-    int achunk[3];
-#pragma unroll
-    for (int pn = 0; pn < 3; ++pn) achunk[pn] = ((2 * pn + lh) ^ swz) * 4;
-    const int arow = (wm * TM * 32 + li) * APITCH;
-    const int bcol = A_STAGE + (8 * lh) * BN + grp * BNG + wn * TN * 32 + li;
-
-    // Operand registers of one slab: the raw fp32 activations of this lane's fragments and the weight fragments.  Two
-    // sets: a free-running (NG == 1) wave reads slab t+1 from LDS while it multiplies slab t.
-    struct Frags {
-        float raw[TN][8];
-        bf16x8 af[3][TM];
-    };
-    Frags fr0, fr1;
-    uint32_t pl[3][TN][4];   // the three bf16 planes of the slab being multiplied, as k-pairs
-    float res[TN][8];
-    // The split of pair e (k = 2e, 2e+1) of fragment j into its plane-1 and plane-2 dwords, as two half steps of
-    // 5 VALU (what fits in the shadow of one MFMA): first residual + plane 1, then second residual + plane 2.
-    auto split_half = [&](const Frags& f, int j, int e, int half) {
-        if (half == 0) {
-            res[j][2 * e] = residual(f.raw[j][2 * e]);
-            res[j][2 * e + 1] = residual(f.raw[j][2 * e + 1]);
-            pl[1][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, res[j][2 * e]), __builtin_bit_cast(uint32_t, res[j][2 * e + 1]));
-        } else {
-            const float s0 = residual(res[j][2 * e]), s1 = residual(res[j][2 * e + 1]);
-            pl[2][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
-        }
-    };
-    // LDS -> registers: raw activations (a tap on padding reads the rows of zeros instead) and weight fragments, as
-    // NREAD separate steps (a k-pair of one activation fragment = one ds_read2st64_b32, or one 16-byte weight read) so
-    // that a pipelined wave can deal them out between its MFMAs: eight waves that all burst 13+ reads right after the
-    // barrier queue up behind the LDS pipeline for ~200 cycles before anybody's first MFMA issues.
-    int ctap = 0;   // tap of the slab being read (WIDE 3x3 only)
-    constexpr int NREAD = 4 * TN + 3 * TM;
-    const uint32_t* rd_src[TN];
-    const uint32_t* rd_a;
-    auto read_begin = [&](uint32_t st_off) {
-        const uint32_t* Ls = lds + st_off;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            rd_src[j] = Ls + bcol + j * 32;
-            if (WIDE && KK > 1) {
-                const bool inside = (fmask[j] >> ctap) & 1u;
-                rd_src[j] = inside ? rd_src[j] : lds + NSTAGE * STAGE + li;
-            }
-        }
-        rd_a = Ls + arow;
-        if (WIDE && KK > 1) ctap = (ctap + 1 == KK) ? 0 : ctap + 1;
-    };
-    auto read_step = [&](Frags& f, int k) {   // k is a compile-time constant at every call site
-        if (k < 4 * TN) {
-            const int j = k / 4, e = k % 4;
-            f.raw[j][2 * e] = __builtin_bit_cast(float, rd_src[j][(2 * e) * BN]);
-            f.raw[j][2 * e + 1] = __builtin_bit_cast(float, rd_src[j][(2 * e + 1) * BN]);
-        } else {
-            const int q = k - 4 * TN, pn = q / TM, i = q % TM;
-            f.af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(rd_a + i * 32 * APITCH + achunk[pn]));
-        }
-    };
-    auto read_frags = [&](uint32_t st_off, Frags& f) {
-        read_begin(st_off);
-#pragma unroll
-        for (int k = 0; k < NREAD; ++k) read_step(f, k);
-    };
-    // top plane (one v_perm per k-pair); `all_planes`: also the two lower ones (the ping-pong groups split while the
-    // other group multiplies; a free-running wave does that in the shadow of its own MFMAs instead, see mfma)
-    auto top_plane = [&](const Frags& f, bool all_planes) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pl[0][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, f.raw[j][2 * e]),
-                                        __builtin_bit_cast(uint32_t, f.raw[j][2 * e + 1]));
-                if (all_planes) {
-                    split_half(f, j, e, 0);
-                    split_half(f, j, e, 1);
-                }
-            }
-    };
-    auto front = [&](uint32_t st_off, bool all_planes) {
-        read_frags(st_off, fr0);
-        top_plane(fr0, all_planes);
-    };
-    // Six partial products per accumulator tile.  The three that only need the TOP plane of the activations go first,
-    // then plane 1, then plane 2, and (`interleave`) the 8 * TN half steps that produce the two lower planes are dealt
-    // out behind those first MFMAs, fenced in place: the matrix pipe starts as soon as the LDS reads are back and the
-    // ~40 VALU per fragment run in its shadow.  (The running fp32 accumulator already holds the earlier slabs, so the
-    // order of the six products inside a slab is immaterial for rounding.)  With `dma` the pieces of the slab two
-    // ahead are dealt out between the MFMAs as well.
-    auto mfma = [&](auto dma_tag, auto il_tag, const Frags& f, uint32_t dma_stage, Frags& nxt) {
-        constexpr bool dma = decltype(dma_tag)::value;
-        constexpr bool interleave = decltype(il_tag)::value;
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
-        constexpr int NM = 6 * TM * TN;
-        constexpr int NTOP = 3 * TM * TN;   // MFMAs that need plane 0 only
-        constexpr int NSTEP = 8 * TN;   // half steps
-        constexpr int EVERY = NM / NLOAD > 0 ? NM / NLOAD : 1;
-        if (dma) issue_begin(dma_stage);
-        if (interleave) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const bf16x8 b = __builtin_bit_cast(
-                        bf16x8, u32x4{pl[PB[c]][j][0], pl[PB[c]][j][1], pl[PB[c]][j][2], pl[PB[c]][j][3]});
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.af[PA[c]][i], b, acc[i][j], 0, 0, 0);
-                    const int idx = (c * TM + i) * TN + j;
-                    if (interleave && idx < NTOP) {
-#pragma unroll
-                        for (int st = idx * NSTEP / NTOP; st < (idx + 1) * NSTEP / NTOP; ++st)
-                            split_half(f, st / 8, (st % 8) / 2, st % 2);
-                    }
-                    if (interleave) {   // the LDS reads of the next slab (into the other register set)
-#pragma unroll
-                        for (int k = idx * NREAD / NM; k < (idx + 1) * NREAD / NM; ++k) read_step(nxt, k);
-                    }
-                    if (dma && (idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) issue_piece((idx + 1) / EVERY - 1);
-                    if (interleave) __builtin_amdgcn_sched_barrier(0);
-                }
-        if (dma) {
-#pragma unroll
-            for (int k = NM / EVERY; k < NLOAD; ++k) issue_piece(k);
-        }
-    };
-
-    // tooling (tools/prio_x6.py): dbg bit 5 = static priority for the waves in odd hardware wave slots, bit 6 = raised
-    // priority around every MFMA block
-    if ((p.dbg & 32) && wave_uniform((int)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1u)))
-        __builtin_amdgcn_s_setprio(2);
-    X6_PH_DECL;
-    if (NG == 1) {
-        // Free-running waves, software-pipelined through two register sets: in iteration t the wave multiplies slab t out
-        // of registers while its LDS reads of slab t+1 and the DMA of slab t+3 are in flight, so neither the LDS round
-        // trip nor the split sits in front of the matrix pipe.  Ring slots: t+1 (being read), t+2 (landing), and the
-        // slot of slab t, free since every wave finished reading it before the barrier, takes slab t+3.
-        issue(2 * STAGE);
-        SSN_WAIT_VMCNT(2 * NLOAD);
-        __builtin_amdgcn_s_barrier();
-        read_frags(0, fr0);
-        uint32_t s_cur = 0, s_n1 = STAGE, s_n2 = 2 * STAGE;   // ring slots of slabs t, t+1, t+2
-        auto half = [&](const Frags& cur, Frags& nxt) {
-            SSN_WAIT_VMCNT(NLOAD);   // this wave's pieces of slab t+1 (slab t+2's may still be in flight)
-            SSN_WAIT_LGKM0();        // ... and its reads of slab t are back
-            X6_PH(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            X6_PH(1);
-            read_begin(s_n1);
-            top_plane(cur, false);
-            X6_PH(3);
-            mfma(std::true_type{}, std::true_type{}, cur, s_cur, nxt);
-            X6_PH(5);
-            const uint32_t o = s_cur;
-            s_cur = s_n1;
-            s_n1 = s_n2;
-            s_n2 = o;
-        };
-        // two slabs per trip (the register sets swap roles); an odd slab count runs one all-zero slab at the end
-        for (int t = 0; t < nslab; t += 2) {
-            half(fr0, fr1);
-            half(fr1, fr0);
-        }
-        SSN_WAIT_LGKM0();
-    } else {
-        uint32_t stage = 0;   // dword offset of the ring slot holding slab t
-        for (int t = 0; t < nslab; ++t) {
-            // slab t has landed once at most the NLOAD pieces of slab t+1 (real or out-of-range) are still in flight
-            SSN_WAIT_VMCNT(NLOAD);
-            X6_PH(0);
-            __builtin_amdgcn_s_barrier();   // (a) every wave's share of slab t is visible, (b) slab t-1 is consumed
-            __builtin_amdgcn_sched_barrier(0);
-            X6_PH(1);
-            const uint32_t dst = stage == 0 ? 2 * STAGE : stage - STAGE;   // ring slot of slab t-1, refilled with slab t+2
-            if (grp == 0) {
-                front(stage, true);
-                X6_PH(3);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                X6_PH(4);
-                mfma(std::true_type{}, std::false_type{}, fr0, dst, fr1);
-                X6_PH(5);
-            } else {
-                if (t > 0)
-                    mfma(std::true_type{}, std::false_type{}, fr0, dst, fr1);   // slab t-1, split during the previous half-phase
-                else
-                    issue(dst);
-                X6_PH(3);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                X6_PH(4);
-                front(stage, true);
-                X6_PH(5);
-            }
-            stage = stage == (NSTAGE - 1) * STAGE ? 0 : stage + STAGE;
-        }
-        if (grp == 1) mfma(std::false_type{}, std::false_type{}, fr0, 0u, fr1);
-    }
-    SSN_WAIT_VMCNT(0);   // the out-of-range tail pieces still write (zeros) into the ring the epilogue is about to reuse
-    if (p.trace) tr2 = __builtin_readcyclecounter();
-
-    // ---- epilogue: BN affine + ReLU (forward), or accumulate + fused ReLU/BN backward (dgrad) ----
-    __syncthreads();
-    float* ch = reinterpret_cast<float*>(lds);
-    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid);
-    __syncthreads();
-    EpiArgs e;
-    e.y = p.y;
-    e.mask_y = p.mask_y;
-    e.y_bytes = p.y_bytes;
-    e.mask_bytes = p.mask_bytes;
-    e.howo4 = (uint32_t)(p.Ho * p.Wo) * 4u;
-    e.M = p.M;
-    e.relu = p.relu;
-    e.accumulate = p.accumulate;
-    uint32_t yoff[TN], moff[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int pp = p0 + grp * BNG + (wn * TN + j) * 32 + li;
-        uint32_t n, hw;
-        fd_divmod((uint32_t)(pp < p.P ? pp : 0), p.div_hw, n, hw);
-        const uint32_t row0 = (uint32_t)(m0 + 4 * lh) * e.howo4 + hw * 4u;
-        yoff[j] = pp < p.P ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : EPI_OOB;
-        moff[j] = pp < p.P ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : EPI_OOB;
-    }
-    conv_epilogue<TM, TN, BM>(acc, ch, e, yoff, moff, wm * TM * 32, lh, m0);
-#ifdef X6_PHASE_TRACE
-    if (p.trace && lane == 0 && (wave & 3) == 0) {
-        unsigned long long* t = p.trace + (size_t)blockIdx.x * 32 + 8 + 8 * (wave >> 2);
-        for (int k = 0; k < 6; ++k) t[k] = ph_[k];
-    }
-#endif
-    if (p.trace && tid == 0) {
-        unsigned long long* t = p.trace + (size_t)blockIdx.x * 32;
-        t[0] = tr0;
-        t[1] = tr1;
-        t[2] = tr2;
-        t[3] = __builtin_readcyclecounter();
-        t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID (wave/simd/cu/sh/se bits)
-        t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
-    }
-}
-#undef X6_DMA_B128
+using namespace x6;
 
 // ---- weight split + pack: out[slab][m][8 chunks x 4 dwords] ----
 // slab = g (1x1) or g * 9 + tap (3x3); row k of a slab = channel 16 g + k.  Logical 16-byte chunk c = 2 * plane +
@@ -603,7 +95,7 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
 int g_x6_dbg = 0;   // tooling: bit 4 (16) disables the 16-byte activation loads
 unsigned long long* g_x6_trace = nullptr;
 
-template <int KS, int S, int MODE, int NG, int WM, int WN, int TM, int TN>
+template <int KH, int KW, int S, int MODE, int NG, int WM, int WN, int TM, int TN>
 int launch_cfg(X6Args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = NG * WN * TN * 32;
@@ -615,15 +107,15 @@ int launch_cfg(X6Args& a, hipStream_t stream) {
     // a tile width the 1 KiB pieces divide, and the caller's guarantee that the bytes in front of x are readable
     constexpr bool wide_ok = (S == 1) && BN <= 256 && BN / 16 >= 4 * NG;
     if constexpr (wide_ok) {
-        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && (a.pad > KS - 1 - a.pad ? a.pad : KS - 1 - a.pad) * (a.W + 1) * 4 <= 256 &&
+        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && x6_reach_bytes(a.pad_h, a.pad_w, KH, KW, a.W) <= 256 &&
             !(g_x6_dbg & 16)) {
-            hipLaunchKernelGGL((conv_x6_kernel<KS, S, MODE, true, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0,
+            hipLaunchKernelGGL((conv_x6_kernel<KH, KW, S, MODE, true, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0,
                                stream, a);
             SSN_CHECK_LAUNCH("conv_x6 (wide)");
             return SSN_OK;
         }
     }
-    hipLaunchKernelGGL((conv_x6_kernel<KS, S, MODE, false, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0, stream,
+    hipLaunchKernelGGL((conv_x6_kernel<KH, KW, S, MODE, false, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0, stream,
                        a);
     SSN_CHECK_LAUNCH("conv_x6");
     return SSN_OK;
@@ -633,25 +125,25 @@ int launch_cfg(X6Args& a, hipStream_t stream) {
 //   0 128x128, 1 64x128, 2 96x128, 3 64x64, 4 32x128, 5 128x128 (1x4 waves), 6 64x128 (1x4 waves), 7 128x64
 // 8-15: 8-wave ping-pong workgroups (two groups side by side along the pixel axis):
 //   8 128x256, 9 64x256, 10 96x256, 11 64x128, 12 160x256, 13 128x128, 14 64x256 (1x4 waves), 15 128x256 (1x4 waves)
-template <int KS, int S, int MODE>
+template <int KH, int KW, int S, int MODE>
 int launch_tile(X6Args& a, int cfg, hipStream_t stream) {
     switch (cfg) {
-        case 0: return launch_cfg<KS, S, MODE, 1, 2, 2, 2, 2>(a, stream);
-        case 1: return launch_cfg<KS, S, MODE, 1, 2, 2, 1, 2>(a, stream);
-        case 2: return launch_cfg<KS, S, MODE, 1, 1, 4, 3, 1>(a, stream);
-        case 3: return launch_cfg<KS, S, MODE, 1, 2, 2, 1, 1>(a, stream);
-        case 4: return launch_cfg<KS, S, MODE, 1, 1, 4, 1, 1>(a, stream);
-        case 5: return launch_cfg<KS, S, MODE, 1, 1, 4, 4, 1>(a, stream);
-        case 6: return launch_cfg<KS, S, MODE, 1, 1, 4, 2, 1>(a, stream);
-        case 7: return launch_cfg<KS, S, MODE, 1, 2, 2, 2, 1>(a, stream);
-        case 8: return launch_cfg<KS, S, MODE, 2, 2, 2, 2, 2>(a, stream);
-        case 9: return launch_cfg<KS, S, MODE, 2, 2, 2, 1, 2>(a, stream);
-        case 10: return launch_cfg<KS, S, MODE, 2, 1, 4, 3, 1>(a, stream);
-        case 11: return launch_cfg<KS, S, MODE, 2, 2, 2, 1, 1>(a, stream);
-        case 12: return launch_cfg<KS, S, MODE, 2, 1, 4, 5, 1>(a, stream);
-        case 13: return launch_cfg<KS, S, MODE, 2, 2, 2, 2, 1>(a, stream);
-        case 14: return launch_cfg<KS, S, MODE, 2, 1, 4, 2, 1>(a, stream);
-        case 15: return launch_cfg<KS, S, MODE, 2, 1, 4, 4, 1>(a, stream);
+        case 0: return launch_cfg<KH, KW, S, MODE, 1, 2, 2, 2, 2>(a, stream);
+        case 1: return launch_cfg<KH, KW, S, MODE, 1, 2, 2, 1, 2>(a, stream);
+        case 2: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 3, 1>(a, stream);
+        case 3: return launch_cfg<KH, KW, S, MODE, 1, 2, 2, 1, 1>(a, stream);
+        case 4: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 1, 1>(a, stream);
+        case 5: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 4, 1>(a, stream);
+        case 6: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 2, 1>(a, stream);
+        case 7: return launch_cfg<KH, KW, S, MODE, 1, 2, 2, 2, 1>(a, stream);
+        case 8: return launch_cfg<KH, KW, S, MODE, 2, 2, 2, 2, 2>(a, stream);
+        case 9: return launch_cfg<KH, KW, S, MODE, 2, 2, 2, 1, 2>(a, stream);
+        case 10: return launch_cfg<KH, KW, S, MODE, 2, 1, 4, 3, 1>(a, stream);
+        case 11: return launch_cfg<KH, KW, S, MODE, 2, 2, 2, 1, 1>(a, stream);
+        case 12: return launch_cfg<KH, KW, S, MODE, 2, 1, 4, 5, 1>(a, stream);
+        case 13: return launch_cfg<KH, KW, S, MODE, 2, 2, 2, 2, 1>(a, stream);
+        case 14: return launch_cfg<KH, KW, S, MODE, 2, 1, 4, 2, 1>(a, stream);
+        case 15: return launch_cfg<KH, KW, S, MODE, 2, 1, 4, 4, 1>(a, stream);
     }
     ssn_set_error("conv_x6: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -684,7 +176,8 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
     a.Wo = Wo;
     a.y_img_stride = ys;
     a.P = N * Ho * Wo;
-    a.pad = pad;
+    a.pad_h = pad;
+    a.pad_w = pad;
     a.ngroups = (C + 15) / 16;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
@@ -774,9 +267,9 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
     a.mask_scale = nullptr;
     a.mask_img_stride = 0;
     const int cfg = tile_cfg >= 0 ? tile_cfg : default_tile(Cout, a.P);
-    if (ksize == 1 && stride == 1) return launch_tile<1, 1, MODE_FWD>(a, cfg, stream);
-    if (ksize == 3 && stride == 1) return launch_tile<3, 1, MODE_FWD>(a, cfg, stream);
-    if (ksize == 3 && stride == 2) return launch_tile<3, 2, MODE_FWD>(a, cfg, stream);
+    if (ksize == 1 && stride == 1) return launch_tile<1, 1, 1, MODE_FWD>(a, cfg, stream);
+    if (ksize == 3 && stride == 1) return launch_tile<3, 3, 1, MODE_FWD>(a, cfg, stream);
+    if (ksize == 3 && stride == 2) return launch_tile<3, 3, 2, MODE_FWD>(a, cfg, stream);
     ssn_set_error("conv x6 fwd: (k=%d, s=%d) has no kernel", ksize, stride);
     return SSN_ERR_ARG;
 }
@@ -806,6 +299,6 @@ extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float*
         a.mask_bytes = (uint32_t)mb;
     }
     const int cfg = tile_cfg >= 0 ? tile_cfg : default_tile(Cin, a.P);
-    if (ksize == 1) return launch_tile<1, 1, MODE_DGRAD>(a, cfg, stream);
-    return launch_tile<3, 1, MODE_DGRAD>(a, cfg, stream);
+    if (ksize == 1) return launch_tile<1, 1, 1, MODE_DGRAD>(a, cfg, stream);
+    return launch_tile<3, 3, 1, MODE_DGRAD>(a, cfg, stream);
 }
