@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -40,6 +40,8 @@ _SIGS = {
     "ssn_conv_x6_pack_weights_multi": "ippppppppp",
     "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiip",
     "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiip",
+    "ssn_conv_x6_fwd_rect": "pppppiiiiliiiliiiiiiip",
+    "ssn_conv_x6_pack_weights_rect": "ppiiiip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
     "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
     "ssn_global_avgpool_fwd": "ppiiilp",
@@ -71,7 +73,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
-                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
+                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes",
                                 "ssn_conv_debug_flags",
                                 "ssn_conv_dgrad_layout"])
@@ -93,6 +95,8 @@ class SsnLibrary:
         self.cdll.ssn_conv_packed_floats.argtypes = [ctypes.c_int] * 4
         self.cdll.ssn_conv_x6_packed_floats.restype = ctypes.c_long
         self.cdll.ssn_conv_x6_packed_floats.argtypes = [ctypes.c_int] * 4
+        self.cdll.ssn_conv_x6_packed_floats_rect.restype = ctypes.c_long
+        self.cdll.ssn_conv_x6_packed_floats_rect.argtypes = [ctypes.c_int] * 4
         self.cdll.ssn_conv_wgrad_x6_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_conv_wgrad_x6_workspace_bytes.argtypes = [ctypes.c_int] * 7
         self.cdll.ssn_conv_pick_tile.restype = ctypes.c_int
@@ -121,7 +125,7 @@ _test_lib = None
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into the in-tree libssn_hip.so (cross-compiles on CPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ssn_common.h"), os.path.join(CSRC, "conv_epilogue.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("ssn_common.h", "conv_epilogue.h", "conv_x6_kernel.h")]
     if not force and os.path.exists(LIB_PATH):
         if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
             return LIB_PATH

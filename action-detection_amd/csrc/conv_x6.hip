@@ -46,15 +46,14 @@ struct X6PackTable {
     const float* w0[XP_MAX];
     const float* w1[XP_MAX];
     uint32_t* out[XP_MAX];
-    int cout[XP_MAX], cin[XP_MAX], ks[XP_MAX], mode[XP_MAX], split[XP_MAX];
+    int cout[XP_MAX], cin[XP_MAX], kk[XP_MAX], mode[XP_MAX], split[XP_MAX];   // kk = taps per channel (kh * kw)
     int blk0[XP_MAX + 1];
     int count;
 };
 __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
     int ti = 0;
     while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;
-    const int mode = t.mode[ti], Cout = t.cout[ti], Cin = t.cin[ti], ks = t.ks[ti];
-    const int KK = ks * ks;
+    const int mode = t.mode[ti], Cout = t.cout[ti], Cin = t.cin[ti], KK = t.kk[ti];
     const int M = mode ? Cin : Cout, C = mode ? Cout : Cin;
     const int ngroups = (C + 15) / 16;
     const long total = (long)ngroups * KK * M * 8;     // kpairs
@@ -157,8 +156,7 @@ int default_tile(int M, long P) {
 }
 
 long x6_packed_dwords(int Cout, int Cin, int ksize, int transposed) {
-    const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
-    return (long)((C + 15) / 16) * ksize * ksize * M * APITCH;
+    return x6_packed_dwords_kk(Cout, Cin, ksize * ksize, transposed);
 }
 
 int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, int C, int H, int W, long xs, int M,
@@ -233,7 +231,7 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
             t.out[i] = (uint32_t*)out[j];
             t.cout[i] = cout[j];
             t.cin[i] = cin[j];
-            t.ks[i] = ksize[j];
+            t.kk[i] = ksize[j] * ksize[j];
             t.mode[i] = mode[j];
             t.split[i] = split[j];
             t.blk0[i] = blocks;
@@ -244,6 +242,29 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
         if (blocks) hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
     }
     SSN_CHECK_LAUNCH("conv_x6_pack_weights_multi");
+    return SSN_OK;
+}
+
+// Split + pack ONE forward weight [cout][cin][kh][kw] (rectangular taps: conv_x6_rect.hip); out holds
+// ssn_conv_x6_packed_floats_rect() floats.
+extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cout, int cin, int kh, int kw,
+                                             hipStream_t stream) {
+    SSN_CHECK_ARG(w && out && cout > 0 && cin > 0 && kh > 0 && kw > 0 && kh * kw <= 32, "conv x6 pack rect: bad arguments");
+    X6PackTable t;
+    t.count = 1;
+    t.w0[0] = w;
+    t.w1[0] = nullptr;
+    t.out[0] = (uint32_t*)out;
+    t.cout[0] = cout;
+    t.cin[0] = cin;
+    t.kk[0] = kh * kw;
+    t.mode[0] = 0;
+    t.split[0] = cout;
+    t.blk0[0] = 0;
+    const long triples = x6_packed_dwords_kk(cout, cin, kh * kw, 0) / APITCH * 8;
+    t.blk0[1] = (int)((triples + XP_CHUNK - 1) / XP_CHUNK);
+    hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)t.blk0[1]), dim3(256), 0, stream, t);
+    SSN_CHECK_LAUNCH("conv_x6_pack_weights_rect");
     return SSN_OK;
 }
 

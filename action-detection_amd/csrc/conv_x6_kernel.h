@@ -516,4 +516,18 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
 }
 #undef X6_DMA_B128
 
+// bytes a 16-byte (WIDE) activation load may reach in front of / behind the tile's own pixels: the largest tap
+// displacement of a same-size stride-1 convolution
+static inline int x6_reach_bytes(int pad_h, int pad_w, int kh, int kw, int W) {
+    const int rh = pad_h > kh - 1 - pad_h ? pad_h : kh - 1 - pad_h;
+    const int rw = pad_w > kw - 1 - pad_w ? pad_w : kw - 1 - pad_w;
+    return (rh * W + rw) * 4;
+}
+
+// dwords of the packed split weights: [ceil(C / 16) * kk slabs][M rows][APITCH]
+static inline long x6_packed_dwords_kk(int Cout, int Cin, int kk, int transposed) {
+    const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
+    return (long)((C + 15) / 16) * kk * M * APITCH;
+}
+
 }  // namespace x6

@@ -1,0 +1,108 @@
+// Rectangular-tap forward convolutions on the bf16-split ("x6") kernel of conv_x6_kernel.h, gfx950.
+//
+// BN-Inception only has square 1x1 / 3x3 taps (conv_x6.hip).  The Inception-v3 backbone the reference's tester runs on
+// ActivityNet (/root/reference/ssn_models.py:133-139, BASELINE.json configs[4]) also has 5x5, 1x7, 7x1, 1x3 and 3x1
+// layers with per-axis padding; they are the same kernel template instantiated for KH x KW taps (the slab is still 16
+// channels x one tap, taps innermost, rows of KW), forward only (dense testing runs no backward).  A separate
+// translation unit so that the instantiations compile in parallel with conv_x6.hip.
+#include "conv_epilogue.h"
+#include "ssn_common.h"
+#include "conv_x6_kernel.h"
+
+namespace {
+
+using namespace x6;
+
+template <int KH, int KW, int WM, int WN, int TM, int TN>
+int launch_rect_cfg(X6Args& a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    a.n_ptiles = (a.P + BN - 1) / BN;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
+    const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
+    // 16-byte activation loads under the same conditions as the square kernels (same-size stride-1 convolution,
+    // planes a multiple of 4 pixels, the largest tap displacement inside the readable guard in front of x)
+    if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W &&
+        x6_reach_bytes(a.pad_h, a.pad_w, KH, KW, a.W) <= 256) {
+        hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1, MODE_FWD, true, 1, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
+        SSN_CHECK_LAUNCH("conv_x6_rect (wide)");
+        return SSN_OK;
+    }
+    hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1, MODE_FWD, false, 1, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("conv_x6_rect");
+    return SSN_OK;
+}
+
+// tiles (rows x pixels), ids as in conv_x6.hip: 1 64x128, 2 96x128 (1x4 waves), 5 128x128 (1x4 waves), 6 64x128 (1x4 waves)
+template <int KH, int KW>
+int launch_rect(X6Args& a, int cfg, hipStream_t stream) {
+    if (cfg < 0) cfg = (a.M % 128 == 0 || a.M > 256) ? 5 : (a.M % 96 == 0 ? 2 : (a.M <= 64 ? 6 : 5));
+    switch (cfg) {
+        case 1: return launch_rect_cfg<KH, KW, 2, 2, 1, 2>(a, stream);
+        case 2: return launch_rect_cfg<KH, KW, 1, 4, 3, 1>(a, stream);
+        case 6: return launch_rect_cfg<KH, KW, 1, 4, 2, 1>(a, stream);
+        default: return launch_rect_cfg<KH, KW, 1, 4, 4, 1>(a, stream);
+    }
+}
+
+}  // namespace
+
+extern "C" long ssn_conv_x6_packed_floats_rect(int Cout, int Cin, int kh, int kw) {
+    return x6_packed_dwords_kk(Cout, Cin, kh * kw, 0);
+}
+
+// y = relu?(scale * conv(x, w) + shift), stride 1, taps kh x kw in {5x5, 1x7, 7x1, 1x3, 3x1}, per-axis padding.
+// w_packed from ssn_conv_x6_pack_weights_rect.  Other arguments as ssn_conv_x6_fwd.
+extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                                    int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
+                                    long y_img_stride, int kh, int kw, int pad_h, int pad_w, int relu, int x_guard_bytes,
+                                    int tile_cfg, hipStream_t stream) {
+    SSN_CHECK_ARG(x && w_packed && y, "conv x6 rect: null pointer");
+    SSN_CHECK_ARG(Ho == H + 2 * pad_h - kh + 1 && Wo == W + 2 * pad_w - kw + 1, "conv x6 rect: output %dx%d does not match", Ho, Wo);
+    X6Args a;
+    a.x = x;
+    a.ap = (const uint32_t*)w_packed;
+    a.y = y;
+    a.scale = scale;
+    a.shift = shift;
+    a.N = N;
+    a.C = Cin;
+    a.H = H;
+    a.W = W;
+    a.x_img_stride = x_img_stride;
+    a.M = Cout;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.y_img_stride = y_img_stride;
+    a.P = N * Ho * Wo;
+    a.pad_h = pad_h;
+    a.pad_w = pad_w;
+    a.relu = relu;
+    a.accumulate = 0;
+    a.mask_y = nullptr;
+    a.mask_scale = nullptr;
+    a.mask_img_stride = 0;
+    a.ngroups = (Cin + 15) / 16;
+    a.x_guard = x_guard_bytes;
+    a.trace = nullptr;
+    a.dbg = 0;
+    a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
+    a.div_w = make_fastdiv((uint32_t)Wo);
+    const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
+    const long ab = x6_packed_dwords_kk(Cout, Cin, kh * kw, 0) * 4;
+    const long yb = ((long)(N - 1) * y_img_stride + (long)Cout * Ho * Wo) * 4;
+    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31) && yb < (1l << 31) && (long)N * Ho * Wo < (1l << 31),
+                  "conv x6 rect: operand larger than 2 GiB (buffer addressing)");
+    a.x_bytes = (uint32_t)xb;
+    a.a_bytes = (uint32_t)ab;
+    a.y_bytes = (uint32_t)yb;
+    a.mask_bytes = 0;
+    if (kh == 5 && kw == 5) return launch_rect<5, 5>(a, tile_cfg, stream);
+    if (kh == 1 && kw == 7) return launch_rect<1, 7>(a, tile_cfg, stream);
+    if (kh == 7 && kw == 1) return launch_rect<7, 1>(a, tile_cfg, stream);
+    if (kh == 1 && kw == 3) return launch_rect<1, 3>(a, tile_cfg, stream);
+    if (kh == 3 && kw == 1) return launch_rect<3, 1>(a, tile_cfg, stream);
+    ssn_set_error("conv x6 rect: %dx%d taps have no kernel", kh, kw);
+    return SSN_ERR_ARG;
+}

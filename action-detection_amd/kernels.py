@@ -168,6 +168,26 @@ def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, til
              _stream(lib, w_packed))
 
 
+def pack_weights_rect(w):
+    """Split + pack one [cout, cin, kh, kw] forward weight for conv_x6_fwd_rect."""
+    lib = _check(w)
+    cout, cin, kh, kw = w.shape
+    out = torch.empty(int(lib.cdll.ssn_conv_x6_packed_floats_rect(cout, cin, kh, kw)), device=w.device,
+                      dtype=torch.float32)
+    lib.call("ssn_conv_x6_pack_weights_rect", _p(w.contiguous()), _p(out), cout, cin, kh, kw, _stream(lib, w))
+    return out
+
+
+def conv_x6_fwd_rect(x, w_packed, scale, shift, y, kh, kw, pad_h, pad_w, relu=True, tile_cfg=-1):
+    """Stride-1 forward convolution with kh x kw taps (5x5, 1x7, 7x1, 1x3, 3x1) on the bf16-split kernel."""
+    lib = _check(x, w_packed, scale, shift, y)
+    h, wd = x.hw
+    ho, wo = y.hw
+    lib.call("ssn_conv_x6_fwd_rect", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
+             x.img_stride, y.c, ho, wo, y.img_stride, kh, kw, pad_h, pad_w, int(relu), guard_bytes(x), tile_cfg,
+             _stream(lib, w_packed))
+
+
 def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
     """Stride-1 conv_dgrad on the bf16 matrix cores.  wt: pack_weights_multi([... mode 1], x6=True)."""
     lib = _check(dy, wt, dx, mask_y, mask_scale)

@@ -5,7 +5,7 @@ Same constructor, ``forward`` 7-tuple / test 2-tuple, ``prepare_test_fc``,
 ``get_optim_policies``, BN-freezing ``train()`` and ``state_dict`` keys as the reference, so it
 drops into the loops of ssn_train.py:205-253 and ssn_test.py:78-92.  Differences that are
 deliberate and documented in DESIGN.md:
-  * only the BNInception backbone family is built (resnet/vgg/InceptionV3 raise);
+  * BNInception is built for training and testing, InceptionV3 for testing (forward only); resnet/vgg raise;
   * the backbone is this repo's ``bninception.BNInception`` executor instead of ``model_zoo``;
   * ``bn_mode`` other than 'frozen' raises at forward time;
   * one host sync per forward (prop_type -> row indices) instead of the reference's three
@@ -17,6 +17,7 @@ from torch import nn
 
 from . import functional as FN
 from .bninception import BNInception
+from .inceptionv3 import InceptionV3
 from .ops.ssn_ops import Identity, StructuredTemporalPyramidPooling
 
 _dropout_calls = [0]
@@ -141,11 +142,22 @@ class SSN(torch.nn.Module):
                 self.input_mean = [128]
             elif self.modality == 'RGBDiff':
                 self.input_mean = self.input_mean * (1 + self.new_length)
-        elif ('resnet' in base_model or 'vgg' in base_model or base_model == 'InceptionV3'
-              or 'inception' in base_model):
+        elif base_model == 'InceptionV3':
+            # forward only (dense testing, BASELINE.json configs[4]); see inceptionv3.py
+            self.base_model = InceptionV3()
+            self.base_model.last_layer_name = 'top_cls_fc'
+            self.input_size = 299
+            self.input_mean = [104, 117, 128]
+            self.input_std = [1]
+
+            if self.modality == 'Flow':
+                self.input_mean = [128]
+            elif self.modality == 'RGBDiff':
+                self.input_mean = self.input_mean * (1 + self.new_length)
+        elif 'resnet' in base_model or 'vgg' in base_model or 'inception' in base_model:
             raise NotImplementedError(
-                "base model {} is not built: the MI355X hot path covers BNInception "
-                "(BASELINE.json configs 1-4)".format(base_model))
+                "base model {} is not built: the MI355X hot path covers BNInception (training and testing) and "
+                "InceptionV3 (testing)".format(base_model))
         else:
             raise ValueError('Unknown base model: {}'.format(base_model))
 

@@ -32,7 +32,7 @@ def init_backbone_synthetic(base_model, seed=1234):
             if isinstance(m, nn.Conv2d):
                 fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
                 w = rng.standard_normal(m.weight.shape).astype(np.float32) * np.float32(np.sqrt(2.0 / fan_in))
-                if name.startswith("conv1_"):
+                if name.startswith("conv1_") or name.startswith("conv_1a_"):   # the layer that sees 0..255 pixels
                     w = w / np.float32(PIXEL_STD)
                 m.weight.copy_(torch.from_numpy(w))
                 if m.bias is not None:

@@ -116,6 +116,16 @@ int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N,
                       int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
                       int dy_guard_bytes, int tile_cfg, hipStream_t stream);
 
+/* Rectangular taps (csrc/conv_x6_rect.hip): the forward convolutions of the Inception-v3 backbone the reference's
+ * tester runs on ActivityNet (ssn_models.py:133-139): kh x kw in {5x5, 1x7, 7x1, 1x3, 3x1}, stride 1, per-axis
+ * padding; same kernel, arguments and accuracy class as ssn_conv_x6_fwd.  Forward only (dense testing). */
+long ssn_conv_x6_packed_floats_rect(int Cout, int Cin, int kh, int kw);
+int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cout, int cin, int kh, int kw, hipStream_t stream);
+int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
+                         int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
+                         long y_img_stride, int kh, int kw, int pad_h, int pad_w, int relu, int x_guard_bytes,
+                         int tile_cfg, hipStream_t stream);
+
 /* x6 weight gradient (csrc/conv_wgrad_x6.hip): stride-1 same-size 1x1 / 3x3 convolutions with H*W % 4 == 0, both
  * operands split to bf16 on the fly, 16-byte loads along the pixel axis.  Same result contract as ssn_conv_wgrad
  * (deterministic split-K).  x_guard_bytes >= 256 is REQUIRED (the shifted taps read up to W+1 floats before x). */

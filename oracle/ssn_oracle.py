@@ -123,6 +123,122 @@ class OracleBNInception(nn.Module):
 # STPP (training) -- /root/reference/ops/ssn_ops.py:13-79
 # --------------------------------------------------------------------------------------
 
+class OracleInceptionV3(nn.Module):
+    """torch-CPU Inception-v3 (Szegedy et al. 2016: stem, 3 x block A at 35x35, grid reduction, 4 x block C at 17x17 with
+    factorised 7x7, grid reduction, 2 x block E at 8x8 with split 3x3), the backbone the reference's tester loads with
+    ``getattr(model_zoo, 'InceptionV3')()`` (/root/reference/ssn_models.py:133-139; last layer ``top_cls_fc``, 2048
+    inputs, 299x299).  Not in the reference tree: **unpinned against upstream**, like the BN-Inception above; written
+    block by block here, independently of the product's flat manifest (tests compare the two parameter for parameter).
+    Every conv has a bias and is followed by BatchNorm2d(eps=1e-5) + ReLU; average pools count the padding."""
+
+    def __init__(self, num_classes=1000, in_channels=3):
+        super().__init__()
+
+        def add(name, cin, cout, k, stride=1, pad=0):
+            setattr(self, name, nn.Conv2d(cin, cout, k, stride, pad, bias=True))
+            setattr(self, name + "_bn", nn.BatchNorm2d(cout, eps=1e-5))
+            return cout
+
+        add("conv_1a_3x3", in_channels, 32, 3, 2)
+        add("conv_2a_3x3", 32, 32, 3)
+        add("conv_2b_3x3", 32, 64, 3, 1, 1)
+        add("conv_3b_1x1", 64, 80, 1)
+        add("conv_4a_3x3", 80, 192, 3)
+        cin = 192
+        self.blocks_a = (("mixed_5b", 32), ("mixed_5c", 64), ("mixed_5d", 64))
+        for nm, pf in self.blocks_a:
+            p = nm + "_"
+            add(p + "1x1", cin, 64, 1)
+            add(p + "5x5_reduce", cin, 48, 1)
+            add(p + "5x5", 48, 64, 5, 1, 2)
+            add(p + "double_3x3_reduce", cin, 64, 1)
+            add(p + "double_3x3_1", 64, 96, 3, 1, 1)
+            add(p + "double_3x3_2", 96, 96, 3, 1, 1)
+            add(p + "pool_proj", cin, pf, 1)
+            cin = 64 + 64 + 96 + pf
+        add("mixed_6a_3x3", cin, 384, 3, 2)
+        add("mixed_6a_double_3x3_reduce", cin, 64, 1)
+        add("mixed_6a_double_3x3_1", 64, 96, 3, 1, 1)
+        add("mixed_6a_double_3x3_2", 96, 96, 3, 2)
+        cin = 384 + 96 + cin
+        self.blocks_c = (("mixed_6b", 128), ("mixed_6c", 160), ("mixed_6d", 160), ("mixed_6e", 192))
+        for nm, c7 in self.blocks_c:
+            p = nm + "_"
+            add(p + "1x1", cin, 192, 1)
+            add(p + "7x7_reduce", cin, c7, 1)
+            add(p + "1x7", c7, c7, (1, 7), 1, (0, 3))
+            add(p + "7x1", c7, 192, (7, 1), 1, (3, 0))
+            add(p + "double_7x7_reduce", cin, c7, 1)
+            add(p + "double_7x1_1", c7, c7, (7, 1), 1, (3, 0))
+            add(p + "double_1x7_1", c7, c7, (1, 7), 1, (0, 3))
+            add(p + "double_7x1_2", c7, c7, (7, 1), 1, (3, 0))
+            add(p + "double_1x7_2", c7, 192, (1, 7), 1, (0, 3))
+            add(p + "pool_proj", cin, 192, 1)
+            cin = 768
+        add("mixed_7a_3x3_reduce", cin, 192, 1)
+        add("mixed_7a_3x3", 192, 320, 3, 2)
+        add("mixed_7a_7x7x3_reduce", cin, 192, 1)
+        add("mixed_7a_7x7x3_1x7", 192, 192, (1, 7), 1, (0, 3))
+        add("mixed_7a_7x7x3_7x1", 192, 192, (7, 1), 1, (3, 0))
+        add("mixed_7a_7x7x3_3x3", 192, 192, 3, 2)
+        cin = 320 + 192 + cin
+        for nm in ("mixed_7b", "mixed_7c"):
+            p = nm + "_"
+            add(p + "1x1", cin, 320, 1)
+            add(p + "3x3_reduce", cin, 384, 1)
+            add(p + "3x3_1x3", 384, 384, (1, 3), 1, (0, 1))
+            add(p + "3x3_3x1", 384, 384, (3, 1), 1, (1, 0))
+            add(p + "double_3x3_reduce", cin, 448, 1)
+            add(p + "double_3x3_1", 448, 384, 3, 1, 1)
+            add(p + "double_3x3_1x3", 384, 384, (1, 3), 1, (0, 1))
+            add(p + "double_3x3_3x1", 384, 384, (3, 1), 1, (1, 0))
+            add(p + "pool_proj", cin, 192, 1)
+            cin = 2048
+        self.top_cls_fc = nn.Linear(2048, num_classes)
+
+    def _cbr(self, name, x):
+        return F.relu(getattr(self, name + "_bn")(getattr(self, name)(x)))
+
+    def features(self, x):
+        c = self._cbr
+        x = c("conv_2b_3x3", c("conv_2a_3x3", c("conv_1a_3x3", x)))
+        x = F.max_pool2d(x, 3, 2)
+        x = c("conv_4a_3x3", c("conv_3b_1x1", x))
+        x = F.max_pool2d(x, 3, 2)
+        for nm, _ in self.blocks_a:
+            p = nm + "_"
+            x = torch.cat([c(p + "1x1", x), c(p + "5x5", c(p + "5x5_reduce", x)),
+                           c(p + "double_3x3_2", c(p + "double_3x3_1", c(p + "double_3x3_reduce", x))),
+                           c(p + "pool_proj", F.avg_pool2d(x, 3, 1, 1, count_include_pad=True))], 1)
+        p = "mixed_6a_"
+        x = torch.cat([c(p + "3x3", x), c(p + "double_3x3_2", c(p + "double_3x3_1", c(p + "double_3x3_reduce", x))),
+                       F.max_pool2d(x, 3, 2)], 1)
+        for nm, _ in self.blocks_c:
+            p = nm + "_"
+            b7 = c(p + "7x1", c(p + "1x7", c(p + "7x7_reduce", x)))
+            bd = c(p + "double_7x7_reduce", x)
+            for s in ("double_7x1_1", "double_1x7_1", "double_7x1_2", "double_1x7_2"):
+                bd = c(p + s, bd)
+            x = torch.cat([c(p + "1x1", x), b7, bd,
+                           c(p + "pool_proj", F.avg_pool2d(x, 3, 1, 1, count_include_pad=True))], 1)
+        p = "mixed_7a_"
+        b7 = c(p + "7x7x3_reduce", x)
+        for s in ("7x7x3_1x7", "7x7x3_7x1", "7x7x3_3x3"):
+            b7 = c(p + s, b7)
+        x = torch.cat([c(p + "3x3", c(p + "3x3_reduce", x)), b7, F.max_pool2d(x, 3, 2)], 1)
+        for nm in ("mixed_7b", "mixed_7c"):
+            p = nm + "_"
+            b3 = c(p + "3x3_reduce", x)
+            bd = c(p + "double_3x3_1", c(p + "double_3x3_reduce", x))
+            x = torch.cat([c(p + "1x1", x), c(p + "3x3_1x3", b3), c(p + "3x3_3x1", b3),
+                           c(p + "double_3x3_1x3", bd), c(p + "double_3x3_3x1", bd),
+                           c(p + "pool_proj", F.avg_pool2d(x, 3, 1, 1, count_include_pad=True))], 1)
+        return F.adaptive_avg_pool2d(x, 1).flatten(1)
+
+    def forward(self, x):
+        return self.top_cls_fc(self.features(x))
+
+
 def parse_stage_config(cfg):
     """/root/reference/ops/ssn_ops.py:13-19."""
     if isinstance(cfg, int):
@@ -332,11 +448,11 @@ def activity_loss(logits, target):
 # --------------------------------------------------------------------------------------
 
 class OracleSSN(nn.Module):
-    """Restatement of the reference SSN for BNInception (ssn_models.py:10-300)."""
+    """Restatement of the reference SSN for BNInception / InceptionV3 (ssn_models.py:10-300)."""
 
     def __init__(self, num_class, starting_segment=2, course_segment=5, ending_segment=2,
                  modality="RGB", new_length=None, dropout=0.8, no_regression=False,
-                 test_mode=False, stpp_cfg=(1, (1, 2), 1), bn_mode="frozen"):
+                 test_mode=False, stpp_cfg=(1, (1, 2), 1), bn_mode="frozen", base_model="BNInception"):
         super().__init__()
         self.modality = modality
         self.starting_segment, self.course_segment, self.ending_segment = (
@@ -350,16 +466,21 @@ class OracleSSN(nn.Module):
         self.num_class = num_class
         # ssn_models.py:121-131 + :318-343 (flow: first conv gets 2*new_length input channels)
         cin = 3 if modality == "RGB" else 2 * self.new_length
-        self.base_model = OracleBNInception(in_channels=3)
-        feat = self.base_model.fc.in_features
+        if base_model == "InceptionV3":     # ssn_models.py:133-139
+            self.base_model = OracleInceptionV3(in_channels=3)
+            self.last_layer_name, first = "top_cls_fc", "conv_1a_3x3"
+        else:
+            self.base_model = OracleBNInception(in_channels=3)
+            self.last_layer_name, first = "fc", "conv1_7x7_s2"
+        feat = getattr(self.base_model, self.last_layer_name).in_features
         # ssn_models.py:69-74
-        self.base_model.fc = nn.Identity() if dropout == 0 else nn.Dropout(p=dropout)
+        setattr(self.base_model, self.last_layer_name, nn.Identity() if dropout == 0 else nn.Dropout(p=dropout))
         if modality == "Flow":
-            old = self.base_model.conv1_7x7_s2
-            new = nn.Conv2d(cin, 64, 7, 2, 3, bias=True)
+            old = getattr(self.base_model, first)
+            new = nn.Conv2d(cin, old.out_channels, old.kernel_size, old.stride, old.padding, bias=True)
             new.weight.data = old.weight.data.mean(dim=1, keepdim=True).expand(-1, cin, -1, -1).contiguous()
             new.bias.data = old.bias.data
-            self.base_model.conv1_7x7_s2 = new
+            setattr(self.base_model, first, new)
         mult = sum(parse_stage_config(c)[1] for c in stpp_cfg)
         self.feat_multiplier = mult
         # ssn_models.py:76-91
@@ -392,7 +513,7 @@ class OracleSSN(nn.Module):
     def forward(self, input, aug_scaling=None, target=None, reg_target=None, prop_type=None):
         sample_len = (3 if self.modality == "RGB" else 2) * self.new_length
         x = input.reshape((-1, sample_len) + tuple(input.shape[-2:]))
-        base_out = self.base_model.fc(self.base_model.features(x))
+        base_out = getattr(self.base_model, self.last_layer_name)(self.base_model.features(x))
         if self.test_mode:
             # ssn_models.py:291-300
             return self.test_fc(base_out), base_out

@@ -461,3 +461,28 @@ def test_conv_wgrad_x6(backend):
         xw[:, 8:].copy_(backend.put(x))
         K.conv_wgrad_x6(K.full(backend.put(gy)), K.ChanSlice(xw, 8, cin), dw, None, k, p, ws, cfg)
         assert rel_err(dw, w.grad) < 5e-5, ("wgrad x6 slice", n, cin, h, cout, k, cfg)
+
+
+def test_conv_x6_rect_fwd(backend):
+    """Rectangular taps of the Inception-v3 layers (5x5, 1x7, 7x1, 1x3, 3x1) on the x6 kernel vs fp64 torch, with and
+    without the 16-byte-load path (planes that are / are not a multiple of 4 pixels), channel tails, every tile."""
+    g = torch.Generator().manual_seed(41)
+    cases = ([(3, 48, 16, 64, 5, 5, 2, 2, -1), (2, 128, 17, 128, 1, 7, 0, 3, 2), (2, 128, 17, 192, 7, 1, 3, 0, 5),
+              (2, 96, 8, 100, 1, 3, 0, 1, 6), (2, 40, 8, 96, 3, 1, 1, 0, 1), (2, 32, 12, 64, 1, 7, 0, 3, -1),
+              (1, 64, 35, 96, 5, 5, 2, 2, 2)] if backend.is_gpu else
+             [(1, 8, 6, 40, 5, 5, 2, 2, -1), (1, 20, 5, 33, 1, 7, 0, 3, 2), (1, 16, 6, 64, 7, 1, 3, 0, 6),
+              (1, 8, 4, 32, 1, 3, 0, 1, 1), (1, 8, 4, 70, 3, 1, 1, 0, 5)])
+    for (n, cin, h, cout, kh, kw, ph, pw, tile) in cases:
+        x = torch.randn(n, cin, h, h, generator=g)
+        w = torch.randn(cout, cin, kh, kw, generator=g) * 0.1
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g) * 0.1
+        ref = F.relu(F.conv2d(x.double(), w.double(), None, 1, (ph, pw)) * scale.double().view(1, -1, 1, 1)
+                     + shift.double().view(1, -1, 1, 1))
+        dev = backend.put(torch.zeros(1)).device
+        xd = K.guarded_empty(x.shape, dev)
+        xd.copy_(x)
+        wp = K.pack_weights_rect(backend.put(w))
+        y = backend.put(torch.empty(n, cout, h, h))
+        K.conv_x6_fwd_rect(K.full(xd), wp, backend.put(scale), backend.put(shift), K.full(y), kh, kw, ph, pw, True, tile)
+        assert rel_err(y, ref) < 2e-6, ("x6 rect", n, cin, h, cout, kh, kw, tile)
