@@ -41,6 +41,8 @@ _SIGS = {
     "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiip",
     "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiip",
     "ssn_conv_x6_fwd_rect": "pppppiiiiliiiliiiiiiip",
+    "ssn_conv_x6_pack_dgrad_s2": "ppiip",
+    "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiip",
     "ssn_conv_x6_pack_weights_rect": "ppiiiip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
     "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
@@ -73,7 +75,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
-                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
+                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes",
                                 "ssn_conv_debug_flags",
                                 "ssn_conv_dgrad_layout"])
@@ -95,6 +97,8 @@ class SsnLibrary:
         self.cdll.ssn_conv_packed_floats.argtypes = [ctypes.c_int] * 4
         self.cdll.ssn_conv_x6_packed_floats.restype = ctypes.c_long
         self.cdll.ssn_conv_x6_packed_floats.argtypes = [ctypes.c_int] * 4
+        self.cdll.ssn_conv_x6_dgrad_s2_packed_floats.restype = ctypes.c_long
+        self.cdll.ssn_conv_x6_dgrad_s2_packed_floats.argtypes = [ctypes.c_int] * 2
         self.cdll.ssn_conv_x6_packed_floats_rect.restype = ctypes.c_long
         self.cdll.ssn_conv_x6_packed_floats_rect.argtypes = [ctypes.c_int] * 4
         self.cdll.ssn_conv_wgrad_x6_workspace_bytes.restype = ctypes.c_long

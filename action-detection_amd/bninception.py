@@ -419,9 +419,15 @@ class BNInception(nn.Module):
         dg_x6 = {op["lids"][0]: (self.conv_precision == "bf16x6" and op["k"] in (1, 3) and op["s"] == 1
                                  and x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1]))
                  for op in dg_ops}
+        # 3x3 / stride-2 layers: four parity-class stride-1 launches on the x6 kernel (no tap that does not contribute)
+        dg_s2 = {op["lids"][0]: (self.conv_precision == "bf16x6" and dg_layout[op["lids"][0]] == 2 and len(op["lids"]) == 1)
+                 for op in dg_ops}
         packed_dg = {}
+        for op in dg_ops:
+            if dg_s2[op["lids"][0]]:
+                packed_dg[op["lids"][0]] = K.pack_dgrad_s2(getattr(self, op["lids"][0]).weight.detach())
         for x6 in (False, True):
-            ops = [op for op in dg_ops if dg_x6[op["lids"][0]] == x6]
+            ops = [op for op in dg_ops if dg_x6[op["lids"][0]] == x6 and not dg_s2[op["lids"][0]]]
             packed_dg.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
                 [([getattr(self, lid).weight.detach() for lid in op["lids"]], 1 if x6 else dg_layout[op["lids"][0]])
                  for op in ops], x6=x6)))
@@ -517,7 +523,12 @@ class BNInception(nn.Module):
                     acc_flag = key in inited
                     my, ms = mask_args(idx, op, cin)
                     dx = ChanSlice(gbuf(op["src"]), op["src_c0"], cin)
-                    if dg_x6[lids[0]]:
+                    if dg_s2[lids[0]]:
+                        self._timed("conv_dgrad_x6", lids[0], flops,
+                                    lambda: K.conv_x6_dgrad_s2(g, wt, dx, acc_flag,
+                                                               tuned_tile("dgrad6s2", n, cin, cout, k, s, hin),
+                                                               mask_y=my, mask_scale=ms))
+                    elif dg_x6[lids[0]]:
                         self._timed("conv_dgrad_x6", lids[0], flops,
                                     lambda: K.conv_x6_dgrad(g, wt, dx, k, p, acc_flag,
                                                             tuned_tile("dgrad6", n, cin, cout, k, s, hin),

@@ -47,6 +47,8 @@ struct X6PackTable {
     const float* w1[XP_MAX];
     uint32_t* out[XP_MAX];
     int cout[XP_MAX], cin[XP_MAX], kk[XP_MAX], mode[XP_MAX], split[XP_MAX];   // kk = taps per channel (kh * kw)
+    int srckk[XP_MAX];          // taps per channel of the SOURCE weight (== kk unless a tap subset is packed)
+    unsigned tapmap[XP_MAX];    // srckk != kk: nibble t = source tap of packed tap t
     int blk0[XP_MAX + 1];
     int count;
 };
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
                 const int co = mode ? c : m, ci = mode ? m : c;
                 const float* src = co < t.split[ti] ? t.w0[ti] : t.w1[ti];
                 const int cor = co < t.split[ti] ? co : co - t.split[ti];
-                x = src[((long)cor * Cin + ci) * KK + tap];
+                const int stap = t.srckk[ti] == KK ? tap : (int)((t.tapmap[ti] >> (4 * tap)) & 15u);
+                x = src[((long)cor * Cin + ci) * t.srckk[ti] + stap];
             }
             v[e] = x;
         }
@@ -187,6 +190,7 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
     }
     a.dbg = g_x6_dbg;
     a.trace = g_x6_trace;
+    a.sub_a = a.sub_b = a.sub_W = a.sub_HW = 0;
     a.x_bytes = (uint32_t)xb;
     a.a_bytes = (uint32_t)ab;
     const long yb = ((long)(N - 1) * ys + (long)M * Ho * Wo) * 4;
@@ -232,6 +236,8 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
             t.cout[i] = cout[j];
             t.cin[i] = cin[j];
             t.kk[i] = ksize[j] * ksize[j];
+            t.srckk[i] = t.kk[i];
+            t.tapmap[i] = 0;
             t.mode[i] = mode[j];
             t.split[i] = split[j];
             t.blk0[i] = blocks;
@@ -258,6 +264,8 @@ extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cou
     t.cout[0] = cout;
     t.cin[0] = cin;
     t.kk[0] = kh * kw;
+    t.srckk[0] = kh * kw;
+    t.tapmap[0] = 0;
     t.mode[0] = 0;
     t.split[0] = cout;
     t.blk0[0] = 0;
@@ -265,6 +273,45 @@ extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cou
     t.blk0[1] = (int)((triples + XP_CHUNK - 1) / XP_CHUNK);
     hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)t.blk0[1]), dim3(256), 0, stream, t);
     SSN_CHECK_LAUNCH("conv_x6_pack_weights_rect");
+    return SSN_OK;
+}
+
+// dgrad operand of a 3x3 / stride-2 / pad-1 convolution, one section per parity class (a, b) = (hi & 1, wi & 1) of
+// the input pixel, class = 2a + b, sections back to back (ssn_conv_x6_dgrad_s2_packed_floats): class (a, b) only
+// receives the taps r = a + 1 (mod 2), s = b + 1 (mod 2), i.e. a (1 + a) x (1 + b) stride-1 problem over dy with
+//   A[m = ci][k = co][tap (dr, ds)] = w[co][ci][a ? 2 - 2 dr : 1][b ? 2 - 2 ds : 1].
+extern "C" int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, int cin, hipStream_t stream) {
+    SSN_CHECK_ARG(w && out && cout > 0 && cin > 0, "conv x6 pack dgrad s2: bad arguments");
+    X6PackTable t;
+    t.count = 4;
+    int blocks = 0;
+    long off = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int a = cls >> 1, b = cls & 1, kh = 1 + a, kw = 1 + b;
+        unsigned map = 0;
+        for (int dr = 0; dr < kh; ++dr)
+            for (int ds = 0; ds < kw; ++ds) {
+                const int r = a ? 2 - 2 * dr : 1, sx = b ? 2 - 2 * ds : 1;
+                map |= (unsigned)(r * 3 + sx) << (4 * (dr * kw + ds));
+            }
+        t.w0[cls] = w;
+        t.w1[cls] = nullptr;
+        t.out[cls] = (uint32_t*)out + off;
+        t.cout[cls] = cout;
+        t.cin[cls] = cin;
+        t.kk[cls] = kh * kw;
+        t.srckk[cls] = 9;
+        t.tapmap[cls] = map;
+        t.mode[cls] = 1;
+        t.split[cls] = cout;
+        t.blk0[cls] = blocks;
+        const long dwords = x6_packed_dwords_kk(cout, cin, kh * kw, 1);
+        blocks += (int)((dwords / APITCH * 8 + XP_CHUNK - 1) / XP_CHUNK);
+        off += dwords;
+    }
+    t.blk0[4] = blocks;
+    hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    SSN_CHECK_LAUNCH("conv_x6_pack_dgrad_s2");
     return SSN_OK;
 }
 

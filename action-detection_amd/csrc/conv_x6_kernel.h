@@ -36,6 +36,10 @@ struct X6Args {
     int n_ptiles, n_mtiles, ngroups;   // ngroups = ceil(C / 16)
     uint32_t x_bytes, a_bytes, y_bytes, mask_bytes;
     int x_guard;   // readable bytes in front of x (>= 256 enables the 16-byte activation loads)
+    // sub-sampled output (stride-2 dgrad as four stride-1 problems, one per parity class of the input pixel): the
+    // enumerated pixel (u, v) is stored at (2u + sub_a, 2v + sub_b) of planes sub_W wide with sub_HW elements.
+    // sub_HW == 0: dense output.
+    int sub_a, sub_b, sub_W, sub_HW;
     unsigned long long* trace;   // tooling only: per-block phase timestamps (tools/trace_x6.py), normally null
     int dbg;      // tooling only (tools/ablate_x6.py)
     FastDiv div_hw, div_w, div_mt;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
     e.mask_y = p.mask_y;
     e.y_bytes = p.y_bytes;
     e.mask_bytes = p.mask_bytes;
-    e.howo4 = (uint32_t)(p.Ho * p.Wo) * 4u;
+    e.howo4 = (uint32_t)(p.sub_HW ? p.sub_HW : p.Ho * p.Wo) * 4u;
     e.M = p.M;
     e.relu = p.relu;
     e.accumulate = p.accumulate;
@@ -493,6 +497,11 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
         const int pp = p0 + grp * BNG + (wn * TN + j) * 32 + li;
         uint32_t n, hw;
         fd_divmod((uint32_t)(pp < p.P ? pp : 0), p.div_hw, n, hw);
+        if (p.sub_HW) {
+            uint32_t u, v;
+            fd_divmod(hw, p.div_w, u, v);
+            hw = (2u * u + (uint32_t)p.sub_a) * (uint32_t)p.sub_W + 2u * v + (uint32_t)p.sub_b;
+        }
         const uint32_t row0 = (uint32_t)(m0 + 4 * lh) * e.howo4 + hw * 4u;
         yoff[j] = pp < p.P ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : EPI_OOB;
         moff[j] = pp < p.P ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : EPI_OOB;

@@ -34,12 +34,18 @@ int launch_rect_cfg(X6Args& a, hipStream_t stream) {
     return SSN_OK;
 }
 
-// tiles (rows x pixels), ids as in conv_x6.hip: 1 64x128, 2 96x128 (1x4 waves), 5 128x128 (1x4 waves), 6 64x128 (1x4 waves)
+// tiles (rows x pixels), ids as in conv_x6.hip: 1 64x128, 3 64x64, 2 96x128 (1x4 waves), 5 128x128 (1x4 waves), 6 64x128 (1x4 waves)
 template <int KH, int KW>
 int launch_rect(X6Args& a, int cfg, hipStream_t stream) {
-    if (cfg < 0) cfg = (a.M % 128 == 0 || a.M > 256) ? 5 : (a.M % 96 == 0 ? 2 : (a.M <= 64 ? 6 : 5));
+    if (cfg < 0) {
+        cfg = (a.M % 128 == 0 || a.M > 256) ? 5 : (a.M % 96 == 0 ? 2 : (a.M <= 64 ? 6 : 5));
+        // a small problem does not fill the 512 workgroup slots with 128-pixel tiles: take 64 x 64 ones
+        const long wg = ((a.P + 127) / 128) * ((a.M + 127) / 128);
+        if (wg < 384) cfg = 3;
+    }
     switch (cfg) {
         case 1: return launch_rect_cfg<KH, KW, 2, 2, 1, 2>(a, stream);
+        case 3: return launch_rect_cfg<KH, KW, 2, 2, 1, 1>(a, stream);
         case 2: return launch_rect_cfg<KH, KW, 1, 4, 3, 1>(a, stream);
         case 6: return launch_rect_cfg<KH, KW, 1, 4, 2, 1>(a, stream);
         default: return launch_rect_cfg<KH, KW, 1, 4, 4, 1>(a, stream);
@@ -47,6 +53,81 @@ int launch_rect(X6Args& a, int cfg, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" long ssn_conv_x6_dgrad_s2_packed_floats(int Cout, int Cin) {
+    long tot = 0;
+    for (int cls = 0; cls < 4; ++cls) tot += x6_packed_dwords_kk(Cout, Cin, (1 + (cls >> 1)) * (1 + (cls & 1)), 1);
+    return tot;
+}
+
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution (even H, W) on the bf16-split kernel: four stride-1 launches,
+// one per parity class of the input pixel (see ssn_conv_x6_pack_dgrad_s2), each a (1 + a) x (1 + b)-tap gather over
+// dy whose results are stored at the class's pixels of dx.  No tap is multiplied that does not contribute (the
+// exact-f32 kernel of conv_igemm.hip gets there with a parity-ordered pixel enumeration; this is the same idea on
+// the 2.65x faster matrix path).  accumulate / mask_y / mask_scale as ssn_conv_x6_dgrad.
+extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
+                                    long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int accumulate,
+                                    const float* mask_y, long mask_img_stride, const float* mask_scale,
+                                    int dy_guard_bytes, int tile_cfg, hipStream_t stream) {
+    SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad s2: null pointer");
+    SSN_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2,
+                  "conv x6 dgrad s2: needs a 3x3 / stride-2 / pad-1 convolution with even input size (%dx%d -> %dx%d)", H, W, Ho, Wo);
+    long off = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ca = cls >> 1, cb = cls & 1, kh = 1 + ca, kw = 1 + cb;
+        X6Args a;
+        a.x = dy;
+        a.ap = (const uint32_t*)wt_packed + off;
+        a.y = dx;
+        a.scale = nullptr;
+        a.shift = nullptr;
+        a.N = N;
+        a.C = Cout;
+        a.H = Ho;
+        a.W = Wo;
+        a.x_img_stride = dy_img_stride;
+        a.M = Cin;
+        a.Ho = Ho;          // enumerated grid = the class's pixels (u, v), same size as dy
+        a.Wo = Wo;
+        a.y_img_stride = dx_img_stride;
+        a.P = N * Ho * Wo;
+        a.pad_h = 0;
+        a.pad_w = 0;
+        a.relu = 0;
+        a.accumulate = accumulate;
+        a.mask_y = mask_scale ? mask_y : nullptr;
+        a.mask_scale = mask_y ? mask_scale : nullptr;
+        a.mask_img_stride = mask_img_stride;
+        a.ngroups = (Cout + 15) / 16;
+        a.x_guard = dy_guard_bytes;
+        a.trace = nullptr;
+        a.dbg = 0;
+        a.sub_a = ca;
+        a.sub_b = cb;
+        a.sub_W = W;
+        a.sub_HW = H * W;
+        a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
+        a.div_w = make_fastdiv((uint32_t)Wo);
+        const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4;
+        const long ab = x6_packed_dwords_kk(Cout, Cin, kh * kw, 1) * 4;
+        const long yb = ((long)(N - 1) * dx_img_stride + (long)Cin * H * W) * 4;
+        const long mb = a.mask_y ? ((long)(N - 1) * mask_img_stride + (long)Cin * H * W) * 4 : 0;
+        SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31) && yb < (1l << 31) && mb < (1l << 31),
+                      "conv x6 dgrad s2: operand larger than 2 GiB (buffer addressing)");
+        a.x_bytes = (uint32_t)xb;
+        a.a_bytes = (uint32_t)ab;
+        a.y_bytes = (uint32_t)yb;
+        a.mask_bytes = (uint32_t)mb;
+        int rc;
+        if (cls == 0) rc = launch_rect<1, 1>(a, tile_cfg, stream);
+        else if (cls == 1) rc = launch_rect<1, 2>(a, tile_cfg, stream);
+        else if (cls == 2) rc = launch_rect<2, 1>(a, tile_cfg, stream);
+        else rc = launch_rect<2, 2>(a, tile_cfg, stream);
+        if (rc != SSN_OK) return rc;
+        off += ab / 4;
+    }
+    return SSN_OK;
+}
 
 extern "C" long ssn_conv_x6_packed_floats_rect(int Cout, int Cin, int kh, int kw) {
     return x6_packed_dwords_kk(Cout, Cin, kh * kw, 0);
@@ -87,6 +168,7 @@ extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const
     a.x_guard = x_guard_bytes;
     a.trace = nullptr;
     a.dbg = 0;
+    a.sub_a = a.sub_b = a.sub_W = a.sub_HW = 0;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
     const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;

@@ -200,6 +200,26 @@ def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, 
              _stream(lib, wt))
 
 
+def pack_dgrad_s2(w):
+    """dgrad operand of a 3x3 / stride-2 / pad-1 conv for conv_x6_dgrad_s2 (four parity-class sections)."""
+    lib = _check(w)
+    cout, cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3)
+    out = torch.empty(int(lib.cdll.ssn_conv_x6_dgrad_s2_packed_floats(cout, cin)), device=w.device, dtype=torch.float32)
+    lib.call("ssn_conv_x6_pack_dgrad_s2", _p(w.contiguous()), _p(out), cout, cin, _stream(lib, w))
+    return out
+
+
+def conv_x6_dgrad_s2(dy, wt, dx, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
+    """dgrad of a 3x3 / stride-2 / pad-1 conv (even input size) on the bf16 matrix cores.  wt: pack_dgrad_s2(w)."""
+    lib = _check(dy, wt, dx, mask_y, mask_scale)
+    ho, wo = dy.hw
+    h, w = dx.hw
+    lib.call("ssn_conv_x6_dgrad_s2", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
+             dx.img_stride, int(accumulate), _p(mask_y), mask_y.img_stride if mask_y is not None else 0,
+             _p(mask_scale), guard_bytes(dy), tile_cfg, _stream(lib, wt))
+
+
 def relu_bn_bwd(dy, y, scale):
     """In place: dy <- dy * (y > 0) * scale[c].  dy, y: ChanSlice with equal channel counts."""
     lib = _check(dy, y, scale)

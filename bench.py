@@ -187,7 +187,7 @@ def main():
                    "global_batch_proposals": 8 * v * world, "images_per_gpu": 72 * v,
                    "parallelism": "dp%d" % world, "launch": launch,
                    "conv_precision": ("fp32 in/out; 1x1/3x3 multiplies = 6 bf16-MFMA products of exact 3-way bf16 operand "
-                                      "splits (fp32-class error), 7x7 and stride-2 dgrad on the exact-f32 MFMA"
+                                      "splits (fp32-class error), 7x7 stem on the exact-f32 MFMA"
                                       if args.precision == "bf16x6" else "exact-f32 MFMA everywhere")},
         "final_loss": float(loss.item()),
     }
@@ -213,7 +213,7 @@ def main():
             x6_fl, x6_ms, x6_n = agg(("conv_fwd_x6", "conv_dgrad_x6"))
             if x6_n:
                 dom_name = ("conv_x6_kernel (implicit GEMM, fp32 operands split into 3 bf16 terms, 6 "
-                            "v_mfma_f32_32x32x16_bf16 per k16 step; fwd + stride-1 dgrad launches)")
+                            "v_mfma_f32_32x32x16_bf16 per k16 step; fwd + dgrad launches)")
                 dom_fl, dom_ms, dom_n, dom_peak = x6_fl, x6_ms, x6_n, X6_PEAK_TFLOPS
                 pmc_keys = ("conv_x6_kernel_fwd", "conv_x6_kernel_dgrad")
             else:   # --precision f32: the exact-f32 MFMA kernel carries everything

@@ -126,6 +126,17 @@ int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const float* sca
                          long y_img_stride, int kh, int kw, int pad_h, int pad_w, int relu, int x_guard_bytes,
                          int tile_cfg, hipStream_t stream);
 
+/* Data gradient of the 3x3 / stride-2 / pad-1 layers (even input size) on the x6 kernel: four stride-1 launches, one
+ * per parity class of the input pixel, each multiplying only the taps that reach that class (cuDNN dgrad behind
+ * loss.backward(), ssn_train.py:236).  wt_packed: ssn_conv_x6_pack_dgrad_s2 (ssn_conv_x6_dgrad_s2_packed_floats
+ * floats) of the torch-layout weight [Cout][Cin][3][3].  Other arguments as ssn_conv_x6_dgrad. */
+long ssn_conv_x6_dgrad_s2_packed_floats(int Cout, int Cin);
+int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, int cin, hipStream_t stream);
+int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
+                         long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int accumulate,
+                         const float* mask_y, long mask_img_stride, const float* mask_scale, int dy_guard_bytes,
+                         int tile_cfg, hipStream_t stream);
+
 /* x6 weight gradient (csrc/conv_wgrad_x6.hip): stride-1 same-size 1x1 / 3x3 convolutions with H*W % 4 == 0, both
  * operands split to bf16 on the fly, 16-byte loads along the pixel axis.  Same result contract as ssn_conv_wgrad
  * (deterministic split-K).  x_guard_bytes >= 256 is REQUIRED (the shifted taps read up to W+1 floats before x). */

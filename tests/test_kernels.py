@@ -486,3 +486,37 @@ def test_conv_x6_rect_fwd(backend):
         y = backend.put(torch.empty(n, cout, h, h))
         K.conv_x6_fwd_rect(K.full(xd), wp, backend.put(scale), backend.put(shift), K.full(y), kh, kw, ph, pw, True, tile)
         assert rel_err(y, ref) < 2e-6, ("x6 rect", n, cin, h, cout, kh, kw, tile)
+
+
+def test_conv_x6_dgrad_s2(backend):
+    """Stride-2 dgrad as four parity-class stride-1 problems on the x6 kernel vs torch autograd in fp64: plain,
+    accumulating, with the fused ReLU/BN backward, into a channel slice; 16-byte-load and narrow paths."""
+    g = torch.Generator().manual_seed(43)
+    cases = ([(3, 128, 28, 160, -1), (2, 96, 28, 96, 2), (2, 128, 14, 192, 3), (2, 256, 14, 256, 5), (1, 40, 12, 70, 6),
+              (2, 24, 6, 33, 1)] if backend.is_gpu else [(1, 8, 8, 40, -1), (2, 20, 4, 33, 3), (1, 16, 6, 20, 2)])
+    for (n, cin, h, cout, tile) in cases:
+        x = torch.randn(n, cin, h, h, generator=g).double().requires_grad_()
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1)
+        y = F.conv2d(x, w.double(), None, 2, 1)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy.double())
+        dev = backend.put(torch.zeros(1)).device
+        gd = K.guarded_empty(gy.shape, dev)
+        gd.copy_(gy)
+        wt = K.pack_dgrad_s2(backend.put(w))
+        dx = backend.put(torch.full((n, cin, h, h), 7.0))
+        K.conv_x6_dgrad_s2(K.full(gd), wt, K.full(dx), False, tile)
+        assert rel_err(dx, x.grad) < 2e-6, ("dgrad s2", n, cin, h, cout, tile)
+        # accumulate + last-writer mask, into a slice of a wider tensor
+        prev = torch.randn(n, cin + 5, h, h, generator=g)
+        act = torch.randn(n, cin + 5, h, h, generator=g)
+        msc = torch.rand(cin, generator=g) + 0.5
+        msc[::3] = -msc[::3]                                     # channels that are not ReLU outputs
+        wide = backend.put(prev.clone())
+        K.conv_x6_dgrad_s2(K.full(gd), wt, K.ChanSlice(wide, 5, cin), True, tile,
+                           mask_y=K.ChanSlice(backend.put(act), 5, cin), mask_scale=backend.put(msc))
+        tot = prev[:, 5:].double() + x.grad
+        m = msc.view(1, -1, 1, 1).double()
+        ref = torch.where(m < 0, tot * -m, torch.where(act[:, 5:].double() > 0, tot * m, torch.zeros_like(tot)))
+        assert rel_err(wide[:, 5:], ref) < 2e-6, ("dgrad s2 acc+mask", n, cin, h, cout, tile)
+        assert torch.equal(wide[:, :5].cpu(), prev[:, :5])
