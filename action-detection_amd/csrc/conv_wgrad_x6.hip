@@ -37,7 +37,8 @@ struct WgX6Args {
     long g_img_stride;
     int K;    // Cin*KS*KS
     int ldp;  // K + 1 (last column = bias gradient)
-    int P;    // N*H*W
+    int P;    // N * HWp pixel slots
+    int HWp;  // pixel slots per image: H*W rounded up to a multiple of 4 (PAD: the slots past H*W hold zeros)
     int pad;
     int splits, chunks_per_split;  // chunk = 16 pixels
     int n_mtiles, n_ktiles;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void wg_split4(const float (&v)[4], uint32_t (&pl)[3]
     }
 }
 
-template <int KS, int WM, int WN, int TM, int TN>
+template <int KS, bool PAD, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
     struct Staged {
         u32x4 a[NAR], b[NBR];
         uint32_t ho, wo;   // first pixel of the group
+        uint32_t hw;
     };
     const int total_chunks = (p.P + CP - 1) / CP;
     const int c_begin = (int)z * p.chunks_per_split;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
         uint32_t n, hw;
         fd_divmod((uint32_t)(valid ? pp : 0), p.div_hw, n, hw);
         fd_divmod(hw, p.div_w, s.ho, s.wo);
+        s.hw = hw;
         const uint32_t abase = (uint32_t)((long)n * p.g_img_stride * 4) + hw * 4u;
         const uint32_t bbase = (uint32_t)((long)n * p.x_img_stride * 4) + hw * 4u;
 #pragma unroll
@@ -204,6 +207,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
                                 ((unsigned)(ww[2 * half + e] + b_dw[i]) < (unsigned)p.W);
                 v[e] = ok ? v[e] : 0.f;
             }
+            // planes that are not a multiple of 4 pixels: the last group of an image runs past the plane
+            if (PAD) v[e] = (s.hw + (uint32_t)(2 * half + e) < (uint32_t)HW) ? v[e] : 0.f;
         }
         if (is_a && do_bias) rowsum[i] += v[0] + v[1];
         const float r0 = wg_residual(v[0]), r1 = wg_residual(v[1]);
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
 
 template <int KS, int WM, int WN, int TM, int TN>
 int launch_wgx6(WgX6Args& a, hipStream_t stream) {
+    const bool pad = a.HWp != a.H * a.W;
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     a.n_mtiles = (a.M + BM - 1) / BM;
@@ -318,7 +324,10 @@ int launch_wgx6(WgX6Args& a, hipStream_t stream) {
     const unsigned tiles = (unsigned)a.n_mtiles * (unsigned)a.n_ktiles;
     a.div_tiles = make_fastdiv(tiles);
     a.div_kt = make_fastdiv((uint32_t)a.n_ktiles);
-    hipLaunchKernelGGL((wgrad_x6_kernel<KS, WM, WN, TM, TN>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
+    if (pad)
+        hipLaunchKernelGGL((wgrad_x6_kernel<KS, true, WM, WN, TM, TN>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((wgrad_x6_kernel<KS, false, WM, WN, TM, TN>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("conv_wgrad_x6");
     return SSN_OK;
 }
@@ -384,18 +393,18 @@ extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int 
     const int K = Cin * ksize * ksize;
     const int cfg = (tile_cfg >= 0 && tile_cfg < NCFG) ? tile_cfg : pick_tile(Cout, K);
     int splits, cps;
-    plan(Cout, K, (long)N * H * W, cfg, &splits, &cps);
+    plan(Cout, K, (long)N * ((H * W + 3) / 4 * 4), cfg, &splits, &cps);
     return (long)splits * Cout * (K + 1) * (long)sizeof(float);
 }
 
-// Stride-1, same-size (2*pad == ksize-1) convolutions with H*W a multiple of 4; x_guard_bytes >= 256 (see header).
+// Stride-1, same-size (2*pad == ksize-1) convolutions; x_guard_bytes >= 256 (see header).  Planes whose H*W is not a
+// multiple of 4 (the 7x7 stage) are enumerated in groups of 4 pixel slots per image, the slots past the plane zeroed.
 extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                                  long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
                                  void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream) {
     SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv wgrad x6: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(2 * pad == ksize - 1, "conv wgrad x6: only same-size stride-1 convolutions (pad %d, ksize %d)", pad, ksize);
-    SSN_CHECK_ARG((H * W) % 4 == 0, "conv wgrad x6: H*W = %d is not a multiple of 4", H * W);
     SSN_CHECK_ARG((pad * W + pad) * 4 <= (int)GUARD, "conv wgrad x6: image rows of %d pixels are too wide for the guard", W);
     SSN_CHECK_ARG(x_guard_bytes >= (int)GUARD, "conv wgrad x6: needs %u readable bytes in front of x (got %d)", GUARD,
                   x_guard_bytes);
@@ -412,9 +421,10 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.g_img_stride = g_img_stride;
     a.K = Cin * ksize * ksize;
     a.ldp = a.K + 1;
-    a.P = N * H * W;
+    a.HWp = (H * W + 3) / 4 * 4;
+    a.P = N * a.HWp;
     a.pad = pad;
-    a.div_hw = make_fastdiv((uint32_t)(H * W));
+    a.div_hw = make_fastdiv((uint32_t)a.HWp);
     a.div_w = make_fastdiv((uint32_t)W);
     const long gb = ((long)(N - 1) * g_img_stride + (long)Cout * H * W) * 4;
     const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;

@@ -259,7 +259,7 @@ def conv_wgrad(g, x, dw, db, ksize, stride, pad, workspace, tile_cfg=-1):
 
 def wgrad_x6_supported(ksize, stride, pad, h, w):
     """Layers the x6 weight-gradient kernel takes (the others stay on the exact-f32 kernel)."""
-    return ksize in (1, 3) and stride == 1 and 2 * pad == ksize - 1 and (h * w) % 4 == 0 and (pad * w + pad) * 4 <= 256
+    return ksize in (1, 3) and stride == 1 and 2 * pad == ksize - 1 and (pad * w + pad) * 4 <= 256
 
 
 def wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg=-1):
