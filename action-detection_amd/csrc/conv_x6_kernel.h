@@ -81,7 +81,9 @@ __device__ __forceinline__ float residual(float x) {
 #endif
 
 template <int KH, int KW, int S, int MODE, bool WIDE, int NG, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256 * NG, 2) void conv_x6_kernel(X6Args p) {
+// big register tiles (TM * TN >= 6, e.g. 128 x 64 per wave) run one wave per SIMD with up to 512 VGPRs: a third of the
+// LDS traffic per MFMA of the 1 x 4-wave tiles, the software pipeline hides the LDS round trip without a partner wave
+__global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void conv_x6_kernel(X6Args p) {
     constexpr int NW = 4 * NG;              // waves per workgroup
     constexpr int NT = 64 * NW;
     constexpr int BM = WM * TM * 32;

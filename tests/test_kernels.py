@@ -329,6 +329,8 @@ X6_CASES_SMALL = [
     # 8-wave ping-pong workgroups (tile ids 8-15)
     (2, 32, 10, 130, 3, 1, 1, 8), (3, 16, 7, 40, 1, 1, 0, 9), (2, 24, 8, 100, 3, 1, 1, 10), (2, 16, 10, 33, 3, 2, 1, 11),
     (1, 16, 12, 170, 3, 1, 1, 12), (2, 40, 6, 64, 1, 1, 0, 13), (3, 16, 6, 70, 3, 1, 1, 14), (2, 16, 8, 128, 1, 1, 0, 15),
+    # one-workgroup-per-CU tiles with 128x64 / 96x64 register tiles per wave
+    (2, 16, 12, 130, 3, 1, 1, 16), (2, 24, 8, 70, 1, 1, 0, 17),
 ]
 X6_CASES_GPU = [
     (9, 64, 56, 192, 3, 1, 1, -1), (18, 192, 28, 64, 1, 1, 0, -1), (18, 128, 28, 160, 3, 2, 1, -1),
@@ -338,6 +340,7 @@ X6_CASES_GPU = [
     (5, 96, 28, 96, 3, 1, 1, 4), (5, 96, 28, 160, 3, 1, 1, 5), (5, 96, 28, 96, 1, 1, 0, 6), (5, 96, 28, 96, 1, 1, 0, 7),
     (5, 96, 28, 96, 3, 1, 1, 8), (5, 96, 28, 96, 3, 1, 1, 9), (5, 96, 28, 96, 3, 1, 1, 10), (5, 96, 28, 96, 3, 2, 1, 11),
     (5, 96, 28, 160, 3, 1, 1, 12), (5, 96, 28, 96, 1, 1, 0, 13), (5, 96, 28, 96, 1, 1, 0, 14), (5, 96, 28, 130, 3, 1, 1, 15),
+    (5, 96, 28, 130, 3, 1, 1, 16), (5, 96, 28, 96, 1, 1, 0, 17), (3, 64, 28, 100, 3, 2, 1, 16), (4, 96, 14, 96, 3, 1, 1, 17),
 ]
 
 
