@@ -127,7 +127,7 @@ int launch_cfg(X6Args& a, hipStream_t stream) {
 //   0 128x128, 1 64x128, 2 96x128, 3 64x64, 4 32x128, 5 128x128 (1x4 waves), 6 64x128 (1x4 waves), 7 128x64
 // 8-15: 8-wave ping-pong workgroups (two groups side by side along the pixel axis):
 //   8 128x256, 9 64x256, 10 96x256, 11 64x128, 12 160x256, 13 128x128, 14 64x256 (1x4 waves), 15 128x256 (1x4 waves)
-// 16-17: 4-wave workgroups with 128x64 / 96x64 register tiles per wave, one workgroup per CU:   16 128x256, 17 96x256
+// 16-17: 4-wave workgroups with 128x64 / 96x64 register tiles per wave, one workgroup per CU:   16 128x256, 17 96x256, 18 160x256, 19 192x256
 template <int KH, int KW, int S, int MODE>
 int launch_tile(X6Args& a, int cfg, hipStream_t stream) {
     switch (cfg) {
@@ -149,6 +149,8 @@ int launch_tile(X6Args& a, int cfg, hipStream_t stream) {
         case 15: return launch_cfg<KH, KW, S, MODE, 2, 1, 4, 4, 1>(a, stream);
         case 16: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 4, 2>(a, stream);
         case 17: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 3, 2>(a, stream);
+        case 18: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 5, 2>(a, stream);
+        case 19: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 6, 2>(a, stream);
     }
     ssn_set_error("conv_x6: unknown tile config %d", cfg);
     return SSN_ERR_ARG;

@@ -340,7 +340,7 @@ X6_CASES_GPU = [
     (5, 96, 28, 96, 3, 1, 1, 4), (5, 96, 28, 160, 3, 1, 1, 5), (5, 96, 28, 96, 1, 1, 0, 6), (5, 96, 28, 96, 1, 1, 0, 7),
     (5, 96, 28, 96, 3, 1, 1, 8), (5, 96, 28, 96, 3, 1, 1, 9), (5, 96, 28, 96, 3, 1, 1, 10), (5, 96, 28, 96, 3, 2, 1, 11),
     (5, 96, 28, 160, 3, 1, 1, 12), (5, 96, 28, 96, 1, 1, 0, 13), (5, 96, 28, 96, 1, 1, 0, 14), (5, 96, 28, 130, 3, 1, 1, 15),
-    (5, 96, 28, 130, 3, 1, 1, 16), (5, 96, 28, 96, 1, 1, 0, 17), (3, 64, 28, 100, 3, 2, 1, 16), (4, 96, 14, 96, 3, 1, 1, 17),
+    (5, 96, 28, 130, 3, 1, 1, 16), (5, 96, 28, 96, 1, 1, 0, 17), (3, 64, 28, 100, 3, 2, 1, 16), (4, 96, 14, 96, 3, 1, 1, 17), (5, 128, 14, 160, 3, 1, 1, 18), (5, 96, 28, 200, 1, 1, 0, 19),
 ]
 
 
