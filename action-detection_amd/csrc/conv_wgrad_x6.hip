@@ -73,8 +73,10 @@ __device__ __forceinline__ void wg_split4(const float (&v)[4], uint32_t (&pl)[3]
     }
 }
 
+// tiles of 8+ MFMA tiles per wave run one wave per SIMD (up to 512 VGPRs): the elements to split per MFMA drop with
+// the tile size, which moves the kernel from VALU-bound towards matrix-bound
 template <int KS, bool PAD, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(WgX6Args p) {
+__global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX6Args p) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     constexpr int NAR = (BM + 63) / 64;   // G rows per thread (thread = one row x 4 pixels of a chunk)
@@ -334,10 +336,11 @@ int launch_wgx6(WgX6Args& a, hipStream_t stream) {
 
 // tile configs as in conv_wgrad.hip:
 //   0: 64(co) x 64(kk)   1: 32 x 128   2: 128 x 128   3: 64 x 128   4: 96 x 128   5: 64 x 128 (waves along kk)   6: 128 x 64
-// and two larger ones (fewer elements to split per MFMA: the kernel is VALU-bound):   7: 96 x 256   8: 192 x 128
-constexpr int NCFG = 9;
-const int kBM[NCFG] = {64, 32, 128, 64, 96, 64, 128, 96, 192};
-const int kBN[NCFG] = {64, 128, 128, 128, 128, 128, 64, 256, 128};
+// and larger ones (fewer elements to split per MFMA: the kernel is VALU-bound):   7: 96 x 256   8: 192 x 128
+// one workgroup per CU, one wave per SIMD:   9: 128 x 256   10: 160 x 256   11: 192 x 256
+constexpr int NCFG = 12;
+const int kBM[NCFG] = {64, 32, 128, 64, 96, 64, 128, 96, 192, 128, 160, 192};
+const int kBN[NCFG] = {64, 128, 128, 128, 128, 128, 64, 256, 128, 256, 256, 256};
 
 template <int KS>
 int launch_wgx6_tile(WgX6Args& a, int cfg, hipStream_t stream) {
@@ -351,6 +354,9 @@ int launch_wgx6_tile(WgX6Args& a, int cfg, hipStream_t stream) {
         case 6: return launch_wgx6<KS, 2, 2, 2, 1>(a, stream);
         case 7: return launch_wgx6<KS, 1, 4, 3, 2>(a, stream);
         case 8: return launch_wgx6<KS, 2, 2, 3, 2>(a, stream);
+        case 9: return launch_wgx6<KS, 1, 4, 4, 2>(a, stream);
+        case 10: return launch_wgx6<KS, 1, 4, 5, 2>(a, stream);
+        case 11: return launch_wgx6<KS, 2, 2, 3, 4>(a, stream);
     }
     ssn_set_error("conv_wgrad_x6: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -371,7 +377,7 @@ int pick_tile(int M, int K) {
 }
 
 // co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 112 B, VGPRs as compiled)
-const int kOcc[NCFG] = {5, 4, 2, 3, 2, 3, 3, 2, 2};
+const int kOcc[NCFG] = {5, 4, 2, 3, 2, 3, 3, 2, 2, 1, 1, 1};
 
 void plan(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
     const long tiles = (long)((M + kBM[cfg] - 1) / kBM[cfg]) * ((K + kBN[cfg] - 1) / kBN[cfg]);

@@ -440,9 +440,10 @@ def test_conv_wgrad_x6(backend):
               (2, 20, 14, 33, 3, 0), (2, 16, 28, 100, 3, 1), (2, 64, 14, 130, 1, 3), (2, 16, 14, 96, 3, 4),
               (2, 32, 14, 64, 1, 5), (2, 16, 14, 128, 3, 6), (3, 32, 14, 96, 3, 7), (2, 24, 28, 200, 3, 8),
               (1, 64, 14, 100, 1, 7), (3, 16, 14, 192, 1, 8), (5, 192, 7, 320, 3, -1), (4, 1056, 7, 128, 1, 2),
-              (3, 40, 7, 96, 3, 7), (2, 24, 5, 64, 1, 0)] if backend.is_gpu else
+              (3, 40, 7, 96, 3, 7), (2, 24, 5, 64, 1, 0), (3, 64, 14, 130, 3, 9), (3, 48, 14, 160, 3, 10), (2, 96, 14, 200, 1, 11),
+              (4, 32, 7, 192, 3, 11)] if backend.is_gpu else
              [(2, 6, 8, 40, 3, 0), (1, 16, 6, 33, 1, 1), (1, 8, 10, 130, 3, 2), (2, 4, 6, 70, 3, 3), (1, 20, 8, 96, 1, 4),
-              (1, 4, 14, 64, 3, 5), (2, 8, 6, 128, 1, 6), (3, 5, 4, 20, 3, -1), (1, 30, 6, 100, 3, 7), (1, 8, 6, 200, 1, 8), (3, 12, 7, 40, 3, 4), (2, 20, 5, 33, 1, 0)])
+              (1, 4, 14, 64, 3, 5), (2, 8, 6, 128, 1, 6), (3, 5, 4, 20, 3, -1), (1, 30, 6, 100, 3, 7), (1, 8, 6, 200, 1, 8), (3, 12, 7, 40, 3, 4), (2, 20, 5, 33, 1, 0), (1, 30, 4, 130, 3, 9), (1, 20, 4, 200, 1, 11)])
     for (n, cin, h, cout, k, cfg) in cases:
         p = (k - 1) // 2
         x = torch.randn(n, cin, h, h, generator=g)
