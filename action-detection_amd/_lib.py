@@ -14,7 +14,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "frames.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -54,6 +54,7 @@ _SIGS = {
     "ssn_stpp_bwd": "ppppiipp",
     "ssn_stpp_reorg": "piippppiiiiipppp",
     "ssn_crop_mean": "ppiiip",
+    "ssn_frames_crop_normalize": "ppiiiiiiipppiipipip",
     "ssn_reg_denorm": "plffffp",
     "ssn_linear_fwd": "ppppiiip",
     "ssn_linear_bwd": "ppppppiiiip",

@@ -366,6 +366,22 @@ def reg_denorm(reg, mean0, std0, mean1, std1):
              _stream(lib, reg))
 
 
+def frames_crop_normalize(src, dst, crops, roll, invert_even, mean, std):
+    """src uint8 [n_img, Hs, Ws, C] -> dst fp32 [n_crops, n_img, C, ch, cw]; crops = [(off_x, off_y, flip), ...];
+    mean / std: device float tensors (repeat over the stacked channels like GroupNormalize)."""
+    import ctypes
+    lib = _check(src, dst, mean, std)
+    assert src.dtype == torch.uint8 and src.dim() == 4 and dst.dim() == 5 and src.is_contiguous() and dst.is_contiguous()
+    n_img, hs, ws, c = src.shape
+    nc, _, _, ch, cw = dst.shape
+    assert nc == len(crops) and dst.shape[1] == n_img and dst.shape[2] == c
+    arr = ctypes.c_int * nc
+    ox, oy, fl = arr(*[int(t[0]) for t in crops]), arr(*[int(t[1]) for t in crops]), arr(*[int(bool(t[2])) for t in crops])
+    lib.call("ssn_frames_crop_normalize", _p(src), _p(dst), n_img, hs, ws, c, ch, cw, nc,
+             ctypes.cast(ox, ctypes.c_void_p), ctypes.cast(oy, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p),
+             int(roll), int(invert_even), _p(mean), mean.numel(), _p(std), std.numel(), _stream(lib, src))
+
+
 def linear_fwd(x, w, b, out):
     lib = _check(x, w, b, out)
     lib.call("ssn_linear_fwd", _p(x), _p(w), _p(b), _p(out), x.shape[0], w.shape[0], w.shape[1], _stream(lib, x))

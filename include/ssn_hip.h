@@ -209,6 +209,18 @@ int ssn_stpp_reorg(const float* scores, int T, int D, const int* ranges, const i
 int ssn_crop_mean(const float* x, float* y, int num_crop, int T, int D, hipStream_t stream);
 int ssn_reg_denorm(float* reg, long n_pairs, float mean0, float std0, float mean1, float std1, hipStream_t stream);
 
+/* Input side (csrc/frames.hip): the arithmetic of the reference's transform chain after decoding / scaling --
+ * GroupOverSample or crop + horizontal flip, Stack(roll), ToTorchFormatTensor(div=False), GroupNormalize
+ * (transforms.py:103-132, 49-64, 256-288, 67-80) -- on decoded uint8 frames.
+ * src [n_img][Hs][Ws][C] uint8 HWC -> dst [n_crops][n_img][C][crop_h][crop_w] fp32; crop k is (off_x, off_y, flip);
+ * roll: reverse the channel order (RGB -> BGR, Stack(roll=True)); invert_even: 255 - px on the even images of
+ * flipped crops (flow x component); mean / stdv (DEVICE arrays of n_mean / n_std floats) repeat over the stacked
+ * channels like GroupNormalize. */
+int ssn_frames_crop_normalize(const unsigned char* src, float* dst, int n_img, int Hs, int Ws, int C, int crop_h,
+                              int crop_w, int n_crops, const int* off_x, const int* off_y, const int* flip, int roll,
+                              int invert_even, const float* mean, int n_mean, const float* stdv, int n_std,
+                              hipStream_t stream);
+
 /* ------------------------------------------------------------------ heads
  * nn.Linear fwd/bwd for activity_fc / completeness_fc / regressor_fc / test_fc
  * (ssn_models.py:77-78,87,272-273,283,300; cuBLAS GEMMs in the reference). */

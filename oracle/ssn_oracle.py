@@ -383,6 +383,40 @@ def dense_test_video(net, frames_gen, frame_cnt, prop_ticks, prop_scaling, num_c
 
 
 # --------------------------------------------------------------------------------------
+# Input transforms after decoding / scaling -- /root/reference/transforms.py
+# --------------------------------------------------------------------------------------
+
+def oversample_transform(frames, crop_w, crop_h, mean, std, roll, is_flow):
+    """frames: list of uint8 HxWxC (RGB) or HxW ('L', flow) arrays = the img_group after GroupScale.  Follows
+    GroupOverSample (transforms.py:103-132), Stack(roll) (:256-268), ToTorchFormatTensor(div=False) (:271-288) and
+    GroupNormalize (:67-80) with numpy slicing in place of the PIL calls (crop, FLIP_LEFT_RIGHT, ImageOps.invert)."""
+    image_h, image_w = frames[0].shape[:2]
+    w_step, h_step = (image_w - crop_w) // 4, (image_h - crop_h) // 4          # fill_fix_offset(False, ...), :184-193
+    offsets = [(0, 0), (4 * w_step, 0), (0, 4 * h_step), (4 * w_step, 4 * h_step), (2 * w_step, 2 * h_step)]
+    group = []
+    for o_w, o_h in offsets:
+        normal, flip = [], []
+        for i, img in enumerate(frames):
+            crop = img[o_h:o_h + crop_h, o_w:o_w + crop_w]
+            normal.append(crop)
+            fc = crop[:, ::-1]
+            flip.append(255 - fc if (is_flow and i % 2 == 0) else fc)
+        group += normal + flip
+    if is_flow:
+        stacked = np.concatenate([np.expand_dims(x, 2) for x in group], axis=2)
+    elif roll:
+        stacked = np.concatenate([np.array(x)[:, :, ::-1] for x in group], axis=2)
+    else:
+        stacked = np.concatenate(group, axis=2)
+    t = torch.from_numpy(np.ascontiguousarray(stacked)).permute(2, 0, 1).contiguous().float()
+    rep_mean = list(mean) * (t.size(0) // len(mean))
+    rep_std = list(std) * (t.size(0) // len(std))
+    for ch, m, sd in zip(t, rep_mean, rep_std):
+        ch.sub_(m).div_(sd)
+    return t
+
+
+# --------------------------------------------------------------------------------------
 # Losses -- /root/reference/ops/ssn_ops.py:173-258, /root/reference/ssn_train.py:133,210-214
 # --------------------------------------------------------------------------------------
 

@@ -11,4 +11,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
 done
 cd "$R"
 python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc/summary.json > gpurun_out/pmc/summary.log 2>&1; tail -3 gpurun_out/pmc/summary.log
-find gpurun_out/pmc -name "*.csv" -size +2M -delete; du -sh gpurun_out/pmc
+find gpurun_out/pmc -name "*kernel_trace.csv" -delete; du -sh gpurun_out/pmc

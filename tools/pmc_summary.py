@@ -17,8 +17,8 @@ import re
 import sys
 
 FAMILIES = [  # (family, regex on the kernel name, wide 16-byte reads?)
-    ("conv_x6_kernel_fwd", r"conv_x6_kernel<\d+,\s*\d+,\s*0,", True),
-    ("conv_x6_kernel_dgrad", r"conv_x6_kernel<\d+,\s*\d+,\s*1,", True),
+    ("conv_x6_kernel_fwd", r"conv_x6_kernel<\d+,\s*\d+,\s*\d+,\s*0,", True),
+    ("conv_x6_kernel_dgrad", r"conv_x6_kernel<\d+,\s*\d+,\s*\d+,\s*1,", True),
     ("wgrad_x6_kernel", r"wgrad_x6_kernel", True),
     ("conv_igemm_kernel_fwd", r"conv_igemm_kernel<\d+,\s*\d+,\s*0,", False),
     ("conv_igemm_kernel_dgrad", r"conv_igemm_kernel<\d+,\s*\d+,\s*[12],", False),
