@@ -11,6 +11,11 @@ import os
 import subprocess
 import threading
 
+# torch first: it bundles its own HIP runtime, and libssn_hip.so must bind to THAT copy (same SONAME).  If this
+# library were dlopen-ed before torch, /opt/rocm's runtime would be loaded first and the process would end up with
+# two HIP runtimes ("no ROCm-capable device is detected" at the first launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
