@@ -132,29 +132,64 @@ _lib = None
 _test_lib = None
 
 
+def _source_stamp(deps, flags):
+    """sha256 over the compile flags and the contents of every source / header the library is built from."""
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into the in-tree libssn_hip.so (cross-compiles on CPU)."""
+    """Compile every HIP source for gfx950 into the in-tree libssn_hip.so (cross-compiles on CPU).
+
+    Up-to-date check by CONTENT (a stamp file next to the library holds the hash of the sources it was built from):
+    file times do not survive being copied to another box.  A file lock serialises concurrent builders (the ranks of
+    a multi-GPU launch all call this)."""
+    import fcntl
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in ("ssn_common.h", "conv_epilogue.h", "conv_x6_kernel.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-            return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    procs = []
-    for s in srcs:
-        o = os.path.join(CSRC, os.path.basename(s) + ".o")
-        objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, p in procs:
-        out, _ = p.communicate()
-        if verbose and out:
-            print(out.decode())
-        if p.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    stamp_path = LIB_PATH + ".stamp"
+    want = _source_stamp(deps, flags)
+
+    def fresh():
+        if not os.path.exists(LIB_PATH) or not os.path.exists(stamp_path):
+            return False
+        with open(stamp_path) as f:
+            return f.read().strip() == want
+
+    if not force and fresh():
+        return LIB_PATH
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():      # another process built it while this one waited
+                return LIB_PATH
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            objs = []
+            procs = []
+            for s in srcs:
+                o = os.path.join(CSRC, os.path.basename(s) + ".o")
+                objs.append(o)
+                cmd = [hipcc] + flags + ["-c", s, "-o", o]
+                procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            for cmd, p in procs:
+                out, _ = p.communicate()
+                if verbose and out:
+                    print(out.decode())
+                if p.returncode != 0:
+                    raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+            tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+            os.replace(tmp, LIB_PATH)      # readers never see a half-written library
+            with open(stamp_path, "w") as f:
+                f.write(want + "\n")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
