@@ -63,13 +63,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    if os.environ.get("SSN_BENCH_ONE_DEVICE") == "1":   # tooling: several ranks on one GPU (control-flow check with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("SSN_FORCE_ALLREDUCE") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SSN_BENCH_BACKEND", "nccl")   # "nccl" == RCCL; gloo only for the one-GPU control-flow check
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import action_detection_amd as pkg
     from action_detection_amd.ops.ssn_ops import ActivityLoss, ClassWiseRegressionLoss, CompletenessLoss
@@ -93,12 +99,12 @@ def main():
     batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank)]
     global_comp_rows = 7 * v * world
 
-    def step():
+    def step(collectives=True):
         out = model(*batch)
         loss = (act_crit(out[0], out[1]) + 0.1 * comp_crit(out[2], out[3], 1, 7, global_rows=global_comp_rows)
                 + 0.1 * reg_crit(out[4], out[5], out[6]))
         loss.backward()
-        if reducer is not None:
+        if reducer is not None and collectives:
             reducer.reduce_heads()
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -155,9 +161,12 @@ def main():
         overlap, lanes = model.base_model.overlap_wgrad, model.base_model.branch_streams
         model.base_model.overlap_wgrad = False   # one kernel at a time, so an event pair times exactly one launch
         model.base_model.branch_streams = False
+        # rank 0 only: no collectives in this pass (the other ranks are already waiting at the fence below)
+        hook, model.base_model.grad_ready_hook = model.base_model.grad_ready_hook, None
         for _ in range(args.steps):
-            step()
+            step(collectives=False)
         torch.cuda.synchronize()
+        model.base_model.grad_ready_hook = hook
         model.base_model.overlap_wgrad, model.base_model.branch_streams = overlap, lanes
         model.base_model.profiler = None
     fence()
