@@ -180,6 +180,45 @@ def golden_ssn(ref_models, ref_ops):
     np.savez_compressed(os.path.join(OUT, "ref_ssn.npz"), **out)
 
 
+def golden_binary(ref_binary, ref_ops):
+    """BinaryClassifier (binary_model.py) on the stub backbone: train forward + CE loss + gradients, test path."""
+    ref_binary.Identity = ref_ops.Identity      # the reference forgets to import it (NameError at dropout == 0)
+    out = {}
+    for tag, modality, size in (("rgb", "RGB", 32), ("flow", "Flow", 32)):
+        torch.manual_seed(0)
+        seg, n = 3, 4
+        m = ref_binary.BinaryClassifier(2, seg, modality, base_model="BNInception", dropout=0)
+        init_backbone_synthetic(m.base_model)
+        rs = np.random.RandomState(7)
+        with torch.no_grad():
+            m.classifier_fc.weight.copy_(torch.from_numpy(rs.standard_normal(m.classifier_fc.weight.shape).astype(np.float32) * 0.05))
+            m.classifier_fc.bias.copy_(torch.from_numpy(rs.standard_normal(2).astype(np.float32) * 0.05))
+        m.train()
+        c = 3 if modality == "RGB" else 10
+        x = torch.from_numpy(rs.randint(0, 256, (n, seg * c, size, size)).astype(np.float32)) - 110.0
+        tgt = torch.from_numpy(rs.randint(0, 2, (n, 1)).astype(np.int64))
+        logits, t = m(x, tgt)
+        loss = torch.nn.CrossEntropyLoss()(logits, t)
+        loss.backward()
+        out.update({tag + "_x": x.numpy(), tag + "_target": tgt.numpy(), tag + "_logits": logits.detach().numpy(),
+                    tag + "_loss": np.array([loss.item()]), tag + "_fc_w": m.classifier_fc.weight.detach().numpy(),
+                    tag + "_fc_b": m.classifier_fc.bias.detach().numpy(),
+                    tag + "_grad_fc_w": m.classifier_fc.weight.grad.numpy(),
+                    tag + "_grad_conv1_w": m.base_model.conv1_7x7_s2.weight.grad.numpy(),
+                    tag + "_grad_5b_1x1_b": m.base_model.inception_5b_1x1.bias.grad.numpy()})
+        pol = m.get_optim_policies()
+        out[tag + "_policy_sizes"] = np.array([[len(g["params"]), sum(p.numel() for p in g["params"])] for g in pol])
+        out[tag + "_state_keys"] = np.array(sorted(m.state_dict().keys()))
+        m.test_mode = True
+        m.prepare_test_fc()
+        m.eval()
+        with torch.no_grad():
+            sc, base = m(x[:, :c], None)
+        out[tag + "_test_scores"] = sc.numpy()
+        out[tag + "_test_base"] = base.numpy()
+    np.savez_compressed(os.path.join(OUT, "ref_binary.npz"), **out)
+
+
 def main():
     assert os.path.isdir(REF), "this script needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -190,6 +229,8 @@ def main():
     golden_losses(ref_ops)
     golden_reorg(ref_ops)
     golden_ssn(ref_models, ref_ops)
+    import binary_model as ref_binary
+    golden_binary(ref_binary, ref_ops)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

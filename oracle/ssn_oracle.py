@@ -590,6 +590,55 @@ class OracleSSN(nn.Module):
         self.test_fc.bias.data = b
 
 
+class OracleBinaryClassifier(nn.Module):
+    """Restatement of the reference's actionness classifier, /root/reference/binary_model.py:7-254, for the
+    BNInception backbone: backbone -> (Dropout) -> mean over the course segments (:229-231) -> classifier_fc (:232);
+    test mode: test_fc on single frames (:237-240, :245-254)."""
+
+    def __init__(self, num_class, course_segment, modality="RGB", new_length=None, dropout=0.8, test_mode=False):
+        super().__init__()
+        self.modality, self.course_segment, self.test_mode = modality, course_segment, test_mode
+        self.new_length = (1 if modality == "RGB" else 5) if new_length is None else new_length
+        cin = 3 if modality == "RGB" else 2 * self.new_length
+        self.base_model = OracleBNInception(in_channels=3)
+        feat = self.base_model.fc.in_features
+        self.base_model.fc = nn.Identity() if dropout == 0 else nn.Dropout(p=dropout)      # :121-125
+        if modality == "Flow":                                                             # :54-79
+            old = self.base_model.conv1_7x7_s2
+            new = nn.Conv2d(cin, 64, 7, 2, 3, bias=True)
+            new.weight.data = old.weight.data.mean(dim=1, keepdim=True).expand(-1, cin, -1, -1).contiguous()
+            new.bias.data = old.bias.data
+            self.base_model.conv1_7x7_s2 = new
+        self.classifier_fc = nn.Linear(feat, num_class)                                     # :127-130
+        nn.init.normal_(self.classifier_fc.weight, 0, 0.001)
+        nn.init.constant_(self.classifier_fc.bias, 0)
+        self.test_fc = None
+
+    def train(self, mode=True):
+        """:203-216 (bn_mode 'frozen': every BatchNorm2d in eval mode)."""
+        super().train(mode)
+        for m in self.base_model.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+                m.weight.requires_grad = False
+                m.bias.requires_grad = False
+        return self
+
+    def prepare_test_fc(self):
+        self.test_fc = nn.Linear(self.classifier_fc.in_features, self.classifier_fc.out_features)
+        self.test_fc.weight.data = self.classifier_fc.weight.data
+        self.test_fc.bias.data = self.classifier_fc.bias.data
+
+    def forward(self, inputdata, target=None):
+        sample_len = (3 if self.modality == "RGB" else 2) * self.new_length
+        x = inputdata.reshape((-1, sample_len) + tuple(inputdata.shape[-2:]))
+        base_out = self.base_model.fc(self.base_model.features(x))
+        if self.test_mode:
+            return self.test_fc(base_out), base_out
+        src = base_out.view(-1, self.course_segment, base_out.size(1))
+        return self.classifier_fc(src.mean(dim=1)), target.view(-1)
+
+
 def ssn_total_loss(outputs, num_videos, comp_weight=0.1, reg_weight=0.1, ohem_ratio=0.17,
                    fg_per_video=1, group_size=7):
     """Loss mix of /root/reference/ssn_train.py:210-214 with differentiable torch pieces.
