@@ -219,6 +219,25 @@ def golden_binary(ref_binary, ref_ops):
     np.savez_compressed(os.path.join(OUT, "ref_binary.npz"), **out)
 
 
+def golden_proposal_io():
+    """ops/io.py: parse a normalised list (a slice of the reference's own ActivityNet list + synthetic corner cases:
+    a video without proposals, one without ground truth) and convert it to a processed list."""
+    import json
+    from ops import io as ref_io
+    src = open(os.path.join(REF, "data", "activitynet1.2_tag_val_normalized_proposal_list.txt")).read().split("# ")
+    text = "".join("# " + r for r in src[1:6])
+    text += "# 6\nvid_no_props\n1\n1\n1\n3 0.1000 0.9000\n0\n# 7\nvid_no_gt\n1\n1\n0\n2\n0 0.0000 0.0000 0.1000 0.4000\n7 0.5000 1.0000 0.2500 0.7500\n"
+    norm_path = os.path.join(OUT, "proposal_list_norm.txt")
+    open(norm_path, "w").write(text)
+    parsed = ref_io.load_proposal_file(norm_path)
+    frame_dict = {rec[0]: ("frames/" + rec[0], 900 + 37 * i, 0) for i, rec in enumerate(parsed)}
+    proc_path = os.path.join(OUT, "proposal_list_processed.txt")
+    ref_io.process_proposal_list(norm_path, proc_path, frame_dict)
+    reparsed = ref_io.load_proposal_file(proc_path)
+    json.dump({"parsed": parsed, "frame_dict": frame_dict, "reparsed": reparsed},
+              open(os.path.join(OUT, "proposal_list_expected.json"), "w"))
+
+
 def main():
     assert os.path.isdir(REF), "this script needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -231,6 +250,7 @@ def main():
     golden_ssn(ref_models, ref_ops)
     import binary_model as ref_binary
     golden_binary(ref_binary, ref_ops)
+    golden_proposal_io()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

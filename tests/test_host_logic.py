@@ -191,3 +191,18 @@ def test_inceptionv3_spec_matches_oracle_and_known_answers():
     for k in ps:
         assert ps[k].shape == os_[k].shape, k
     assert set(dict(prod.named_buffers())) == set(dict(orc.named_buffers()))
+
+
+def test_proposal_list_io_matches_reference(tmp_path):
+    """ops/io.py:7-59: parser and normalised -> processed conversion against files written by the reference."""
+    import json
+    from action_detection_amd.proposal_io import load_proposal_file, process_proposal_list
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = json.load(open(os.path.join(gdir, "proposal_list_expected.json")))
+    as_lists = lambda recs: [[r[0], r[1], [list(b) for b in r[2]], [list(b) for b in r[3]]] for r in recs]  # noqa: E731
+    norm = os.path.join(gdir, "proposal_list_norm.txt")
+    assert as_lists(load_proposal_file(norm)) == exp["parsed"]
+    out = str(tmp_path / "processed.txt")
+    process_proposal_list(norm, out, {k: tuple(v) for k, v in exp["frame_dict"].items()})
+    assert open(out).read() == open(os.path.join(gdir, "proposal_list_processed.txt")).read()
+    assert as_lists(load_proposal_file(out)) == exp["reparsed"]
