@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "f32"],
                     help="matrix path of the 1x1/3x3 convolutions: exact 3-way bf16 split on the bf16 MFMA (fp32-class "
                          "error, default) or the exact-f32 MFMA for every layer")
+    ap.add_argument("--collectives", default="separate", choices=["separate", "overlapped"],
+                    help="N > 1: 'separate' = graph(fwd+bwd) -> eager RCCL all-reduce of the flat gradient -> graph(SGD), "
+                         "the well-trodden path; 'overlapped' = bucketed all-reduces issued from inside the backward and "
+                         "captured in the one step graph (overlaps the ~0.5 ms ring with the remaining backward)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP event timing")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly from Python instead of replaying one captured hipGraph per step")
@@ -94,19 +98,37 @@ def main():
     model.to(dev).train()
     policies = model.get_optim_policies()
     opt = SSNSGD(policies, lr=0.001, momentum=0.9, weight_decay=5e-4)
-    reducer = GradReducer(model) if use_dist else None
+    overlapped = use_dist and args.collectives == "overlapped"
+    reducer = GradReducer(model) if overlapped else None
     act_crit, comp_crit, reg_crit = ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss()
     batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank)]
     global_comp_rows = 7 * v * world
+    params = [p for g in opt.param_groups for p in g["params"]]
 
-    def step(collectives=True):
+    def fwd_bwd():
         out = model(*batch)
         loss = (act_crit(out[0], out[1]) + 0.1 * comp_crit(out[2], out[3], 1, 7, global_rows=global_comp_rows)
                 + 0.1 * reg_crit(out[4], out[5], out[6]))
         loss.backward()
-        if reducer is not None and collectives:
+        return loss
+
+    def allreduce_grads():
+        """'separate' mode: one RCCL all-reduce (sum) of all gradients; the 1/world lands in the SGD kernel."""
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])          # 42 MB gather / scatter: bookkeeping copies
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+    def update():
+        opt.step(grad_scale=(1.0 / world) if (use_dist and not overlapped) else 1.0)
+
+    def step(collectives=True):
+        loss = fwd_bwd()
+        if collectives and overlapped:
             reducer.reduce_heads()
-        opt.step()
+        elif collectives and use_dist:
+            allreduce_grads()
+        update()
         opt.zero_grad(set_to_none=True)
         return loss
 
@@ -115,8 +137,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- one hipGraph per step: the ~560 launches of a step are captured once and replayed, so the GPU is
-    # not paced by the Python launch loop.  Falls back to eager launches if capture is not possible.
+    # ---- hipGraphs: the ~330 launches of a step are captured once and replayed, so the GPU is not paced by the
+    # Python launch loop.  One graph per step (single GPU, or N > 1 with --collectives overlapped); with separate
+    # collectives two graphs (forward + backward, optimizer) around the eager all-reduce.  Falls back to eager
+    # launches if capture is not possible.
     launch = "eager"
     run_step = step
     static = {}
@@ -129,14 +153,32 @@ def main():
                     step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static["loss"] = step()
+            # with a process group alive, its watchdog thread polls HIP events at any time: in the default "global"
+            # capture mode such a call from another thread aborts the capture ("operation not permitted when stream
+            # is capturing"), so captures are thread-local whenever torch.distributed is initialised
+            cap_mode = "thread_local" if use_dist else "global"
+            if use_dist and not overlapped:
+                g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb, capture_error_mode=cap_mode):
+                    static["loss"] = fwd_bwd()         # parameter .grad tensors become static buffers of this graph
+                with torch.cuda.graph(g_up, pool=g_fb.pool(), capture_error_mode=cap_mode):
+                    update()
 
-            def run_step():
-                graph.replay()
-                return static["loss"]
-            launch = "hipGraph replay (1 graph = 1 step)"
+                def run_step():
+                    g_fb.replay()
+                    allreduce_grads()
+                    g_up.replay()
+                    return static["loss"]
+                launch = "hipGraph replay (fwd+bwd graph, eager RCCL all-reduce, optimizer graph)"
+            else:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode=cap_mode):
+                    static["loss"] = step()
+
+                def run_step():
+                    graph.replay()
+                    return static["loss"]
+                launch = "hipGraph replay (1 graph = 1 step)"
         except Exception as e:  # noqa: BLE001 -- report and keep going eagerly
             launch = "eager (graph capture failed: %s)" % (str(e).splitlines()[0][:120])
             run_step = step
@@ -163,6 +205,7 @@ def main():
         model.base_model.branch_streams = False
         # rank 0 only: no collectives in this pass (the other ranks are already waiting at the fence below)
         hook, model.base_model.grad_ready_hook = model.base_model.grad_ready_hook, None
+        opt.zero_grad(set_to_none=True)
         for _ in range(args.steps):
             step(collectives=False)
         torch.cuda.synchronize()
@@ -195,6 +238,7 @@ def main():
                                % (args.modality, v, args.num_class),
                    "global_batch_proposals": 8 * v * world, "images_per_gpu": 72 * v,
                    "parallelism": "dp%d" % world, "launch": launch,
+                   "collectives": (args.collectives if use_dist else "none"),
                    "conv_precision": ("fp32 in/out; 1x1/3x3 multiplies = 6 bf16-MFMA products of exact 3-way bf16 operand "
                                       "splits (fp32-class error), 7x7 stem on the exact-f32 MFMA"
                                       if args.precision == "bf16x6" else "exact-f32 MFMA everywhere")},
