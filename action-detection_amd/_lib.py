@@ -19,7 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "frames.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -59,6 +59,7 @@ _SIGS = {
     "ssn_stpp_bwd": "ppppiipp",
     "ssn_stpp_reorg": "piippppiiiiipppp",
     "ssn_crop_mean": "ppiiip",
+    "ssn_detections": "pppppppppiiiiidip",
     "ssn_frames_crop_normalize": "ppiiiiiiipppiipipip",
     "ssn_reg_denorm": "plffffp",
     "ssn_linear_fwd": "ppppiiip",
@@ -77,7 +78,7 @@ _SIGS = {
     "ssn_sumsq": "plpipp",
     "ssn_scale": "plpfp",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float,
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double,
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",

@@ -382,6 +382,25 @@ def frames_crop_normalize(src, dst, crops, roll, invert_even, mean, std):
              int(roll), int(invert_even), _p(mean), mean.numel(), _p(std), std.numel(), _stream(lib, src))
 
 
+def detections(act, comp, reg, rel_prop, top_k, include_bg, nms_thresh, regress):
+    """One video: -> (combined [P, C] fp32, dets [C, max_det, 5] fp64, counts [C] int32).  See ssn_detections."""
+    lib = _check(act, comp, reg, rel_prop)
+    p, c = comp.shape
+    assert act.shape == (p, c + 1) and rel_prop.shape == (p, 2) and rel_prop.dtype == torch.float64
+    dev = act.device
+    max_det = max(1, p)
+    combined = torch.empty((p, c), device=dev, dtype=torch.float32)
+    dets = torch.zeros((c, max_det, 5), device=dev, dtype=torch.float64)
+    counts = torch.zeros(c, device=dev, dtype=torch.int32)
+    ws = torch.zeros(2, device=dev, dtype=torch.int32)
+    lib.call("ssn_detections", _p(act), _p(comp), _p(reg), _p(rel_prop), _p(combined), _p(ws[:1]), _p(dets), _p(counts),
+             _p(ws[1:]), p, c, max_det, int(top_k), int(bool(include_bg)), float(nms_thresh), int(bool(regress)),
+             _stream(lib, act))
+    if int(ws[1].item()):
+        raise RuntimeError("a class has more than 2048 detection candidates in one video")
+    return combined, dets, counts
+
+
 def linear_fwd(x, w, b, out):
     lib = _check(x, w, b, out)
     lib.call("ssn_linear_fwd", _p(x), _p(w), _p(b), _p(out), x.shape[0], w.shape[0], w.shape[1], _stream(lib, x))

@@ -221,6 +221,17 @@ int ssn_frames_crop_normalize(const unsigned char* src, float* dst, int n_img, i
                               int invert_even, const float* mean, int n_mean, const float* stdv, int n_std,
                               hipStream_t stream);
 
+/* Detection post-processing of one video (csrc/detect.hip): score fusion softmax(activity)[1:] * exp(completeness),
+ * top-k over all (proposal, class) pairs, temporal NMS per class and location regression
+ * (eval_detection_results.py:91-128, 167-178; ops/utils.py:56-82).  act [P][C+1], comp [P][C], reg [P][C][2] or NULL
+ * (fp32); rel_prop [P][2] fp64 normalised spans; combined [P][C] fp32 out; thr_ws / error: one 32-bit device word
+ * each; dets [C][max_det][5] fp64 = (start, end, score, loc, dur) in descending score order, counts [C] int32.
+ * include_bg: softmax over all C+1 activity scores (the reference's top_k <= 0 branch) instead of the C class
+ * scores; top_k <= 0 keeps every pair; error[0] = 1 when a class has more than 2048 candidates. */
+int ssn_detections(const float* act, const float* comp, const float* reg, const double* rel_prop, float* combined,
+                   unsigned int* thr_ws, double* dets, int* counts, int* error, int P, int C, int max_det, int top_k,
+                   int include_bg, double nms_thresh, int regress, hipStream_t stream);
+
 /* ------------------------------------------------------------------ heads
  * nn.Linear fwd/bwd for activity_fc / completeness_fc / regressor_fc / test_fc
  * (ssn_models.py:77-78,87,272-273,283,300; cuBLAS GEMMs in the reference). */

@@ -590,6 +590,61 @@ class OracleSSN(nn.Module):
         self.test_fc.bias.data = b
 
 
+def detections_for_video(rel_prop, act_scores, comp_scores, reg_scores, num_class, nms_threshold, top_k=0,
+                         no_regression=False):
+    """The per-video part of /root/reference/eval_detection_results.py: gen_detection_results (:91-128, the two
+    branches without external class scores), temporal_nms (ops/utils.py:56-82) and perform_regression (:167-178).
+    -> {cls: float64 array [n, 5] = (start, end, score, loc, dur)}"""
+    def softmax(scores):                                           # ops/utils.py:35-37
+        es = np.exp(scores - scores.max(axis=-1)[..., None])
+        return es / es.sum(axis=-1)[..., None]
+
+    def temporal_nms(bboxes, thresh):                              # ops/utils.py:56-82
+        t1, t2, scores = bboxes[:, 0], bboxes[:, 1], bboxes[:, 2]
+        durations = t2 - t1
+        order = scores.argsort()[::-1]
+        keep = []
+        while order.size > 0:
+            i = order[0]
+            keep.append(i)
+            tt1 = np.maximum(t1[i], t1[order[1:]])
+            tt2 = np.minimum(t2[i], t2[order[1:]])
+            intersection = tt2 - tt1
+            iou = intersection / (durations[i] + durations[order[1:]] - intersection).astype(float)
+            inds = np.where(iou <= thresh)[0]
+            order = order[inds + 1]
+        return bboxes[keep, :]
+
+    rel_prop = np.asarray(rel_prop)
+    rel_prop = np.squeeze(rel_prop, 0) if rel_prop.ndim == 3 else rel_prop
+    act_scores, comp_scores = np.asarray(act_scores), np.asarray(comp_scores)
+    if reg_scores is None:
+        reg_scores = np.zeros((len(rel_prop), num_class, 2), dtype=np.float32)
+    reg_scores = np.asarray(reg_scores).reshape((-1, num_class, 2))
+    dets = {}
+    if top_k <= 0:
+        combined = softmax(act_scores)[:, 1:] * np.exp(comp_scores)
+        for i in range(num_class):
+            dets[i] = np.concatenate((rel_prop, combined[:, i][:, None], reg_scores[:, i, 0][:, None],
+                                      reg_scores[:, i, 1][:, None]), axis=1)
+    else:
+        combined = softmax(act_scores[:, 1:]) * np.exp(comp_scores)
+        for k in np.argsort(combined.ravel())[-top_k:]:
+            cls, prop_idx = k % num_class, k // num_class
+            row = [rel_prop[prop_idx, 0], rel_prop[prop_idx, 1], combined[prop_idx, cls],
+                   reg_scores[prop_idx, cls, 0], reg_scores[prop_idx, cls, 1]]
+            dets[cls] = np.array([row]) if cls not in dets else np.vstack([dets[cls], row])
+    dets = {c: temporal_nms(v, nms_threshold) for c, v in dets.items()}
+    if not no_regression:
+        for c, d in dets.items():
+            center, duration = (d[:, 0] + d[:, 1]) / 2, d[:, 1] - d[:, 0]
+            new_center = center + duration * d[:, 3]
+            new_duration = duration * np.exp(d[:, 4])
+            dets[c] = np.concatenate((np.clip(new_center - new_duration / 2, 0, 1)[:, None],
+                                      np.clip(new_center + new_duration / 2, 0, 1)[:, None], d[:, 2:]), axis=1)
+    return {c: d for c, d in dets.items() if len(d)}, combined
+
+
 class OracleBinaryClassifier(nn.Module):
     """Restatement of the reference's actionness classifier, /root/reference/binary_model.py:7-254, for the
     BNInception backbone: backbone -> (Dropout) -> mean over the course segments (:229-231) -> classifier_fc (:232);
