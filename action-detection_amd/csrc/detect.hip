@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256) void det_nms_kernel(DetArgs a) {
 extern "C" int ssn_detections(const float* act, const float* comp, const float* reg, const double* rel_prop, float* combined,
                               unsigned int* thr_ws, double* dets, int* counts, int* error, int P, int C, int max_det,
                               int top_k, int include_bg, double nms_thresh, int regress, hipStream_t stream) {
-    SSN_CHECK_ARG(act && comp && rel_prop && combined && thr_ws && dets && counts && error, "detections: null pointer");
+    SSN_CHECK_ARG(thr_ws && dets && counts && error, "detections: null pointer");
     SSN_CHECK_ARG(P >= 0 && C >= 1 && max_det >= 1, "detections: bad sizes");
+    SSN_CHECK_ARG(P == 0 || (act && comp && rel_prop && combined), "detections: null pointer");
     if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)C, stream) != hipSuccess ||
         hipMemsetAsync(error, 0, sizeof(int), stream) != hipSuccess) {
         ssn_set_error("detections: memset failed");

@@ -154,9 +154,10 @@ __global__ __launch_bounds__(256) void reg_denorm_kernel(float* reg, long n_pair
 }  // namespace
 
 extern "C" int ssn_crop_mean(const float* x, float* y, int num_crop, int T, int D, hipStream_t stream) {
-    SSN_CHECK_ARG(x && y && num_crop >= 1 && T >= 0 && D >= 1, "crop_mean: bad arguments");
+    SSN_CHECK_ARG(num_crop >= 1 && T >= 0 && D >= 1, "crop_mean: bad arguments");
     const long TD = (long)T * D;
-    if (TD == 0) return SSN_OK;
+    if (TD == 0) return SSN_OK;      // empty tensors have no storage (NULL) and nothing to do
+    SSN_CHECK_ARG(x && y, "crop_mean: null pointer");
     const float inv = 1.0f / (float)num_crop;
     if (TD % 4 == 0)
         hipLaunchKernelGGL(crop_mean_kernel<true>, dim3((unsigned)((TD / 4 + 255) / 256)), dim3(256), 0, stream, x, y,
@@ -170,8 +171,9 @@ extern "C" int ssn_crop_mean(const float* x, float* y, int num_crop, int T, int 
 
 extern "C" int ssn_reg_denorm(float* reg, long n_pairs, float mean0, float std0, float mean1, float std1,
                               hipStream_t stream) {
-    SSN_CHECK_ARG(reg && n_pairs >= 0, "reg_denorm: bad arguments");
+    SSN_CHECK_ARG(n_pairs >= 0, "reg_denorm: bad arguments");
     if (n_pairs == 0) return SSN_OK;
+    SSN_CHECK_ARG(reg, "reg_denorm: null pointer");
     hipLaunchKernelGGL(reg_denorm_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, reg, n_pairs,
                        mean0, std0, mean1, std1);
     SSN_CHECK_LAUNCH("reg_denorm");
@@ -206,11 +208,11 @@ extern "C" int ssn_stpp_reorg(const float* scores, int T, int D, const int* rang
                               const float* scaling, const int* part_scale_col, int P, int n_parts, int act_len,
                               int comp_len, int reg_len, float* out_act, float* out_comp, float* out_reg,
                               hipStream_t stream) {
+    if (P == 0) return SSN_OK;       // no proposals: the output tensors are empty (NULL storage)
     SSN_CHECK_ARG(scores && ranges && act_range && scaling && part_scale_col && out_act && out_comp,
                   "stpp_reorg: null pointer");
     SSN_CHECK_ARG(D >= act_len + n_parts * (comp_len + (out_reg ? reg_len : 0)), "stpp_reorg: score width %d too small",
                   D);
-    if (P == 0) return SSN_OK;
     hipLaunchKernelGGL(stpp_reorg_kernel, dim3(P), dim3(256), 0, stream, scores, T, D, ranges, act_range, scaling,
                        part_scale_col, n_parts, act_len, comp_len, reg_len, out_act, out_comp, out_reg);
     SSN_CHECK_LAUNCH("stpp_reorg");

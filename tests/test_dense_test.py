@@ -71,3 +71,21 @@ def test_dense_tester_matches_reference_loop(hip_library, modality, num_crop, ti
     assert rel_err(act, torch.from_numpy(r_act)) < 1e-4
     assert rel_err(comp, torch.from_numpy(r_comp)) < 1e-4
     assert rel_err(reg, torch.from_numpy(r_reg)) < 1e-4
+
+
+def test_empty_inputs(backend):
+    """Zero proposals / zero ticks / zero pairs: every entry point of the test path returns empty results, no launch."""
+    from action_detection_amd.detection_post import DetectionPostProcessor
+    from action_detection_amd.ops.ssn_ops import STPPReorgainzed
+    dev = backend.device
+    out = backend.put(torch.empty(0, 16))
+    K.crop_mean(backend.put(torch.empty(0, 16)), 10, out)
+    reorg = STPPReorgainzed(21 + 20 * 3 + 40 * 3, 21, 20, 40, True, stpp_cfg=(1, 1, 1))
+    scores = backend.put(torch.randn(9, 201))
+    act, comp, reg = reorg.forward(scores, torch.zeros((0, 4), dtype=torch.int64), torch.zeros((0, 2)))
+    assert act.shape == (0, 21) and comp.shape == (0, 20) and reg.shape == (0, 40)
+    dets, comb = DetectionPostProcessor(20, 0.2, 2000).process_video(
+        torch.zeros((0, 2), dtype=torch.float64), backend.put(torch.zeros(0, 21)), backend.put(torch.zeros(0, 20)),
+        backend.put(torch.zeros(0, 20, 2)), device=dev)
+    assert dets == {} and comb.shape == (0, 20)
+    K.reg_denorm(backend.put(torch.empty(0, 20, 2)), 0.0, 1.0, 0.0, 1.0)
