@@ -25,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: without this RCCL's buffer exchange between the ranks fails
+# (hipIpcGetMemHandle: invalid argument); already exported on the GPU boxes, kept here for any other launcher
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
