@@ -203,7 +203,8 @@ class CompletenessLoss(torch.nn.Module):
 
     ``global_rows`` (optional) lets a data-parallel rank reproduce the reference's denominator,
     which DataParallel computes from the gathered batch: pass the number of
-    completeness rows over ALL ranks.
+    completeness rows over ALL ranks.  The loss returned is then ``local hinge sum / (global denominator / world)``,
+    so that the average over the ranks (what the gradient all-reduce computes) equals the gathered-batch value.
     """
 
     def __init__(self, ohem_ratio=0.17):
@@ -225,7 +226,9 @@ class CompletenessLoss(torch.nn.Module):
         n_groups = rows // sample_group_size
         pos_cnt = n_groups * pos_group_size
         neg_cnt = int(n_groups * neg_group_size * self.ohem_ratio)
-        den = float(pos_cnt + neg_cnt)
+        # per-rank losses (and gradients) are AVERAGED over the ranks, like the per-rank means of the other two
+        # losses: this rank's share of the global denominator makes that average equal the gathered-batch loss
+        den = float(pos_cnt + neg_cnt) * (float(n_rows) / float(rows))
         return FN.CompletenessFn.apply(pred, labels.reshape(-1), sample_group_size, sample_split, keep_pos, keep_neg,
                                        den)
 

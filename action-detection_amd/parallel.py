@@ -12,8 +12,9 @@ losses, and the gradients are summed with ``torch.distributed`` (backend "nccl" 
 * the three head layers are reduced in one flat bucket after ``loss.backward()``.
 
 To reproduce the reference's numbers exactly, the completeness loss must use the GLOBAL
-denominator (``CompletenessLoss(..., global_rows=)``); cross-entropy and smooth-L1 are means
-over equal per-rank counts, so averaging per-rank gradients is exact.
+denominator (``CompletenessLoss(..., global_rows=)`` divides by this rank's share of it, so that the
+average over the ranks is the gathered-batch loss); cross-entropy and smooth-L1 are means over equal
+per-rank counts, so averaging per-rank gradients is exact.
 """
 import os
 

@@ -211,3 +211,25 @@ def test_product_ssn_matches_reference_gpu(tag, hip_library):
 @pytest.mark.skipif(os.environ.get("SSN_SLOW") != "1", reason="~10 min through the host emulator; set SSN_SLOW=1")
 def test_product_ssn_matches_reference_emulated(emu):
     _product_vs_golden("rgb", "cpu")
+
+
+def test_sharded_completeness_loss_averages_to_the_gathered_loss(backend):
+    """Data parallelism: per-rank CompletenessLoss(global_rows=) averaged over the ranks -- what
+    the gradient all-reduce does -- equals the reference loss on the gathered batch, values and gradients; V = 100
+    videos is a case where the global int() truncation differs from the sum of the per-rank ones."""
+    rng = np.random.RandomState(5)
+    for v, world in ((4, 2), (100, 4)):
+        c = 20
+        pred = torch.from_numpy((rng.standard_normal((7 * v, c)) * 1.5).astype(np.float32))
+        labels = torch.from_numpy(rng.randint(1, c + 1, size=7 * v).astype(np.int64))
+        full_loss, full_grad = O.completeness_loss(pred, labels.numpy(), 1, 7)
+        per = v // world
+        tot, grads = 0.0, []
+        for r in range(world):
+            p = backend.put(pred[7 * per * r:7 * per * (r + 1)].clone()).requires_grad_()
+            l = P.CompletenessLoss()(p, backend.put(labels[7 * per * r:7 * per * (r + 1)]), 1, 7, global_rows=7 * v)
+            l.backward()
+            tot += float(l) / world
+            grads.append(p.grad.cpu() / world)
+        assert abs(tot - float(full_loss)) < 1e-6 * max(1.0, abs(float(full_loss)))
+        assert np.allclose(torch.cat(grads).numpy(), full_grad, rtol=1e-5, atol=1e-8)
