@@ -55,3 +55,26 @@ class SSNSGD(torch.optim.Optimizer):
         for (momentum, first), (ws, grads, bufs, lrs, wds) in batches.items():
             K.sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale, first)
         return None
+
+
+def clip_grad_norm(parameters, max_norm):
+    """``torch.nn.utils.clip_grad_norm`` as the reference's loop calls it (/root/reference/ssn_train.py:245-248) on the
+    ssn_sumsq / ssn_scale kernels: total 2-norm over all gradients, gradients scaled by ``max_norm / (norm + 1e-6)``
+    when that is below 1.  Returns the total norm as a Python float (one host sync, as in the reference)."""
+    ps = [p for p in parameters if p.grad is not None]
+    if not ps:
+        return 0.0
+    dev = ps[0].grad.device
+    out = torch.zeros(1, device=dev, dtype=torch.float32)
+    ws = torch.empty(1024, device=dev, dtype=torch.float32)
+    for i, p in enumerate(ps):
+        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+        K.sumsq(g, out, i > 0, ws)
+    total_norm = float(out.item()) ** 0.5
+    clip_coef = float(max_norm) / (total_norm + 1e-6)
+    if clip_coef < 1:
+        for p in ps:
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+            K.scale_(p.grad, None, clip_coef)
+    return total_norm

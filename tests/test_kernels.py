@@ -246,6 +246,24 @@ def test_sgd_and_norm(backend):
     assert rel_err(x, gr * 0.5) < 1e-7
 
 
+def test_clip_grad_norm(backend):
+    """optim.clip_grad_norm (ssn_train.py:245-248) against torch.nn.utils.clip_grad_norm_, clipping and not clipping."""
+    from action_detection_amd.optim import clip_grad_norm
+    g = torch.Generator().manual_seed(12)
+    shapes = [(64, 3, 7, 7), (64,), (21, 1024), (5, 1000)]
+    for max_norm in (0.5, 1e6):
+        ref = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        got = [torch.nn.Parameter(backend.put(torch.zeros(s))) for s in shapes]
+        for r, p in zip(ref, got):
+            r.grad = torch.randn(r.shape, generator=g)
+            p.grad = backend.put(r.grad.clone())
+        n_ref = float(torch.nn.utils.clip_grad_norm_(ref, max_norm))
+        n_got = clip_grad_norm(got, max_norm)
+        assert abs(n_got - n_ref) < 1e-5 * n_ref
+        for r, p in zip(ref, got):
+            assert rel_err(p.grad, r.grad) < 1e-6
+
+
 def test_fused_relu_bn_backward_epilogues(backend):
     """dgrad / max-pool backward as LAST writer: dx <- (dx_old + contribution) * (y > 0) * scale, |scale| where < 0."""
     g = torch.Generator().manual_seed(10)
