@@ -130,30 +130,25 @@ class SSN(torch.nn.Module):
             raise ValueError("unknown bn mode")
 
     # ---- /root/reference/ssn_models.py:107-154
+    _BACKBONES = {   # name -> (constructor, last layer, input size): the ones built on the MI355X kernels
+        'BNInception': (BNInception, 'fc', 224),            # training and testing
+        'InceptionV3': (InceptionV3, 'top_cls_fc', 299),    # forward only (dense testing, BASELINE.json configs[4])
+    }
+
     def _prepare_base_model(self, base_model):
-        if base_model == 'BNInception':
-            self.base_model = BNInception()
-            self.base_model.last_layer_name = 'fc'
-            self.input_size = 224
-            self.input_mean = [104, 117, 128]
+        if base_model in SSN._BACKBONES:      # (BinaryClassifier borrows this method)
+            ctor, last, size = SSN._BACKBONES[base_model]
+            self.base_model = ctor()
+            self.base_model.last_layer_name = last
+            self.input_size = size
+            # Caffe-heritage statistics: BGR means on the 0..255 scale, unit std; flow is centred at 128
             self.input_std = [1]
-
             if self.modality == 'Flow':
                 self.input_mean = [128]
             elif self.modality == 'RGBDiff':
-                self.input_mean = self.input_mean * (1 + self.new_length)
-        elif base_model == 'InceptionV3':
-            # forward only (dense testing, BASELINE.json configs[4]); see inceptionv3.py
-            self.base_model = InceptionV3()
-            self.base_model.last_layer_name = 'top_cls_fc'
-            self.input_size = 299
-            self.input_mean = [104, 117, 128]
-            self.input_std = [1]
-
-            if self.modality == 'Flow':
-                self.input_mean = [128]
-            elif self.modality == 'RGBDiff':
-                self.input_mean = self.input_mean * (1 + self.new_length)
+                self.input_mean = [104, 117, 128] * (1 + self.new_length)
+            else:
+                self.input_mean = [104, 117, 128]
         elif 'resnet' in base_model or 'vgg' in base_model or 'inception' in base_model:
             raise NotImplementedError(
                 "base model {} is not built: the MI355X hot path covers BNInception (training and testing) and "
@@ -204,39 +199,29 @@ class SSN(torch.nn.Module):
 
     # ---- /root/reference/ssn_models.py:203-251
     def get_optim_policies(self):
-        first_conv_weight, first_conv_bias, normal_weight, normal_bias, bn = [], [], [], [], []
-        conv_cnt = 0
+        """Five parameter groups with the reference's multipliers: the first convolution (weight / bias), every other
+        convolution and linear layer (weight / bias), BatchNorm1d parameters; BatchNorm2d is frozen and gets none."""
+        groups = {"first_conv_weight": [], "first_conv_bias": [], "normal_weight": [], "normal_bias": [],
+                  "BN scale/shift": []}
+        seen_conv = False
         for m in self.modules():
-            if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv1d)):
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv1d, torch.nn.Linear)):
+                first = isinstance(m, (torch.nn.Conv2d, torch.nn.Conv1d)) and not seen_conv
+                seen_conv = seen_conv or isinstance(m, (torch.nn.Conv2d, torch.nn.Conv1d))
                 ps = list(m.parameters())
-                conv_cnt += 1
-                if conv_cnt == 1:
-                    first_conv_weight.append(ps[0])
-                    if len(ps) == 2:
-                        first_conv_bias.append(ps[1])
-                else:
-                    normal_weight.append(ps[0])
-                    if len(ps) == 2:
-                        normal_bias.append(ps[1])
-            elif isinstance(m, torch.nn.Linear):
-                ps = list(m.parameters())
-                normal_weight.append(ps[0])
+                groups["first_conv_weight" if first else "normal_weight"].append(ps[0])
                 if len(ps) == 2:
-                    normal_bias.append(ps[1])
+                    groups["first_conv_bias" if first else "normal_bias"].append(ps[1])
             elif isinstance(m, torch.nn.BatchNorm1d):
-                bn.extend(list(m.parameters()))
+                groups["BN scale/shift"].extend(m.parameters())
             elif isinstance(m, torch.nn.BatchNorm2d):
-                pass  # BN layers are all frozen in SSN
-            elif len(m._modules) == 0:
-                if len(list(m.parameters())) > 0:
-                    raise ValueError("New atomic module type: {}. Need to give it a learning policy".format(type(m)))
-        return [
-            {'params': first_conv_weight, 'lr_mult': 1, 'decay_mult': 1, 'name': "first_conv_weight"},
-            {'params': first_conv_bias, 'lr_mult': 2, 'decay_mult': 0, 'name': "first_conv_bias"},
-            {'params': normal_weight, 'lr_mult': 1, 'decay_mult': 1, 'name': "normal_weight"},
-            {'params': normal_bias, 'lr_mult': 2, 'decay_mult': 0, 'name': "normal_bias"},
-            {'params': bn, 'lr_mult': 1, 'decay_mult': 0, 'name': "BN scale/shift"},
-        ]
+                continue
+            elif len(m._modules) == 0 and len(list(m.parameters())) > 0:
+                raise ValueError("New atomic module type: {}. Need to give it a learning policy".format(type(m)))
+        mult = {"first_conv_weight": (1, 1), "first_conv_bias": (2, 0), "normal_weight": (1, 1), "normal_bias": (2, 0),
+                "BN scale/shift": (1, 0)}
+        return [{'params': ps, 'lr_mult': mult[name][0], 'decay_mult': mult[name][1], 'name': name}
+                for name, ps in groups.items()]
 
     # ---- /root/reference/ssn_models.py:253-300
     def forward(self, input, aug_scaling=None, target=None, reg_target=None, prop_type=None):
@@ -298,24 +283,21 @@ class SSN(torch.nn.Module):
 
     # ---- /root/reference/ssn_models.py:318-343
     def _construct_flow_model(self, base_model):
-        modules = list(self.base_model.modules())
-        first_conv_idx = list(filter(lambda x: isinstance(modules[x], nn.Conv2d), list(range(len(modules)))))[0]
-        conv_layer = modules[first_conv_idx]
-        container = modules[first_conv_idx - 1]
-
-        params = [x.clone() for x in conv_layer.parameters()]
-        kernel_size = params[0].size()
-        new_kernel_size = kernel_size[:1] + (2 * self.new_length,) + kernel_size[2:]
-        new_kernels = params[0].data.mean(dim=1, keepdim=True).expand(new_kernel_size).contiguous()
-
-        new_conv = nn.Conv2d(2 * self.new_length, conv_layer.out_channels,
-                             conv_layer.kernel_size, conv_layer.stride, conv_layer.padding,
-                             bias=True if len(params) == 2 else False)
-        new_conv.weight.data = new_kernels
-        if len(params) == 2:
-            new_conv.bias.data = params[1].data
-        layer_name = list(container.state_dict().keys())[0][:-7]
-        setattr(container, layer_name, new_conv)
+        """First-conv surgery for stacked optical flow: the RGB kernel averaged over its input channels and repeated
+        over the 2 * new_length flow channels, bias kept; the new layer replaces the old one under the same name."""
+        name, old = next((n, m) for n, m in base_model.named_modules() if isinstance(m, nn.Conv2d))
+        holder = base_model
+        *path, leaf = name.split(".")
+        for part in path:
+            holder = getattr(holder, part)
+        c_flow = 2 * self.new_length
+        has_bias = old.bias is not None
+        new = nn.Conv2d(c_flow, old.out_channels, old.kernel_size, old.stride, old.padding, bias=has_bias)
+        with torch.no_grad():
+            new.weight.copy_(old.weight.mean(dim=1, keepdim=True).expand(-1, c_flow, -1, -1))
+            if has_bias:
+                new.bias.copy_(old.bias)
+        setattr(holder, leaf, new)
         return base_model
 
     # ---- /root/reference/ssn_models.py:378-395

@@ -206,3 +206,20 @@ def test_proposal_list_io_matches_reference(tmp_path):
     process_proposal_list(norm, out, {k: tuple(v) for k, v in exp["frame_dict"].items()})
     assert open(out).read() == open(os.path.join(gdir, "proposal_list_processed.txt")).read()
     assert as_lists(load_proposal_file(out)) == exp["reparsed"]
+
+
+def test_flow_first_conv_surgery():
+    """ssn_models.py:318-343: the flow model's first conv = the RGB kernel averaged over its input channels, repeated
+    over the 2 * new_length flow channels; bias kept; same attribute name, so state_dict keys do not change."""
+    from action_detection_amd.ssn_models import SSN
+    torch.manual_seed(3)
+    rgb = SSN(20, 2, 5, 2, "RGB")
+    torch.manual_seed(3)
+    flow = SSN(20, 2, 5, 2, "Flow")
+    w_rgb, w_flow = rgb.base_model.conv1_7x7_s2.weight, flow.base_model.conv1_7x7_s2.weight
+    assert tuple(w_flow.shape) == (64, 10, 7, 7)
+    assert torch.allclose(w_flow, w_rgb.mean(dim=1, keepdim=True).expand(-1, 10, -1, -1))
+    assert torch.equal(flow.base_model.conv1_7x7_s2.bias, rgb.base_model.conv1_7x7_s2.bias)
+    assert sorted(flow.state_dict().keys()) == sorted(rgb.state_dict().keys())
+    assert flow.input_mean == [128] and rgb.input_mean == [104, 117, 128]
+    assert len(flow.get_optim_policies()[0]["params"]) == 1 and flow.get_optim_policies()[0]["params"][0] is w_flow
