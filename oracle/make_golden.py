@@ -238,6 +238,36 @@ def golden_proposal_io():
               open(os.path.join(OUT, "proposal_list_expected.json"), "w"))
 
 
+def golden_sampling():
+    """SSNDataSet (ssn_dataset.py) without image files: `_load_image` returns the frame INDEX it was asked for and the
+    transform stacks those, so `get_training_data` yields exactly which frames the reference would have loaded."""
+    import json
+    np.int = int                                   # ssn_dataset.py:397 uses the alias numpy removed
+    import ssn_dataset as ref_ds
+    prop_file = os.path.join(OUT, "proposal_list_processed.txt")
+    out = {}
+    for tag, kw in (("train", dict(random_shift=True)), ("val", dict(random_shift=False)),
+                    ("flow", dict(random_shift=True, new_length=5))):
+        ds = ref_ds.SSNDataSet("", prop_file, transform=lambda fr: torch.tensor(fr, dtype=torch.int64), verbose=False, **kw)
+        ds._load_image = lambda directory, idx: [idx]
+        rec = {"stats": np.asarray(ds.stats).tolist(), "n_videos": len(ds.video_list),
+               "pools": [len(ds.fg_pool), len(ds.incomp_pool), len(ds.bg_pool)], "samples": [], "tests": []}
+        for i in range(len(ds.video_list)):
+            for seed in (0, 1):
+                np.random.seed(100 * i + seed)
+                fr, plen, scal, ptype, lab, reg, split = ds.get_training_data(i)
+                rec["samples"].append({"video": i, "seed": 100 * i + seed, "frames": fr.tolist(),
+                                       "scaling": scal.numpy().tolist(), "prop_type": ptype.tolist(),
+                                       "labels": lab.tolist(), "reg_targets": reg.numpy().tolist(),
+                                       "stage_split": split.tolist()})
+            gen, n_ticks, rel, pticks, scaling = ds.get_test_data(ds.video_list[i], ds.test_interval)
+            rec["tests"].append({"video": i, "n_ticks": int(n_ticks), "rel": rel.numpy().tolist(),
+                                 "ticks": pticks.numpy().tolist(), "scaling": scaling.numpy().tolist()})
+        rec["all_gt"] = ds.get_all_gt()
+        out[tag] = rec
+    json.dump(out, open(os.path.join(OUT, "sampling_expected.json"), "w"))
+
+
 def main():
     assert os.path.isdir(REF), "this script needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -251,6 +281,7 @@ def main():
     import binary_model as ref_binary
     golden_binary(ref_binary, ref_ops)
     golden_proposal_io()
+    golden_sampling()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 from torch import nn
@@ -223,3 +224,34 @@ def test_flow_first_conv_surgery():
     assert sorted(flow.state_dict().keys()) == sorted(rgb.state_dict().keys())
     assert flow.input_mean == [128] and rgb.input_mean == [104, 117, 128]
     assert len(flow.get_optim_policies()[0]["params"]) == 1 and flow.get_optim_policies()[0]["params"][0] is w_flow
+
+
+def test_proposal_sampler_matches_reference_dataset():
+    """ssn_dataset.py:258-488: same seeds -> the same proposals, frame indices, labels, regression targets, scalings and
+    test ticks as the reference's SSNDataSet (fixture: oracle/make_golden.py golden_sampling)."""
+    import json
+    from action_detection_amd.proposal_sampling import ProposalSampler
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = json.load(open(os.path.join(gdir, "sampling_expected.json")))
+    prop_file = os.path.join(gdir, "proposal_list_processed.txt")
+    for tag, kw in (("train", dict(random_shift=True)), ("val", dict(random_shift=False)),
+                    ("flow", dict(random_shift=True, new_length=5))):
+        e = exp[tag]
+        s = ProposalSampler(prop_file, **kw)
+        assert len(s) == e["n_videos"]
+        assert [len(s.fg_pool), len(s.incomp_pool), len(s.bg_pool)] == e["pools"]
+        assert np.allclose(s.stats, np.array(e["stats"]), rtol=1e-12)
+        for smp in e["samples"]:
+            np.random.seed(smp["seed"])
+            props, arrays = s.sample_video(smp["video"])
+            assert [f for p in props for f in p.frame_indices] == smp["frames"], (tag, smp["video"], smp["seed"])
+            assert arrays["prop_type"].tolist() == smp["prop_type"] and arrays["labels"].tolist() == smp["labels"]
+            assert np.array_equal(arrays["scaling"], np.array(smp["scaling"], dtype=np.float32))
+            assert np.array_equal(arrays["reg_targets"], np.array(smp["reg_targets"], dtype=np.float32))
+            assert [p.stage_split for p in props] == smp["stage_split"]
+        for t in e["tests"]:
+            ticks, rel, pticks, scaling = s.test_ticks(s.video_list[t["video"]])
+            assert len(ticks) == t["n_ticks"]
+            assert np.array_equal(rel, np.array(t["rel"])) and np.array_equal(pticks, np.array(t["ticks"]))
+            assert np.array_equal(scaling, np.array(t["scaling"]))
+        assert s.all_gt() == e["all_gt"]
