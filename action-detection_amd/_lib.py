@@ -59,7 +59,7 @@ _SIGS = {
     "ssn_stpp_bwd": "ppppiipp",
     "ssn_stpp_reorg": "piippppiiiiipppp",
     "ssn_crop_mean": "ppiiip",
-    "ssn_detections": "pppppppppiiiiidip",
+    "ssn_detections": "ppppppppuiiiiidip",
     "ssn_frames_crop_normalize": "ppiiiiiiipppiipipip",
     "ssn_reg_denorm": "plffffp",
     "ssn_linear_fwd": "ppppiiip",
@@ -83,7 +83,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
-                                "ssn_conv_wgrad_x6_workspace_bytes",
+                                "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags",
                                 "ssn_conv_dgrad_layout"])
 
@@ -110,6 +110,8 @@ class SsnLibrary:
         self.cdll.ssn_conv_x6_packed_floats_rect.argtypes = [ctypes.c_int] * 4
         self.cdll.ssn_conv_wgrad_x6_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_conv_wgrad_x6_workspace_bytes.argtypes = [ctypes.c_int] * 7
+        self.cdll.ssn_detections_workspace_bytes.restype = ctypes.c_size_t
+        self.cdll.ssn_detections_workspace_bytes.argtypes = [ctypes.c_int] * 2
         self.cdll.ssn_conv_pick_tile.restype = ctypes.c_int
         self.cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
         self._fn = {}

@@ -247,9 +247,10 @@ class BNInception(nn.Module):
             return acts[name]
 
         def scale_slice(name, c0, c):
-            # per tensor: folded-BN scale of every channel (-1: channel is not a conv+ReLU output)
+            # per tensor: folded-BN scale of every channel (NaN: channel is not a conv+ReLU output; out of band, so that a
+            # negative folded scale -- gamma < 0 occurs in trained checkpoints -- keeps its sign)
             if name not in tscale:
-                tscale[name] = torch.full((shapes[name][0],), -1.0, device=dev, dtype=torch.float32)
+                tscale[name] = torch.full((shapes[name][0],), float("nan"), device=dev, dtype=torch.float32)
             return tscale[name][c0:c0 + c]
 
         # frozen-BN folding of all 69 layers in two launches (scale into the per-tensor vectors, shift into one

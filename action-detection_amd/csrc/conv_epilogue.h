@@ -31,7 +31,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, uin
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// ch[0,BM) = scale (1 if none), ch[BM,2BM) = shift (0), ch[2BM,3BM) = mask scale (-1: pass through).  All threads of
+// ch[0,BM) = scale (1 if none), ch[BM,2BM) = shift (0), ch[2BM,3BM) = mask scale (NaN: pass through).  All threads of
 // the workgroup call this between two barriers (LDS is free once the main loop has ended).
 template <int BM, int NT>
 __device__ __forceinline__ void epi_stage_channels(float* ch, const float* scale, const float* shift,
@@ -41,7 +41,7 @@ __device__ __forceinline__ void epi_stage_channels(float* ch, const float* scale
         const bool ok = m < M;
         ch[r] = (ok && scale) ? scale[m] : 1.f;
         ch[BM + r] = (ok && scale) ? shift[m] : 0.f;
-        ch[2 * BM + r] = (ok && mask_scale) ? mask_scale[m] : -1.f;
+        ch[2 * BM + r] = (ok && mask_scale) ? mask_scale[m] : __builtin_nanf("");
     }
 }
 
@@ -98,7 +98,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                 if (e.relu) v = fmaxf(v, 0.f);
                 v += old[b][q];
                 const float sc = ch[2 * BM + sr + 4 * lh];
-                v = (sc < 0.f) ? v * -sc : (mk[b][q] > 0.f ? v * sc : 0.f);
+                v = (sc != sc) ? v : (mk[b][q] > 0.f ? v * sc : 0.f);   // NaN marks a channel that is not a ReLU output
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
                                                       sr < mlim ? yoff[j] : EPI_OOB, (uint32_t)sr * e.howo4, 0);
             }

@@ -63,7 +63,7 @@ struct ConvArgs {
     int pad;
     int relu, accumulate;
     const float* mask_y;      // dgrad only: activation of the tensor whose gradient is being finalised
-    const float* mask_scale;  // its per-channel folded-BN scale (< 0: channel is not a ReLU output, use |scale|)
+    const float* mask_scale;  // its per-channel folded-BN scale (NaN: channel is not a ReLU output, gradient passes through)
     long mask_img_stride;
     int n_ptiles, n_mtiles, nslab;
     int dbg;             // ablation switches for tools/ablate_conv.py (0 in production)
@@ -643,7 +643,8 @@ extern "C" int ssn_conv_dgrad_layout(int ksize, int stride, int pad, int H, int 
 // wt_packed = ssn_conv_pack_weights(w, ..., transposed = 1)
 // mask_y / mask_scale (optional): when this launch is the LAST writer of dx, apply the backward of the ReLU +
 // frozen BN that produced the tensor dx is the gradient of: dx <- dx * (mask_y > 0) * mask_scale[ci]
-// (mask_scale[ci] < 0 marks a channel that is not a ReLU output: dx <- dx * |mask_scale|).
+// (a NaN mask_scale[ci] marks a channel that is not a ReLU output: dx passes through; any finite scale, negative
+// ones included -- BN gammas of trained checkpoints can be negative -- is applied with its sign).
 extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                               long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize,
                               int stride, int pad, int accumulate, const float* mask_y, long mask_img_stride,

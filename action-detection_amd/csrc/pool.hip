@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
         if (p.accumulate) g += *dst;
         if (p.mask_y) {
             const float sc = p.mask_scale[c];
-            g = (sc < 0.f) ? g * -sc : (p.mask_y[(long)n * p.mask_img_stride + rem] > 0.f ? g * sc : 0.f);
+            g = (sc != sc) ? g : (p.mask_y[(long)n * p.mask_img_stride + rem] > 0.f ? g * sc : 0.f);
         }
         *dst = g;
     }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void pool3_vec_kernel(PoolVecArgs p) {
                 }
                 const float sc = p.mask_scale[c];
 #pragma unroll
-                for (int e = 0; e < V; ++e) out[e] = (sc < 0.f) ? out[e] * -sc : (mk[e] > 0.f ? out[e] * sc : 0.f);
+                for (int e = 0; e < V; ++e) out[e] = (sc != sc) ? out[e] : (mk[e] > 0.f ? out[e] * sc : 0.f);
             }
         }
         pool_store_wide<V>(p.y + o, out);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void pool_max2_bwd_vec_kernel(PoolBwdArgs p, F
                                                             (long)hi * p.W + wi0);
             const float sc = p.mask_scale[c];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = (sc < 0.f) ? g[e] * -sc : (t[e] > 0.f ? g[e] * sc : 0.f);
+            for (int e = 0; e < 4; ++e) g[e] = (sc != sc) ? g[e] : (t[e] > 0.f ? g[e] * sc : 0.f);
         }
         *reinterpret_cast<f32x4*>(p.dx + o) = f32x4{g[0], g[1], g[2], g[3]};
     }

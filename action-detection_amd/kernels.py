@@ -392,12 +392,11 @@ def detections(act, comp, reg, rel_prop, top_k, include_bg, nms_thresh, regress)
     combined = torch.empty((p, c), device=dev, dtype=torch.float32)
     dets = torch.zeros((c, max_det, 5), device=dev, dtype=torch.float64)
     counts = torch.zeros(c, device=dev, dtype=torch.int32)
-    ws = torch.zeros(2, device=dev, dtype=torch.int32)
-    lib.call("ssn_detections", _p(act), _p(comp), _p(reg), _p(rel_prop), _p(combined), _p(ws[:1]), _p(dets), _p(counts),
-             _p(ws[1:]), p, c, max_det, int(top_k), int(bool(include_bg)), float(nms_thresh), int(bool(regress)),
+    ws_bytes = int(lib.cdll.ssn_detections_workspace_bytes(p, c))
+    ws = torch.zeros((ws_bytes + 3) // 4, device=dev, dtype=torch.int32)
+    lib.call("ssn_detections", _p(act), _p(comp), _p(reg), _p(rel_prop), _p(combined), _p(dets), _p(counts), _p(ws),
+             ws_bytes, p, c, max_det, int(top_k), int(bool(include_bg)), float(nms_thresh), int(bool(regress)),
              _stream(lib, act))
-    if int(ws[1].item()):
-        raise RuntimeError("a class has more than 2048 detection candidates in one video")
     return combined, dets, counts
 
 

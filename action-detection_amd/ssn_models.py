@@ -245,8 +245,7 @@ class SSN(torch.nn.Module):
         raw_act_fc = self.activity_fc(activity_ft)
         raw_comp_fc = self.completeness_fc(completeness_ft)
 
-        # the reference's three nonzero() calls (ssn_models.py:275-282) -> one host read of prop_type,
-        # cached while the same prop_type tensor is fed again (so a step can be captured in a hipGraph)
+        # the reference's three nonzero() calls (ssn_models.py:275-282) -> one host read of prop_type
         dev = raw_act_fc.device
         act_indexer, comp_indexer, reg_indexer = self._row_indexers(prop_type, dev)
         target = target.reshape(-1).to(dev)
@@ -266,15 +265,27 @@ class SSN(torch.nn.Module):
                     FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), sel(target, comp_indexer))
 
     def _row_indexers(self, prop_type, dev):
-        key = (prop_type.data_ptr(), prop_type._version, tuple(prop_type.shape), str(dev))
+        """Rows of the activity / completeness / regression heads by proposal type (ssn_models.py:275-282).  The
+        reference recomputes ``nonzero()`` on every forward (three device syncs); here ``prop_type`` is read to the
+        host once per forward (no sync at all when it is a CPU tensor, as the DataLoader delivers it) and the device
+        index tensors are reused only while its CONTENTS are unchanged.  During hipGraph capture nothing can be read
+        back: the pattern of the last eager forward on the same tensor is used, and the graph is only valid for it."""
         cache = getattr(self, "_indexer_cache", None)
-        if cache is not None and cache[0] == key:
-            return cache[1]
-        type_host = prop_type.reshape(-1).cpu()
+        capturing = prop_type.is_cuda and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            key = (prop_type.data_ptr(), tuple(prop_type.shape), str(dev))
+            if cache is None or cache[0] != key:
+                raise RuntimeError("hipGraph capture of SSN.forward needs one eager forward with the same prop_type "
+                                   "tensor first (its proposal-type pattern is baked into the captured graph)")
+            return cache[2]
+        type_host = prop_type.detach().reshape(-1).cpu()
+        if cache is not None and cache[0][2] == str(dev) and torch.equal(cache[1], type_host):
+            self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), cache[1], cache[2])
+            return cache[2]
         idx = (torch.nonzero((type_host == 0) | (type_host == 2)).reshape(-1).to(dev),
                torch.nonzero((type_host == 0) | (type_host == 1)).reshape(-1).to(dev),
                torch.nonzero(type_host == 0).reshape(-1).to(dev))
-        self._indexer_cache = (key, idx)
+        self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), type_host.clone(), idx)
         return idx
 
     def test_forward(self, input):

@@ -17,13 +17,14 @@ from torch import nn
 PIXEL_STD = 74.0  # std of (uniform 0..255 pixel - mean): the first conv is scaled for this input range
 
 
-def init_backbone_synthetic(base_model, seed=1234):
+def init_backbone_synthetic(base_model, seed=1234, negative_gamma_frac=0.0):
     """He-normal conv weights, small biases, non-trivial frozen-BN statistics.
 
     A real BN-Inception checkpoint absorbs the 0..255 pixel scale in its first conv / BN; the
     synthetic one does the same by dividing the first conv's He-normal weights by PIXEL_STD, so
     activations stay O(1) through all 69 layers and a few SGD steps at the reference's default
-    lr=0.001 remain finite.
+    lr=0.001 remain finite.  ``negative_gamma_frac``: fraction of BN scales whose sign is flipped (trained
+    checkpoints do contain negative gammas; the fused ReLU/BN backward must keep their sign).
     """
     rng = np.random.RandomState(seed)
     mods = sorted(((n, m) for n, m in base_model.named_modules()), key=lambda t: t[0])
@@ -39,7 +40,11 @@ def init_backbone_synthetic(base_model, seed=1234):
                     m.bias.copy_(torch.from_numpy((rng.standard_normal(m.bias.shape) * 0.01).astype(np.float32)))
             elif isinstance(m, nn.BatchNorm2d):
                 c = m.num_features
-                m.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)))
+                gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+                if negative_gamma_frac > 0:
+                    flip = np.random.RandomState(seed + 7 + c).uniform(0, 1, c) < negative_gamma_frac
+                    gamma = np.where(flip, -gamma, gamma).astype(np.float32)
+                m.weight.copy_(torch.from_numpy(gamma))
                 m.bias.copy_(torch.from_numpy((rng.standard_normal(c) * 0.1).astype(np.float32)))
                 m.running_mean.copy_(torch.from_numpy((rng.standard_normal(c) * 0.1).astype(np.float32)))
                 m.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)))

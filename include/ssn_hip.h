@@ -21,6 +21,8 @@
 #ifndef SSN_HIP_H
 #define SSN_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -81,7 +83,8 @@ int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C,
  * dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S].
  * mask_y / mask_scale (optional, both or neither): when this call is the last writer of dx, the
  * backward of the ReLU + frozen BN that produced the tensor dx belongs to is fused into the store:
- * dx <- dx * (mask_y > 0) * mask_scale[ci]   (mask_scale[ci] < 0: not a ReLU output, dx <- dx * |scale|).
+ * dx <- dx * (mask_y > 0) * mask_scale[ci]   (mask_scale[ci] NaN: not a ReLU output, dx unchanged;
+ * finite scales of either sign are applied as they are).
  * wt_layout = ssn_conv_dgrad_layout(...): 2 selects the parity-ordered stride-2 path (3x3/s2/p1, even input),
  * whose weights must have been packed with transposed = 2; otherwise 1. */
 int ssn_conv_dgrad_layout(int ksize, int stride, int pad, int H, int W);
@@ -224,12 +227,17 @@ int ssn_frames_crop_normalize(const unsigned char* src, float* dst, int n_img, i
 /* Detection post-processing of one video (csrc/detect.hip): score fusion softmax(activity)[1:] * exp(completeness),
  * top-k over all (proposal, class) pairs, temporal NMS per class and location regression
  * (eval_detection_results.py:91-128, 167-178; ops/utils.py:56-82).  act [P][C+1], comp [P][C], reg [P][C][2] or NULL
- * (fp32); rel_prop [P][2] fp64 normalised spans; combined [P][C] fp32 out; thr_ws / error: one 32-bit device word
- * each; dets [C][max_det][5] fp64 = (start, end, score, loc, dur) in descending score order, counts [C] int32.
- * include_bg: softmax over all C+1 activity scores (the reference's top_k <= 0 branch) instead of the C class
- * scores; top_k <= 0 keeps every pair; error[0] = 1 when a class has more than 2048 candidates. */
+ * (fp32); rel_prop [P][2] fp64 normalised spans; combined [P][C] fp32 out; dets [C][max_det][5] fp64 = (start, end,
+ * score, loc, dur) in descending score order, counts [C] int32; workspace: ssn_detections_workspace_bytes(P, C) bytes
+ * of device scratch.  include_bg: softmax over all C+1 activity scores (the reference's top_k <= 0 branch) instead of
+ * the C class scores; top_k <= 0 keeps every pair, otherwise EXACTLY top_k pairs are kept as np.argsort(...)[-top_k:]
+ * does (ties at the k-th score: the higher flat indices, i.e. a stable sort's choice).  Score ties inside a class:
+ * higher proposal index first (scores.argsort()[::-1] of a stable sort).  Non-finite scores are ordered as numpy
+ * orders them (NaN above +inf) and can never cause an out-of-range access.  Any P is accepted (P > 2048 sorts in the
+ * workspace instead of LDS). */
+size_t ssn_detections_workspace_bytes(int P, int C);
 int ssn_detections(const float* act, const float* comp, const float* reg, const double* rel_prop, float* combined,
-                   unsigned int* thr_ws, double* dets, int* counts, int* error, int P, int C, int max_det, int top_k,
+                   double* dets, int* counts, void* workspace, size_t ws_bytes, int P, int C, int max_det, int top_k,
                    int include_bg, double nms_thresh, int regress, hipStream_t stream);
 
 /* ------------------------------------------------------------------ heads

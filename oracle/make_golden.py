@@ -268,6 +268,114 @@ def golden_sampling():
     json.dump(out, open(os.path.join(OUT, "sampling_expected.json"), "w"))
 
 
+def _reference_functions(path, names):
+    """Compile the named top-level functions of a reference SCRIPT (one that parses argv and loads files at import
+    time, so it cannot be imported) from the file where it lies; returns the namespace they were defined in -- the
+    caller fills in the module globals they use.  Nothing is copied: the source is read and compiled at run time."""
+    import ast
+    tree = ast.parse(open(path).read(), path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names)
+    ns = {}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def golden_detection():
+    """eval_detection_results.py:91-128 (gen_detection_results), :158-171 (perform_regression) and
+    ops/utils.py:35-37, 56-82 (softmax, temporal_nms) -- the reference's own functions -- on seeded videos.  No case
+    holds two exactly equal fused scores (asserted), so numpy's unstable default sort cannot influence the result."""
+    from ops import utils as ref_utils
+    out = {}
+    cases = [  # P, C, top_k, nms, no_regression, with_reg, seed, spoil
+        (60, 6, 100, 0.2, False, True, 1, None),      # THUMOS14-style: top-k over all pairs
+        (40, 4, 0, 0.4, False, True, 2, None),        # all-pairs branch (softmax incl. background)
+        (30, 5, 10 ** 6, 0.3, True, True, 3, None),   # top_k > number of pairs, --no_regression
+        (25, 3, 20, 0.6, False, False, 4, None),      # no regression scores in the pickle (None)
+        (1, 3, 2, 0.5, False, True, 5, None),         # a single proposal
+        (50, 4, 40, 0.5, False, True, 6, "overflow"),  # completeness scores that overflow exp(): one inf, one NaN
+    ]
+    for ci, (p, c, top_k, thr, no_reg, with_reg, seed, spoil) in enumerate(cases):
+        rs = np.random.RandomState(100 + seed)
+        start = rs.uniform(0, 0.8, p)
+        rel = np.stack([start, np.minimum(start + rs.uniform(0.02, 0.5, p), 1.0)], axis=1)
+        act = (rs.standard_normal((p, c + 1)) * 2).astype(np.float32)
+        comp = rs.standard_normal((p, c)).astype(np.float32)
+        reg = (rs.standard_normal((p, c, 2)) * 0.3).astype(np.float32) if with_reg else None
+        if spoil == "overflow":
+            comp[7, 1] = 95.0            # exp -> inf, times a positive softmax -> inf
+            comp[11, 2] = 120.0          # exp -> inf ...
+            act[11, :] = [0, 0, 0, -200, 0][:c + 1]     # ... times a softmax that underflows to 0 -> NaN
+        ns = _reference_functions(os.path.join(REF, "eval_detection_results.py"),
+                                  ["gen_detection_results", "perform_regression"])
+        ns.update(np=np, softmax=ref_utils.softmax, num_class=c, top_k=top_k, cls_score_dict=None,
+                  dataset_detections=[dict() for _ in range(c)])
+        with np.errstate(all="ignore"):
+            ns["gen_detection_results"]("v", (rel[None], act, comp, reg))
+            dets = [{k: ref_utils.temporal_nms(v, thr) for k, v in d.items()} for d in ns["dataset_detections"]]
+            if not no_reg:
+                dets = [{k: ns["perform_regression"](v) for k, v in d.items()} for d in dets]
+            sm = ref_utils.softmax(act)[:, 1:] if top_k <= 0 else ref_utils.softmax(act[:, 1:])
+            combined = sm * np.exp(comp)
+        flat = combined.ravel()
+        finite = flat[np.isfinite(flat)]
+        assert len(np.unique(finite)) == len(finite) and (~np.isfinite(flat)).sum() <= 2, "exact ties in fixture %d" % ci
+        rows = [d["v"] if "v" in d else np.zeros((0, 5)) for d in dets]
+        out.update({"d%d_rel" % ci: rel, "d%d_act" % ci: act, "d%d_comp" % ci: comp,
+                    "d%d_reg" % ci: reg if with_reg else np.zeros(0, np.float32),
+                    "d%d_cfg" % ci: np.array([p, c, top_k, int(no_reg), int(with_reg)], np.int64),
+                    "d%d_thr" % ci: np.array([thr]), "d%d_counts" % ci: np.array([len(r) for r in rows], np.int64),
+                    "d%d_dets" % ci: np.concatenate(rows, 0), "d%d_combined" % ci: combined.astype(np.float32)})
+    out["n_cases"] = np.array([len(cases)])
+    np.savez_compressed(os.path.join(OUT, "ref_detection.npz"), **out)
+
+
+def golden_transforms():
+    """transforms.py on PIL images: the test chain GroupOverSample -> Stack(roll) -> ToTorchFormatTensor(div=False) ->
+    GroupNormalize (ssn_test.py:101-112, ssn_dataset.py:434-450) and the training augmentation
+    GroupMultiScaleCrop + GroupRandomHorizontalFlip (ssn_models.py:386-395) with seeded `random`."""
+    import random
+    from PIL import Image
+    import transforms as ref_tf
+    rs = np.random.RandomState(3)
+    out = {}
+
+    def chain(group, roll, mean, std):
+        x = ref_tf.Stack(roll=roll)(group)
+        x = ref_tf.ToTorchFormatTensor(div=False)(x)
+        return ref_tf.GroupNormalize(list(mean), list(std))(x).numpy()
+
+    rgb = rs.randint(0, 256, size=(3, 32, 43, 3)).astype(np.uint8)
+    flow = rs.randint(0, 256, size=(10, 30, 40)).astype(np.uint8)
+    out["rgb_frames"], out["flow_frames"] = rgb, flow
+    rgb_imgs = [Image.fromarray(f, "RGB") for f in rgb]
+    flow_imgs = [Image.fromarray(f, "L") for f in flow]
+    out["over_rgb_roll"] = chain(ref_tf.GroupOverSample(24)(rgb_imgs), True, [104, 117, 128], [1])
+    out["over_rgb_std"] = chain(ref_tf.GroupOverSample((28, 20))(rgb_imgs), False, [0.485, 0.456, 0.406],
+                                [0.229, 0.224, 0.225])
+    out["over_flow"] = chain(ref_tf.GroupOverSample(22)(flow_imgs), True, [128], [1])
+    # training augmentation (host side; PIL crop + bilinear resize + flip) at several seeds
+    big_rgb = rs.randint(0, 256, size=(2, 64, 86, 3)).astype(np.uint8)
+    big_flow = rs.randint(0, 256, size=(4, 64, 86)).astype(np.uint8)
+    out["aug_rgb_frames"], out["aug_flow_frames"] = big_rgb, big_flow
+    for tag, imgs, scales, is_flow in (("rgb", [Image.fromarray(f, "RGB") for f in big_rgb], [1, .875, .75, .66], False),
+                                       ("flow", [Image.fromarray(f, "L") for f in big_flow], [1, .875, .75], True)):
+        for seed in range(6):
+            random.seed(seed)
+            g = ref_tf.GroupMultiScaleCrop(56, scales)(imgs)
+            g = ref_tf.GroupRandomHorizontalFlip(is_flow=is_flow)(g)
+            out["aug_%s_%d" % (tag, seed)] = np.stack([np.asarray(im) for im in g])
+    # crop-parameter sampling alone, for a sweep of frame sizes (no pixels involved)
+    rec = []
+    for (w, h) in ((340, 256), (320, 240), (455, 256), (256, 256), (224, 224)):
+        for seed in range(8):
+            random.seed(1000 + seed)
+            cw, ch, ow, oh = ref_tf.GroupMultiScaleCrop(224, [1, .875, .75, .66])._sample_crop_size((w, h))
+            rec.append([w, h, 1000 + seed, cw, ch, ow, oh, int(random.random() < 0.5)])
+    out["crop_params"] = np.array(rec, np.int64)
+    np.savez_compressed(os.path.join(OUT, "ref_transforms.npz"), **out)
+
+
 def main():
     assert os.path.isdir(REF), "this script needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -281,7 +389,8 @@ def main():
     import binary_model as ref_binary
     golden_binary(ref_binary, ref_ops)
     golden_proposal_io()
-    golden_sampling()
+    golden_detection()
+    golden_transforms()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -594,7 +594,13 @@ def detections_for_video(rel_prop, act_scores, comp_scores, reg_scores, num_clas
                          no_regression=False):
     """The per-video part of /root/reference/eval_detection_results.py: gen_detection_results (:91-128, the two
     branches without external class scores), temporal_nms (ops/utils.py:56-82) and perform_regression (:167-178).
-    -> {cls: float64 array [n, 5] = (start, end, score, loc, dur)}"""
+    -> {cls: float64 array [n, 5] = (start, end, score, loc, dur)}
+
+    The reference calls ``np.argsort`` with numpy's default (unstable) sort, so WHICH of several exactly equal scores
+    it keeps / ranks first is an accident of the numpy build.  This restatement -- and the product -- pin the choice a
+    stable sort makes (``kind="stable"``): of scores tied at the k-th place the higher flat indices survive the top-k,
+    and inside a class tied scores are visited higher proposal index first.  Pinned against the reference's own
+    functions by tests/golden/ref_detection.npz (cases without exact ties, where the sort kind cannot matter)."""
     def softmax(scores):                                           # ops/utils.py:35-37
         es = np.exp(scores - scores.max(axis=-1)[..., None])
         return es / es.sum(axis=-1)[..., None]
@@ -602,7 +608,7 @@ def detections_for_video(rel_prop, act_scores, comp_scores, reg_scores, num_clas
     def temporal_nms(bboxes, thresh):                              # ops/utils.py:56-82
         t1, t2, scores = bboxes[:, 0], bboxes[:, 1], bboxes[:, 2]
         durations = t2 - t1
-        order = scores.argsort()[::-1]
+        order = scores.argsort(kind="stable")[::-1]
         keep = []
         while order.size > 0:
             i = order[0]
@@ -629,7 +635,7 @@ def detections_for_video(rel_prop, act_scores, comp_scores, reg_scores, num_clas
                                       reg_scores[:, i, 1][:, None]), axis=1)
     else:
         combined = softmax(act_scores[:, 1:]) * np.exp(comp_scores)
-        for k in np.argsort(combined.ravel())[-top_k:]:
+        for k in np.argsort(combined.ravel(), kind="stable")[-top_k:]:
             cls, prop_idx = k % num_class, k // num_class
             row = [rel_prop[prop_idx, 0], rel_prop[prop_idx, 1], combined[prop_idx, cls],
                    reg_scores[prop_idx, cls, 0], reg_scores[prop_idx, cls, 1]]

@@ -1,11 +1,23 @@
-"""Detection post-processing (csrc/detect.hip) against the oracle's restatement of eval_detection_results.py +
-ops/utils.temporal_nms: same kept boxes per class in the same order, fused scores / regressed spans to 1e-6."""
+"""Detection post-processing (csrc/detect.hip).
+
+Pinned three ways: (1) against tests/golden/ref_detection.npz -- outputs of the REFERENCE's own
+gen_detection_results / temporal_nms / perform_regression (oracle/make_golden.py:golden_detection), including a video
+whose completeness scores overflow exp() (inf and NaN fused scores); (2) against the oracle's restatement on larger
+seeded cases (same kept boxes per class in the same order, fused scores / regressed spans to 2e-6) and on exact score
+ties, where the restatement fixes the choice of a stable sort; (3) robustness: whatever the scores are (inf, NaN, huge)
+the call returns and every kept box is one of the input proposals -- round 1's kernel sorted raw floats, which is not a
+total order under NaN, and could index 16 GB out of bounds."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
 import action_detection_amd  # noqa: F401
 import ssn_oracle as O
 from action_detection_amd.detection_post import DetectionPostProcessor
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def synthetic_video(rs, p, c):
@@ -18,19 +30,27 @@ def synthetic_video(rs, p, c):
     return rel, act, comp, reg
 
 
+def run_product(backend, rel, act, comp, reg, c, thr, top_k, no_reg):
+    post = DetectionPostProcessor(c, thr, top_k, no_reg)
+    return post.process_video(torch.from_numpy(rel[None]), backend.put(torch.from_numpy(act)),
+                              backend.put(torch.from_numpy(comp)),
+                              backend.put(torch.from_numpy(reg)) if reg is not None else None, device=backend.device)
+
+
+def assert_same(got, ref, tol=2e-6):
+    assert sorted(got) == sorted(ref), (sorted(got), sorted(ref))
+    for cls in ref:
+        assert got[cls].shape == ref[cls].shape, (cls, got[cls].shape, ref[cls].shape)
+        assert np.allclose(got[cls], ref[cls], rtol=tol, atol=1e-9, equal_nan=True), cls
+
+
 def check(backend, p, c, top_k, thr, no_reg, seed, with_reg=True):
     rs = np.random.RandomState(seed)
     rel, act, comp, reg = synthetic_video(rs, p, c)
     ref, ref_comb = O.detections_for_video(rel[None], act, comp, reg if with_reg else None, c, thr, top_k, no_reg)
-    post = DetectionPostProcessor(c, thr, top_k, no_reg)
-    got, comb = post.process_video(torch.from_numpy(rel[None]), backend.put(torch.from_numpy(act)),
-                                   backend.put(torch.from_numpy(comp)),
-                                   backend.put(torch.from_numpy(reg)) if with_reg else None, device=backend.device)
+    got, comb = run_product(backend, rel, act, comp, reg if with_reg else None, c, thr, top_k, no_reg)
     assert np.allclose(comb.cpu().numpy(), ref_comb, rtol=2e-6, atol=1e-30)
-    assert sorted(got) == sorted(ref), (sorted(got), sorted(ref))
-    for cls in ref:
-        assert got[cls].shape == ref[cls].shape, (cls, got[cls].shape, ref[cls].shape)
-        assert np.allclose(got[cls], ref[cls], rtol=2e-6, atol=1e-9), cls
+    assert_same(got, ref)
 
 
 def test_detections_match_reference_logic(backend):
@@ -40,9 +60,104 @@ def test_detections_match_reference_logic(backend):
         check(backend, 187, 100, 60, 0.6, False, 2)
         check(backend, 300, 20, 0, 0.4, False, 3)
         check(backend, 1500, 3, 0, 0.7, False, 7)
+        check(backend, 5000, 4, 0, 0.3, False, 8)           # more than 2048 candidates per class: sorted in the workspace
+        check(backend, 3000, 6, 9000, 0.5, False, 9)
     # (the emulator runs every barrier of the sort / suppression loops through fibers: small cases only)
     check(backend, 24, 6, 50, 0.2, False, 1)
     check(backend, 20, 4, 0, 0.4, False, 3)
     check(backend, 16, 5, 10 ** 6, 0.3, True, 4)          # top_k larger than the number of pairs, no regression
     check(backend, 12, 3, 20, 0.5, False, 5, with_reg=False)
     check(backend, 1, 3, 2, 0.5, False, 6)
+    check(backend, 2100, 2, 3000, 0.5, False, 9)          # > 2048 candidates per class (workspace path)
+
+
+def golden_cases():
+    d = np.load(os.path.join(GOLDEN, "ref_detection.npz"))
+    for ci in range(int(d["n_cases"][0])):
+        p, c, top_k, no_reg, with_reg = (int(v) for v in d["d%d_cfg" % ci])
+        counts = d["d%d_counts" % ci]
+        rows, ref, o = d["d%d_dets" % ci], {}, 0
+        for cls, n in enumerate(counts):
+            if n:
+                ref[cls] = rows[o:o + n]
+            o += n
+        yield dict(rel=d["d%d_rel" % ci], act=d["d%d_act" % ci], comp=d["d%d_comp" % ci],
+                   reg=d["d%d_reg" % ci] if with_reg else None, c=c, top_k=top_k, no_reg=bool(no_reg),
+                   thr=float(d["d%d_thr" % ci][0]), ref=ref, combined=d["d%d_combined" % ci])
+
+
+def test_oracle_restatement_matches_reference_functions():
+    """(a)-tier: the numpy restatement against what the reference's own functions returned."""
+    for k in golden_cases():
+        with np.errstate(all="ignore"):
+            got, comb = O.detections_for_video(k["rel"][None], k["act"], k["comp"], k["reg"], k["c"], k["thr"],
+                                               k["top_k"], k["no_reg"])
+        assert np.array_equal(comb.astype(np.float32), k["combined"], equal_nan=True)
+        assert_same(got, k["ref"], tol=0)
+
+
+def test_product_matches_reference_functions(backend):
+    """The HIP path against the reference's own outputs (incl. the overflowed video: inf and NaN fused scores)."""
+    for k in golden_cases():
+        got, comb = run_product(backend, k["rel"], k["act"], k["comp"], k["reg"], k["c"], k["thr"], k["top_k"],
+                                k["no_reg"])
+        assert np.allclose(comb.cpu().numpy(), k["combined"], rtol=2e-6, atol=1e-30, equal_nan=True)
+        assert_same(got, k["ref"])
+
+
+def test_exact_ties_follow_a_stable_sort(backend):
+    """Equal fused scores (duplicated proposals' scores): exactly top_k pairs survive, the higher flat indices of the
+    ties at the k-th place; inside a class the higher proposal index is visited first."""
+    rs = np.random.RandomState(21)
+    p, c = 18, 3
+    rel, act, comp, reg = synthetic_video(rs, p, c)
+    for dst, src in ((3, 2), (9, 2), (10, 5), (17, 16)):       # rows with identical scores, different spans
+        act[dst], comp[dst] = act[src], comp[src]
+    for top_k in (0, 7, 12, 20, 31, 40):
+        ref, _ = O.detections_for_video(rel[None], act, comp, reg, c, 0.45, top_k, False)
+        got, comb = run_product(backend, rel, act, comp, reg, c, 0.45, top_k, False)
+        if top_k > 0:
+            # exactly top_k candidates entered NMS: every pair is either kept or suppressed by a kept one of its class
+            # (cannot be read off the output), so check the number the oracle kept instead
+            assert sum(len(v) for v in got.values()) == sum(len(v) for v in ref.values())
+        assert_same(got, ref)
+    # all scores equal: top-k is decided by index alone
+    act[:], comp[:] = 0.25, -1.0
+    ref, _ = O.detections_for_video(rel[None], act, comp, reg, c, 0.9, 10, False)
+    got, _ = run_product(backend, rel, act, comp, reg, c, 0.9, 10, False)
+    assert_same(got, ref)
+
+
+@pytest.mark.parametrize("spoil", ["inf_comp", "nan_everywhere", "huge_act", "neg_inf", "mixed"])
+def test_non_finite_scores_never_fault(backend, spoil):
+    """Overflowed / non-finite network outputs: the call returns, counts are sane and every kept row is an input
+    proposal.  Where numpy's own result is well defined (at most one NaN per class, no ties) it is matched."""
+    rs = np.random.RandomState(31)
+    p, c = (600, 20) if backend.is_gpu else (40, 4)
+    rel, act, comp, reg = synthetic_video(rs, p, c)
+    if spoil == "inf_comp":
+        comp[:] = 100.0 + rs.standard_normal(comp.shape).astype(np.float32)          # exp -> inf everywhere
+    elif spoil == "nan_everywhere":
+        comp[:] = np.nan
+    elif spoil == "huge_act":
+        act *= 1e30
+        comp *= 60
+    elif spoil == "neg_inf":
+        act[:, 1:] = -np.inf
+        comp[::3] = np.inf
+    else:
+        comp[rs.randint(0, p, 5), rs.randint(0, c, 5)] = np.inf
+        act[rs.randint(0, p, 5), rs.randint(0, c + 1, 5)] = np.nan
+        comp[rs.randint(0, p, 5), rs.randint(0, c, 5)] = -np.inf
+    for top_k in (0, 5 * c):
+        got, comb = run_product(backend, rel, act, comp, reg, c, 0.4, top_k, False)
+        total = 0
+        for cls, rows in got.items():
+            assert 0 <= cls < c and 0 < len(rows) <= p
+            total += len(rows)
+            # loc / dur columns are copied from reg[p, cls]: every kept row must be one of the input proposals
+            keys = {(np.float32(a).tobytes(), np.float32(b).tobytes()) for a, b in reg[:, cls]}
+            for r in rows:
+                assert (np.float32(r[3]).tobytes(), np.float32(r[4]).tobytes()) in keys
+        if top_k:
+            assert total <= top_k

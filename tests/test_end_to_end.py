@@ -12,13 +12,12 @@ import ssn_oracle as O
 from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic
 from test_kernels import rel_err
 
-# OPEN ISSUE (end of round 1): the first GPU run of this file got through the whole tester chain (it stopped at a
-# near-tie in the detection comparison, since fixed by spreading the scores), the second run -- both tests, head weights
-# with std 1.0, i.e. exp() overflow in the fused scores -- ended in a fatal error of the process, and the round's GPU
-# budget was spent before it could be diagnosed.  Every component used here has its own passing GPU test; the chain is
-# opt-in until the crash is understood:  SSN_E2E=1 python -m pytest tests/test_end_to_end.py -m gpu
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SSN_E2E") != "1", reason="opt-in (SSN_E2E=1): see the note above")]
+# History: at the end of round 1 the second GPU run of this file (head weights with std 1.0, i.e. exp() overflow in the
+# fused scores) killed the process.  Cause: csrc/detect.hip sorted raw float scores -- not a total order once NaNs
+# (inf * 0) appear -- so the bitonic network could move its padding entries (index 0x7fffffff) in front of real ones and
+# the NMS stage read the proposal table ~16 GB out of bounds.  The kernel now sorts monotone integer keys (NaN on top,
+# as numpy orders it) and clamps every index; test_tester_chain_overflowed_scores is the regression test.
+pytestmark = [pytest.mark.gpu]
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -28,7 +27,7 @@ def frame_pixels(video_id, idx, h=256, w=340):
     return rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
 
 
-def test_tester_chain(hip_library):
+def _tester_chain(head_std, strict):
     from action_detection_amd.dense_test import DenseTester
     from action_detection_amd.detection_post import DetectionPostProcessor
     from action_detection_amd.input_pipeline import GpuFrameTransform
@@ -42,7 +41,7 @@ def test_tester_chain(hip_library):
     torch.manual_seed(0)
     net = SSN(num_class, 2, 5, 2, "RGB", test_mode=True, stpp_cfg=(1, 1, 1))
     init_backbone_synthetic(net.base_model)
-    init_heads_synthetic(net, std=0.2)      # spread scores (no near-ties at the top-k / NMS decisions), no overflow
+    init_heads_synthetic(net, std=head_std)
     oracle = O.OracleSSN(num_class, 2, 5, 2, "RGB", test_mode=True, stpp_cfg=(1, 1, 1))
     oracle.load_state_dict(net.state_dict())
     net.prepare_test_fc()
@@ -64,17 +63,37 @@ def test_tester_chain(hip_library):
     stats = np.array([[0.05, -0.1], [0.8, 0.6]])
     tester = DenseTester(net, num_class, stats=stats, tick_batch=3)
     act, comp, reg, out = tester.score_video(gpu_batches(), len(ticks), torch.from_numpy(pticks), torch.from_numpy(scaling))
-    r_act, r_comp, r_reg, r_out = O.dense_test_video(oracle, cpu_batches(), len(ticks), pticks, scaling, num_class, stats=stats)
-    assert rel_err(out, torch.from_numpy(r_out)) < 1e-4 and rel_err(act, torch.from_numpy(r_act)) < 1e-4
-    assert rel_err(comp, torch.from_numpy(r_comp)) < 1e-4 and rel_err(reg, torch.from_numpy(r_reg)) < 1e-4
+    if strict:
+        r_act, r_comp, r_reg, r_out = O.dense_test_video(oracle, cpu_batches(), len(ticks), pticks, scaling, num_class,
+                                                         stats=stats)
+        assert rel_err(out, torch.from_numpy(r_out)) < 1e-4 and rel_err(act, torch.from_numpy(r_act)) < 1e-4
+        assert rel_err(comp, torch.from_numpy(r_comp)) < 1e-4 and rel_err(reg, torch.from_numpy(r_reg)) < 1e-4
     post = DetectionPostProcessor(num_class, 0.6, top_k=60)
-    dets, _ = post.process_video(torch.from_numpy(rel), act, comp, reg)
+    dets, combined = post.process_video(torch.from_numpy(rel), act, comp, reg)
+    torch.cuda.synchronize()
+    if not strict:
+        # overflowed scores (inf / NaN, many exact ties at inf): the call must come back with sane rows
+        assert not np.isfinite(combined.cpu().numpy()).all(), "this configuration is meant to overflow exp()"
+        n_kept = sum(len(v) for v in dets.values())
+        assert 0 < n_kept <= 60
+        for c, rows in dets.items():
+            assert 0 <= c < num_class and rows.shape[1] == 5
+            assert ((rows[:, 0] >= 0) & (rows[:, 1] <= 1)).all()
+        return
     # the reference chain on the product's scores (near-ties in the top-k make a scores-from-oracle comparison brittle)
     ref, _ = O.detections_for_video(rel, act.cpu().numpy(), comp.cpu().numpy(), reg.cpu().numpy(), num_class, 0.6, 60)
     assert sorted(dets) == sorted(ref)
     for c in ref:
         assert dets[c].shape == ref[c].shape, (c, dets[c].shape, ref[c].shape)
         assert np.allclose(dets[c], ref[c], rtol=1e-5, atol=1e-9)
+
+
+def test_tester_chain(hip_library):
+    _tester_chain(0.2, True)     # spread scores (no near-ties at the top-k / NMS decisions), no overflow
+
+
+def test_tester_chain_overflowed_scores(hip_library):
+    _tester_chain(1.0, False)    # the configuration that killed the process in round 1
 
 
 def test_trainer_chain(hip_library):

@@ -265,19 +265,21 @@ def test_clip_grad_norm(backend):
 
 
 def test_fused_relu_bn_backward_epilogues(backend):
-    """dgrad / max-pool backward as LAST writer: dx <- (dx_old + contribution) * (y > 0) * scale, |scale| where < 0."""
+    """dgrad / max-pool backward as LAST writer: dx <- (dx_old + contribution) * (y > 0) * scale with the scale's sign
+    (negative folded BN scales are real), unchanged where the scale is NaN (channel is not a ReLU output)."""
     g = torch.Generator().manual_seed(10)
     n, cin, h, cout, k, s, p = (4, 32, 14, 48, 3, 1, 1) if backend.is_gpu else (2, 6, 7, 40, 3, 1, 1)
     w = torch.randn(cout, cin, k, k, generator=g) * 0.1
     gy = torch.randn(n, cout, h, h, generator=g)
     y_in = torch.relu(torch.randn(n, cin, h, h, generator=g))
     scale = torch.rand(cin, generator=g) + 0.5
-    scale[::3] = -1.0                                         # pass-through channels
+    scale[1::3] *= -1.0                                       # negative folded scales (gamma < 0)
+    scale[::3] = float("nan")                                 # pass-through channels
+    passthru = torch.isnan(scale).view(1, -1, 1, 1)
     old = torch.randn(n, cin, h, h, generator=g)
     contrib = torch.nn.grad.conv2d_input((n, cin, h, h), w, gy, s, p)
     tot = old + contrib
-    ref = torch.where(scale.view(1, -1, 1, 1) < 0, tot * (-scale).view(1, -1, 1, 1),
-                      torch.where(y_in > 0, tot * scale.view(1, -1, 1, 1), torch.zeros_like(tot)))
+    ref = torch.where(passthru, tot, torch.where(y_in > 0, tot * scale.view(1, -1, 1, 1), torch.zeros_like(tot)))
     dx = backend.put(old.clone())
     K.conv_dgrad(K.full(backend.put(gy)), K.pack_weights(backend.put(w), True), K.full(dx), k, s, p, True,
                  mask_y=K.full(backend.put(y_in)), mask_scale=backend.put(scale))
@@ -289,7 +291,7 @@ def test_fused_relu_bn_backward_epilogues(backend):
     yp.backward(gp)
     am = backend.put(torch.zeros(yp.shape, dtype=torch.uint8))
     K.pool_fwd("max", K.full(backend.put(x.detach())), K.full(backend.put(torch.empty(yp.shape))), am, 3, 2, 0)
-    ref = torch.where(scale.view(1, -1, 1, 1) < 0, x.grad * (-scale).view(1, -1, 1, 1),
+    ref = torch.where(passthru, x.grad,
                       torch.where(x.detach() > 0, x.grad * scale.view(1, -1, 1, 1), torch.zeros_like(x.grad)))
     dxp = backend.put(torch.empty(x.shape))
     K.pool_bwd("max", K.full(backend.put(gp)), am, K.full(dxp), 3, 2, 0, False,
@@ -440,11 +442,12 @@ def test_conv_x6_fused_pair_and_mask(backend):
     gy = torch.randn(n, 64, h, h, generator=g)
     y_in = torch.relu(torch.randn(n, cin, h, h, generator=g))
     scale = torch.rand(cin, generator=g) + 0.5
-    scale[::3] = -1.0
+    scale[1::3] *= -1.0                         # negative folded scales keep their sign
+    scale[::3] = float("nan")                   # not a ReLU output: pass through
+    passthru = torch.isnan(scale).view(1, -1, 1, 1)
     old = torch.randn(n, cin, h, h, generator=g)
     tot = old + torch.nn.grad.conv2d_input((n, cin, h, h), wcat, gy, 1, 0)
-    ref = torch.where(scale.view(1, -1, 1, 1) < 0, tot * (-scale).view(1, -1, 1, 1),
-                      torch.where(y_in > 0, tot * scale.view(1, -1, 1, 1), torch.zeros_like(tot)))
+    ref = torch.where(passthru, tot, torch.where(y_in > 0, tot * scale.view(1, -1, 1, 1), torch.zeros_like(tot)))
     dx = backend.put(old.clone())
     K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), 1, 0, True, mask_y=K.full(backend.put(y_in)),
                     mask_scale=backend.put(scale))
@@ -534,12 +537,13 @@ def test_conv_x6_dgrad_s2(backend):
         prev = torch.randn(n, cin + 5, h, h, generator=g)
         act = torch.randn(n, cin + 5, h, h, generator=g)
         msc = torch.rand(cin, generator=g) + 0.5
-        msc[::3] = -msc[::3]                                     # channels that are not ReLU outputs
+        msc[1::3] = -msc[1::3]                                   # negative folded scales
+        msc[::3] = float("nan")                                  # channels that are not ReLU outputs
         wide = backend.put(prev.clone())
         K.conv_x6_dgrad_s2(K.full(gd), wt, K.ChanSlice(wide, 5, cin), True, tile,
                            mask_y=K.ChanSlice(backend.put(act), 5, cin), mask_scale=backend.put(msc))
         tot = prev[:, 5:].double() + x.grad
         m = msc.view(1, -1, 1, 1).double()
-        ref = torch.where(m < 0, tot * -m, torch.where(act[:, 5:].double() > 0, tot * m, torch.zeros_like(tot)))
+        ref = torch.where(torch.isnan(m), tot, torch.where(act[:, 5:].double() > 0, tot * m, torch.zeros_like(tot)))
         assert rel_err(wide[:, 5:], ref) < 2e-6, ("dgrad s2 acc+mask", n, cin, h, cout, tile)
         assert torch.equal(wide[:, :5].cpu(), prev[:, :5])

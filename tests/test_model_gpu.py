@@ -18,10 +18,10 @@ from test_kernels import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def build(modality, cfg, dropout=0.0, num_class=20):
+def build(modality, cfg, dropout=0.0, num_class=20, negative_gamma_frac=0.0):
     torch.manual_seed(0)
     m = SSN(num_class, 2, 5, 2, modality, dropout=dropout, stpp_cfg=cfg)
-    init_backbone_synthetic(m.base_model)
+    init_backbone_synthetic(m.base_model, negative_gamma_frac=negative_gamma_frac)
     init_heads_synthetic(m)
     o = O.OracleSSN(num_class, 2, 5, 2, modality, dropout=dropout, stpp_cfg=cfg)
     o.load_state_dict(m.state_dict())
@@ -78,6 +78,25 @@ def test_fwd_bwd_matches_oracle(hip_library, modality, cfg):
         if e > worst[1]:
             worst = (n1, e)
     print("worst fp32-vs-fp32 gradient rel err:", worst)
+
+
+def test_negative_bn_gammas(hip_library):
+    """A quarter of the frozen-BN scales negative (as in trained checkpoints): the fused ReLU/BN backward in the dgrad /
+    pool epilogues must apply them with their sign (round 1 used 'scale < 0' as its 'not a ReLU output' marker and
+    silently produced wrong backbone gradients for such channels)."""
+    m, o = build("RGB", (1, 1, 1), negative_gamma_frac=0.25)
+    assert sum(int((b.weight < 0).sum()) for b in o.modules() if isinstance(b, torch.nn.BatchNorm2d)) > 1000
+    batch = make_batch(2, "RGB", 20, seed=9)
+    out = m(*[t.cuda() for t in batch])
+    ref = o(*batch)
+    for i in (0, 2, 4):
+        assert rel_err(out[i], ref[i]) < 1e-4, (i, rel_err(out[i], ref[i]))
+    a, c, r = losses(out, 2)
+    (a + 0.1 * c + 0.1 * r).backward()
+    O.ssn_total_loss(ref, 2)[0].backward()
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), o.named_parameters()):
+        if p2.grad is not None:
+            assert rel_err(p1.grad, p2.grad) < 5e-3, (n1, rel_err(p1.grad, p2.grad))
 
 
 def test_single_video_forward_only(hip_library):
