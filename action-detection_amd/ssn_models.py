@@ -321,5 +321,18 @@ class SSN(torch.nn.Module):
         return self.input_size * 256 // 224
 
     def get_augmentation(self):
-        raise NotImplementedError(
-            "CPU image augmentation (transforms.py) is outside the hot path; see SURVEY.md section 2 row 7")
+        """The training augmentation the driver composes in front of Stack / ToTorchFormatTensor / GroupNormalize
+        (ssn_train.py:65, 106-111): scale-jittered fixed-position crop resized to the input size, then a random
+        horizontal flip -- PIL images on the loader workers, like the reference (`transforms` is this package's own
+        implementation, RNG-compatible with the reference's; see action_detection_amd/transforms.py)."""
+        from . import transforms as T
+        if self.modality == 'RGB':
+            return T.Compose([T.GroupMultiScaleCrop(self.input_size, [1, .875, .75, .66]),
+                              T.GroupRandomHorizontalFlip(is_flow=False)])
+        if self.modality == 'Flow':
+            return T.Compose([T.GroupMultiScaleCrop(self.input_size, [1, .875, .75]),
+                              T.GroupRandomHorizontalFlip(is_flow=True)])
+        if self.modality == 'RGBDiff':
+            return T.Compose([T.GroupMultiScaleCrop(self.input_size, [1, .875, .75]),
+                              T.GroupRandomHorizontalFlip(is_flow=False)])
+        raise ValueError("unknown modality {}".format(self.modality))

@@ -1,8 +1,15 @@
 #!/usr/bin/env python
 """SSN hot-path benchmark (BASELINE.json metric: proposals/s, 9-segment BNInception SSN fwd+bwd).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (one process per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or under a launcher
+
+Like the reference, where ONE command starts all GPUs (/root/reference/ssn_train.py:67, DataParallel over
+`args.gpus`), `python bench.py --gpus N` is self-contained: when no launcher has set WORLD_SIZE, the process
+re-executes itself N times (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT), one rank
+per GPU over RCCL, waits for the ranks, and rank 0 prints the JSON line.  On a box with fewer GPUs than ranks the
+control flow can still be exercised with SSN_BENCH_ONE_DEVICE=1 SSN_BENCH_BACKEND=gloo (all ranks share GPU 0; not
+a performance configuration).
 
 One "step" = the loop body of /root/reference/ssn_train.py:205-253 on synthetic THUMOS14-shape
 data that is already resident in HBM: SSN forward (backbone -> dropout -> STPP -> heads -> row
@@ -37,6 +44,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (no 2:1 sparsity)
 X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6  # algorithmic fp32 flops through the 3-way bf16 split (6 MFMA products)
 PMC_SUMMARY = "r1_pmc_summary_x6.json"
 FWD_GFLOP_PER_IMAGE = {"RGB": 4.063152128, "Flow": 4.613883904}  # 2 * conv MACs
+# conv1 (7x7/2, 64 outputs of 112x112): 2 * Cin * 49 * 64 * 112^2 flop that a dgrad would cost and nobody needs
+CONV1_DGRAD_GFLOP_PER_IMAGE = {"RGB": 2 * 3 * 49 * 64 * 112 * 112 / 1e9, "Flow": 2 * 10 * 49 * 64 * 112 * 112 / 1e9}
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 
 
 def parse():
@@ -47,8 +57,10 @@ def parse():
     ap.add_argument("--videos-per-gpu", type=int, default=4)
     ap.add_argument("--modality", default="RGB", choices=["RGB", "Flow"])
     ap.add_argument("--num-class", type=int, default=20)
-    ap.add_argument("--cpu-baseline-videos", type=int, default=2,
-                    help="videos in the CPU-oracle sample (0 disables the cpu_baseline leg)")
+    ap.add_argument("--cpu-baseline-videos", type=int, default=4,
+                    help="videos in the CPU-oracle sample (default: the full config-2 batch, 4 videos = 32 proposals; "
+                         "0 disables the cpu_baseline leg)")
+    ap.add_argument("--cpu-baseline-reps", type=int, default=3, help="timed repetitions of the CPU sample (median)")
     ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "f32"],
                     help="matrix path of the 1x1/3x3 convolutions: exact 3-way bf16 split on the bf16 MFMA (fp32-class "
                          "error, default) or the exact-f32 MFMA for every layer")
@@ -62,19 +74,62 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n):
+    """No launcher around us: start the N ranks ourselves (one process per GPU), as ssn_train.py:67 starts all its GPUs
+    from one command.  Children inherit stdout, so rank 0's JSON line is this command's output; the first failing rank
+    takes the others down with it."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher set WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     if os.environ.get("SSN_BENCH_ONE_DEVICE") == "1":   # tooling: several ranks on one GPU (control-flow check with gloo)
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: this box has %d GPU(s); --gpus %d needs one GPU per rank (SSN_BENCH_ONE_DEVICE=1 "
+                         "SSN_BENCH_BACKEND=gloo shares GPU 0 for a control-flow check)"
+                         % (rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("SSN_FORCE_ALLREDUCE") == "1"
+    backend = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -202,6 +257,9 @@ def main():
     prof = None
     if not args.no_kernel_events and rank == 0:
         prof = []
+        hbm_prof = []
+        import action_detection_amd.kernels as K_
+        K_.HBM_PROFILER = hbm_prof
         model.base_model.profiler = prof
         overlap, lanes = model.base_model.overlap_wgrad, model.base_model.branch_streams
         model.base_model.overlap_wgrad = False   # one kernel at a time, so an event pair times exactly one launch
@@ -215,6 +273,7 @@ def main():
         model.base_model.grad_ready_hook = hook
         model.base_model.overlap_wgrad, model.base_model.branch_streams = overlap, lanes
         model.base_model.profiler = None
+        K_.HBM_PROFILER = None
     fence()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -242,6 +301,8 @@ def main():
                    "global_batch_proposals": 8 * v * world, "images_per_gpu": 72 * v,
                    "parallelism": "dp%d" % world, "launch": launch,
                    "collectives": (args.collectives if use_dist else "none"),
+                   "ranks": (dist.get_world_size() if use_dist else 1),
+                   "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if use_dist else None),
                    "conv_precision": ("fp32 in/out; 1x1/3x3 multiplies = 6 bf16-MFMA products of exact 3-way bf16 operand "
                                       "splits (fp32-class error), 7x7 stem on the exact-f32 MFMA"
                                       if args.precision == "bf16x6" else "exact-f32 MFMA everywhere")},
@@ -316,10 +377,35 @@ def main():
                                          "frac_of_f32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                                          "ms_per_step": round(ms / args.steps, 3)}
             det["conv_ms_per_step"] = round(sum(f[1] for f in fam.values()) / args.steps, 3)
-            det["whole_step_frac_of_f32_mfma_peak"] = round(
-                (3 * FWD_GFLOP_PER_IMAGE[args.modality] * 72 * v * 1e9 / (elapsed / args.steps)) / 1e12
-                / F32_MFMA_PEAK_TFLOPS, 4)
+            # fwd + dgrad + wgrad = 3 x forward flops minus the data gradient of conv1, which is never computed
+            step_gflop = (3 * FWD_GFLOP_PER_IMAGE[args.modality] - CONV1_DGRAD_GFLOP_PER_IMAGE[args.modality]) * 72 * v
+            det["step_algorithmic_gflop"] = round(step_gflop, 1)
+            det["whole_step_tflops"] = round(step_gflop * 1e9 / (elapsed / args.steps) / 1e12, 2)
+            det["whole_step_frac_of_f32_mfma_peak"] = round(det["whole_step_tflops"] / F32_MFMA_PEAK_TFLOPS, 4)
+            det["whole_step_frac_of_bf16x6_peak"] = round(det["whole_step_tflops"] / X6_PEAK_TFLOPS, 4)
             result["roofline_detail"] = det
+
+        # ---------------- HBM-bound kernels of the path (STPP, heads, row selection, losses): achieved GB/s ----------
+        if prof is not None and hbm_prof:
+            hk = {}
+            for name, nbytes, s_, e_ in hbm_prof:
+                h = hk.setdefault(name, [0, 0.0, 0])
+                h[0] += nbytes
+                h[1] += s_.elapsed_time(e_)
+                h[2] += 1
+            out_h = {}
+            for name, (nbytes, ms, n) in sorted(hk.items()):
+                gbps = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                out_h[name] = {"launches_per_step": round(n / args.steps, 2), "bytes_per_launch": int(nbytes / n),
+                               "avg_us": round(1e3 * ms / n, 2), "gbps": round(gbps, 1),
+                               "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 5)}
+            tot_b = sum(h[0] for h in hk.values())
+            tot_ms = sum(h[1] for h in hk.values())
+            result["hbm_kernels"] = {"peak_gbps": HBM_PEAK_GBPS, "note": "algorithmic bytes (operands + results) / HIP-event "
+                                     "duration per launch; these launches move <= 5 MB each and are latency-bound",
+                                     "total_ms_per_step": round(tot_ms / args.steps, 4),
+                                     "total_gbps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1) if tot_ms else None,
+                                     "kernels": out_h}
 
         # ---------------- CPU baseline: the oracle on the host cores, bounded sample ----------------
         if args.cpu_baseline_videos > 0:
@@ -330,21 +416,28 @@ def main():
             sd = {k: t.detach().cpu() for k, t in model.state_dict().items()}
             oracle.load_state_dict(sd)
             oracle.train()
-            cb = make_batch(cv, args.modality, args.num_class, seed=10_000)
+            # the identical tensors the GPU was timed on (rank 0's batch) when the sample is the full per-GPU batch
+            cb = ([t.detach().cpu() for t in batch] if cv == v
+                  else make_batch(cv, args.modality, args.num_class, seed=10_000))
             times = []
-            for rep in range(2):
+            for rep in range(1 + max(1, args.cpu_baseline_reps)):     # first repetition = warm-up (allocator, threads)
                 c0 = time.perf_counter()
                 ref = oracle(*cb)
                 tot, _, _, _ = O.ssn_total_loss(ref, cv)
                 tot.backward()
                 times.append(time.perf_counter() - c0)
                 oracle.zero_grad(set_to_none=True)
-            ct = min(times)
+            times = sorted(times[1:])
+            ct = times[len(times) // 2]
             result["cpu_baseline"] = {
                 "value": round(8 * cv / ct, 4), "unit": "proposals/s", "cores": torch.get_num_threads(),
                 "kind": "port",
                 "sample": "oracle/ssn_oracle.py (torch-CPU fp32 restatement of the reference SSN), %d videos = %d "
-                          "proposals = %d frames, fwd + losses + bwd, best of 2 (%.2f s)" % (cv, 8 * cv, 72 * cv, ct),
+                          "proposals = %d frames%s, fwd + losses + bwd, median of %d after 1 warm-up (%.2f s); the "
+                          "reference's own classes (kind 'reference') need /root/reference, which does not exist on the "
+                          "GPU box -- the oracle is pinned to them by tests/golden"
+                          % (cv, 8 * cv, 72 * cv, " (the tensors of the timed GPU batch)" if cv == v else "",
+                             len(times), ct),
             }
             # parity in the same run (eval mode: dropout off on both sides)
             model.eval()

@@ -85,11 +85,12 @@ def _tester_chain(head_std, strict):
     assert sorted(dets) == sorted(ref)
     for c in ref:
         assert dets[c].shape == ref[c].shape, (c, dets[c].shape, ref[c].shape)
-        assert np.allclose(dets[c], ref[c], rtol=1e-5, atol=1e-9)
+        assert np.allclose(dets[c], ref[c], rtol=1e-5, atol=1e-9, equal_nan=True)
 
 
 def test_tester_chain(hip_library):
-    _tester_chain(0.2, True)     # spread scores (no near-ties at the top-k / NMS decisions), no overflow
+    _tester_chain(0.2, True)     # spread scores (no near-ties at the top-k / NMS decisions); a few fused scores still
+                                 # overflow to NaN with 100 classes, which both sides must order the same way
 
 
 def test_tester_chain_overflowed_scores(hip_library):
