@@ -51,6 +51,8 @@ _SIGS = {
     "ssn_conv_x6_pack_weights_rect": "ppiiiip",
     "ssn_pool_fwd": "ipppiiiiliiliiip",
     "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
+    "ssn_avgpool_affine_fwd": "ppppiiiiiliiliiip",
+    "ssn_channel_sum": "ppiiilp",
     "ssn_global_avgpool_fwd": "ppiiilp",
     "ssn_global_avgpool_bwd": "ppiiilip",
     "ssn_dropout_fwd": "ppplfupp",

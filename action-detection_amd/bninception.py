@@ -102,6 +102,8 @@ class BNInception(nn.Module):
         # "bf16x6": 1x1/3x3 convolutions (forward, stride-1 dgrad) multiply on the bf16 matrix cores with every fp32
         # operand split exactly into three bf16 terms (fp32-class accuracy, csrc/conv_x6.hip); "f32": exact-f32 MFMA
         self.conv_precision = "bf16x6"
+        # average-pool branches: pool BEHIND the 1x1 projection (see _move_avg_pools); False = the manifest's order
+        self.pool_after_projection = os.environ.get("SSN_POOL_ORDER", "") != "manifest"
 
     def _timed(self, family, lid, flops, fn):
         """Run one conv launch; with a profiler attached, bracket it with events on the current stream."""
@@ -227,7 +229,38 @@ class BNInception(nn.Module):
             else:
                 _, lid, src, dst = op
                 plan.append(dict(kind="gap", lid=lid, src=src, dst=dst))
+        if self.pool_after_projection:
+            plan = self._move_avg_pools(plan, shapes)
         return plan, shapes
+
+    @staticmethod
+    def _move_avg_pools(plan, shapes):
+        """<block>_pool (3x3 / s1 / p1 average, count_include_pad) -> <block>_pool_proj (1x1) + BN + ReLU is evaluated
+        as  relu(scale * avgpool(conv1x1_nobias(x)) + shift): a 1x1 convolution commutes with a zero-padded average
+        pool (both linear, the bias / folded BN shift is added after the pool either way).  The pool then runs on the
+        projection's 32-128 output channels instead of the block's 192-1056 input channels (4-8x less HBM traffic in
+        forward and backward), applies the affine + ReLU itself, and the projection joins the other 1x1 convolutions
+        that read the block input directly."""
+        out, i = [], 0
+        while i < len(plan):
+            op = plan[i]
+            nxt = plan[i + 1] if i + 1 < len(plan) else None
+            if (op["kind"] == "pool" and op["pool"] == "avg" and (op["k"], op["s"], op["p"]) == (3, 1, 1)
+                    and nxt is not None and nxt["kind"] == "conv" and nxt["src"] == op["dst"] and nxt["k"] == 1
+                    and len(nxt["lids"]) == 1
+                    and sum(1 for q in plan if q["src"] == op["dst"]) == 1):
+                z = nxt["lids"][0] + "_z"
+                cout = nxt["cout"]
+                shapes[z] = (cout, shapes[op["src"]][1], shapes[op["src"]][2])
+                out.append(dict(nxt, src=op["src"], src_c0=0, dst=z, dst_c0=0, raw=True,
+                                final=(nxt["dst"], nxt["dst_c0"])))
+                out.append(dict(kind="pool_aff", lid=op["lid"], conv=nxt["lids"][0], src=z, dst=nxt["dst"],
+                                dst_c0=nxt["dst_c0"], c=cout, k=3, s=1, p=1))
+                i += 2
+                continue
+            out.append(op)
+            i += 1
+        return out
 
     # ------------------------------------------------------------------ forward executor
     def _run_forward(self, x, keep):
@@ -265,10 +298,12 @@ class BNInception(nn.Module):
                 continue
             shift_of[op["lids"][0]] = shift_flat[soff:soff + op["cout"]]
             off = 0
+            # (a projection whose pool runs behind it: its BN affine belongs to the slice the POOL writes)
+            aff_dst, aff_c0 = op.get("final", (op["dst"], op["dst_c0"]))
             for lid, c in zip(op["lids"], op["couts"]):
                 conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
                 for lst, v in zip(fold, (conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                                         bn.running_var, bn.eps, scale_slice(op["dst"], op["dst_c0"] + off, c),
+                                         bn.running_var, bn.eps, scale_slice(aff_dst, aff_c0 + off, c),
                                          shift_flat[soff + off:soff + off + c])):
                     lst.append(v)
                 off += c
@@ -304,6 +339,8 @@ class BNInception(nn.Module):
 
         def lane_of(op):
             lid = op["lids"][0] if op["kind"] == "conv" else op["lid"]
+            if op["kind"] == "conv" and op.get("raw"):
+                return 2
             if "_double_3x3_1" in lid or "_double_3x3_2" in lid:
                 return 1
             if lid.endswith("_pool") or lid.endswith("_pool_proj"):
@@ -333,9 +370,10 @@ class BNInception(nn.Module):
                     lane_ctx.__enter__()
             if op["kind"] == "conv":
                 cout, cin, k, s, p = op["cout"], op["cin"], op["k"], op["s"], op["p"]
-                shift = shift_of[op["lids"][0]]
+                raw = bool(op.get("raw"))      # no affine / ReLU here: the pool behind this projection applies them
+                shift = None if raw else shift_of[op["lids"][0]]
                 wp = packed_fwd[op["lids"][0]]
-                scale = scale_slice(op["dst"], op["dst_c0"], cout)
+                scale = None if raw else scale_slice(op["dst"], op["dst_c0"], cout)
                 ho = shapes[op["dst"]][1]
                 hin = shapes[op["src"]][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
@@ -344,11 +382,11 @@ class BNInception(nn.Module):
                 if op["x6"]:
                     self._timed("conv_fwd_x6", op["lids"][0], flops,
                                 lambda: K.conv_x6_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
-                                                      True, tuned_tile("fwd6", n, cin, cout, k, s, hin)))
+                                                      not raw, tuned_tile("fwd6", n, cin, cout, k, s, hin)))
                 else:
                     self._timed("conv_fwd_f32", op["lids"][0], flops,
                                 lambda: K.conv_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
-                                                   True, tuned_tile("fwd", n, cin, cout, k, s, hin)))
+                                                   not raw, tuned_tile("fwd", n, cin, cout, k, s, hin)))
             elif op["kind"] == "pool":
                 c = op["c"]
                 out = ChanSlice(get(op["dst"]), op["dst_c0"], c)
@@ -358,6 +396,11 @@ class BNInception(nn.Module):
                     am = torch.empty((n, c, ho, wo), device=dev, dtype=torch.uint8)
                     argmax[op["lid"]] = am
                 K.pool_fwd(op["pool"], full(acts[op["src"]]), out, am, op["k"], op["s"], op["p"])
+            elif op["kind"] == "pool_aff":
+                c = op["c"]
+                K.avgpool_affine_fwd(full(acts[op["src"]]), ChanSlice(get(op["dst"]), op["dst_c0"], c),
+                                     scale_slice(op["dst"], op["dst_c0"], c), shift_of[op["conv"]], True,
+                                     op["k"], op["s"], op["p"])
             else:
                 feat = torch.empty((n, shapes[op["src"]][0]), device=dev, dtype=torch.float32)
                 K.gap_fwd(full(acts[op["src"]]), feat)
@@ -484,11 +527,23 @@ class BNInception(nn.Module):
                            full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=key in inited,
                            mask_y=my, mask_scale=ms)
                 inited.add(key)
+            elif op["kind"] == "pool_aff":
+                # y = relu(scale * avgpool(z) + shift): finish the slice's ReLU/BN backward if no later launch did, then
+                # the pool's backward (for 3x3 / s1 / p1 with count_include_pad: the same stencil on the gradient)
+                c = op["c"]
+                g = ChanSlice(grads[op["dst"]], op["dst_c0"], c)
+                if not is_masked(op["dst"], op["dst_c0"], c):
+                    K.relu_bn_bwd(g, ChanSlice(acts[op["dst"]], op["dst_c0"], c),
+                                  tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + c])
+                    masked.setdefault(op["dst"], []).append((op["dst_c0"], op["dst_c0"] + c))
+                K.pool_bwd("avg", g, None, full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=False)
+                inited.add((op["src"], 0))
             else:
                 cout, cin, k, s, p = op["cout"], op["cin"], op["k"], op["s"], op["p"]
                 lids = op["lids"]
                 g = ChanSlice(grads[op["dst"]], op["dst_c0"], cout)
-                if not is_masked(op["dst"], op["dst_c0"], cout):
+                raw = bool(op.get("raw"))       # bias-free, affine-free projection in front of a pool: nothing to undo
+                if not raw and not is_masked(op["dst"], op["dst_c0"], cout):
                     K.relu_bn_bwd(g, ChanSlice(acts[op["dst"]], op["dst_c0"], cout),
                                   tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + cout])
                 wo, wn, bo, bn = lay[lids[0]]
@@ -508,6 +563,15 @@ class BNInception(nn.Module):
                 else:
                     wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
                     run_wgrad = lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg)   # noqa: E731
+                if raw:
+                    # the bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's backward
+                    # (the wgrad kernel's bias column sums the pooled gradient, which differs at the image border)
+                    g_pre = ChanSlice(grads[op["final"][0]], op["final"][1], cout)
+                    inner_wgrad = run_wgrad
+
+                    def run_wgrad():
+                        inner_wgrad()
+                        K.channel_sum(g_pre, db)
                 wfam = "conv_wgrad_x6" if wg_x6[lids[0]] else "conv_wgrad_f32"
                 if use_side:
                     ready = torch.cuda.Event()

@@ -16,8 +16,11 @@
 //    registers afterwards (two compares per pixel and row).  Loads of the shifted taps reach up to (W+1) floats in
 //    front of x: the caller guarantees 256 readable bytes there (x_guard_bytes, see include/ssn_hip.h).
 //  * Both operands are activations, so both are split on the fly: once per element, by the thread that stages it
-//    (22 VALU per 4 pixels), written to LDS as three bf16 planes per row ([row][plane][16 k], 112-byte pitch) so
-//    that every MFMA operand is one conflict-free ds_read_b128.
+//    (22 VALU per 4 pixels), written to LDS as three bf16 planes ([operand][plane][row][16 k]: 32-byte rows, the two
+//    16-byte halves of a row swapped in every other group of 8 rows).  With that image every MFMA operand is one
+//    conflict-free ds_read_b128 AND the 8-byte plane stores of the staging threads (4 rows x 4 pixel groups per
+//    16-lane store group = 32 consecutive dwords) are conflict-free too -- the 112-byte row pitch of the first version
+//    put a third of the store cycles into bank conflicts (profiles/r1_pmc_summary_x6.json).
 //  * Loads run two chunks (2 x 16 pixels) ahead of the MFMAs in two alternating register sets: one chunk of MFMAs
 //    (~0.8k cycles per wave) does not cover a global round trip.
 #include "ssn_common.h"
@@ -47,31 +50,14 @@ struct WgX6Args {
 };
 
 constexpr int CP = 16;          // pixels per chunk = one bf16 MFMA k-step
-constexpr int PITCH_DW = 28;    // LDS row: 3 planes x 32 B + 16 B pad
+constexpr int ROW_DW = 8;       // LDS row of one plane: 16 bf16 = 32 B
 constexpr uint32_t OOB = 0x80000000u;
 constexpr uint32_t GUARD = 256u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ uint32_t wg_pack_hi16(uint32_t even, uint32_t odd) {
-    return __builtin_amdgcn_perm(odd, even, 0x07060302u);
-}
-__device__ __forceinline__ float wg_residual(float x) {
-    return x - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
-}
-// 4 consecutive k values -> 2 dwords per plane (k even in the low half)
-__device__ __forceinline__ void wg_split4(const float (&v)[4], uint32_t (&pl)[3][2]) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float x0 = v[2 * e], x1 = v[2 * e + 1];
-        const float r0 = wg_residual(x0), r1 = wg_residual(x1);
-        const float s0 = wg_residual(r0), s1 = wg_residual(r1);
-        pl[0][e] = wg_pack_hi16(__builtin_bit_cast(uint32_t, x0), __builtin_bit_cast(uint32_t, x1));
-        pl[1][e] = wg_pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
-        pl[2][e] = wg_pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
-    }
-}
+// (operand split: bf16_split3_pair of ssn_common.h -- round-to-nearest, exact in 3 terms)
 
 // tiles of 8+ MFMA tiles per wave run one wave per SIMD (up to 512 VGPRs): the elements to split per MFMA drop with
 // the tile size, which moves the kernel from VALU-bound towards matrix-bound
@@ -82,7 +68,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     constexpr int NAR = (BM + 63) / 64;   // G rows per thread (thread = one row x 4 pixels of a chunk)
     constexpr int NBR = (BN + 63) / 64;   // X rows per thread
     constexpr int KK = KS * KS;
-    constexpr int STAGE = (BM + BN) * PITCH_DW;
+    constexpr int STAGE = 3 * (BM + BN) * ROW_DW;   // [A plane 0..2][B plane 0..2], rows x 8 dwords each
     static_assert(WM * WN == 4, "4 waves per workgroup");
 
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
@@ -213,15 +199,14 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
             if (PAD) v[e] = (s.hw + (uint32_t)(2 * half + e) < (uint32_t)HW) ? v[e] : 0.f;
         }
         if (is_a && do_bias) rowsum[i] += v[0] + v[1];
-        const float r0 = wg_residual(v[0]), r1 = wg_residual(v[1]);
-        const float s0 = wg_residual(r0), s1 = wg_residual(r1);
-        plw[0][half] = wg_pack_hi16(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]));
-        plw[1][half] = wg_pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
-        plw[2][half] = wg_pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+        bf16_split3_pair(v[0], v[1], plw[0][half], plw[1][half], plw[2][half]);
         if (half == 1) {
-            uint32_t* dst = lds + buf * STAGE + (is_a ? 0 : BM * PITCH_DW) + (row0 + 64 * i) * PITCH_DW + pxg * 2;
+            // 16-byte half (pxg >> 1), swapped in odd groups of 8 rows (row0 and row0 + 64 i share bit 3)
+            uint32_t* dst = lds + buf * STAGE + (is_a ? 0 : 3 * BM * ROW_DW) + (row0 + 64 * i) * ROW_DW +
+                            (((pxg >> 1) ^ ((row0 >> 3) & 1)) * 4) + (pxg & 1) * 2;
 #pragma unroll
-            for (int pn = 0; pn < 3; ++pn) *reinterpret_cast<uint2*>(dst + pn * 8) = uint2{plw[pn][0], plw[pn][1]};
+            for (int pn = 0; pn < 3; ++pn)
+                *reinterpret_cast<uint2*>(dst + pn * (is_a ? BM : BN) * ROW_DW) = uint2{plw[pn][0], plw[pn][1]};
         }
     };
     auto store_chunk = [&](const Staged& s, int buf) {
@@ -241,17 +226,18 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     // multiply the chunk in LDS buffer `buf`; behind the MFMAs: split + store the staged chunk `st` into the other
     // buffer, then fetch chunk `next_chunk` into the register set that has just been drained
     auto compute = [&](int buf, Staged& st, int next_chunk) {
-        const uint32_t* As = lds + buf * STAGE + (wm * TM * 32 + li) * PITCH_DW + lh * 4;
-        const uint32_t* Bs = lds + buf * STAGE + BM * PITCH_DW + (wn * TN * 32 + li) * PITCH_DW + lh * 4;
+        const int half = (lh ^ ((li >> 3) & 1)) * 4;   // this lane's k-half of its row (tile rows are 32 apart: bit 3 = li's)
+        const uint32_t* As = lds + buf * STAGE + (wm * TM * 32 + li) * ROW_DW + half;
+        const uint32_t* Bs = lds + buf * STAGE + 3 * BM * ROW_DW + (wn * TN * 32 + li) * ROW_DW + half;
         bf16x8 af[3][TM], bf[3][TN];
 #pragma unroll
         for (int pn = 0; pn < 3; ++pn) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + i * 32 * PITCH_DW + pn * 8));
+                af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + i * 32 * ROW_DW + pn * BM * ROW_DW));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[pn][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + j * 32 * PITCH_DW + pn * 8));
+                bf[pn][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + j * 32 * ROW_DW + pn * BN * ROW_DW));
         }
         stage_begin(st);
         __builtin_amdgcn_sched_barrier(0);
@@ -376,7 +362,7 @@ int pick_tile(int M, int K) {
     return bc;
 }
 
-// co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 112 B, VGPRs as compiled)
+// co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 96 B, VGPRs as compiled)
 const int kOcc[NCFG] = {5, 4, 2, 3, 2, 3, 3, 2, 2, 1, 1, 1};
 
 void plan(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {

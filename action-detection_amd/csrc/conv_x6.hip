@@ -82,14 +82,14 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
             }
             v[e] = x;
         }
-        const float r0 = residual(v[0]), r1 = residual(v[1]);
-        const float s0 = residual(r0), s1 = residual(r1);
+        uint32_t p0, p1, p2;
+        bf16_split3_pair(v[0], v[1], p0, p1, p2);
         uint32_t* row = t.out[ti] + ((long)slab * M + m) * APITCH;
         const int swz = (m >> 1) & 7;
         const int khalf = kp >> 2, w = kp & 3;
-        row[((0 + khalf) ^ swz) * 4 + w] = pack_hi16(__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]));
-        row[((2 + khalf) ^ swz) * 4 + w] = pack_hi16(__builtin_bit_cast(uint32_t, r0), __builtin_bit_cast(uint32_t, r1));
-        row[((4 + khalf) ^ swz) * 4 + w] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+        row[((0 + khalf) ^ swz) * 4 + w] = p0;
+        row[((2 + khalf) ^ swz) * 4 + w] = p1;
+        row[((4 + khalf) ^ swz) * 4 + w] = p2;
         row[((6 + khalf) ^ swz) * 4 + w] = 0u;   // padding chunks
     }
 }

@@ -49,13 +49,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// bf16 pair (k even -> low half, k odd -> high half) of the top 16 bits of two fp32 values
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t even, uint32_t odd) {
-    return __builtin_amdgcn_perm(odd, even, 0x07060302u);
-}
-__device__ __forceinline__ float residual(float x) {
-    return x - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
-}
+// (operand split: bf16_pair_rne / bf16_pair_lo / bf16_pair_hi of ssn_common.h -- round-to-nearest, exact in 3 terms)
 
 // The 16-byte LDS-DMA form only exists for gfx950; hipcc's HOST pass (no target features) rejects it and then
 // silently drops the kernel's launch stub, so it is compiled for the device pass only.
@@ -292,14 +286,15 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
     float res[TN][8];
     // The split of pair e (k = 2e, 2e+1) of fragment j into its plane-1 and plane-2 dwords, as two half steps of
     // 5 VALU (what fits in the shadow of one MFMA): first residual + plane 1, then second residual + plane 2.
+    // (pl[0][j][e] of this slab must already hold the top plane: top_plane() runs before any half step.)
     auto split_half = [&](const Frags& f, int j, int e, int half) {
         if (half == 0) {
-            res[j][2 * e] = residual(f.raw[j][2 * e]);
-            res[j][2 * e + 1] = residual(f.raw[j][2 * e + 1]);
-            pl[1][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, res[j][2 * e]), __builtin_bit_cast(uint32_t, res[j][2 * e + 1]));
+            res[j][2 * e] = f.raw[j][2 * e] - bf16_pair_lo(pl[0][j][e]);
+            res[j][2 * e + 1] = f.raw[j][2 * e + 1] - bf16_pair_hi(pl[0][j][e]);
+            pl[1][j][e] = bf16_pair_rne(res[j][2 * e], res[j][2 * e + 1]);
         } else {
-            const float s0 = residual(res[j][2 * e]), s1 = residual(res[j][2 * e + 1]);
-            pl[2][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1));
+            const float s0 = res[j][2 * e] - bf16_pair_lo(pl[1][j][e]), s1 = res[j][2 * e + 1] - bf16_pair_hi(pl[1][j][e]);
+            pl[2][j][e] = bf16_pair_rne(s0, s1);
         }
     };
     // LDS -> registers: raw activations (a tap on padding reads the rows of zeros instead) and weight fragments, as
@@ -338,15 +333,14 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
 #pragma unroll
         for (int k = 0; k < NREAD; ++k) read_step(f, k);
     };
-    // top plane (one v_perm per k-pair); `all_planes`: also the two lower ones (the ping-pong groups split while the
+    // top plane (one v_cvt_pk_bf16_f32 per k-pair); `all_planes`: also the two lower ones (the ping-pong groups split while the
     // other group multiplies; a free-running wave does that in the shadow of its own MFMAs instead, see mfma)
     auto top_plane = [&](const Frags& f, bool all_planes) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pl[0][j][e] = pack_hi16(__builtin_bit_cast(uint32_t, f.raw[j][2 * e]),
-                                        __builtin_bit_cast(uint32_t, f.raw[j][2 * e + 1]));
+                pl[0][j][e] = bf16_pair_rne(f.raw[j][2 * e], f.raw[j][2 * e + 1]);
                 if (all_planes) {
                     split_half(f, j, e, 0);
                     split_half(f, j, e, 1);

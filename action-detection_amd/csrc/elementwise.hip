@@ -46,6 +46,29 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_kernel(float* dy, const float
     }
 }
 
+// out[c] = sum over images and pixels of g[n][c][:] -- one workgroup per channel, fixed summation order (deterministic):
+// the bias gradient of a projection whose pooling runs behind it (the weight-gradient kernel's own bias column would
+// sum the POOLED gradient, which differs at the image border).
+__global__ __launch_bounds__(1024) void channel_sum_kernel(const float* g, float* out, int N, int HW, long img_stride) {
+    __shared__ float red[16];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float* base = g + (long)c * HW;
+    float s = 0.f;
+    const long total = (long)N * HW;
+    for (long i = tid; i < total; i += 1024) {
+        const long n = i / HW, hw = i - n * HW;
+        s += base[n * img_stride + hw];
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[c] = t;
+    }
+}
+
 // Counter-based RNG for dropout: Philox-4x32-10 keyed by (seed), counter = element index / 4.
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
                                              uint32_t k1) {
@@ -219,6 +242,13 @@ extern "C" int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, in
                        dy_img_stride, y_img_stride, total, make_fastdiv((uint32_t)(C * HW)),
                        make_fastdiv((uint32_t)HW));
     SSN_CHECK_LAUNCH("relu_bn_bwd");
+    return SSN_OK;
+}
+
+extern "C" int ssn_channel_sum(const float* g, float* out, int N, int C, int HW, long img_stride, hipStream_t stream) {
+    SSN_CHECK_ARG(g && out && N >= 1 && C >= 1 && HW >= 1, "channel_sum: bad arguments");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C), dim3(1024), 0, stream, g, out, N, HW, img_stride);
+    SSN_CHECK_LAUNCH("channel_sum");
     return SSN_OK;
 }
 

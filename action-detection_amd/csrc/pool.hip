@@ -29,6 +29,11 @@ struct PoolArgs {
     int k, stride, pad;
     long total;
     uint32_t x_bytes;
+    // optional per-channel affine + ReLU on the pooled value (average pools only): the Inception "pool projection"
+    // branch computed as  relu(scale * avgpool(conv1x1(x)) + shift)  -- see ssn_avgpool_affine_fwd
+    const float* aff_scale;
+    const float* aff_shift;
+    int aff_relu;
     FastDiv div_chw, div_hw, div_w;
 };
 
@@ -81,6 +86,10 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
             if (he > p.H + PC) he = p.H + PC;
             if (we > p.W + PC) we = p.W + PC;
             out = s_ / (float)((he - h0) * (we - w0));
+            if (p.aff_scale) {
+                out = out * p.aff_scale[c] + p.aff_shift[c];
+                if (p.aff_relu) out = fmaxf(out, 0.f);
+            }
         }
         p.y[(long)n * p.y_img_stride + rem] = out;
     }
@@ -187,6 +196,9 @@ struct PoolVecArgs {
     const float* mask_y;      // avg backward only: fused ReLU + frozen-BN backward (see PoolBwdArgs)
     const float* mask_scale;
     long mask_img_stride;
+    const float* aff_scale;   // average forward only: per-channel affine + ReLU on the pooled value (see PoolArgs)
+    const float* aff_shift;
+    int aff_relu;
     FastDiv div_chq, div_hq, div_q;   // C*Ho*Wq, Ho*Wq, Wq  (Wq = Wo / V)
 };
 
@@ -282,6 +294,14 @@ __global__ __launch_bounds__(256) void pool3_vec_kernel(PoolVecArgs p) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) s_ += v[t / 3][e * SC + t % 3];
                 out[e] = s_ / 9.f;   // count_include_pad: a 3x3 / s1 / p1 window is never clipped by the padded extent
+            }
+        }
+        if (!MAX && !BWD && p.aff_scale) {
+            const float sc = p.aff_scale[c], sh = p.aff_shift[c];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                out[e] = out[e] * sc + sh;
+                if (p.aff_relu) out[e] = fmaxf(out[e], 0.f);
             }
         }
         const long o = (long)n * p.y_img_stride + (long)c * howo + (long)ho * p.Wo + wo0;
@@ -423,11 +443,14 @@ inline unsigned grid_for(long total, int cap = 65536) {
 
 }  // namespace
 
-extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W,
-                            long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
-                            hipStream_t stream) {
+static int pool_fwd_impl(int is_max, const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W,
+                         long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
+                         const float* aff_scale, const float* aff_shift, int aff_relu, hipStream_t stream) {
     SSN_CHECK_ARG(x && y, "pool_fwd: null pointer");
     PoolArgs a;
+    a.aff_scale = aff_scale;
+    a.aff_shift = aff_shift;
+    a.aff_relu = aff_relu;
     a.x = x;
     a.y = y;
     a.idx = (uint8_t*)argmax;
@@ -476,6 +499,9 @@ extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char*
         v.mask_y = nullptr;
         v.mask_scale = nullptr;
         v.mask_img_stride = 0;
+        v.aff_scale = aff_scale;
+        v.aff_shift = aff_shift;
+        v.aff_relu = aff_relu;
         v.div_chq = make_fastdiv((uint32_t)(C * Ho * (Wo / vec)));
         v.div_hq = make_fastdiv((uint32_t)(Ho * (Wo / vec)));
         v.div_q = make_fastdiv((uint32_t)(Wo / vec));
@@ -505,6 +531,25 @@ extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char*
     }
     SSN_CHECK_LAUNCH("pool_fwd");
     return SSN_OK;
+}
+
+extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W,
+                            long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
+                            hipStream_t stream) {
+    return pool_fwd_impl(is_max, x, y, argmax, N, C, H, W, x_img_stride, Ho, Wo, y_img_stride, ksize, stride, pad, nullptr,
+                         nullptr, 0, stream);
+}
+
+// y = relu?(scale[c] * avgpool(x) + shift[c]): the pool-projection branch of an Inception block with the pool moved
+// BEHIND its (linear, bias-free) 1x1 convolution -- avgpool(conv1x1(x)) == conv1x1(avgpool(x)) for zero padding with
+// count_include_pad -- so the pool runs on the projection's few output channels instead of the block's many input
+// channels, and the folded BN affine + ReLU of the projection are applied here.
+extern "C" int ssn_avgpool_affine_fwd(const float* x, float* y, const float* scale, const float* shift, int relu, int N,
+                                      int C, int H, int W, long x_img_stride, int Ho, int Wo, long y_img_stride,
+                                      int ksize, int stride, int pad, hipStream_t stream) {
+    SSN_CHECK_ARG(scale && shift, "avgpool_affine_fwd: null pointer");
+    return pool_fwd_impl(0, x, y, nullptr, N, C, H, W, x_img_stride, Ho, Wo, y_img_stride, ksize, stride, pad, scale, shift,
+                         relu, stream);
 }
 
 extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H,
@@ -571,6 +616,9 @@ extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* ar
         v.mask_y = a.mask_y;
         v.mask_scale = a.mask_scale;
         v.mask_img_stride = mask_img_stride;
+        v.aff_scale = nullptr;
+        v.aff_shift = nullptr;
+        v.aff_relu = 0;
         v.div_chq = make_fastdiv((uint32_t)(C * H * (W / vec)));
         v.div_hq = make_fastdiv((uint32_t)(H * (W / vec)));
         v.div_q = make_fastdiv((uint32_t)(W / vec));

@@ -122,6 +122,28 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 #define SSN_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #endif
 
+// ---- exact 3-way bf16 split of fp32 values (the "x6" kernels) ----
+// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), every conversion ROUND-TO-NEAREST-EVEN
+// (v_cvt_pk_bf16_f32 on gfx950: two values per instruction, the same instruction count as a truncating split).  The sum
+// is exact -- the remainder after a rounding to 8 significant bits has at most 16, then at most 8 of them -- and,
+// unlike truncation, the terms have no preferred sign: the partial products an x6 kernel drops (x2*w3, x3*w2, x3*w3)
+// then neither add up systematically nor exceed 2^-26 |x w| each (tests/test_kernels.py::test_conv_x6_error_growth_with_k).
+typedef __bf16 ssn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ssn_f32x2 __attribute__((ext_vector_type(2)));
+// bf16 pair of two fp32 values, `even` in the low half (k even -> low half of an MFMA operand dword)
+__device__ __forceinline__ uint32_t bf16_pair_rne(float even, float odd) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(ssn_f32x2{even, odd}, ssn_bf16x2));
+}
+__device__ __forceinline__ float bf16_pair_lo(uint32_t pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf16_pair_hi(uint32_t pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
+// the three plane dwords of one k-pair
+__device__ __forceinline__ void bf16_split3_pair(float v0, float v1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = bf16_pair_rne(v0, v1);
+    const float r0 = v0 - bf16_pair_lo(p0), r1 = v1 - bf16_pair_hi(p0);
+    p1 = bf16_pair_rne(r0, r1);
+    p2 = bf16_pair_rne(r0 - bf16_pair_lo(p1), r1 - bf16_pair_hi(p1));
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -323,6 +323,22 @@ def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, 
              mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _stream(lib, dx))
 
 
+def avgpool_affine_fwd(x, y, scale, shift, relu, ksize, stride, pad):
+    """y = relu?(scale[c] * avgpool(x) + shift[c]) on ChanSlices (see ssn_avgpool_affine_fwd)."""
+    lib = _check(x, y, scale, shift)
+    h, w = x.hw
+    ho, wo = y.hw
+    lib.call("ssn_avgpool_affine_fwd", _p(x), _p(y), _p(scale), _p(shift), int(bool(relu)), x.n, x.c, h, w,
+             x.img_stride, ho, wo, y.img_stride, ksize, stride, pad, _stream(lib, y))
+
+
+def channel_sum(g, out):
+    """out[c] = sum over images and pixels of the ChanSlice g."""
+    lib = _check(g, out)
+    h, w = g.hw
+    lib.call("ssn_channel_sum", _p(g), _p(out), g.n, g.c, h * w, g.img_stride, _stream(lib, out))
+
+
 @_hbm_timed
 def gap_fwd(x, y):
     lib = _check(x, y)

@@ -69,6 +69,9 @@ def parse():
                          "the well-trodden path; 'overlapped' = bucketed all-reduces issued from inside the backward and "
                          "captured in the one step graph (overlaps the ~0.5 ms ring with the remaining backward)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP event timing")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="profiling aid: no side streams (weight-gradient chain, forward branches), so that with --no-graph "
+                         "every kernel runs alone and rocprofv3's per-kernel durations are free of mutual slow-down")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly from Python instead of replaying one captured hipGraph per step")
     return ap.parse_args()
@@ -153,6 +156,9 @@ def main():
     init_backbone_synthetic(model.base_model)  # same weights on every rank (same seed)
     init_heads_synthetic(model, std=0.001)
     model.base_model.conv_precision = args.precision
+    if args.single_stream:
+        model.base_model.overlap_wgrad = False
+        model.base_model.branch_streams = False
     model.to(dev).train()
     policies = model.get_optim_policies()
     opt = SSNSGD(policies, lr=0.001, momentum=0.9, weight_decay=5e-4)

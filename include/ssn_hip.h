@@ -171,6 +171,15 @@ int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float
                  long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride, int pad,
                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
                  hipStream_t stream);
+/* y = relu?(scale[c] * avgpool(x) + shift[c]) (average pools only): the pool-projection branch of an Inception block
+ * (<block>_pool -> <block>_pool_proj + BN + ReLU) evaluated as avgpool(conv1x1(x)) -- identical to conv1x1(avgpool(x))
+ * for zero padding with count_include_pad -- so that the pool touches the projection's output channels only. */
+int ssn_avgpool_affine_fwd(const float* x, float* y, const float* scale, const float* shift, int relu, int N, int C,
+                           int H, int W, long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride,
+                           int pad, hipStream_t stream);
+/* out[c] = sum_{n,hw} g[n][c][hw] (fixed order): bias gradient of such a projection (the gradient BEFORE the pool's
+ * backward; the wgrad kernel's bias column sees the pooled gradient). */
+int ssn_channel_sum(const float* g, float* out, int N, int C, int HW, long img_stride, hipStream_t stream);
 int ssn_global_avgpool_fwd(const float* x, float* y, int N, int C, int HW, long x_img_stride, hipStream_t stream);
 int ssn_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, long dx_img_stride, int accumulate,
                            hipStream_t stream);

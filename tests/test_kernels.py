@@ -147,6 +147,48 @@ def test_pools(backend):
             assert rel_err(dx.cpu() - 1.0, x.grad) < 1e-6, (kind, h, "bwd")
 
 
+def test_avgpool_behind_projection(backend):
+    """The pool-projection branch with the pool moved behind the 1x1 convolution (ssn_avgpool_affine_fwd,
+    ssn_channel_sum): relu(scale * avgpool(conv1x1(x)) + shift) equals torch's relu(bn(conv1x1(avgpool(x)) + bias)) in
+    the forward pass AND in every gradient (input, weight, bias), negative BN scales included."""
+    g = torch.Generator().manual_seed(41)
+    for h in ((28, 14, 7) if backend.is_gpu else (8, 6, 7)):
+        n, cin, cout = (3, 24, 16) if backend.is_gpu else (2, 5, 4)
+        x = torch.relu(torch.randn(n, cin, h, h, generator=g)).requires_grad_()
+        w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.3).requires_grad_()
+        b = (torch.randn(cout, generator=g) * 0.1).requires_grad_()
+        scale = torch.rand(cout, generator=g) + 0.5
+        scale[1::3] *= -1.0
+        beta = torch.randn(cout, generator=g) * 0.1
+        # reference order: pool, conv + bias, affine (a frozen BN folded to scale / beta), ReLU
+        ref = torch.relu(F.conv2d(F.avg_pool2d(x, 3, 1, 1, ceil_mode=True, count_include_pad=True), w, b)
+                         * scale.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1))
+        gy = torch.randn(ref.shape, generator=g)
+        ref.backward(gy)
+        shift = (b.detach() * scale + beta)                                 # what bn_fold produces
+        # product order: z = conv1x1 without bias (torch here; the conv kernels have their own tests), pool + affine + ReLU
+        z = F.conv2d(x.detach(), w.detach())
+        y = backend.put(torch.zeros(n, cout + 2, h, h))
+        K.avgpool_affine_fwd(K.full(backend.put(z)), K.ChanSlice(y, 2, cout), backend.put(scale), backend.put(shift),
+                             True, 3, 1, 1)
+        assert rel_err(y.cpu()[:, 2:], ref) < 1e-6, h
+        # backward: mask (ReLU + scale), bias gradient = channel sums BEFORE the pool's backward, pool backward -> dz
+        gfull = torch.zeros(n, cout + 2, h, h)
+        gfull[:, 2:] = gy
+        gdev = backend.put(gfull)
+        gs = K.ChanSlice(gdev, 2, cout)
+        K.relu_bn_bwd(gs, K.ChanSlice(y, 2, cout), backend.put(scale))
+        db = backend.put(torch.zeros(cout))
+        K.channel_sum(gs, db)
+        assert rel_err(db, b.grad) < 1e-5, (h, "bias")
+        dz = backend.put(torch.empty(n, cout, h, h))
+        K.pool_bwd("avg", gs, None, K.full(dz), 3, 1, 1, False)
+        dz_t = dz.cpu()
+        dw = torch.einsum("nohw,nchw->oc", dz_t, x.detach()).view_as(w)
+        dx = torch.nn.grad.conv2d_input(x.shape, w.detach(), dz_t)
+        assert rel_err(dw, w.grad) < 1e-5 and rel_err(dx, x.grad) < 1e-5, h
+
+
 def test_global_avgpool_and_dropout(backend):
     g = torch.Generator().manual_seed(5)
     n, c, h = 4, 32, 7
@@ -424,6 +466,48 @@ def test_conv_x6_is_fp32_accurate(backend):
     err_bf16 = (F.conv2d(bf(x), bf(w), None, 1, 1) - ref64).abs().max().item()
     assert err6 < 2 * err32 + 1e-6, (err6, err32)
     assert err6 < err_bf16 / 100, (err6, err_bf16)
+
+
+def test_conv_x6_error_growth_with_k(backend):
+    """K-sweep of the bf16 3-way split (K = Cin * 9 from 27 to 2304, the longest reduction in BN-Inception): maximum
+    error and BIAS (mean signed error) relative to sum|x w| against float64, next to the exact-f32 MFMA kernel and a
+    plain fp32 (torch CPU) convolution on the same data -- on zero-mean data and on all-positive data (worst case for a
+    systematic error: nothing cancels).
+
+    Operands are split with round-to-nearest (x = x1 + x2 + x3 exactly, ssn_common.h): the three dropped partial
+    products are <= 2^-26 |x w| each and have no preferred sign.  (Round 1 split by truncation: its dropped terms all
+    had the sign of x*w -- a relative bias of -1.0e-7 = 2^-23 on positive data in this very test, max error 7.6e-7 at
+    K = 27; with rounding: -1.5e-8 and 4.6e-7.)  What remains is fp32 accumulation error, common to all three kernels:
+    the bounds below tie the x6 kernel to the fp32 kernels at every K instead of to absolute numbers."""
+    g = torch.Generator().manual_seed(77)
+    cins = (3, 16, 64, 128, 256) if backend.is_gpu else (3, 16, 48)
+    n, h, cout = (2, 14, 64) if backend.is_gpu else (1, 5, 32)
+    rows = []
+    for cin in cins:
+        for signed in (True, False):
+            x = torch.randn(n, cin, h, h, generator=g)
+            w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+            if not signed:
+                x, w = x.abs(), w.abs()
+            ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+            mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)          # sum |x w| per output
+            xd, wd = backend.put(x), backend.put(w)
+            y6 = backend.put(torch.empty(n, cout, h, h))
+            (wp,) = K.pack_weights_multi([([wd], 0)], x6=True)
+            K.conv_x6_fwd(K.full(xd), wp, None, None, K.full(y6), 3, 1, 1, False)
+            y32 = backend.put(torch.empty(n, cout, h, h))
+            K.conv_fwd(K.full(xd), K.pack_weights(wd, False), None, None, K.full(y32), 3, 1, 1, False)
+            ycpu = F.conv2d(x, w, None, 1, 1)
+            e6 = (y6.cpu().double() - ref) / mag
+            e32 = (y32.cpu().double() - ref) / mag
+            ecpu = (ycpu.double() - ref) / mag
+            rows.append((cin * 9, signed, e6.abs().max().item(), e6.mean().item(), e32.abs().max().item(),
+                         e32.mean().item(), ecpu.abs().max().item()))
+    for k, signed, m6, b6, m32, b32, mcpu in rows:
+        print("K=%5d %s  x6: max %.2e bias %+.2e | f32 MFMA: max %.2e bias %+.2e | torch fp32: max %.2e"
+              % (k, "signed  " if signed else "positive", m6, b6, m32, b32, mcpu))
+        assert m6 <= 3.0 * max(m32, mcpu) + 2.0 ** -22, (k, signed, m6, m32, mcpu)     # the accuracy class of fp32
+        assert abs(b6) <= 3.0 * abs(b32) + 2.0 ** -24, (k, signed, b6, b32)             # no systematic error of its own
 
 
 def test_conv_x6_fused_pair_and_mask(backend):
