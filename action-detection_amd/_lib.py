@@ -33,28 +33,29 @@ class SsnStppTable(ctypes.Structure):
 
 # signature codes: p pointer, i int, l long, f float, u unsigned long long
 _SIGS = {
-    "ssn_conv_bn_relu_fwd": "pppppiiiiliiiliiiiip",
+    "ssn_conv_bn_relu_fwd": "pppppiiiiliiiliiiiipp",
     "ssn_bn_fold": "pppppfppip",
-    "ssn_relu_bn_bwd": "pppiiillp",
-    "ssn_conv_dgrad": "pppiiiiliiiliiiiplpiip",
+    "ssn_relu_bn_bwd": "pppiiillpp",
+    "ssn_conv_dgrad": "pppiiiiliiiliiiiplpiipp",
     "ssn_conv_pack_weights": "ppiiiip",
     "ssn_conv_pack_weights_multi": "ippppppppp",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
-    "ssn_conv_wgrad_x6": "ppppiiiililiiiplip",
+    "ssn_conv_wgrad_x6": "ppppiiiililiiiplippp",
     "ssn_wgrad_reduce": "pppiiip",
     "ssn_conv_x6_pack_weights_multi": "ippppppppp",
-    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiip",
-    "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiip",
-    "ssn_conv_x6_fwd_rect": "pppppiiiiliiiliiiiiiip",
+    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiippp",
+    "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiippp",
+    "ssn_conv_x6_fwd_rect": "pppppiiiiliiiliiiiiiippp",
     "ssn_conv_x6_pack_dgrad_s2": "ppiip",
-    "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiip",
+    "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiippp",
     "ssn_conv_x6_pack_weights_rect": "ppiiiip",
-    "ssn_pool_fwd": "ipppiiiiliiliiip",
-    "ssn_pool_bwd": "ipppiiiiliiliiiiplpp",
-    "ssn_avgpool_affine_fwd": "ppppiiiiiliiliiip",
-    "ssn_channel_sum": "ppiiilp",
+    "ssn_pool_fwd": "ipppiiiiliiliiipp",
+    "ssn_pool_bwd": "ipppiiiiliiliiiiplppp",
+    "ssn_avgpool_affine_fwd": "ppppiiiiiliiliiipp",
+    "ssn_channel_sum": "ppiiilpup",
+    "ssn_tensor_amax": "plpp",
     "ssn_global_avgpool_fwd": "ppiiilp",
-    "ssn_global_avgpool_bwd": "ppiiilip",
+    "ssn_global_avgpool_bwd": "ppiiilipp",
     "ssn_dropout_fwd": "ppplfupp",
     "ssn_dropout_bwd": "ppplfp",
     "ssn_stpp_fwd": "ppppiipp",
@@ -86,7 +87,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
-                                "ssn_conv_debug_flags",
+                                "ssn_conv_debug_flags", "ssn_channel_sum_shares",
                                 "ssn_conv_dgrad_layout"])
 
 

@@ -99,9 +99,11 @@ class BNInception(nn.Module):
         self.overlap_wgrad = True     # run wgrad launches on a second stream, concurrently with the dgrad chain
         self.branch_streams = True    # forward: the branches of an Inception block run on three HIP streams
         self.profiler = None          # list; when set, every conv launch is bracketed by HIP events
-        # "bf16x6": 1x1/3x3 convolutions (forward, stride-1 dgrad) multiply on the bf16 matrix cores with every fp32
-        # operand split exactly into three bf16 terms (fp32-class accuracy, csrc/conv_x6.hip); "f32": exact-f32 MFMA
-        self.conv_precision = "bf16x6"
+        # "split": 1x1/3x3 convolutions (forward, dgrad, wgrad) multiply on the f16 matrix cores with every fp32 operand
+        # scaled per tensor and split into two f16 terms, three products per multiply (fp32-class accuracy,
+        # csrc/conv_x6.hip); "f32": exact-f32 MFMA
+        self.conv_precision = "split"
+        self.wgrad_x6 = True          # weight gradients on the split kernel too (False: exact-f32 MFMA wgrad; bisecting aid)
         # average-pool branches: pool BEHIND the 1x1 projection (see _move_avg_pools); False = the manifest's order
         self.pool_after_projection = os.environ.get("SSN_POOL_ORDER", "") != "manifest"
 
@@ -272,11 +274,17 @@ class BNInception(nn.Module):
         for i, op in enumerate(plan):
             last_use[op["src"]] = i
 
+        # one amax slot per activation tensor (kernels.py: "amax slots"): the kernels that write a tensor raise its
+        # slot, the split convolutions that read it take their operand scale from it
+        slot_pool = torch.zeros(len(shapes) + 1, device=dev, dtype=torch.float32)
+        slot_of = {}
+
         def get(name):
             if name not in acts:
                 c, h, w = shapes[name]
+                i = slot_of.setdefault(name, len(slot_of))
                 # readable floats in front of every activation: lets the x6 kernels use 16-byte loads
-                acts[name] = K.guarded_empty((n, c, h, w), dev)
+                acts[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), slot_pool[i:i + 1])
             return acts[name]
 
         def scale_slice(name, c0, c):
@@ -312,7 +320,7 @@ class BNInception(nn.Module):
         # all forward weight operands in two launches (fused pairs read both sources directly: no concatenation)
         conv_ops = [op for op in plan if op["kind"] == "conv"]
         for op in conv_ops:      # which matrix path each layer takes (bf16 3-way split, or exact f32 MFMA)
-            op["x6"] = (self.conv_precision == "bf16x6" and op["k"] in (1, 3)
+            op["x6"] = (self.conv_precision == "split" and op["k"] in (1, 3)
                         and x6_wins("fwd", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1]))
         packed_fwd = {}
         for x6 in (False, True):
@@ -432,10 +440,14 @@ class BNInception(nn.Module):
         grads = {}
         inited = set()      # (tensor, c0) gradient slices that already hold a contribution
 
+        gslot_pool = torch.zeros(len(shapes) + 1, device=dev, dtype=torch.float32)   # amax slots of the gradient tensors
+        gslot_of = {}
+
         def gbuf(name):
             if name not in grads:
                 c, h, w = shapes[name]
-                grads[name] = K.guarded_empty((n, c, h, w), dev)
+                i = gslot_of.setdefault(name, len(gslot_of))
+                grads[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), gslot_pool[i:i + 1])
             return grads[name]
 
         ws_bytes = 0
@@ -443,7 +455,7 @@ class BNInception(nn.Module):
         for op in plan:
             if op["kind"] == "conv":
                 hin, win = shapes[op["src"]][1], shapes[op["src"]][2]
-                x6 = (self.conv_precision == "bf16x6" and op["src"] != "data"
+                x6 = (self.conv_precision == "split" and self.wgrad_x6 and op["src"] != "data"
                       and K.wgrad_x6_supported(op["k"], op["s"], op["p"], hin, win)
                       and x6_wins("wgrad", op["cin"], op["cout"], op["k"], op["s"], hin))
                 wg_x6[op["lids"][0]] = x6
@@ -455,16 +467,18 @@ class BNInception(nn.Module):
                     ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(
                         n, op["cin"], op["cout"], shapes[op["dst"]][1], shapes[op["dst"]][2], op["k"],
                         tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
+                if op.get("raw"):
+                    ws_bytes = max(ws_bytes, K.channel_sum_workspace_bytes(n, op["cout"]))
         ws = self._workspace(ws_bytes, dev)
         # all dgrad weight operands in two launches
         dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
         dg_layout = {op["lids"][0]: K.dgrad_layout(op["k"], op["s"], op["p"], shapes[op["src"]][1],
                                                    shapes[op["src"]][2]) for op in dg_ops}
-        dg_x6 = {op["lids"][0]: (self.conv_precision == "bf16x6" and op["k"] in (1, 3) and op["s"] == 1
+        dg_x6 = {op["lids"][0]: (self.conv_precision == "split" and op["k"] in (1, 3) and op["s"] == 1
                                  and x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1]))
                  for op in dg_ops}
         # 3x3 / stride-2 layers: four parity-class stride-1 launches on the x6 kernel (no tap that does not contribute)
-        dg_s2 = {op["lids"][0]: (self.conv_precision == "bf16x6" and dg_layout[op["lids"][0]] == 2 and len(op["lids"]) == 1)
+        dg_s2 = {op["lids"][0]: (self.conv_precision == "split" and dg_layout[op["lids"][0]] == 2 and len(op["lids"]) == 1)
                  for op in dg_ops}
         packed_dg = {}
         for op in dg_ops:
@@ -571,7 +585,7 @@ class BNInception(nn.Module):
 
                     def run_wgrad():
                         inner_wgrad()
-                        K.channel_sum(g_pre, db)
+                        K.channel_sum(g_pre, db, ws)
                 wfam = "conv_wgrad_x6" if wg_x6[lids[0]] else "conv_wgrad_f32"
                 if use_side:
                     ready = torch.cuda.Event()

@@ -2,8 +2,10 @@
 //
 // A wave holds TM x TN accumulator tiles of the 32x32 MFMA layout (lane (li, lh), register r:
 // row = (r & 3) + 8 (r >> 2) + 4 lh, column = li).  The store applies, per output channel (row m):
-//   forward : y = relu?(acc * scale[m] + shift[m])
-//   dgrad   : y = maskfn((accumulate ? y_old : 0) + acc),  maskfn = fused backward of the producer's ReLU + frozen BN
+//   forward : y = relu?(acc * inv * scale[m] + shift[m])
+//   dgrad   : y = maskfn((accumulate ? y_old : 0) + acc * inv),  maskfn = fused backward of the producer's ReLU + frozen BN
+// (inv = 1 / (operand scales) of the split kernels, 1 for the exact-f32 kernel), and -- when the output tensor has an
+// amax slot -- max-es the magnitudes it stores into it (ssn_common.h: amax_emit).
 // Two things keep this phase short (it used to cost as much as a third of the main loop):
 //   * the per-channel vectors are staged in LDS once per workgroup -- a global load placed after a store to a
 //     pointer the compiler cannot disambiguate is never hoisted, i.e. one dependent memory round trip PER ELEMENT;
@@ -25,21 +27,22 @@ struct EpiArgs {
     uint32_t howo4;        // bytes between consecutive channels of y (and of mask_y)
     int M;
     int relu, accumulate;
+    float* amax;           // nullptr: the output tensor is not tracked
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// ch[0,BM) = scale (1 if none), ch[BM,2BM) = shift (0), ch[2BM,3BM) = mask scale (NaN: pass through).  All threads of
-// the workgroup call this between two barriers (LDS is free once the main loop has ended).
+// ch[0,BM) = inv * scale (inv if none), ch[BM,2BM) = shift (0), ch[2BM,3BM) = mask scale (NaN: pass through).  All
+// threads of the workgroup call this between two barriers (LDS is free once the main loop has ended).
 template <int BM, int NT>
 __device__ __forceinline__ void epi_stage_channels(float* ch, const float* scale, const float* shift,
-                                                   const float* mask_scale, int m0, int M, int tid) {
+                                                   const float* mask_scale, int m0, int M, int tid, float inv = 1.f) {
     for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         const bool ok = m < M;
-        ch[r] = (ok && scale) ? scale[m] : 1.f;
+        ch[r] = (ok && scale) ? scale[m] * inv : inv;
         ch[BM + r] = (ok && scale) ? shift[m] : 0.f;
         ch[2 * BM + r] = (ok && mask_scale) ? mask_scale[m] : __builtin_nanf("");
     }
@@ -54,10 +57,14 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
     const __amdgpu_buffer_rsrc_t yrsrc = epi_rsrc(e.y, e.y_bytes);
     const int mlim = e.M - m0 - 4 * lh;   // rows srow (without the lane-half term) below this are inside the tensor
     auto srow = [&](int i, int r) { return row0 + i * 32 + (r & 3) + 8 * (r >> 2); };
+    // amax of what is stored: rows past the tensor compute exact zeros (zero weight rows, shift staged as 0), so only
+    // the pixel columns that do not exist have to be kept out
+    float vmax = 0.f;
     if (!e.accumulate && !e.mask_y) {
         // pure stores: nothing in this path waits on memory
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            float cmax = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -65,9 +72,12 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                     const int sr = srow(i, r);
                     float v = acc[i][j][r] * ch[sr + 4 * lh] + ch[BM + sr + 4 * lh];
                     if (e.relu) v = fmaxf(v, 0.f);
+                    cmax = fmaxf(cmax, fabsf(v));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
                                                           sr < mlim ? yoff[j] : EPI_OOB, (uint32_t)sr * e.howo4, 0);
                 }
+            vmax = fmaxf(vmax, yoff[j] != EPI_OOB ? cmax : 0.f);
+        }
     } else {
         // read-modify-write: the operands of half-tile g+1 are requested before half-tile g is stored
         const __amdgpu_buffer_rsrc_t orsrc = epi_rsrc(e.y, e.accumulate ? e.y_bytes : 0u);
@@ -99,11 +109,13 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                 v += old[b][q];
                 const float sc = ch[2 * BM + sr + 4 * lh];
                 v = (sc != sc) ? v : (mk[b][q] > 0.f ? v * sc : 0.f);   // NaN marks a channel that is not a ReLU output
+                vmax = fmaxf(vmax, (sr < mlim && yoff[j] != EPI_OOB) ? fabsf(v) : 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
                                                       sr < mlim ? yoff[j] : EPI_OOB, (uint32_t)sr * e.howo4, 0);
             }
         }
     }
+    amax_emit(e.amax, vmax);
 }
 
 }  // namespace

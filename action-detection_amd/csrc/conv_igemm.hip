@@ -72,6 +72,7 @@ struct ConvArgs {
     uint32_t x_bytes, a_bytes;  // extents of the gather source / packed weights (buffer descriptors)
     uint32_t y_bytes, mask_bytes;   // extents of the output / mask tensors (epilogue buffer descriptors)
     FastDiv div_hw, div_w, div_mt;
+    float* y_amax;       // amax slot of the output tensor (nullptr: not tracked); see ssn_common.h: amax_emit
 };
 
 // Raw buffer descriptor over [base, base + bytes): loads whose byte offset is >= bytes return 0, which is
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     e.M = p.M;
     e.relu = p.relu;
     e.accumulate = p.accumulate;
+    e.amax = p.y_amax;
     uint32_t yoff[TN], moff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -580,7 +582,7 @@ extern "C" int ssn_conv_pack_weights_multi(int count, const float* const* w0, co
 extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                                     float* y, int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho,
                                     int Wo, long y_img_stride, int ksize, int stride, int pad, int relu,
-                                    int tile_cfg, hipStream_t stream) {
+                                    int tile_cfg, float* y_amax, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv fwd: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 7, "conv fwd: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv fwd: stride %d unsupported", stride);
@@ -604,6 +606,7 @@ extern "C" int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const
     a.pad = pad;
     a.relu = relu;
     a.accumulate = 0;
+    a.y_amax = y_amax;
     a.mask_y = nullptr;
     a.mask_scale = nullptr;
     a.mask_img_stride = 0;
@@ -648,7 +651,8 @@ extern "C" int ssn_conv_dgrad_layout(int ksize, int stride, int pad, int H, int 
 extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                               long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize,
                               int stride, int pad, int accumulate, const float* mask_y, long mask_img_stride,
-                              const float* mask_scale, int wt_layout, int tile_cfg, hipStream_t stream) {
+                              const float* mask_scale, int wt_layout, int tile_cfg, float* dx_amax,
+                              hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv dgrad: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv dgrad: stride %d unsupported", stride);
@@ -671,6 +675,7 @@ extern "C" int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx
     a.pad = pad;
     a.relu = 0;
     a.accumulate = accumulate;
+    a.y_amax = dx_amax;
     a.mask_y = mask_scale ? mask_y : nullptr;
     a.mask_scale = mask_y ? mask_scale : nullptr;
     a.mask_img_stride = mask_img_stride;

@@ -1,6 +1,7 @@
-// Weight (and bias) gradient of the stride-1 1x1 / 3x3 backbone convolutions on the bf16 matrix cores with
-// fp32-class accuracy ("x6" scheme of conv_x6.hip: every fp32 operand split exactly into three bf16 terms, six
-// partial products per k16 step accumulated in fp32), gfx950.
+// Weight (and bias) gradient of the stride-1 1x1 / 3x3 backbone convolutions on the f16 matrix cores with
+// fp32-class accuracy (the split scheme of conv_x6.hip: every fp32 operand scaled by a per-tensor power of two and
+// split into two f16 terms, three partial products per k16 step accumulated in fp32; "x6" is the family's historical
+// name), gfx950.
 //
 // Same contract as conv_wgrad.hip (the cuDNN wgrad behind loss.backward(), /root/reference/ssn_train.py:236):
 //   dW[co][kk] = sum_p G[co][p] * X[kk][p]        kk = (ci, r, s),  p = (n, ho, wo)
@@ -15,9 +16,10 @@
 //    is one load even when it runs over the end of an image row; the taps that fall on padding are zeroed in
 //    registers afterwards (two compares per pixel and row).  Loads of the shifted taps reach up to (W+1) floats in
 //    front of x: the caller guarantees 256 readable bytes there (x_guard_bytes, see include/ssn_hip.h).
-//  * Both operands are activations, so both are split on the fly: once per element, by the thread that stages it
-//    (22 VALU per 4 pixels), written to LDS as three bf16 planes ([operand][plane][row][16 k]: 32-byte rows, the two
-//    16-byte halves of a row swapped in every other group of 8 rows).  With that image every MFMA operand is one
+//  * Both operands are activations, so both are scaled and split on the fly: once per element, by the thread that
+//    stages it (12 VALU per 4 pixels), written to LDS as two f16 planes ([operand][plane][row][16 k]: 32-byte rows, the
+//    two 16-byte halves of a row swapped in every other group of 8 rows).  The scales come from the amax slots of the
+//    two tensors (g_amax, x_amax; ssn_common.h), their reciprocal is applied when the partial slab is stored.  With that image every MFMA operand is one
 //    conflict-free ds_read_b128 AND the 8-byte plane stores of the staging threads (4 rows x 4 pixel groups per
 //    16-lane store group = 32 consecutive dwords) are conflict-free too -- the 112-byte row pitch of the first version
 //    put a third of the store cycles into bank conflicts (profiles/r1_pmc_summary_x6.json).
@@ -27,13 +29,14 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct WgX6Args {
     const float* g;  // [N][..Cout..][H][W] channel-slice base (stride 1, same-size convolution)
     const float* x;  // [N][..Cin..][H][W] channel-slice base
     float* part;     // [splits][M][ldp]
+    const float* g_amax;   // amax slots of the tensors g and x belong to (required)
+    const float* x_amax;
     int N, Cin, H, W;
     long x_img_stride;
     int M;
@@ -49,15 +52,15 @@ struct WgX6Args {
     FastDiv div_hw, div_w, div_tiles, div_kt;
 };
 
-constexpr int CP = 16;          // pixels per chunk = one bf16 MFMA k-step
-constexpr int ROW_DW = 8;       // LDS row of one plane: 16 bf16 = 32 B
+constexpr int CP = 16;          // pixels per chunk = one f16 MFMA k-step
+constexpr int ROW_DW = 8;       // LDS row of one plane: 16 f16 = 32 B
 constexpr uint32_t OOB = 0x80000000u;
 constexpr uint32_t GUARD = 256u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-// (operand split: bf16_split3_pair of ssn_common.h -- round-to-nearest, exact in 3 terms)
+// (operand scaling and split: f16_scale_of / f16_split2_pair of ssn_common.h)
 
 // tiles of 8+ MFMA tiles per wave run one wave per SIMD (up to 512 VGPRs): the elements to split per MFMA drop with
 // the tile size, which moves the kernel from VALU-bound towards matrix-bound
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     constexpr int NAR = (BM + 63) / 64;   // G rows per thread (thread = one row x 4 pixels of a chunk)
     constexpr int NBR = (BN + 63) / 64;   // X rows per thread
     constexpr int KK = KS * KS;
-    constexpr int STAGE = 3 * (BM + BN) * ROW_DW;   // [A plane 0..2][B plane 0..2], rows x 8 dwords each
+    constexpr int STAGE = 2 * (BM + BN) * ROW_DW;   // [A plane 0..1][B plane 0..1], rows x 8 dwords each
     static_assert(WM * WN == 4, "4 waves per workgroup");
 
     __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
@@ -86,6 +89,9 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     fd_divmod(tile, p.div_kt, mt, kt);
     const int m0 = (int)mt * BM;
     const int kk0 = (int)kt * BN;
+
+    const float sg = f16_scale_of(*p.g_amax), sx = f16_scale_of(*p.x_amax);   // power-of-two operand scales
+    const float inv = 1.f / (sg * sx);
 
     const int pxg = tid & 3;       // which 4-pixel group of the chunk
     const int row0 = tid >> 2;     // 0..63; this thread stages rows row0 + 64 i
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     // multiply, then both split -- which leaves the matrix pipe idle two thirds of the time.
     constexpr int NROW = NAR + NBR, NSTEP = 2 * NROW;
     int hh[4], ww[4];          // coordinates of the 4 pixels of the staged group (a group may run over a row end)
-    uint32_t plw[3][2];
+    uint32_t plw[2][2];
     auto stage_begin = [&](const Staged& s) {
         if (KS != 1) {
 #pragma unroll
@@ -199,13 +205,13 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
             if (PAD) v[e] = (s.hw + (uint32_t)(2 * half + e) < (uint32_t)HW) ? v[e] : 0.f;
         }
         if (is_a && do_bias) rowsum[i] += v[0] + v[1];
-        bf16_split3_pair(v[0], v[1], plw[0][half], plw[1][half], plw[2][half]);
+        f16_split2_pair(v[0], v[1], is_a ? sg : sx, plw[0][half], plw[1][half]);
         if (half == 1) {
             // 16-byte half (pxg >> 1), swapped in odd groups of 8 rows (row0 and row0 + 64 i share bit 3)
-            uint32_t* dst = lds + buf * STAGE + (is_a ? 0 : 3 * BM * ROW_DW) + (row0 + 64 * i) * ROW_DW +
+            uint32_t* dst = lds + buf * STAGE + (is_a ? 0 : 2 * BM * ROW_DW) + (row0 + 64 * i) * ROW_DW +
                             (((pxg >> 1) ^ ((row0 >> 3) & 1)) * 4) + (pxg & 1) * 2;
 #pragma unroll
-            for (int pn = 0; pn < 3; ++pn)
+            for (int pn = 0; pn < 2; ++pn)
                 *reinterpret_cast<uint2*>(dst + pn * (is_a ? BM : BN) * ROW_DW) = uint2{plw[pn][0], plw[pn][1]};
         }
     };
@@ -228,29 +234,29 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     auto compute = [&](int buf, Staged& st, int next_chunk) {
         const int half = (lh ^ ((li >> 3) & 1)) * 4;   // this lane's k-half of its row (tile rows are 32 apart: bit 3 = li's)
         const uint32_t* As = lds + buf * STAGE + (wm * TM * 32 + li) * ROW_DW + half;
-        const uint32_t* Bs = lds + buf * STAGE + 3 * BM * ROW_DW + (wn * TN * 32 + li) * ROW_DW + half;
-        bf16x8 af[3][TM], bf[3][TN];
+        const uint32_t* Bs = lds + buf * STAGE + 2 * BM * ROW_DW + (wn * TN * 32 + li) * ROW_DW + half;
+        f16x8 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int pn = 0; pn < 3; ++pn) {
+        for (int pn = 0; pn < 2; ++pn) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + i * 32 * ROW_DW + pn * BM * ROW_DW));
+                af[pn][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(As + i * 32 * ROW_DW + pn * BM * ROW_DW));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[pn][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + j * 32 * ROW_DW + pn * BN * ROW_DW));
+                bf[pn][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(Bs + j * 32 * ROW_DW + pn * BN * ROW_DW));
         }
         stage_begin(st);
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-        constexpr int NM = 6 * TM * TN;
+        constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_lo + g_hi x_hi
+        constexpr int PB[3] = {0, 1, 0};
+        constexpr int NM = 3 * TM * TN;
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[c]][i], bf[PB[c]][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA[c]][i], bf[PB[c]][j], acc[i][j], 0, 0, 0);
                     const int idx = (c * TM + i) * TN + j;
 #pragma unroll
                     for (int k = idx * NSTEP / NM; k < (idx + 1) * NSTEP / NM; ++k) stage_step(st, buf ^ 1, k);
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M) out[(long)m * p.ldp + kk] = acc[i][j][r];
+                if (m < p.M) out[(long)m * p.ldp + kk] = acc[i][j][r] * inv;
             }
         }
     }
@@ -362,7 +368,7 @@ int pick_tile(int M, int K) {
     return bc;
 }
 
-// co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 96 B, VGPRs as compiled)
+// co-resident workgroups per CU of each tile config (LDS 2 x (BM + BN) x 64 B, VGPRs as compiled)
 const int kOcc[NCFG] = {5, 4, 2, 3, 2, 3, 3, 2, 2, 1, 1, 1};
 
 void plan(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
@@ -393,8 +399,10 @@ extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int 
 // multiple of 4 (the 7x7 stage) are enumerated in groups of 4 pixel slots per image, the slots past the plane zeroed.
 extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                                  long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
-                                 void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream) {
+                                 void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
+                                 hipStream_t stream) {
     SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
+    SSN_CHECK_ARG(g_amax && x_amax, "conv wgrad x6: the amax slots of both operand tensors are required");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv wgrad x6: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(2 * pad == ksize - 1, "conv wgrad x6: only same-size stride-1 convolutions (pad %d, ksize %d)", pad, ksize);
     SSN_CHECK_ARG((pad * W + pad) * 4 <= (int)GUARD, "conv wgrad x6: image rows of %d pixels are too wide for the guard", W);
@@ -404,6 +412,8 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.g = g;
     a.x = x;
     a.part = (float*)workspace;
+    a.g_amax = g_amax;
+    a.x_amax = x_amax;
     a.N = N;
     a.Cin = Cin;
     a.H = H;

@@ -1,27 +1,30 @@
-// Implicit-GEMM convolution with fp32-class accuracy on the bf16 matrix cores ("x6" path), gfx950.
+// Implicit-GEMM convolution with fp32-class accuracy on the f16 matrix cores (the "split" path; file and symbol names
+// keep the "x6" of the first version, which split into three bf16 terms and multiplied six partial products), gfx950.
 //
 // Same role and same operands as conv_igemm.hip (forward conv + frozen-BN + ReLU, and dgrad, of the
 // BN-Inception layers behind /root/reference/ssn_models.py:266,298), but the multiply runs on
-// v_mfma_f32_32x32x16_bf16 instead of the 16x slower exact-f32 MFMA:
+// v_mfma_f32_32x32x16_f16 instead of the 16x slower exact-f32 MFMA:
 //
-//   every fp32 operand x is split EXACTLY into three bf16 terms by truncation,
-//        x = x1 + x2 + x3,   x1 = top 16 bits of x,  x2 = top 16 bits of (x - x1),  x3 = x - x1 - x2
-//   (8 + 8 + 8 = 24 significand bits, so nothing is lost), and a*b is accumulated in fp32 from the six
-//   partial products with i + j <= 4:  a3b1 + a1b3 + a2b2 + a2b1 + a1b2 + a1b1  (smallest first).
-//   The three dropped products are <= 2^-24 |ab|; measured error against float64 equals that of the f32
-//   MFMA (tools/proto/run_bf16x6.py: 2.4e-7 vs 3.0e-7 of sum|ab|), at 6/16 of its matrix-pipe time.
+//   every fp32 operand x, scaled by a per-tensor power of two s, is split into two f16 terms (round to nearest),
+//        x s = hi + lo + e,   hi = f16(x s),  lo = f16(x s - hi),  |e| <= 2^-22 |x s|,
+//   and a*b is accumulated in fp32 from three partial products  a_lo b_hi + a_hi b_hi + a_hi b_lo; the dropped
+//   a_lo b_lo is <= 2^-22 |ab|.  The accumulators are multiplied by 1 / (s_a s_b) in the epilogue (exact).  Measured
+//   error against float64: within 2x of an fp32 FMA chain (test_conv_split_error_growth_with_k), at 3/16 of the
+//   exact-f32 kernel's matrix-pipe time -- and half of the first version's (three bf16 terms, six products).
+//   The scales come from per-tensor maxima: weights are measured when they are packed (the value travels behind the
+//   packed rows), activations / gradients by the kernels that write them (ssn_common.h: amax_emit; x_amax / y_amax).
 //
-// Structure (what keeps the loop matrix-bound now that a slab is only ~0.4-0.8k matrix cycles per wave):
-//  * K runs in slabs of 16 rows = one bf16 MFMA.  1x1: 16 channels.  3x3: 16 channels x ONE tap, taps innermost:
+// Structure (what keeps the loop matrix-bound now that a slab is only ~0.2-0.4k matrix cycles per wave):
+//  * K runs in slabs of 16 rows = one f16 MFMA.  1x1: 16 channels.  3x3: 16 channels x ONE tap, taps innermost:
 //    all rows of a slab share the tap, so a lane needs one gather offset per slab (base + scalar tap delta, a
 //    9-bit validity mask) and the channel part of the address is a scalar soffset.
 //  * Operands reach LDS by LDS-DMA (`buffer_load ... lds`), two slabs ahead in a 3-stage ring: no VGPR staging,
 //    no VALU, no ds_write; the global round trip (~1.5-2k cycles under load) is hidden behind two slabs of MFMAs.
-//      - weights: split and packed once per step (ssn_conv_x6_pack_weights_multi) into exactly the LDS image
-//        (row = 8 chunks of 16 B: 3 planes x 2 k-halves + pad, chunk-swizzled), copied 1 KiB per instruction;
+//      - weights: scaled, split and packed once per step (ssn_conv_x6_pack_weights_multi) into exactly the LDS image
+//        (row = 4 chunks of 16 B: 2 planes x 2 k-halves, chunk-swizzled), copied 1 KiB per instruction;
 //      - activations: RAW fp32, 16 k-rows x BN pixels (the DMA deposits lane-consecutive dwords = pixel-major
-//        rows); a wave splits them into bf16 planes while building its B fragments (8 ds_read_b32 + ~44 VALU per
-//        32-pixel fragment and slab).
+//        rows); a wave scales and splits them into f16 planes while building its B fragments (8 ds_read_b32 + ~24
+//        VALU per 32-pixel fragment and slab).
 //  * NG = 2 ("ping-pong") workgroups have 8 waves = two groups that share the A tile and own half of the pixel
 //    columns each.  Two s_barriers per slab hold the groups half a slab apart: while one group issues its MFMAs the
 //    other reads LDS and splits, so each SIMD's matrix pipe always has one wave feeding it (free-running co-resident
@@ -34,24 +37,40 @@ namespace {
 
 using namespace x6;
 
-// ---- weight split + pack: out[slab][m][8 chunks x 4 dwords] ----
+// ---- weight scale + split + pack: out[slab][m][4 chunks x 4 dwords], then [amax, 0, 0, 0] ----
 // slab = g (1x1) or g * 9 + tap (3x3); row k of a slab = channel 16 g + k.  Logical 16-byte chunk c = 2 * plane +
-// khalf holds bf16 k = 8 * khalf + 0..7 of that plane (c = 6, 7: zero padding); it is stored at chunk position
-// c ^ ((m >> 1) & 7), which makes the straight LDS copy conflict-free for the ds_read_b128 fragment reads.
+// khalf holds f16 k = 8 * khalf + 0..7 of that plane; it is stored at chunk position c ^ ((m >> 2) & 3), which makes
+// the straight LDS copy conflict-free for the ds_read_b128 fragment reads.
 //   mode 0 (forward operand): A[m][c][tap] = w[m][c][tap];  mode 1 (dgrad operand): A[m][c][tap] = w[c][m][tap]
 // Two sources (fused pair): output channel co < split comes from w0, the rest from w1.
+// Three launches: clear the amax tails, max |w| of every entry into its tail (XP_AMAX_BLOCKS workgroups per entry,
+// unsigned atomic max), then the packing proper, which derives the entry's power-of-two scale from that tail.
 constexpr int XP_MAX = 40;
 constexpr int XP_CHUNK = 4096;   // (slab, m, kpair) triples per block
+constexpr int XP_AMAX_BLOCKS = 8;
 struct X6PackTable {
     const float* w0[XP_MAX];
     const float* w1[XP_MAX];
     uint32_t* out[XP_MAX];
+    long rows_dw[XP_MAX];       // dwords of the packed rows; the tail starts there
     int cout[XP_MAX], cin[XP_MAX], kk[XP_MAX], mode[XP_MAX], split[XP_MAX];   // kk = taps per channel (kh * kw)
     int srckk[XP_MAX];          // taps per channel of the SOURCE weight (== kk unless a tap subset is packed)
     unsigned tapmap[XP_MAX];    // srckk != kk: nibble t = source tap of packed tap t
     int blk0[XP_MAX + 1];
     int count;
 };
+__global__ __launch_bounds__(64) void pack_x6_clear_tail_kernel(X6PackTable t) {
+    for (int i = threadIdx.x; i < t.count * ATAIL; i += 64) t.out[i / ATAIL][t.rows_dw[i / ATAIL] + i % ATAIL] = 0u;
+}
+__global__ __launch_bounds__(256) void pack_x6_amax_kernel(X6PackTable t) {
+    const int ti = blockIdx.x / XP_AMAX_BLOCKS, part = blockIdx.x % XP_AMAX_BLOCKS;
+    const long n0 = (long)t.split[ti] * t.cin[ti] * t.srckk[ti];                    // elements of w0
+    const long n1 = (long)(t.cout[ti] - t.split[ti]) * t.cin[ti] * t.srckk[ti];     // elements of w1 (fused pair)
+    float m = 0.f;
+    for (long i = (long)part * 256 + threadIdx.x; i < n0 + n1; i += 256 * XP_AMAX_BLOCKS)
+        m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : t.w1[ti][i - n0]));
+    amax_emit(reinterpret_cast<float*>(t.out[ti] + t.rows_dw[ti]), m);
+}
 __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
     int ti = 0;
     while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;
@@ -62,6 +81,7 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
     const long base = (long)((int)blockIdx.x - t.blk0[ti]) * XP_CHUNK;
     long end = base + XP_CHUNK;
     if (end > total) end = total;
+    const float sa = f16_scale_of(__builtin_bit_cast(float, t.out[ti][t.rows_dw[ti]]));
     for (long idx = base + threadIdx.x; idx < end; idx += 256) {
         const int kp = (int)(idx & 7);
         const long sm = idx >> 3;
@@ -82,16 +102,22 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
             }
             v[e] = x;
         }
-        uint32_t p0, p1, p2;
-        bf16_split3_pair(v[0], v[1], p0, p1, p2);
+        uint32_t hi, lo;
+        f16_split2_pair(v[0], v[1], sa, hi, lo);
         uint32_t* row = t.out[ti] + ((long)slab * M + m) * APITCH;
-        const int swz = (m >> 1) & 7;
+        const int swz = (m >> 2) & 3;
         const int khalf = kp >> 2, w = kp & 3;
-        row[((0 + khalf) ^ swz) * 4 + w] = p0;
-        row[((2 + khalf) ^ swz) * 4 + w] = p1;
-        row[((4 + khalf) ^ swz) * 4 + w] = p2;
-        row[((6 + khalf) ^ swz) * 4 + w] = 0u;   // padding chunks
+        row[((0 + khalf) ^ swz) * 4 + w] = hi;
+        row[((2 + khalf) ^ swz) * 4 + w] = lo;
     }
+}
+// the three launches of a filled table (blk0[count] = blocks of the packing launch)
+int launch_pack(const X6PackTable& t, hipStream_t stream) {
+    if (t.count == 0 || t.blk0[t.count] == 0) return SSN_OK;
+    hipLaunchKernelGGL(pack_x6_clear_tail_kernel, dim3(1), dim3(64), 0, stream, t);
+    hipLaunchKernelGGL(pack_x6_amax_kernel, dim3((unsigned)(t.count * XP_AMAX_BLOCKS)), dim3(256), 0, stream, t);
+    hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)t.blk0[t.count]), dim3(256), 0, stream, t);
+    return SSN_OK;
 }
 
 int g_x6_dbg = 0;   // tooling: bit 4 (16) disables the 16-byte activation loads
@@ -168,10 +194,16 @@ long x6_packed_dwords(int Cout, int Cin, int ksize, int transposed) {
 }
 
 int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, int C, int H, int W, long xs, int M,
-              int Ho, int Wo, long ys, int ksize, int pad, const char* what) {
+              int Ho, int Wo, long ys, int ksize, int pad, const float* x_amax, float* y_amax, const char* what) {
+    if (!x_amax) {
+        ssn_set_error("%s: the source tensor's amax slot is required (operand scaling of the f16 split)", what);
+        return SSN_ERR_ARG;
+    }
     a.x = x;
     a.ap = ap;
     a.y = y;
+    a.x_amax = x_amax;
+    a.y_amax = y_amax;
     a.N = N;
     a.C = C;
     a.H = H;
@@ -188,7 +220,7 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
     const long xb = ((long)(N - 1) * xs + (long)C * H * W) * 4;
-    const long ab = (long)a.ngroups * ksize * ksize * M * APITCH * 4;
+    const long ab = (long)a.ngroups * ksize * ksize * M * APITCH * 4;   // packed rows (the amax tail follows them)
     if (!(xb < (1l << 31) && ab < (1l << 31) && (long)N * Ho * Wo < (1l << 31))) {
         ssn_set_error("%s: operand larger than 2 GiB (buffer addressing)", what);
         return SSN_ERR_ARG;
@@ -220,7 +252,7 @@ extern "C" long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int tran
     return x6_packed_dwords(Cout, Cin, ksize, transposed);
 }
 
-// Split + pack `count` weights (HOST arrays, one entry per layer; see ssn_conv_pack_weights_multi for w1/split).
+// Scale + split + pack `count` weights (HOST arrays, one entry per layer; see ssn_conv_pack_weights_multi for w1/split).
 extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1,
                                               float* const* out, const int* cout, const int* cin, const int* ksize,
                                               const int* mode, const int* split, hipStream_t stream) {
@@ -246,11 +278,12 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
             t.mode[i] = mode[j];
             t.split[i] = split[j];
             t.blk0[i] = blocks;
-            const long triples = x6_packed_dwords(cout[j], cin[j], ksize[j], mode[j]) / APITCH * 8;
+            t.rows_dw[i] = x6_row_dwords_kk(cout[j], cin[j], t.kk[i], mode[j]);
+            const long triples = t.rows_dw[i] / APITCH * 8;
             blocks += (int)((triples + XP_CHUNK - 1) / XP_CHUNK);
         }
         t.blk0[t.count] = blocks;
-        if (blocks) hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+        launch_pack(t, stream);
     }
     SSN_CHECK_LAUNCH("conv_x6_pack_weights_multi");
     return SSN_OK;
@@ -274,9 +307,10 @@ extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cou
     t.mode[0] = 0;
     t.split[0] = cout;
     t.blk0[0] = 0;
-    const long triples = x6_packed_dwords_kk(cout, cin, kh * kw, 0) / APITCH * 8;
+    t.rows_dw[0] = x6_row_dwords_kk(cout, cin, kh * kw, 0);
+    const long triples = t.rows_dw[0] / APITCH * 8;
     t.blk0[1] = (int)((triples + XP_CHUNK - 1) / XP_CHUNK);
-    hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)t.blk0[1]), dim3(256), 0, stream, t);
+    launch_pack(t, stream);
     SSN_CHECK_LAUNCH("conv_x6_pack_weights_rect");
     return SSN_OK;
 }
@@ -310,12 +344,12 @@ extern "C" int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, i
         t.mode[cls] = 1;
         t.split[cls] = cout;
         t.blk0[cls] = blocks;
-        const long dwords = x6_packed_dwords_kk(cout, cin, kh * kw, 1);
-        blocks += (int)((dwords / APITCH * 8 + XP_CHUNK - 1) / XP_CHUNK);
-        off += dwords;
+        t.rows_dw[cls] = x6_row_dwords_kk(cout, cin, kh * kw, 1);
+        blocks += (int)((t.rows_dw[cls] / APITCH * 8 + XP_CHUNK - 1) / XP_CHUNK);
+        off += t.rows_dw[cls] + ATAIL;
     }
     t.blk0[4] = blocks;
-    hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    launch_pack(t, stream);
     SSN_CHECK_LAUNCH("conv_x6_pack_dgrad_s2");
     return SSN_OK;
 }
@@ -323,13 +357,13 @@ extern "C" int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, i
 extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                                float* y, int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                                long y_img_stride, int ksize, int stride, int pad, int relu, int x_guard_bytes,
-                               int tile_cfg, hipStream_t stream) {
+                               int tile_cfg, const float* x_amax, float* y_amax, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv x6 fwd: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 fwd: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv x6 fwd: stride %d unsupported", stride);
     X6Args a;
     int rc = fill_args(a, x, (const uint32_t*)w_packed, y, N, Cin, H, W, x_img_stride, Cout, Ho, Wo, y_img_stride,
-                       ksize, pad, "conv x6 fwd");
+                       ksize, pad, x_amax, y_amax, "conv x6 fwd");
     if (rc != SSN_OK) return rc;
     a.x_guard = x_guard_bytes;
     a.scale = scale;
@@ -351,12 +385,13 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
 extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                                  long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                                 int dy_guard_bytes, int tile_cfg, hipStream_t stream) {
+                                 int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax,
+                                 hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 dgrad: ksize %d unsupported", ksize);
     X6Args a;
     int rc = fill_args(a, dy, (const uint32_t*)wt_packed, dx, N, Cout, Ho, Wo, dy_img_stride, Cin, H, W,
-                       dx_img_stride, ksize, pad, "conv x6 dgrad");
+                       dx_img_stride, ksize, pad, dy_amax, dx_amax, "conv x6 dgrad");
     if (rc != SSN_OK) return rc;
     a.x_guard = dy_guard_bytes;
     a.scale = nullptr;

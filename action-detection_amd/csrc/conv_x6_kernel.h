@@ -1,5 +1,7 @@
-// The bf16-split ("x6") implicit-GEMM convolution kernel template, shared by conv_x6.hip (the square 1x1 / 3x3 layers
-// of BN-Inception, forward and dgrad) and conv_x6_rect.hip (rectangular taps: 5x5, 1x7, 7x1, 1x3, 3x1 forward).
+// The split-operand implicit-GEMM convolution kernel template (fp32 operands as two f16 terms, three f16 MFMAs per k16
+// step; the family keeps its historical "x6" name from the first version, which used three bf16 terms and six
+// products), shared by conv_x6.hip (the square 1x1 / 3x3 layers of BN-Inception, forward and dgrad) and
+// conv_x6_rect.hip (rectangular taps: 5x5, 1x7, 7x1, 1x3, 3x1 forward, and the stride-2 dgrad classes).
 // Design notes: see the head of conv_x6.hip.
 #pragma once
 #include "conv_epilogue.h"
@@ -10,15 +12,17 @@ namespace x6 {
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int APITCH = 32;    // dwords per packed weight row: 8 chunks of 16 B (6 data + 2 pad), chunk-swizzled
+constexpr int APITCH = 16;    // dwords per packed weight row: 4 chunks of 16 B (2 planes x 2 k-halves), chunk-swizzled
+constexpr int ATAIL = 4;      // dwords behind the packed rows of a weight: [amax of the weight, 0, 0, 0]
 constexpr uint32_t OOB = 0x80000000u;
 
 struct X6Args {
     const float* x;       // gather source (channel-slice base), fp32 NCHW
-    const uint32_t* ap;   // packed split weights [nslab][M][APITCH]
+    const uint32_t* ap;   // packed split weights [nslab][M][APITCH], then ATAIL dwords (the weight's amax)
+    const float* x_amax;  // amax slot of the gather source's tensor (required)
+    float* y_amax;        // amax slot of the output tensor (nullptr: not tracked)
     float* y;
     const float* scale;
     const float* shift;
@@ -49,7 +53,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// (operand split: bf16_pair_rne / bf16_pair_lo / bf16_pair_hi of ssn_common.h -- round-to-nearest, exact in 3 terms)
+// (operand split and scaling: f16_pair_rne / f16_pair_lo / f16_pair_hi / f16_scale_of of ssn_common.h)
 
 // The 16-byte LDS-DMA form only exists for gfx950; hipcc's HOST pass (no target features) rejects it and then
 // silently drops the kernel's launch stub, so it is compiled for the device pass only.
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
     constexpr int BNG = WN * TN * 32;       // pixel columns of one wave group
     constexpr int BN = NG * BNG;
     constexpr int KK = KH * KW;
-    constexpr int A_PIECES = BM / 8;        // 1 KiB pieces of the BM x 128 B weight tile
+    constexpr int A_PIECES = BM / 16;       // 1 KiB pieces of the BM x 64 B weight tile
     constexpr int NA = (A_PIECES + NW - 1) / NW;
     constexpr int A_STAGE = NA * NW * 256;  // dwords; padded so that every wave copies exactly NA pieces
     constexpr int B_STAGE = 16 * BN;        // dwords
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
         const int f = (q * NW + wave) * 64 + lane;   // 16-byte chunk of the tile
-        aoff[q] = (f < BM * 8 && m0 + f / 8 < p.M) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : OOB;
+        aoff[q] = (f < BM * 4 && m0 + f / 4 < p.M) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : OOB;
     }
     const __amdgpu_buffer_rsrc_t xrsrc = make_rsrc(reinterpret_cast<const char*>(p.x) - GUARD, p.x_bytes + GUARD);
     const __amdgpu_buffer_rsrc_t arsrc = make_rsrc(p.ap, p.a_bytes);
@@ -267,11 +271,18 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
     issue(STAGE);   // past the last slab the pieces turn into out-of-range (all-zero) copies: no branches in the loop
     if (p.trace) tr1 = __builtin_readcyclecounter();
 
-    // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 1) & 7)
-    const int swz = (li >> 1) & 7;
-    int achunk[3];
+    // operand scales (powers of two, exact): the weight's amax sits behind its packed rows, the activations' in the
+    // slot their producers maintained
+    const float sa = f16_scale_of(__builtin_bit_cast(float, p.ap[p.a_bytes >> 2]));
+    const float sb = f16_scale_of(*p.x_amax);
+    const float inv = 1.f / (sa * sb);
+
+    // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 2) & 3): the 16 lanes of a
+    // ds_read_b128 group (li in {0-3,12-15,20-27} or {4-11,16-19,28-31}) then cover all 16 bank quads once
+    const int swz = (li >> 2) & 3;
+    int achunk[2];
 #pragma unroll
-    for (int pn = 0; pn < 3; ++pn) achunk[pn] = ((2 * pn + lh) ^ swz) * 4;
+    for (int pn = 0; pn < 2; ++pn) achunk[pn] = ((2 * pn + lh) ^ swz) * 4;
     const int arow = (wm * TM * 32 + li) * APITCH;
     const int bcol = A_STAGE + (8 * lh) * BN + grp * BNG + wn * TN * 32 + li;
 
@@ -279,30 +290,22 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
     // sets: a free-running (NG == 1) wave reads slab t+1 from LDS while it multiplies slab t.
     struct Frags {
         float raw[TN][8];
-        bf16x8 af[3][TM];
+        f16x8 af[2][TM];
     };
     Frags fr0, fr1;
-    uint32_t pl[3][TN][4];   // the three bf16 planes of the slab being multiplied, as k-pairs
-    float res[TN][8];
-    // The split of pair e (k = 2e, 2e+1) of fragment j into its plane-1 and plane-2 dwords, as two half steps of
-    // 5 VALU (what fits in the shadow of one MFMA): first residual + plane 1, then second residual + plane 2.
-    // (pl[0][j][e] of this slab must already hold the top plane: top_plane() runs before any half step.)
-    auto split_half = [&](const Frags& f, int j, int e, int half) {
-        if (half == 0) {
-            res[j][2 * e] = f.raw[j][2 * e] - bf16_pair_lo(pl[0][j][e]);
-            res[j][2 * e + 1] = f.raw[j][2 * e + 1] - bf16_pair_hi(pl[0][j][e]);
-            pl[1][j][e] = bf16_pair_rne(res[j][2 * e], res[j][2 * e + 1]);
-        } else {
-            const float s0 = res[j][2 * e] - bf16_pair_lo(pl[1][j][e]), s1 = res[j][2 * e + 1] - bf16_pair_hi(pl[1][j][e]);
-            pl[2][j][e] = bf16_pair_rne(s0, s1);
-        }
+    uint32_t pl[2][TN][4];   // the two f16 planes of the slab being multiplied, as k-pairs
+    // The low plane of pair e (k = 2e, 2e+1) of fragment j: residual against the top plane + conversion, 4 VALU (two
+    // v_cvt_f32_f16, one packed subtract, one v_cvt_pk_f16_f32) -- what fits in the shadow of half an MFMA.
+    // (f.raw already holds the SCALED values and pl[0][j][e] the top plane: top_plane() runs before any low step.)
+    auto low_step = [&](const Frags& f, int j, int e) {
+        pl[1][j][e] = f16_pair_rne(f.raw[j][2 * e] - f16_pair_lo(pl[0][j][e]), f.raw[j][2 * e + 1] - f16_pair_hi(pl[0][j][e]));
     };
     // LDS -> registers: raw activations (a tap on padding reads the rows of zeros instead) and weight fragments, as
     // NREAD separate steps (a k-pair of one activation fragment = one ds_read2st64_b32, or one 16-byte weight read) so
     // that a pipelined wave can deal them out between its MFMAs: eight waves that all burst 13+ reads right after the
     // barrier queue up behind the LDS pipeline for ~200 cycles before anybody's first MFMA issues.
     int ctap = 0;   // tap of the slab being read (WIDE 3x3 only)
-    constexpr int NREAD = 4 * TN + 3 * TM;
+    constexpr int NREAD = 4 * TN + 2 * TM;
     const uint32_t* rd_src[TN];
     const uint32_t* rd_a;
     auto read_begin = [&](uint32_t st_off) {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
             f.raw[j][2 * e + 1] = __builtin_bit_cast(float, rd_src[j][(2 * e + 1) * BN]);
         } else {
             const int q = k - 4 * TN, pn = q / TM, i = q % TM;
-            f.af[pn][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(rd_a + i * 32 * APITCH + achunk[pn]));
+            f.af[pn][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(rd_a + i * 32 * APITCH + achunk[pn]));
         }
     };
     auto read_frags = [&](uint32_t st_off, Frags& f) {
@@ -333,55 +336,54 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
 #pragma unroll
         for (int k = 0; k < NREAD; ++k) read_step(f, k);
     };
-    // top plane (one v_cvt_pk_bf16_f32 per k-pair); `all_planes`: also the two lower ones (the ping-pong groups split while the
-    // other group multiplies; a free-running wave does that in the shadow of its own MFMAs instead, see mfma)
-    auto top_plane = [&](const Frags& f, bool all_planes) {
+    // scale the raw values in place and take the top plane (one packed multiply + one v_cvt_pk_f16_f32 per k-pair);
+    // `all_planes`: also the low one (the ping-pong groups split while the other group multiplies; a free-running wave
+    // does that in the shadow of its own MFMAs instead, see mfma)
+    auto top_plane = [&](Frags& f, bool all_planes) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pl[0][j][e] = bf16_pair_rne(f.raw[j][2 * e], f.raw[j][2 * e + 1]);
-                if (all_planes) {
-                    split_half(f, j, e, 0);
-                    split_half(f, j, e, 1);
-                }
+                f.raw[j][2 * e] *= sb;
+                f.raw[j][2 * e + 1] *= sb;
+                pl[0][j][e] = f16_pair_rne(f.raw[j][2 * e], f.raw[j][2 * e + 1]);
+                if (all_planes) low_step(f, j, e);
             }
     };
     auto front = [&](uint32_t st_off, bool all_planes) {
         read_frags(st_off, fr0);
         top_plane(fr0, all_planes);
     };
-    // Six partial products per accumulator tile.  The three that only need the TOP plane of the activations go first,
-    // then plane 1, then plane 2, and (`interleave`) the 8 * TN half steps that produce the two lower planes are dealt
-    // out behind those first MFMAs, fenced in place: the matrix pipe starts as soon as the LDS reads are back and the
-    // ~40 VALU per fragment run in its shadow.  (The running fp32 accumulator already holds the earlier slabs, so the
-    // order of the six products inside a slab is immaterial for rounding.)  With `dma` the pieces of the slab two
-    // ahead are dealt out between the MFMAs as well.
+    // Three partial products per accumulator tile: w_lo x_hi, w_hi x_hi, w_hi x_lo.  The two that only need the TOP plane
+    // of the activations go first and (`interleave`) the 4 * TN low steps that produce the low plane are dealt out
+    // behind those MFMAs, fenced in place: the matrix pipe starts as soon as the LDS reads are back and the ~16 VALU
+    // per fragment run in its shadow.  (The running fp32 accumulator already holds the earlier slabs, so the order of
+    // the products inside a slab is immaterial for rounding.)  With `dma` the pieces of the slab two ahead are dealt
+    // out between the MFMAs as well.
     auto mfma = [&](auto dma_tag, auto il_tag, const Frags& f, uint32_t dma_stage, Frags& nxt) {
         constexpr bool dma = decltype(dma_tag)::value;
         constexpr bool interleave = decltype(il_tag)::value;
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int PB[6] = {0, 0, 0, 1, 1, 2};
-        constexpr int NM = 6 * TM * TN;
-        constexpr int NTOP = 3 * TM * TN;   // MFMAs that need plane 0 only
-        constexpr int NSTEP = 8 * TN;   // half steps
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 0, 1};
+        constexpr int NM = 3 * TM * TN;
+        constexpr int NTOP = 2 * TM * TN;   // MFMAs that need plane 0 only
+        constexpr int NSTEP = 4 * TN;       // low steps
         constexpr int EVERY = NM / NLOAD > 0 ? NM / NLOAD : 1;
         if (dma) issue_begin(dma_stage);
         if (interleave) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const bf16x8 b = __builtin_bit_cast(
-                        bf16x8, u32x4{pl[PB[c]][j][0], pl[PB[c]][j][1], pl[PB[c]][j][2], pl[PB[c]][j][3]});
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.af[PA[c]][i], b, acc[i][j], 0, 0, 0);
+                    const f16x8 b = __builtin_bit_cast(
+                        f16x8, u32x4{pl[PB[c]][j][0], pl[PB[c]][j][1], pl[PB[c]][j][2], pl[PB[c]][j][3]});
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.af[PA[c]][i], b, acc[i][j], 0, 0, 0);
                     const int idx = (c * TM + i) * TN + j;
                     if (interleave && idx < NTOP) {
 #pragma unroll
-                        for (int st = idx * NSTEP / NTOP; st < (idx + 1) * NSTEP / NTOP; ++st)
-                            split_half(f, st / 8, (st % 8) / 2, st % 2);
+                        for (int st = idx * NSTEP / NTOP; st < (idx + 1) * NSTEP / NTOP; ++st) low_step(f, st / 4, st % 4);
                     }
                     if (interleave) {   // the LDS reads of the next slab (into the other register set)
 #pragma unroll
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
         __builtin_amdgcn_s_barrier();
         read_frags(0, fr0);
         uint32_t s_cur = 0, s_n1 = STAGE, s_n2 = 2 * STAGE;   // ring slots of slabs t, t+1, t+2
-        auto half = [&](const Frags& cur, Frags& nxt) {
+        auto half = [&](Frags& cur, Frags& nxt) {
             SSN_WAIT_VMCNT(NLOAD);   // this wave's pieces of slab t+1 (slab t+2's may still be in flight)
             SSN_WAIT_LGKM0();        // ... and its reads of slab t are back
             X6_PH(0);
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
     // ---- epilogue: BN affine + ReLU (forward), or accumulate + fused ReLU/BN backward (dgrad) ----
     __syncthreads();
     float* ch = reinterpret_cast<float*>(lds);
-    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid);
+    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid, inv);
     __syncthreads();
     EpiArgs e;
     e.y = p.y;
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
     e.M = p.M;
     e.relu = p.relu;
     e.accumulate = p.accumulate;
+    e.amax = p.y_amax;
     uint32_t yoff[TN], moff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -529,10 +532,14 @@ static inline int x6_reach_bytes(int pad_h, int pad_w, int kh, int kw, int W) {
     return (rh * W + rw) * 4;
 }
 
-// dwords of the packed split weights: [ceil(C / 16) * kk slabs][M rows][APITCH]
-static inline long x6_packed_dwords_kk(int Cout, int Cin, int kk, int transposed) {
+// dwords of the packed rows of a split weight: [ceil(C / 16) * kk slabs][M rows][APITCH] ...
+static inline long x6_row_dwords_kk(int Cout, int Cin, int kk, int transposed) {
     const int M = transposed ? Cin : Cout, C = transposed ? Cout : Cin;
     return (long)((C + 15) / 16) * kk * M * APITCH;
+}
+// ... and of the whole packed operand (rows + amax tail)
+static inline long x6_packed_dwords_kk(int Cout, int Cin, int kk, int transposed) {
+    return x6_row_dwords_kk(Cout, Cin, kk, transposed) + ATAIL;
 }
 
 }  // namespace x6

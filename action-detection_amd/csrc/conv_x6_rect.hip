@@ -1,4 +1,4 @@
-// Rectangular-tap forward convolutions on the bf16-split ("x6") kernel of conv_x6_kernel.h, gfx950.
+// Rectangular-tap forward convolutions on the split-operand (f16 x 3, "x6" family) kernel of conv_x6_kernel.h, gfx950.
 //
 // BN-Inception only has square 1x1 / 3x3 taps (conv_x6.hip).  The Inception-v3 backbone the reference's tester runs on
 // ActivityNet (/root/reference/ssn_models.py:133-139, BASELINE.json configs[4]) also has 5x5, 1x7, 7x1, 1x3 and 3x1
@@ -60,7 +60,7 @@ extern "C" long ssn_conv_x6_dgrad_s2_packed_floats(int Cout, int Cin) {
     return tot;
 }
 
-// Data gradient of a 3x3 / stride-2 / pad-1 convolution (even H, W) on the bf16-split kernel: four stride-1 launches,
+// Data gradient of a 3x3 / stride-2 / pad-1 convolution (even H, W) on the split kernel: four stride-1 launches,
 // one per parity class of the input pixel (see ssn_conv_x6_pack_dgrad_s2), each a (1 + a) x (1 + b)-tap gather over
 // dy whose results are stored at the class's pixels of dx.  No tap is multiplied that does not contribute (the
 // exact-f32 kernel of conv_igemm.hip gets there with a parity-ordered pixel enumeration; this is the same idea on
@@ -68,8 +68,10 @@ extern "C" long ssn_conv_x6_dgrad_s2_packed_floats(int Cout, int Cin) {
 extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                                     long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int accumulate,
                                     const float* mask_y, long mask_img_stride, const float* mask_scale,
-                                    int dy_guard_bytes, int tile_cfg, hipStream_t stream) {
+                                    int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax,
+                                    hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad s2: null pointer");
+    SSN_CHECK_ARG(dy_amax, "conv x6 dgrad s2: the source tensor's amax slot is required");
     SSN_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2,
                   "conv x6 dgrad s2: needs a 3x3 / stride-2 / pad-1 convolution with even input size (%dx%d -> %dx%d)", H, W, Ho, Wo);
     long off = 0;
@@ -79,6 +81,8 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         a.x = dy;
         a.ap = (const uint32_t*)wt_packed + off;
         a.y = dx;
+        a.x_amax = dy_amax;
+        a.y_amax = dx_amax;
         a.scale = nullptr;
         a.shift = nullptr;
         a.N = N;
@@ -109,7 +113,7 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
         a.div_w = make_fastdiv((uint32_t)Wo);
         const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4;
-        const long ab = x6_packed_dwords_kk(Cout, Cin, kh * kw, 1) * 4;
+        const long ab = x6_row_dwords_kk(Cout, Cin, kh * kw, 1) * 4;   // packed rows; the amax tail follows
         const long yb = ((long)(N - 1) * dx_img_stride + (long)Cin * H * W) * 4;
         const long mb = a.mask_y ? ((long)(N - 1) * mask_img_stride + (long)Cin * H * W) * 4 : 0;
         SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31) && yb < (1l << 31) && mb < (1l << 31),
@@ -124,7 +128,7 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         else if (cls == 2) rc = launch_rect<2, 1>(a, tile_cfg, stream);
         else rc = launch_rect<2, 2>(a, tile_cfg, stream);
         if (rc != SSN_OK) return rc;
-        off += ab / 4;
+        off += ab / 4 + ATAIL;
     }
     return SSN_OK;
 }
@@ -138,13 +142,16 @@ extern "C" long ssn_conv_x6_packed_floats_rect(int Cout, int Cin, int kh, int kw
 extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                                     int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                                     long y_img_stride, int kh, int kw, int pad_h, int pad_w, int relu, int x_guard_bytes,
-                                    int tile_cfg, hipStream_t stream) {
+                                    int tile_cfg, const float* x_amax, float* y_amax, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv x6 rect: null pointer");
+    SSN_CHECK_ARG(x_amax, "conv x6 rect: the source tensor's amax slot is required");
     SSN_CHECK_ARG(Ho == H + 2 * pad_h - kh + 1 && Wo == W + 2 * pad_w - kw + 1, "conv x6 rect: output %dx%d does not match", Ho, Wo);
     X6Args a;
     a.x = x;
     a.ap = (const uint32_t*)w_packed;
     a.y = y;
+    a.x_amax = x_amax;
+    a.y_amax = y_amax;
     a.scale = scale;
     a.shift = shift;
     a.N = N;
@@ -172,7 +179,7 @@ extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
     const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
-    const long ab = x6_packed_dwords_kk(Cout, Cin, kh * kw, 0) * 4;
+    const long ab = x6_row_dwords_kk(Cout, Cin, kh * kw, 0) * 4;
     const long yb = ((long)(N - 1) * y_img_stride + (long)Cout * Ho * Wo) * 4;
     SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31) && yb < (1l << 31) && (long)N * Ho * Wo < (1l << 31),
                   "conv x6 rect: operand larger than 2 GiB (buffer addressing)");

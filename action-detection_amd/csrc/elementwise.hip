@@ -15,7 +15,7 @@ void ssn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* ssn_last_error(void) { return g_err; }
-extern "C" int ssn_abi_version(void) { return 2; }
+extern "C" int ssn_abi_version(void) { return 3; }
 
 namespace {
 
@@ -34,7 +34,8 @@ __global__ void bn_fold_kernel(const float* bias, const float* gamma, const floa
 // g = dy * (y > 0) * scale[c], in place on dy.  Tensors are NCHW channel slices.
 __global__ __launch_bounds__(256) void relu_bn_bwd_kernel(float* dy, const float* y, const float* scale, int C,
                                                           int HW, long dy_img_stride, long y_img_stride,
-                                                          long total, FastDiv div_chw, FastDiv div_hw) {
+                                                          long total, FastDiv div_chw, FastDiv div_hw, float* amax) {
+    float vmax = 0.f;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw;
         fd_divmod((uint32_t)idx, div_chw, n, rem);
@@ -42,31 +43,61 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_kernel(float* dy, const float
         const long di = (long)n * dy_img_stride + rem;
         const long yi = (long)n * y_img_stride + rem;
         const float yv = y[yi];
-        dy[di] = (yv > 0.f) ? dy[di] * scale[c] : 0.f;
+        const float o = (yv > 0.f) ? dy[di] * scale[c] : 0.f;
+        dy[di] = o;
+        vmax = fmaxf(vmax, fabsf(o));
     }
+    amax_emit(amax, vmax);
 }
 
-// out[c] = sum over images and pixels of g[n][c][:] -- one workgroup per channel, fixed summation order (deterministic):
-// the bias gradient of a projection whose pooling runs behind it (the weight-gradient kernel's own bias column would
-// sum the POOLED gradient, which differs at the image border).
-__global__ __launch_bounds__(1024) void channel_sum_kernel(const float* g, float* out, int N, int HW, long img_stride) {
-    __shared__ float red[16];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const float* base = g + (long)c * HW;
-    float s = 0.f;
-    const long total = (long)N * HW;
-    for (long i = tid; i < total; i += 1024) {
-        const long n = i / HW, hw = i - n * HW;
-        s += base[n * img_stride + hw];
+// slot = max(slot, max |x|) over `n` contiguous floats: the amax slot of a tensor that no tracked kernel produced (the
+// frames the caller hands in, test inputs).  The slot must hold a valid value (normally 0) on entry.
+__global__ __launch_bounds__(256) void tensor_amax_kernel(const float* x, long n, float* slot) {
+    float vmax = 0.f;
+    const long n4 = n >> 2;
+    const bool al = ((uintptr_t)x & 15) == 0;
+    if (al) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            const f32x4 v = x4[i];
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
     }
-    s = wave_sum(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
+    for (long i = (al ? n4 * 4 : 0) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        vmax = fmaxf(vmax, fabsf(x[i]));
+    amax_emit(slot, vmax);
+}
+
+// out[c] = sum over images and pixels of g[n][c][:], in a fixed order (deterministic): the bias gradient of a projection
+// whose pooling runs behind it (the weight-gradient kernel's own bias column would sum the POOLED gradient, which
+// differs at the image border).  Two passes: workgroup (c, s) sums the images of share s of channel c (lanes along
+// the contiguous pixels, no divisions) into part[c][s]; the second pass adds the shares of a channel in order.
+__global__ __launch_bounds__(256) void channel_sum_part_kernel(const float* g, float* part, int N, int HW,
+                                                               long img_stride, int S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const int n0 = (int)((long)N * s / S), n1 = (int)((long)N * (s + 1) / S);
+    float a0 = 0.f, a1 = 0.f;
+    for (int n = n0; n < n1; ++n) {
+        const float* row = g + (long)n * img_stride + (long)c * HW;
+        int hw = tid;
+        for (; hw + 256 < HW; hw += 512) {
+            a0 += row[hw];
+            a1 += row[hw + 256];
+        }
+        if (hw < HW) a0 += row[hw];
+    }
+    const float v = wave_sum(a0 + a1);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += red[w];
-        out[c] = t;
-    }
+    if (tid == 0) part[(long)c * S + s] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* part, float* out, int C, int S) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += part[(long)c * S + s];
+    out[c] = t;
 }
 
 // Counter-based RNG for dropout: Philox-4x32-10 keyed by (seed), counter = element index / 4.
@@ -234,20 +265,39 @@ extern "C" int ssn_bn_fold(const float* conv_bias, const float* gamma, const flo
 }
 
 extern "C" int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C, int HW,
-                               long dy_img_stride, long y_img_stride, hipStream_t stream) {
+                               long dy_img_stride, long y_img_stride, float* dy_amax, hipStream_t stream) {
     SSN_CHECK_ARG(dy && y && scale, "relu_bn_bwd: null pointer");
     const long total = (long)N * C * HW;
     SSN_CHECK_ARG(total < (1l << 31), "relu_bn_bwd: tensor too large");
     hipLaunchKernelGGL(relu_bn_bwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, stream, dy, y, scale, C, HW,
                        dy_img_stride, y_img_stride, total, make_fastdiv((uint32_t)(C * HW)),
-                       make_fastdiv((uint32_t)HW));
+                       make_fastdiv((uint32_t)HW), dy_amax);
     SSN_CHECK_LAUNCH("relu_bn_bwd");
     return SSN_OK;
 }
 
-extern "C" int ssn_channel_sum(const float* g, float* out, int N, int C, int HW, long img_stride, hipStream_t stream) {
-    SSN_CHECK_ARG(g && out && N >= 1 && C >= 1 && HW >= 1, "channel_sum: bad arguments");
-    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C), dim3(1024), 0, stream, g, out, N, HW, img_stride);
+extern "C" int ssn_tensor_amax(const float* x, long n, float* slot, hipStream_t stream) {
+    SSN_CHECK_ARG(x && slot && n >= 0, "tensor_amax: bad arguments");
+    if (n == 0) return SSN_OK;
+    hipLaunchKernelGGL(tensor_amax_kernel, dim3(grid_for((n + 3) / 4, 2048)), dim3(256), 0, stream, x, n, slot);
+    SSN_CHECK_LAUNCH("tensor_amax");
+    return SSN_OK;
+}
+
+// shares per channel of ssn_channel_sum (workspace: C * ssn_channel_sum_shares(N) floats)
+extern "C" int ssn_channel_sum_shares(int N) { return N < 32 ? (N < 1 ? 1 : N) : 32; }
+extern "C" int ssn_channel_sum(const float* g, float* out, int N, int C, int HW, long img_stride, void* workspace,
+                               size_t ws_bytes, hipStream_t stream) {
+    SSN_CHECK_ARG(g && out && workspace && N >= 1 && C >= 1 && HW >= 1, "channel_sum: bad arguments");
+    const int S = ssn_channel_sum_shares(N);
+    if (ws_bytes < (size_t)C * S * sizeof(float)) {
+        ssn_set_error("channel_sum: workspace %zu < %zu bytes", ws_bytes, (size_t)C * S * sizeof(float));
+        return SSN_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(channel_sum_part_kernel, dim3((unsigned)C, (unsigned)S), dim3(256), 0, stream, g,
+                       (float*)workspace, N, HW, img_stride, S);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)workspace, out, C, S);
     SSN_CHECK_LAUNCH("channel_sum");
     return SSN_OK;
 }

@@ -34,6 +34,7 @@ struct PoolArgs {
     const float* aff_scale;
     const float* aff_shift;
     int aff_relu;
+    float* amax;   // amax slot of y's tensor (nullptr: not tracked; ssn_common.h: amax_emit)
     FastDiv div_chw, div_hw, div_w;
 };
 
@@ -42,6 +43,7 @@ template <bool MAX, int KC, int SC, int PC>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
     const int howo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xr = pool_rsrc(p.x, p.x_bytes);
+    float vmax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw, ho, wo;
         fd_divmod((uint32_t)i, p.div_chw, n, rem);
@@ -92,7 +94,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs p) {
             }
         }
         p.y[(long)n * p.y_img_stride + rem] = out;
+        vmax = fmaxf(vmax, fabsf(out));
     }
+    amax_emit(p.amax, vmax);
 }
 
 struct PoolBwdArgs {
@@ -107,6 +111,7 @@ struct PoolBwdArgs {
     long mask_img_stride;
     long total;  // N*C*H*W
     uint32_t dy_bytes, idx_bytes;
+    float* amax;   // amax slot of dx's tensor (nullptr: not tracked)
     FastDiv div_chw, div_hw, div_w;
 };
 
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
     constexpr int NWIN = (KC + SC - 1) / SC;  // max windows per axis covering one input pixel
     const __amdgpu_buffer_rsrc_t dyr = pool_rsrc(p.dy, p.dy_bytes);
     const __amdgpu_buffer_rsrc_t ixr = pool_rsrc(MAX ? (const void*)p.idx : (const void*)p.dy, MAX ? p.idx_bytes : 4u);
+    float vmax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw, hi, wi;
         fd_divmod((uint32_t)i, p.div_chw, n, rem);
@@ -171,7 +177,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
             g = (sc != sc) ? g : (p.mask_y[(long)n * p.mask_img_stride + rem] > 0.f ? g * sc : 0.f);
         }
         *dst = g;
+        vmax = fmaxf(vmax, fabsf(g));
     }
+    amax_emit(p.amax, vmax);
 }
 
 // one wave per (n, c): mean over the HW plane
@@ -199,6 +207,7 @@ struct PoolVecArgs {
     const float* aff_scale;   // average forward only: per-channel affine + ReLU on the pooled value (see PoolArgs)
     const float* aff_shift;
     int aff_relu;
+    float* amax;              // amax slot of y's tensor (nullptr: not tracked)
     FastDiv div_chq, div_hq, div_q;   // C*Ho*Wq, Ho*Wq, Wq  (Wq = Wo / V)
 };
 
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(256) void pool3_vec_kernel(PoolVecArgs p) {
     const int Wq = p.Wo / V;
     const int howo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t xr = pool_rsrc(p.x, p.x_bytes);
+    float vmax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hq, ho, wq;
         fd_divmod((uint32_t)i, p.div_chq, n, rem);
@@ -337,6 +347,8 @@ __global__ __launch_bounds__(256) void pool3_vec_kernel(PoolVecArgs p) {
             }
         }
         pool_store_wide<V>(p.y + o, out);
+#pragma unroll
+        for (int e = 0; e < V; ++e) vmax = fmaxf(vmax, fabsf(out[e]));
         if (MAX && p.idx) {
             uint8_t* ip = p.idx + ((long)n * p.C + c) * howo + (long)ho * p.Wo + wo0;
             if (V == 4)
@@ -345,6 +357,7 @@ __global__ __launch_bounds__(256) void pool3_vec_kernel(PoolVecArgs p) {
                 *reinterpret_cast<uint16_t*>(ip) = (uint16_t)arg;
         }
     }
+    amax_emit(p.amax, vmax);
 }
 
 // 3x3 / stride 2 / pad 0 max-pool backward with W == 2 Wo (and Wo % 2 == 0, so a strip of 4 input pixels starts on an
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(256) void pool_max2_bwd_vec_kernel(PoolBwdArgs p, F
     const int howo = p.Ho * p.Wo;
     const __amdgpu_buffer_rsrc_t dyr = pool_rsrc(p.dy, p.dy_bytes);
     const __amdgpu_buffer_rsrc_t ixr = pool_rsrc(p.idx, p.idx_bytes);
+    float vmax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_q; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hq, hi, q;
         fd_divmod((uint32_t)i, div_chq, n, rem);
@@ -405,7 +419,9 @@ __global__ __launch_bounds__(256) void pool_max2_bwd_vec_kernel(PoolBwdArgs p, F
             for (int e = 0; e < 4; ++e) g[e] = (sc != sc) ? g[e] : (t[e] > 0.f ? g[e] * sc : 0.f);
         }
         *reinterpret_cast<f32x4*>(p.dx + o) = f32x4{g[0], g[1], g[2], g[3]};
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(g[0]), fabsf(g[1]))), fmaxf(fabsf(g[2]), fabsf(g[3])));
     }
+    amax_emit(p.amax, vmax);
 }
 
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, float* y, int NC, int C, int HW,
@@ -422,16 +438,20 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, float* y, 
 }
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* dy, float* dx, long total, int C, int HW,
                                                       long dx_img_stride, int accumulate, FastDiv div_chw,
-                                                      FastDiv div_hw) {
+                                                      FastDiv div_hw, float* amax) {
     const float inv = 1.f / (float)HW;
+    float vmax = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         uint32_t n, rem, c, hw;
         fd_divmod((uint32_t)i, div_chw, n, rem);
         fd_divmod(rem, div_hw, c, hw);
         float* dst = dx + (long)n * dx_img_stride + rem;
         const float g = dy[(long)n * C + c] * inv;
-        *dst = accumulate ? *dst + g : g;
+        const float o = accumulate ? *dst + g : g;
+        *dst = o;
+        vmax = fmaxf(vmax, fabsf(o));
     }
+    amax_emit(amax, vmax);
 }
 
 inline unsigned grid_for(long total, int cap = 65536) {
@@ -445,9 +465,11 @@ inline unsigned grid_for(long total, int cap = 65536) {
 
 static int pool_fwd_impl(int is_max, const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W,
                          long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
-                         const float* aff_scale, const float* aff_shift, int aff_relu, hipStream_t stream) {
+                         const float* aff_scale, const float* aff_shift, int aff_relu, float* y_amax,
+                         hipStream_t stream) {
     SSN_CHECK_ARG(x && y, "pool_fwd: null pointer");
     PoolArgs a;
+    a.amax = y_amax;
     a.aff_scale = aff_scale;
     a.aff_shift = aff_shift;
     a.aff_relu = aff_relu;
@@ -483,6 +505,7 @@ static int pool_fwd_impl(int is_max, const float* x, float* y, unsigned char* ar
                         : 0;
     if (vec) {
         PoolVecArgs v;
+        v.amax = y_amax;
         v.x = x;
         v.y = y;
         v.idx = (uint8_t*)argmax;
@@ -535,9 +558,9 @@ static int pool_fwd_impl(int is_max, const float* x, float* y, unsigned char* ar
 
 extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W,
                             long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
-                            hipStream_t stream) {
+                            float* y_amax, hipStream_t stream) {
     return pool_fwd_impl(is_max, x, y, argmax, N, C, H, W, x_img_stride, Ho, Wo, y_img_stride, ksize, stride, pad, nullptr,
-                         nullptr, 0, stream);
+                         nullptr, 0, y_amax, stream);
 }
 
 // y = relu?(scale[c] * avgpool(x) + shift[c]): the pool-projection branch of an Inception block with the pool moved
@@ -546,18 +569,19 @@ extern "C" int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char*
 // channels, and the folded BN affine + ReLU of the projection are applied here.
 extern "C" int ssn_avgpool_affine_fwd(const float* x, float* y, const float* scale, const float* shift, int relu, int N,
                                       int C, int H, int W, long x_img_stride, int Ho, int Wo, long y_img_stride,
-                                      int ksize, int stride, int pad, hipStream_t stream) {
+                                      int ksize, int stride, int pad, float* y_amax, hipStream_t stream) {
     SSN_CHECK_ARG(scale && shift, "avgpool_affine_fwd: null pointer");
     return pool_fwd_impl(0, x, y, nullptr, N, C, H, W, x_img_stride, Ho, Wo, y_img_stride, ksize, stride, pad, scale, shift,
-                         relu, stream);
+                         relu, y_amax, stream);
 }
 
 extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H,
                             int W, long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride,
                             int pad, int accumulate, const float* mask_y, long mask_img_stride,
-                            const float* mask_scale, hipStream_t stream) {
+                            const float* mask_scale, float* dx_amax, hipStream_t stream) {
     SSN_CHECK_ARG(dy && dx && (!is_max || argmax), "pool_bwd: null pointer");
     PoolBwdArgs a;
+    a.amax = dx_amax;
     a.dy = dy;
     a.idx = (const uint8_t*)argmax;
     a.dx = dx;
@@ -600,6 +624,7 @@ extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* ar
         ((uintptr_t)dy % 16 == 0) && dy_img_stride % 4 == 0) {
         const int vec = W % 4 == 0 ? 4 : 2;
         PoolVecArgs v;
+        v.amax = dx_amax;
         v.x = dy;
         v.y = dx;
         v.idx = nullptr;
@@ -657,11 +682,11 @@ extern "C" int ssn_global_avgpool_fwd(const float* x, float* y, int N, int C, in
     return SSN_OK;
 }
 extern "C" int ssn_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, long dx_img_stride,
-                                      int accumulate, hipStream_t stream) {
+                                      int accumulate, float* dx_amax, hipStream_t stream) {
     SSN_CHECK_ARG(dy && dx, "gap_bwd: null pointer");
     const long total = (long)N * C * HW;
     hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, total, C, HW,
-                       dx_img_stride, accumulate, make_fastdiv((uint32_t)(C * HW)), make_fastdiv((uint32_t)HW));
+                       dx_img_stride, accumulate, make_fastdiv((uint32_t)(C * HW)), make_fastdiv((uint32_t)HW), dx_amax);
     SSN_CHECK_LAUNCH("gap_bwd");
     return SSN_OK;
 }

@@ -122,26 +122,58 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 #define SSN_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #endif
 
-// ---- exact 3-way bf16 split of fp32 values (the "x6" kernels) ----
-// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), every conversion ROUND-TO-NEAREST-EVEN
-// (v_cvt_pk_bf16_f32 on gfx950: two values per instruction, the same instruction count as a truncating split).  The sum
-// is exact -- the remainder after a rounding to 8 significant bits has at most 16, then at most 8 of them -- and,
-// unlike truncation, the terms have no preferred sign: the partial products an x6 kernel drops (x2*w3, x3*w2, x3*w3)
-// then neither add up systematically nor exceed 2^-26 |x w| each (tests/test_kernels.py::test_conv_x6_error_growth_with_k).
-typedef __bf16 ssn_bf16x2 __attribute__((ext_vector_type(2)));
+// ---- fp32 operands on the f16 matrix cores: 2-way split, 3 products (the "split" convolution kernels) ----
+// x * s = hi + lo + e with hi = f16(x s), lo = f16(x s - hi), both ROUND-TO-NEAREST-EVEN (v_cvt_pk_f16_f32 on gfx950),
+// |e| <= 2^-22 |x s|: an f16 carries 11 significant bits, so two terms hold 22 of the 24 bits of an fp32 value, and a
+// product a * b is accumulated in fp32 from THREE partial products  a_lo b_hi + a_hi b_lo + a_hi b_hi  (the dropped
+// a_lo b_lo is <= 2^-22 |a b|): 3 v_mfma_f32_32x32x16_f16 per k16 step instead of 16 exact-f32 MFMAs, measured error
+// against float64 within 2x of an fp32 FMA chain (tests/test_kernels.py::test_conv_split_error_growth_with_k).
+//
+// f16 has 5 exponent bits, so every operand TENSOR is scaled by a power of two s (exact) that puts its largest
+// magnitude just below 2^15: nothing overflows (65504), and lo -- 2^-11 of its element -- stays a normal f16 for every
+// element down to 2^-17 of the tensor's maximum (smaller ones keep an absolute accuracy of 2^-40 of the maximum).  The
+// maximum comes from the kernel that PRODUCED the tensor (amax_emit below: every kernel that writes a tracked tensor
+// max-es what it stores into the tensor's slot; the slot is therefore an upper bound of the final contents), the
+// consumer derives s from it, and the epilogue multiplies the accumulators by 1 / (s_a s_b), again exact.
+typedef _Float16 ssn_f16x2 __attribute__((ext_vector_type(2)));
 typedef float ssn_f32x2 __attribute__((ext_vector_type(2)));
-// bf16 pair of two fp32 values, `even` in the low half (k even -> low half of an MFMA operand dword)
-__device__ __forceinline__ uint32_t bf16_pair_rne(float even, float odd) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(ssn_f32x2{even, odd}, ssn_bf16x2));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// power-of-two scale for a tensor whose largest magnitude is `amax` (>= 0): amax * s lies in [2^14, 2^15).
+// amax == 0 / denormal / Inf / NaN -> 1 (an all-zero tensor needs no scale; non-finite data propagates as in fp32).
+__host__ __device__ inline float f16_scale_of(float amax) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, amax);
+    const int e = (int)((b >> 23) & 0xFFu);            // amax in [2^(e-127), 2^(e-126))
+    if (e == 0 || e == 255) return 1.f;
+    int se = 268 - e;                                  // biased exponent of 2^(141 - e)
+    se = se < 67 ? 67 : (se > 187 ? 187 : se);         // s in [2^-60, 2^60]: s_a * s_b and its reciprocal stay finite
+    return __builtin_bit_cast(float, (uint32_t)se << 23);
 }
-__device__ __forceinline__ float bf16_pair_lo(uint32_t pk) { return __builtin_bit_cast(float, pk << 16); }
-__device__ __forceinline__ float bf16_pair_hi(uint32_t pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
-// the three plane dwords of one k-pair
-__device__ __forceinline__ void bf16_split3_pair(float v0, float v1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
-    p0 = bf16_pair_rne(v0, v1);
-    const float r0 = v0 - bf16_pair_lo(p0), r1 = v1 - bf16_pair_hi(p0);
-    p1 = bf16_pair_rne(r0, r1);
-    p2 = bf16_pair_rne(r0 - bf16_pair_lo(p1), r1 - bf16_pair_hi(p1));
+// f16 pair of two (already scaled) fp32 values, `even` in the low half (k even -> low half of an MFMA operand dword)
+__device__ __forceinline__ uint32_t f16_pair_rne(float even, float odd) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(ssn_f32x2{even, odd}, ssn_f16x2));
+}
+__device__ __forceinline__ float f16_pair_lo(uint32_t pk) { return (float)__builtin_bit_cast(ssn_f16x2, pk)[0]; }
+__device__ __forceinline__ float f16_pair_hi(uint32_t pk) { return (float)__builtin_bit_cast(ssn_f16x2, pk)[1]; }
+// the two plane dwords of one k-pair of UNSCALED values
+__device__ __forceinline__ void f16_split2_pair(float v0, float v1, float s, uint32_t& hi, uint32_t& lo) {
+    const float x0 = v0 * s, x1 = v1 * s;
+    hi = f16_pair_rne(x0, x1);
+    lo = f16_pair_rne(x0 - f16_pair_lo(hi), x1 - f16_pair_hi(hi));
+}
+
+// ---- per-tensor maximum magnitude ("amax slot": one float, zeroed by the host before the tensor's first writer) ----
+// Call with each lane's running max of |values it stored| (wave-uniform control flow).  Non-negative floats order like
+// their bit patterns, so the slot is maintained with an unsigned atomic max; a wave only issues the atomic when it
+// would raise the slot (a stale read costs an unneeded atomic, never a wrong result).
+__device__ __forceinline__ void amax_emit(float* slot, float lane_max) {
+    if (!slot) return;
+    const float m = wave_max(lane_max);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int b = __builtin_bit_cast(unsigned int, m);
+        unsigned int* u = reinterpret_cast<unsigned int*>(slot);
+        if (b > *reinterpret_cast<volatile unsigned int*>(u)) atomicMax(u, b);
+    }
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -77,10 +77,15 @@ class InceptionV3(nn.Module):
         n, dev = x.shape[0], x.device
         acts = {"data": x}
 
+        # one amax slot per activation tensor (kernels.py: "amax slots"), handed out from one zeroed pool
+        slot_pool = torch.zeros(len(shapes) + 1, device=dev, dtype=torch.float32)
+        slot_of = {}
+
         def get(name):
             if name not in acts:
                 c, h, w = shapes[name]
-                acts[name] = K.guarded_empty((n, c, h, w), dev)
+                i = slot_of.setdefault(name, len(slot_of))
+                acts[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), slot_pool[i:i + 1])
             return acts[name]
 
         # folded frozen-BN affine of all layers in one launch

@@ -65,6 +65,43 @@ def _p(t):
     return t.ptr if isinstance(t, ChanSlice) else t.data_ptr()
 
 
+# ------------------------------------------------------------------------------------ amax slots
+# The split-operand ("x6") kernels scale every operand tensor by a power of two derived from an upper bound of its
+# largest magnitude (include/ssn_hip.h: "amax slots").  The association tensor -> slot lives on the torch tensor
+# object (attribute `_ssn_amax`, a 1-element fp32 view): producers hand the slot of their OUTPUT tensor to the kernel,
+# which raises it; consumers hand the slot of their INPUT tensor.  Executors attach zeroed slots to the tensors they
+# allocate (attach_amax); a tensor without a slot (test inputs, the caller's frames) is measured on the spot.
+def attach_amax(t, slot=None):
+    """Give tensor `t` an amax slot (a zeroed 1-element tensor, or the given view of a zeroed pool)."""
+    t._ssn_amax = torch.zeros(1, device=t.device, dtype=torch.float32) if slot is None else slot
+    return t
+
+
+def _tensor_of(x):
+    return x.t if isinstance(x, ChanSlice) else x
+
+
+def _amax_out(x):
+    """Slot pointer of the tensor a kernel writes (None: not tracked)."""
+    return _p(getattr(_tensor_of(x), "_ssn_amax", None))
+
+
+def tensor_amax(t, slot=None):
+    """Measure max |t| into `slot` (a fresh zeroed one by default) and return the slot."""
+    lib = _check(t)
+    if slot is None:
+        slot = torch.zeros(1, device=t.device, dtype=torch.float32)
+    lib.call("ssn_tensor_amax", _p(t), t.numel(), _p(slot), _stream(lib, t))
+    return slot
+
+
+def _amax_in(x):
+    """Slot (tensor, kept alive by the caller) of the tensor a split kernel reads; untracked tensors are measured now."""
+    t = _tensor_of(x)
+    slot = getattr(t, "_ssn_amax", None)
+    return slot if slot is not None else tensor_amax(t)
+
+
 # Measurement hook (bench.py): when a list is installed here, the wrappers of the HBM-bound kernels of the path (STPP,
 # heads, row selection, losses) bracket their launch with HIP events on the launch stream and append
 # (kernel name, algorithmic bytes = operands read + results written, start event, end event).
@@ -132,7 +169,7 @@ def pack_weights_multi(entries, x6=False):
     """entries: list of (weights, mode) with weights = [w] or [wA, wB] (fused pair, concatenated output channels).
 
     Returns one packed tensor per entry (views of a single flat buffer); ceil(len / 40) launches in total.
-    x6=True: split every weight into three bf16 planes for the conv_x6 kernels (modes 0/1, ksize 1/3 only).
+    x6=True: scale + split every weight into two f16 planes for the conv_x6 kernels (modes 0/1, ksize 1/3 only).
     """
     if not entries:
         return []
@@ -168,7 +205,7 @@ def conv_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_c
     ho, wo = y.hw
     assert w_packed.numel() >= packed_floats(y.c, x.c, ksize, False)
     lib.call("ssn_conv_bn_relu_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
-             x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg,
+             x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), tile_cfg, _amax_out(y),
              _stream(lib, w_packed))
 
 
@@ -188,14 +225,15 @@ def guarded_empty(shape, device, guard_floats=64):
 
 
 def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
-    """conv_fwd on the bf16 matrix cores (3-way split, fp32-class accuracy).  w_packed: pack_weights_multi(x6=True)."""
+    """conv_fwd on the f16 matrix cores (2-way split, fp32-class accuracy).  w_packed: pack_weights_multi(x6=True)."""
     lib = _check(x, w_packed, scale, shift, y)
     h, wd = x.hw
     ho, wo = y.hw
     assert w_packed.numel() >= packed_floats(y.c, x.c, ksize, False, True)
+    xa = _amax_in(x)
     lib.call("ssn_conv_x6_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
              x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), guard_bytes(x), tile_cfg,
-             _stream(lib, w_packed))
+             _p(xa), _amax_out(y), _stream(lib, w_packed))
 
 
 def pack_weights_rect(w):
@@ -209,25 +247,27 @@ def pack_weights_rect(w):
 
 
 def conv_x6_fwd_rect(x, w_packed, scale, shift, y, kh, kw, pad_h, pad_w, relu=True, tile_cfg=-1):
-    """Stride-1 forward convolution with kh x kw taps (5x5, 1x7, 7x1, 1x3, 3x1) on the bf16-split kernel."""
+    """Stride-1 forward convolution with kh x kw taps (5x5, 1x7, 7x1, 1x3, 3x1) on the split kernel."""
     lib = _check(x, w_packed, scale, shift, y)
     h, wd = x.hw
     ho, wo = y.hw
+    xa = _amax_in(x)
     lib.call("ssn_conv_x6_fwd_rect", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
              x.img_stride, y.c, ho, wo, y.img_stride, kh, kw, pad_h, pad_w, int(relu), guard_bytes(x), tile_cfg,
-             _stream(lib, w_packed))
+             _p(xa), _amax_out(y), _stream(lib, w_packed))
 
 
 def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
-    """Stride-1 conv_dgrad on the bf16 matrix cores.  wt: pack_weights_multi([... mode 1], x6=True)."""
+    """Stride-1 conv_dgrad on the f16 matrix cores.  wt: pack_weights_multi([... mode 1], x6=True)."""
     lib = _check(dy, wt, dx, mask_y, mask_scale)
     assert wt.numel() >= packed_floats(dy.c, dx.c, ksize, True, True)
     ho, wo = dy.hw
     h, w = dx.hw
+    ga = _amax_in(dy)
     lib.call("ssn_conv_x6_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, ksize, pad, int(accumulate), _p(mask_y),
              mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), guard_bytes(dy), tile_cfg,
-             _stream(lib, wt))
+             _p(ga), _amax_out(dx), _stream(lib, wt))
 
 
 def pack_dgrad_s2(w):
@@ -241,13 +281,14 @@ def pack_dgrad_s2(w):
 
 
 def conv_x6_dgrad_s2(dy, wt, dx, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
-    """dgrad of a 3x3 / stride-2 / pad-1 conv (even input size) on the bf16 matrix cores.  wt: pack_dgrad_s2(w)."""
+    """dgrad of a 3x3 / stride-2 / pad-1 conv (even input size) on the f16 matrix cores.  wt: pack_dgrad_s2(w)."""
     lib = _check(dy, wt, dx, mask_y, mask_scale)
     ho, wo = dy.hw
     h, w = dx.hw
+    ga = _amax_in(dy)
     lib.call("ssn_conv_x6_dgrad_s2", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, int(accumulate), _p(mask_y), mask_y.img_stride if mask_y is not None else 0,
-             _p(mask_scale), guard_bytes(dy), tile_cfg, _stream(lib, wt))
+             _p(mask_scale), guard_bytes(dy), tile_cfg, _p(ga), _amax_out(dx), _stream(lib, wt))
 
 
 def relu_bn_bwd(dy, y, scale):
@@ -255,7 +296,7 @@ def relu_bn_bwd(dy, y, scale):
     lib = _check(dy, y, scale)
     h, w = y.hw
     lib.call("ssn_relu_bn_bwd", _p(dy), _p(y), _p(scale), y.n, y.c, h * w, dy.img_stride, y.img_stride,
-             _stream(lib, scale))
+             _amax_out(dy), _stream(lib, scale))
 
 
 def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None, wt_layout=1):
@@ -270,7 +311,7 @@ def conv_dgrad(dy, wt, dx, ksize, stride, pad, accumulate, tile_cfg=-1, mask_y=N
     lib.call("ssn_conv_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, ksize, stride, pad, int(accumulate), _p(mask_y),
              mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), int(wt_layout), tile_cfg,
-             _stream(lib, wt))
+             _amax_out(dx), _stream(lib, wt))
 
 
 def wgrad_workspace_bytes(n, cin, cout, ho, wo, ksize, tile_cfg=-1):
@@ -297,13 +338,14 @@ def wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg=-1):
 
 
 def conv_wgrad_x6(g, x, dw, db, ksize, pad, workspace, tile_cfg=-1):
-    """conv_wgrad on the bf16 matrix cores (stride 1, same size).  x needs >= 256 readable bytes in front of it."""
+    """conv_wgrad on the f16 matrix cores (stride 1, same size).  x needs >= 256 readable bytes in front of it."""
     lib = _check(g, x, dw, db, workspace)
     h, w = x.hw
     assert g.hw == x.hw
+    ga, xa = _amax_in(g), _amax_in(x)
     lib.call("ssn_conv_wgrad_x6", _p(g), _p(x), _p(dw), _p(db), x.n, x.c, h, w, x.img_stride, g.c, g.img_stride,
              ksize, pad, guard_bytes(x), _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg,
-             _stream(lib, dw))
+             _p(ga), _p(xa), _stream(lib, dw))
 
 
 def pool_fwd(kind, x, y, argmax, ksize, stride, pad):
@@ -311,7 +353,7 @@ def pool_fwd(kind, x, y, argmax, ksize, stride, pad):
     h, w = x.hw
     ho, wo = y.hw
     lib.call("ssn_pool_fwd", int(kind == "max"), _p(x), _p(y), _p(argmax), x.n, x.c, h, w, x.img_stride, ho, wo,
-             y.img_stride, ksize, stride, pad, _stream(lib, x))
+             y.img_stride, ksize, stride, pad, _amax_out(y), _stream(lib, x))
 
 
 def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, mask_scale=None):
@@ -320,7 +362,7 @@ def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, 
     ho, wo = dy.hw
     lib.call("ssn_pool_bwd", int(kind == "max"), _p(dy), _p(argmax), _p(dx), dx.n, dx.c, h, w, dx.img_stride, ho,
              wo, dy.img_stride, ksize, stride, pad, int(accumulate), _p(mask_y),
-             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _stream(lib, dx))
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _amax_out(dx), _stream(lib, dx))
 
 
 def avgpool_affine_fwd(x, y, scale, shift, relu, ksize, stride, pad):
@@ -329,14 +371,19 @@ def avgpool_affine_fwd(x, y, scale, shift, relu, ksize, stride, pad):
     h, w = x.hw
     ho, wo = y.hw
     lib.call("ssn_avgpool_affine_fwd", _p(x), _p(y), _p(scale), _p(shift), int(bool(relu)), x.n, x.c, h, w,
-             x.img_stride, ho, wo, y.img_stride, ksize, stride, pad, _stream(lib, y))
+             x.img_stride, ho, wo, y.img_stride, ksize, stride, pad, _amax_out(y), _stream(lib, y))
 
 
-def channel_sum(g, out):
-    """out[c] = sum over images and pixels of the ChanSlice g."""
-    lib = _check(g, out)
+def channel_sum_workspace_bytes(n, c):
+    return 4 * c * int(_lib.get_lib().cdll.ssn_channel_sum_shares(n))
+
+
+def channel_sum(g, out, workspace):
+    """out[c] = sum over images and pixels of the ChanSlice g (two passes through `workspace`, fixed order)."""
+    lib = _check(g, out, workspace)
     h, w = g.hw
-    lib.call("ssn_channel_sum", _p(g), _p(out), g.n, g.c, h * w, g.img_stride, _stream(lib, out))
+    lib.call("ssn_channel_sum", _p(g), _p(out), g.n, g.c, h * w, g.img_stride, _p(workspace),
+             workspace.numel() * workspace.element_size(), _stream(lib, out))
 
 
 @_hbm_timed
@@ -351,7 +398,7 @@ def gap_bwd(dy, dx, accumulate=False):
     lib = _check(dy, dx)
     h, w = dx.hw
     lib.call("ssn_global_avgpool_bwd", _p(dy), _p(dx), dx.n, dx.c, h * w, dx.img_stride, int(accumulate),
-             _stream(lib, dy))
+             _amax_out(dx), _stream(lib, dy))
 
 
 @_hbm_timed

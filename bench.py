@@ -18,7 +18,7 @@ Workload per GPU = BASELINE.json configs[1]: 4 videos x 8 proposals x 9 segments
 of 224x224 (weak scaling: per-GPU work is fixed as N grows).
 
 Rank 0 prints ONE JSON line.  `roofline` is the MFMA roofline of the dominant kernel family (the
-bf16-split implicit-GEMM convolution `conv_x6_kernel`, forward + stride-1 dgrad launches; with
+split-operand (f16 x 3) implicit-GEMM convolution `conv_x6_kernel`, forward + dgrad launches; with
 --precision f32 the exact-f32 `conv_igemm_kernel`), measured live with HIP events around every
 launch of the same K steps (re-run eagerly right after the timed region, because events cannot be
 recorded inside a hipGraph replay); `roofline_detail` lists every conv kernel family; `cpu_baseline` times the CPU oracle
@@ -40,9 +40,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (no 2:1 sparsity)
-X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6  # algorithmic fp32 flops through the 3-way bf16 split (6 MFMA products)
-PMC_SUMMARY = "r1_pmc_summary_x6.json"
+F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense f16 / bf16 MFMA (no 2:1 sparsity)
+X6_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3  # algorithmic fp32 flops through the 2-way f16 split (3 MFMA products)
+PMC_SUMMARY = "r2_pmc_summary_split.json"
 FWD_GFLOP_PER_IMAGE = {"RGB": 4.063152128, "Flow": 4.613883904}  # 2 * conv MACs
 # conv1 (7x7/2, 64 outputs of 112x112): 2 * Cin * 49 * 64 * 112^2 flop that a dgrad would cost and nobody needs
 CONV1_DGRAD_GFLOP_PER_IMAGE = {"RGB": 2 * 3 * 49 * 64 * 112 * 112 / 1e9, "Flow": 2 * 10 * 49 * 64 * 112 * 112 / 1e9}
@@ -61,9 +61,9 @@ def parse():
                     help="videos in the CPU-oracle sample (default: the full config-2 batch, 4 videos = 32 proposals; "
                          "0 disables the cpu_baseline leg)")
     ap.add_argument("--cpu-baseline-reps", type=int, default=3, help="timed repetitions of the CPU sample (median)")
-    ap.add_argument("--precision", default="bf16x6", choices=["bf16x6", "f32"],
-                    help="matrix path of the 1x1/3x3 convolutions: exact 3-way bf16 split on the bf16 MFMA (fp32-class "
-                         "error, default) or the exact-f32 MFMA for every layer")
+    ap.add_argument("--precision", default="split", choices=["split", "f32"],
+                    help="matrix path of the 1x1/3x3 convolutions: per-tensor scaled 2-way f16 split, 3 products on the "
+                         "f16 MFMA (fp32-class error, default) or the exact-f32 MFMA for every layer")
     ap.add_argument("--collectives", default="separate", choices=["separate", "overlapped"],
                     help="N > 1: 'separate' = graph(fwd+bwd) -> eager RCCL all-reduce of the flat gradient -> graph(SGD), "
                          "the well-trodden path; 'overlapped' = bucketed all-reduces issued from inside the backward and "
@@ -309,9 +309,10 @@ def main():
                    "collectives": (args.collectives if use_dist else "none"),
                    "ranks": (dist.get_world_size() if use_dist else 1),
                    "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if use_dist else None),
-                   "conv_precision": ("fp32 in/out; 1x1/3x3 multiplies = 6 bf16-MFMA products of exact 3-way bf16 operand "
-                                      "splits (fp32-class error), 7x7 stem on the exact-f32 MFMA"
-                                      if args.precision == "bf16x6" else "exact-f32 MFMA everywhere")},
+                   "conv_precision": ("fp32 in/out; 1x1/3x3 multiplies = 3 f16-MFMA products of per-tensor scaled 2-way f16 "
+                                      "operand splits (22 of 24 significand bits per operand, fp32 accumulation: "
+                                      "fp32-class error, tests/test_kernels.py K-sweep), 7x7 stem on the exact-f32 MFMA"
+                                      if args.precision == "split" else "exact-f32 MFMA everywhere")},
         "final_loss": float(loss.item()),
     }
 
@@ -331,12 +332,12 @@ def main():
                 ms = sum(fam[k][1] for k in keys if k in fam)
                 n = sum(fam[k][2] for k in keys if k in fam)
                 return fl, ms, n
-            # dominant kernel: conv_x6_kernel (forward + stride-1 dgrad launches of the 1x1/3x3 layers).  Every fp32
-            # multiply is 6 bf16 MFMA products, so its matrix-pipe ceiling in ALGORITHMIC flops is bf16 dense / 6.
+            # dominant kernel: conv_x6_kernel (forward + dgrad launches of the 1x1/3x3 layers).  Every fp32
+            # multiply is 3 f16 MFMA products, so its matrix-pipe ceiling in ALGORITHMIC flops is f16 dense / 3.
             x6_fl, x6_ms, x6_n = agg(("conv_fwd_x6", "conv_dgrad_x6"))
             if x6_n:
-                dom_name = ("conv_x6_kernel (implicit GEMM, fp32 operands split into 3 bf16 terms, 6 "
-                            "v_mfma_f32_32x32x16_bf16 per k16 step; fwd + dgrad launches)")
+                dom_name = ("conv_x6_kernel (implicit GEMM, fp32 operands scaled per tensor and split into 2 f16 terms, 3 "
+                            "v_mfma_f32_32x32x16_f16 per k16 step; fwd + dgrad launches)")
                 dom_fl, dom_ms, dom_n, dom_peak = x6_fl, x6_ms, x6_n, X6_PEAK_TFLOPS
                 pmc_keys = ("conv_x6_kernel_fwd", "conv_x6_kernel_dgrad")
             else:   # --precision f32: the exact-f32 MFMA kernel carries everything
@@ -361,10 +362,10 @@ def main():
                 "bound": "mfma", "kernel": dom_name,
                 "achieved": round(achieved, 3), "peak": round(dom_peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / dom_peak, 4), "traffic": traffic,
-                "peak_note": ("algorithmic fp32 flops (2*MACs); peak = 2500 TF dense bf16 MFMA / 6 products per multiply"
+                "peak_note": ("algorithmic fp32 flops (2*MACs); peak = 2500 TF dense f16 MFMA / 3 products per multiply"
                               if x6_n else "exact-f32 MFMA peak"),
                 "frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                "issued_bf16_mfma_tflops": round(6 * achieved, 1) if x6_n else None,
+                "issued_f16_mfma_tflops": round(3 * achieved, 1) if x6_n else None,
                 "traffic_note": "HBM bytes/launch, rocprofv3 PMC (profiles/%s)" % PMC_SUMMARY,
                 "avg_launch_us": round(1e3 * dom_ms / dom_n, 2), "launches": dom_n,
                 "algorithmic_gflop_per_launch": round(dom_fl / dom_n / 1e9, 4),
@@ -388,7 +389,7 @@ def main():
             det["step_algorithmic_gflop"] = round(step_gflop, 1)
             det["whole_step_tflops"] = round(step_gflop * 1e9 / (elapsed / args.steps) / 1e12, 2)
             det["whole_step_frac_of_f32_mfma_peak"] = round(det["whole_step_tflops"] / F32_MFMA_PEAK_TFLOPS, 4)
-            det["whole_step_frac_of_bf16x6_peak"] = round(det["whole_step_tflops"] / X6_PEAK_TFLOPS, 4)
+            det["whole_step_frac_of_split_peak"] = round(det["whole_step_tflops"] / X6_PEAK_TFLOPS, 4)
             result["roofline_detail"] = det
 
         # ---------------- HBM-bound kernels of the path (STPP, heads, row selection, losses): achieved GB/s ----------

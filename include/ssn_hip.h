@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define SSN_ERR_WORKSPACE (-3)
 
 const char* ssn_last_error(void);
-int ssn_abi_version(void);
+int ssn_abi_version(void);   /* 3 */
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
@@ -61,7 +61,7 @@ int ssn_conv_pack_weights_multi(int count, const float* const* w0, const float* 
 int ssn_conv_bn_relu_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                          int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                          long y_img_stride, int ksize, int stride, int pad, int relu, int tile_cfg,
-                         hipStream_t stream);
+                         float* y_amax, hipStream_t stream);   /* y_amax: see "amax slots" below; NULL = not tracked */
 
 /* Frozen-BN folding (ssn_models.py:156-174 puts every BatchNorm2d in eval mode):
  * scale = gamma / sqrt(var + eps), shift = (conv_bias - mean) * scale + beta. */
@@ -77,7 +77,7 @@ int ssn_bn_fold_multi(int count, const float* const* conv_bias, const float* con
 /* Backward of ReLU + frozen BN, in place on dy:  dy <- dy * (y > 0) * scale[c]
  * (autograd of the same triples, entered from ssn_train.py:236 loss.backward()). */
 int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, int N, int C, int HW, long dy_img_stride,
-                    long y_img_stride, hipStream_t stream);
+                    long y_img_stride, float* dy_amax, hipStream_t stream);
 
 /* cuDNN dgrad replacement.  wt_packed = ssn_conv_pack_weights(w, transposed=1).
  * dx[n][ci][hi][wi] (+)= sum_{co,r,s} w[co][ci][r][s] * dy[n][co][(hi+pad-r)/S][(wi+pad-s)/S].
@@ -91,15 +91,27 @@ int ssn_conv_dgrad_layout(int ksize, int stride, int pad, int H, int W);
 int ssn_conv_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                    long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int stride,
                    int pad, int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                   int wt_layout, int tile_cfg, hipStream_t stream);
+                   int wt_layout, int tile_cfg, float* dx_amax, hipStream_t stream);
 
-/* ---- "x6" variants: the same convolutions computed on the bf16 matrix cores with fp32-class accuracy.
- * Every fp32 operand is split exactly into three bf16 terms (8+8+8 significand bits) and the product is
- * accumulated in fp32 from the six partial products a_i*b_j with i+j <= 4 (csrc/conv_x6.hip); the dropped
- * terms are <= 2^-24 |ab|, i.e. the result is as accurate as an fp32 FMA chain (the 1e-4 budget of the path is
- * untouched) at 6/16 of the f32-MFMA matrix time.  ksize in {1,3}; forward stride in {1,2}; dgrad stride 1.
+/* ---- amax slots (operand scaling of the split kernels below).  A slot is ONE float in device memory holding an
+ * upper bound of max |t| of a tensor t; the caller zeroes it before the first kernel writes t, every kernel of this
+ * library that stores into t and is handed the slot (the *_amax output arguments; NULL = t is not tracked) raises
+ * it to the largest magnitude it stores (unsigned atomic max on the bit pattern), and the split kernels that READ t
+ * as a matrix operand derive its power-of-two f16 scale from the slot (the const *_amax arguments, required).
+ * ssn_tensor_amax does the same for a tensor no library kernel produced (the frames handed in by the caller). */
+int ssn_tensor_amax(const float* x, long n, float* slot, hipStream_t stream);
+
+/* ---- "x6" variants: the same convolutions computed on the f16 matrix cores with fp32-class accuracy ("x6" is the
+ * family's historical name: its first version multiplied six bf16 partial products).
+ * Every fp32 operand, scaled by a per-tensor power of two, is split into two f16 terms (11+11 significand bits,
+ * round to nearest) and the product is accumulated in fp32 from the three partial products a_lo*b_hi + a_hi*b_hi +
+ * a_hi*b_lo (csrc/conv_x6.hip); the dropped term is <= 2^-22 |ab|, and the measured error against float64 stays
+ * within 2x of an fp32 FMA chain (the 1e-4 budget of the path is untouched) at 3/16 of the f32-MFMA matrix time.
+ * ksize in {1,3}; forward stride in {1,2}; dgrad stride 1.
  * Weights: ssn_conv_x6_pack_weights_multi (mode 0 forward / 1 dgrad operand; same w1/split convention as
- * ssn_conv_pack_weights_multi), ssn_conv_x6_packed_floats() floats per layer.
+ * ssn_conv_pack_weights_multi; measures max |w|, scales, splits and packs), ssn_conv_x6_packed_floats() floats per layer.
+ * x_amax / dy_amax (required): amax slot of the tensor the gathered operand lives in; y_amax / dx_amax: slot of the
+ * output tensor or NULL.
  * x_guard_bytes / dy_guard_bytes: how many bytes directly in FRONT of the gathered tensor the caller guarantees to
  * be readable device memory (e.g. the channels below a channel slice, or an allocation pad).  With >= 256 the
  * stride-1 kernels fetch activations 16 bytes per lane (4 consecutive pixels; border positions are zeroed later),
@@ -113,11 +125,12 @@ int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const floa
                                    const int* split, hipStream_t stream);
 int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
                     int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo, long y_img_stride,
-                    int ksize, int stride, int pad, int relu, int x_guard_bytes, int tile_cfg, hipStream_t stream);
+                    int ksize, int stride, int pad, int relu, int x_guard_bytes, int tile_cfg, const float* x_amax,
+                    float* y_amax, hipStream_t stream);
 int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                       long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                       int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                      int dy_guard_bytes, int tile_cfg, hipStream_t stream);
+                      int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, hipStream_t stream);
 
 /* Rectangular taps (csrc/conv_x6_rect.hip): the forward convolutions of the Inception-v3 backbone the reference's
  * tester runs on ActivityNet (ssn_models.py:133-139): kh x kw in {5x5, 1x7, 7x1, 1x3, 3x1}, stride 1, per-axis
@@ -127,7 +140,7 @@ int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cout, int cin,
 int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                          int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                          long y_img_stride, int kh, int kw, int pad_h, int pad_w, int relu, int x_guard_bytes,
-                         int tile_cfg, hipStream_t stream);
+                         int tile_cfg, const float* x_amax, float* y_amax, hipStream_t stream);
 
 /* Data gradient of the 3x3 / stride-2 / pad-1 layers (even input size) on the x6 kernel: four stride-1 launches, one
  * per parity class of the input pixel, each multiplying only the taps that reach that class (cuDNN dgrad behind
@@ -138,15 +151,17 @@ int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, int cin, hip
 int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                          long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int accumulate,
                          const float* mask_y, long mask_img_stride, const float* mask_scale, int dy_guard_bytes,
-                         int tile_cfg, hipStream_t stream);
+                         int tile_cfg, const float* dy_amax, float* dx_amax, hipStream_t stream);
 
 /* x6 weight gradient (csrc/conv_wgrad_x6.hip): stride-1 same-size 1x1 / 3x3 convolutions with H*W % 4 == 0, both
- * operands split to bf16 on the fly, 16-byte loads along the pixel axis.  Same result contract as ssn_conv_wgrad
+ * operands scaled and split to f16 on the fly (g_amax / x_amax: their tensors' amax slots, required), 16-byte loads
+ * along the pixel axis.  Same result contract as ssn_conv_wgrad
  * (deterministic split-K).  x_guard_bytes >= 256 is REQUIRED (the shifted taps read up to W+1 floats before x). */
 long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int H, int W, int ksize, int tile_cfg);
 int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                       long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
-                      void* workspace, long ws_bytes, int tile_cfg, hipStream_t stream);
+                      void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
+                      hipStream_t stream);
 /* second pass of both wgrad kernels: dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] */
 int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
 
@@ -166,23 +181,25 @@ int ssn_conv_debug_flags(int flags);
  * argmax: uint8 [N][C][Ho][Wo] window-local index, written by fwd(max) and consumed by bwd(max). */
 int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, int N, int C, int H, int W,
                  long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride, int pad,
-                 hipStream_t stream);
+                 float* y_amax, hipStream_t stream);
 int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H, int W,
                  long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride, int pad,
                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                 hipStream_t stream);
+                 float* dx_amax, hipStream_t stream);
 /* y = relu?(scale[c] * avgpool(x) + shift[c]) (average pools only): the pool-projection branch of an Inception block
  * (<block>_pool -> <block>_pool_proj + BN + ReLU) evaluated as avgpool(conv1x1(x)) -- identical to conv1x1(avgpool(x))
  * for zero padding with count_include_pad -- so that the pool touches the projection's output channels only. */
 int ssn_avgpool_affine_fwd(const float* x, float* y, const float* scale, const float* shift, int relu, int N, int C,
                            int H, int W, long x_img_stride, int Ho, int Wo, long y_img_stride, int ksize, int stride,
-                           int pad, hipStream_t stream);
+                           int pad, float* y_amax, hipStream_t stream);
 /* out[c] = sum_{n,hw} g[n][c][hw] (fixed order): bias gradient of such a projection (the gradient BEFORE the pool's
  * backward; the wgrad kernel's bias column sees the pooled gradient). */
-int ssn_channel_sum(const float* g, float* out, int N, int C, int HW, long img_stride, hipStream_t stream);
+int ssn_channel_sum(const float* g, float* out, int N, int C, int HW, long img_stride, void* workspace,
+                    size_t ws_bytes, hipStream_t stream);   /* workspace: C * ssn_channel_sum_shares(N) floats */
+int ssn_channel_sum_shares(int N);
 int ssn_global_avgpool_fwd(const float* x, float* y, int N, int C, int HW, long x_img_stride, hipStream_t stream);
 int ssn_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, long dx_img_stride, int accumulate,
-                           hipStream_t stream);
+                           float* dx_amax, hipStream_t stream);
 
 /* nn.Dropout standing in for the backbone's `fc` (ssn_models.py:71-74). mask: uint8 per element.
  * counter (optional, int64[1] in device memory) is mixed into the Philox key and incremented by the

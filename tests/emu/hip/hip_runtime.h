@@ -267,6 +267,33 @@ inline f32x16_t mfma_32x32x16_bf16(V a, V b, f32x16_t c) {
     return c;
 }
 
+// v_mfma_f32_32x32x16_f16: same operand / result maps as the bf16 form, elements are IEEE halves
+template <class V>
+inline f32x16_t mfma_32x32x16_f16(V a, V b, f32x16_t c) {
+    static_assert(sizeof(V) == 16, "8 x f16 operands");
+    uint32_t u[8];
+    memcpy(&u[0], &a, 16);
+    memcpy(&u[4], &b, 16);
+    auto* buf = wave_exchange(u, 8);
+    const int lane = g_cur->lane;
+    const int col = lane & 31, hi = lane >> 5;
+    auto elem = [&](int src_lane, int base, int kk) {
+        const uint32_t d = buf[src_lane][base + (kk >> 1)];
+        const uint16_t h = (uint16_t)((kk & 1) ? (d >> 16) : (d & 0xFFFFu));
+        _Float16 f;
+        memcpy(&f, &h, 2);
+        return (float)f;
+    };
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc = fmaf(elem((k >> 3) * 32 + row, 0, k & 7), elem((k >> 3) * 32 + col, 4, k & 7), acc);
+        c[r] = acc;
+    }
+    return c;
+}
+
 template <class K, class... Args>
 inline void launch(K kernel, dim3 grid, dim3 block, Args... args) {
     BlockState b;
@@ -319,10 +346,16 @@ static inline int atomicAdd(int* p, int v) {
     *p = o + v;
     return o;
 }
+static inline unsigned int atomicMax(unsigned int* p, unsigned int v) {
+    unsigned int o = *p;
+    if (v > o) *p = v;
+    return o;
+}
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma_32x32x2(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu::mfma_16x16x4(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma_32x32x16_f16(a, b, c)
 // v_perm_b32: selector bytes 0-3 pick bytes of the SECOND operand, 4-7 bytes of the first
 static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
     const uint64_t both = ((uint64_t)s0 << 32) | s1;

@@ -180,7 +180,10 @@ def _product_vs_golden(tag, device):
     total.backward()
     grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
     for n, (norm, s) in zip([str(x) for x in g["%s_grad_names" % tag]], g["%s_grad_stats" % tag]):
-        assert abs(float(grads[n].double().norm()) - norm) <= 1e-3 * norm + 1e-10, n  # gradients: 1e-3 (deep fp32 reduction chains)
+        # gradients: 3e-3 on the norms.  At 32^2 the 7x7-stage planes are single pixels, so one ReLU unit that two fp32
+        # implementations resolve differently (pre-activation within rounding of zero) moves a whole tensor by ~1e-3
+        # (profiles/r2_grad_flip_diag.txt: the reference's own fp32 CPU path is 2.4e-3 off float64 on one tensor at 224^2)
+        assert abs(float(grads[n].double().norm()) - norm) <= 3e-3 * norm + 1e-10, n
     # element-wise gradients: 5e-3 for the deepest chain (conv1: ~60 fp32 reductions in a different order on
     # each side; tests/test_model_gpu.py referees such differences against float64), 1e-3 / 1e-4 near the loss
     assert rel_err(m.base_model.conv1_7x7_s2.bias.grad, torch.from_numpy(g["%s_grad_conv1_b" % tag])) < 5e-3

@@ -179,7 +179,7 @@ def test_avgpool_behind_projection(backend):
         gs = K.ChanSlice(gdev, 2, cout)
         K.relu_bn_bwd(gs, K.ChanSlice(y, 2, cout), backend.put(scale))
         db = backend.put(torch.zeros(cout))
-        K.channel_sum(gs, db)
+        K.channel_sum(gs, db, backend.put(torch.empty(K.channel_sum_workspace_bytes(n, cout) // 4)))
         assert rel_err(db, b.grad) < 1e-5, (h, "bias")
         dz = backend.put(torch.empty(n, cout, h, h))
         K.pool_bwd("avg", gs, None, K.full(dz), 3, 1, 1, False)
@@ -468,17 +468,18 @@ def test_conv_x6_is_fp32_accurate(backend):
     assert err6 < err_bf16 / 100, (err6, err_bf16)
 
 
-def test_conv_x6_error_growth_with_k(backend):
-    """K-sweep of the bf16 3-way split (K = Cin * 9 from 27 to 2304, the longest reduction in BN-Inception): maximum
+def test_conv_split_error_growth_with_k(backend):
+    """K-sweep of the f16 2-way split (K = Cin * 9 from 27 to 2304, the longest reduction in BN-Inception): maximum
     error and BIAS (mean signed error) relative to sum|x w| against float64, next to the exact-f32 MFMA kernel and a
     plain fp32 (torch CPU) convolution on the same data -- on zero-mean data and on all-positive data (worst case for a
     systematic error: nothing cancels).
 
-    Operands are split with round-to-nearest (x = x1 + x2 + x3 exactly, ssn_common.h): the three dropped partial
-    products are <= 2^-26 |x w| each and have no preferred sign.  (Round 1 split by truncation: its dropped terms all
-    had the sign of x*w -- a relative bias of -1.0e-7 = 2^-23 on positive data in this very test, max error 7.6e-7 at
-    K = 27; with rounding: -1.5e-8 and 4.6e-7.)  What remains is fp32 accumulation error, common to all three kernels:
-    the bounds below tie the x6 kernel to the fp32 kernels at every K instead of to absolute numbers."""
+    Operands are scaled per tensor and split with round-to-nearest (x s = hi + lo + e, |e| <= 2^-22 |x s|,
+    ssn_common.h); the dropped lo*lo product is <= 2^-22 |x w| and, like e, has no preferred sign.  What remains is
+    fp32 accumulation error, common to all three kernels: the bounds below tie the split kernel to the fp32 kernels at
+    every K instead of to absolute numbers.  (History: round 1 split into three bf16 terms by truncation -- a relative
+    bias of -1.0e-7 on positive data in this very test; the round-to-nearest 3-term version measured 2.2e-7 / 1.9e-6
+    max error at K = 2304 signed / positive on the MI355X, profiles/r2_ksweep_bf16x6.txt.)"""
     g = torch.Generator().manual_seed(77)
     cins = (3, 16, 64, 128, 256) if backend.is_gpu else (3, 16, 48)
     n, h, cout = (2, 14, 64) if backend.is_gpu else (1, 5, 32)
@@ -508,6 +509,64 @@ def test_conv_x6_error_growth_with_k(backend):
               % (k, "signed  " if signed else "positive", m6, b6, m32, b32, mcpu))
         assert m6 <= 3.0 * max(m32, mcpu) + 2.0 ** -22, (k, signed, m6, m32, mcpu)     # the accuracy class of fp32
         assert abs(b6) <= 3.0 * abs(b32) + 2.0 ** -24, (k, signed, b6, b32)             # no systematic error of its own
+
+
+def test_conv_split_wide_dynamic_range(backend):
+    """The f16 split scales each operand TENSOR by one power of two; elements far below the tensor's maximum keep an
+    absolute (not relative) accuracy.  (a) five decades of element magnitudes inside both operands: the error relative
+    to sum|x w| stays in the fp32 class.  (b) one huge element pins the scale while every other element sits 2^-20
+    below it, where the low f16 term is SUBNORMAL: outputs that do not touch the huge element must still be good to
+    ~2^-20 relative (they would be ~2^-12 if the matrix cores flushed subnormal f16 inputs)."""
+    g = torch.Generator().manual_seed(91)
+    n, cin, h, cout = (2, 128, 14, 64) if backend.is_gpu else (1, 32, 6, 32)
+    x = torch.randn(n, cin, h, h, generator=g) * torch.exp(torch.rand(n, cin, h, h, generator=g) * -12.0)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05 * torch.exp(torch.rand(cout, cin, 3, 3, generator=g) * -12.0)
+
+    def run(x, w):
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+        mag = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+        (wp,) = K.pack_weights_multi([([backend.put(w)], 0)], x6=True)
+        y = backend.put(torch.empty(n, cout, h, h))
+        K.conv_x6_fwd(K.full(backend.put(x)), wp, None, None, K.full(y), 3, 1, 1, False)
+        return (y.cpu().double() - ref).abs() / mag
+
+    e = run(x, w)
+    assert e.max().item() < 2.0 ** -20, e.max().item()          # (a) measured ~5e-7
+    x2 = torch.randn(n, cin, h, h, generator=g) * 2.0 ** -20
+    x2[0, 0, 0, 0] = 1.0
+    w2 = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    e2 = run(x2, w2)
+    e2[0, :, :2, :2] = 0.0                                        # the outputs the huge element reaches
+    assert e2.max().item() < 2.0 ** -17, e2.max().item()         # (b) subnormal low terms survive
+
+
+def test_amax_slots(backend):
+    """Every kernel that writes a tracked tensor raises the tensor's amax slot to the largest magnitude it stores."""
+    g = torch.Generator().manual_seed(92)
+    n, cin, h, cout = 2, 16, 8, 40
+    x = torch.randn(n, cin, h, h, generator=g) * 3.0
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    xd = backend.put(x)
+    assert K.tensor_amax(xd).item() == x.abs().max().item()
+    # forward conv (both kernels), into a channel slice of a wider tracked tensor
+    for x6 in (False, True):
+        y = K.attach_amax(backend.put(torch.zeros(n, cout + 3, h, h)))
+        wp = K.pack_weights_multi([([backend.put(w)], 0)], x6=True)[0] if x6 else K.pack_weights(backend.put(w), False)
+        (K.conv_x6_fwd if x6 else K.conv_fwd)(K.full(xd), wp, None, None, K.ChanSlice(y, 3, cout), 3, 1, 1, True)
+        assert y._ssn_amax.item() == y.abs().max().item() > 0
+    # pools, the in-place ReLU/BN backward, global-pool backward
+    y = K.attach_amax(backend.put(torch.zeros(n, cin, 4, 4)))
+    K.pool_fwd("max", K.full(xd), K.full(y), None, 3, 2, 0)
+    assert y._ssn_amax.item() == y.abs().max().item() > 0
+    dy = K.attach_amax(backend.put(torch.randn(n, cin, h, h, generator=g)))
+    K.relu_bn_bwd(K.full(dy), K.full(xd), backend.put(torch.full((cin,), 2.5)))
+    assert dy._ssn_amax.item() == dy.abs().max().item() > 0
+    dx = K.attach_amax(backend.put(torch.zeros(n, cin, h, h)))
+    K.gap_bwd(backend.put(torch.randn(n, cin, generator=g)), K.full(dx))
+    assert dx._ssn_amax.item() == dx.abs().max().item() > 0
+    dxp = K.attach_amax(backend.put(torch.zeros(n, cin, h, h)))
+    K.pool_bwd("avg", K.full(dy), None, K.full(dxp), 3, 1, 1, False)
+    assert dxp._ssn_amax.item() == dxp.abs().max().item() > 0
 
 
 def test_conv_x6_fused_pair_and_mask(backend):

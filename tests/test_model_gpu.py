@@ -33,9 +33,18 @@ def losses(out, v):
             ClassWiseRegressionLoss()(out[4], out[5], out[6]))
 
 
-@pytest.mark.parametrize("modality,cfg", [("RGB", (1, 1, 1)), ("Flow", (1, (1, 2), 1))])
-def test_fwd_bwd_matches_oracle(hip_library, modality, cfg):
-    v = 2
+@pytest.mark.parametrize("modality,cfg,v", [("RGB", (1, 1, 1), 4), ("Flow", (1, (1, 2), 1), 2)])
+def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v):
+    """RGB: BASELINE config 2 at FULL size (4 videos = 32 proposals = 288 frames of 224^2); Flow: a 2-video slice of
+    config 3.  Logits / losses 1e-4 against the fp32 CPU oracle; gradients against the oracle AND a float64 referee.
+
+    Why the gradient check is a distribution and not a per-tensor bound: the loss is only piecewise smooth in the
+    weights -- a ReLU (or max-pool) unit whose pre-activation is within rounding of zero takes a different branch in
+    two fp32 implementations, and the gradient of every layer below it moves by a finite amount.  The reference's own
+    torch-CPU fp32 path is off the float64 gradient by 2.4e-3 on one tensor for that reason
+    (profiles/r2_grad_flip_diag.txt; identical numbers with the exact-f32 MFMA kernels, so it is not a property of the
+    operand split).  Which units flip is an accident of rounding; how MANY tensors are affected and how close the bulk
+    is to float64 is what a correct implementation controls, and that is what is asserted."""
     m, o = build(modality, cfg)
     batch = make_batch(v, modality, 20, seed=5)
     out = m(*[t.cuda() for t in batch])
@@ -52,32 +61,29 @@ def test_fwd_bwd_matches_oracle(hip_library, modality, cfg):
         assert abs(got.item() - want.item()) <= 1e-4 * abs(want.item()) + 1e-7
     total.backward()
     rt.backward()
-    # fp64 referee (RGB only: ~20 s of CPU): where the two fp32 implementations differ by more than 1e-3
-    # (deep layers: the gradient has passed ~60 fp32 reductions in a different order on each side), the HIP
-    # path must be as close to float64 as the fp32 CPU reference is.
-    ref64 = None
-    if modality == "RGB":
-        o64 = O.OracleSSN(20, 2, 5, 2, modality, dropout=0, stpp_cfg=cfg).double()
-        o64.load_state_dict({k: t.double() for k, t in o.state_dict().items()})
-        o64.train()
-        b64 = [t.double() if t.is_floating_point() else t for t in batch]
-        t64, _, _, _ = O.ssn_total_loss(o64(*b64), v)
-        t64.backward()
-        ref64 = dict((n, p.grad) for n, p in o64.named_parameters() if p.grad is not None)
-    worst = ("", 0.0)
+    o64 = O.OracleSSN(20, 2, 5, 2, modality, dropout=0, stpp_cfg=cfg).double()
+    o64.load_state_dict({k: t.double() for k, t in o.state_dict().items()})
+    o64.train()
+    b64 = [t.double() if t.is_floating_point() else t for t in batch]
+    t64, _, _, _ = O.ssn_total_loss(o64(*b64), v)
+    t64.backward()
+    ref64 = dict((n, p.grad) for n, p in o64.named_parameters() if p.grad is not None)
+    e_hip, e_cpu = [], []
     for (n1, p1), (n2, p2) in zip(m.named_parameters(), o.named_parameters()):
         assert n1 == n2
         if p2.grad is None:
             assert p1.grad is None, n1
             continue
-        e = rel_err(p1.grad, p2.grad)
-        assert e < 5e-3, (n1, e)
-        if e > 1e-3 and ref64 is not None:
-            e_hip, e_cpu = rel_err(p1.grad, ref64[n1]), rel_err(p2.grad, ref64[n1])
-            assert e_hip <= 3 * e_cpu + 1e-4, (n1, e_hip, e_cpu)
-        if e > worst[1]:
-            worst = (n1, e)
-    print("worst fp32-vs-fp32 gradient rel err:", worst)
+        assert rel_err(p1.grad, p2.grad) < 5e-3, (n1, rel_err(p1.grad, p2.grad))       # hard cap, every tensor
+        e_hip.append(rel_err(p1.grad, ref64[n1]))
+        e_cpu.append(rel_err(p2.grad, ref64[n1]))
+    e_hip, e_cpu = torch.tensor(e_hip), torch.tensor(e_cpu)
+    print("gradients vs float64 (%d tensors): HIP median %.2e max %.2e, %d above 1e-3 | torch fp32 CPU median %.2e max "
+          "%.2e, %d above 1e-3" % (len(e_hip), e_hip.median(), e_hip.max(), int((e_hip > 1e-3).sum()), e_cpu.median(),
+                                   e_cpu.max(), int((e_cpu > 1e-3).sum())))
+    assert e_hip.max() < 5e-3
+    assert e_hip.median() <= 2.0 * e_cpu.median() + 1e-5, (e_hip.median(), e_cpu.median())
+    assert int((e_hip > 1e-3).sum()) <= int((e_cpu > 1e-3).sum()) + max(6, len(e_hip) // 50)
 
 
 def test_negative_bn_gammas(hip_library):
