@@ -19,7 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "bn_train.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -54,6 +54,9 @@ _SIGS = {
     "ssn_avgpool_affine_fwd": "ppppiiiiiliiliiipp",
     "ssn_channel_sum": "ppiiilpup",
     "ssn_tensor_amax": "plpp",
+    "ssn_bn_train_stats": "ppppppiiilffpup",
+    "ssn_bn_train_apply": "ppppppiiiillpp",
+    "ssn_bn_train_bwd": "pppppppppiiiillllpupp",
     "ssn_global_avgpool_fwd": "ppiiilp",
     "ssn_global_avgpool_bwd": "ppiiilipp",
     "ssn_dropout_fwd": "ppplfupp",
@@ -65,6 +68,7 @@ _SIGS = {
     "ssn_detections": "ppppppppuiiiiidip",
     "ssn_frames_crop_normalize": "ppiiiiiiipppiipipip",
     "ssn_reg_denorm": "plffffp",
+    "ssn_frame_diff": "ppliiip",
     "ssn_linear_fwd": "ppppiiip",
     "ssn_linear_bwd": "ppppppiiiip",
     "ssn_row_gather": "pppiip",
@@ -87,7 +91,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
-                                "ssn_conv_debug_flags", "ssn_channel_sum_shares",
+                                "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
                                 "ssn_conv_dgrad_layout"])
 
 

@@ -125,7 +125,16 @@ class BNInception(nn.Module):
             conv = getattr(self, lid)
             ps.append(conv.weight)
             ps.append(conv.bias)
+        for lid in self._train_bn_ids():       # bn_mode 'partial' / 'full': gamma / beta of the BatchNorms in training mode
+            bn = getattr(self, lid + "_bn")
+            ps.append(bn.weight)
+            ps.append(bn.bias)
         return ps
+
+    def _train_bn_ids(self):
+        """Layers whose BatchNorm2d is in training mode (SSN.train() leaves the first one -- bn_mode 'partial' -- or all of
+        them -- 'full' -- there, /root/reference/ssn_models.py:95-105,156-174); forward order."""
+        return [lid for lid in self._conv_ids if getattr(self, lid + "_bn").training]
 
     def flat_grad_layout(self):
         """[(layer id, weight offset, weight numel, bias offset, bias numel)], total.
@@ -165,11 +174,6 @@ class BNInception(nn.Module):
     def features(self, x):
         if x.dim() != 4:
             raise ValueError("expected NCHW input")
-        for lid in self._conv_ids:
-            if getattr(self, lid + "_bn").training:
-                raise NotImplementedError(
-                    "bn_mode 'partial'/'full' (training-mode BatchNorm) is not built yet; "
-                    "SSN's default bn_mode='frozen' keeps every BatchNorm2d in eval mode")
         return _BackboneFn.apply(x.contiguous(), self, *self._param_list())
 
     def forward(self, x):
@@ -231,9 +235,30 @@ class BNInception(nn.Module):
             else:
                 _, lid, src, dst = op
                 plan.append(dict(kind="gap", lid=lid, src=src, dst=dst))
-        if self.pool_after_projection:
+        train_bn = set(self._train_bn_ids())
+        if self.pool_after_projection and not train_bn:
             plan = self._move_avg_pools(plan, shapes)
+        if train_bn:
+            plan = self._split_train_bn(plan, shapes, train_bn)
         return plan, shapes
+
+    @staticmethod
+    def _split_train_bn(plan, shapes, train_bn):
+        """A convolution whose BatchNorm2d runs in training mode becomes: the bare convolution (no bias -- a per-channel
+        constant cancels in z - mean(z) --, no affine, no ReLU) into its own tensor z, then a "bn_train" op: batch
+        statistics of z, running-statistics update, y = relu(gamma * xhat + beta) into the layer's destination slice."""
+        out = []
+        for op in plan:
+            if op["kind"] == "conv" and any(lid in train_bn for lid in op["lids"]):
+                assert all(lid in train_bn for lid in op["lids"]), "fused pair with mixed BatchNorm modes: %s" % op["lids"]
+                z = op["lids"][0] + "_zbn"
+                shapes[z] = (op["cout"],) + tuple(shapes[op["dst"]][1:])
+                out.append(dict(op, dst=z, dst_c0=0, raw=True, bn_train=True, final=(op["dst"], op["dst_c0"])))
+                out.append(dict(kind="bn_train", lid=op["lids"][0], lids=op["lids"], couts=op["couts"], src=z,
+                                dst=op["dst"], dst_c0=op["dst_c0"], c=op["cout"]))
+            else:
+                out.append(op)
+        return out
 
     @staticmethod
     def _move_avg_pools(plan, shapes):
@@ -270,6 +295,7 @@ class BNInception(nn.Module):
         n, dev = x.shape[0], x.device
         acts = {"data": x}
         argmax, tscale, wcat = {}, {}, {}
+        bnstat = {}      # training-mode BatchNorm layers: layer id -> (batch mean of z, 1 / sqrt(var + eps))
         last_use = {}
         for i, op in enumerate(plan):
             last_use[op["src"]] = i
@@ -308,6 +334,12 @@ class BNInception(nn.Module):
             off = 0
             # (a projection whose pool runs behind it: its BN affine belongs to the slice the POOL writes)
             aff_dst, aff_c0 = op.get("final", (op["dst"], op["dst_c0"]))
+            if op.get("bn_train"):
+                # batch-statistics layer: nothing to fold; NaN scales = "not a frozen ReLU/BN output", so that the fused
+                # backward epilogues of the consumers leave this slice's gradient alone (the bn_train op owns its backward)
+                scale_slice(aff_dst, aff_c0, op["cout"]).fill_(float("nan"))
+                soff += op["cout"]
+                continue
             for lid, c in zip(op["lids"], op["couts"]):
                 conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
                 for lst, v in zip(fold, (conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
@@ -409,12 +441,32 @@ class BNInception(nn.Module):
                 K.avgpool_affine_fwd(full(acts[op["src"]]), ChanSlice(get(op["dst"]), op["dst_c0"], c),
                                      scale_slice(op["dst"], op["dst_c0"], c), shift_of[op["conv"]], True,
                                      op["k"], op["s"], op["p"])
+            elif op["kind"] == "bn_train":
+                off = 0
+                bws = torch.empty(K.bn_train_workspace_floats(n, op["c"]), device=dev, dtype=torch.float32)
+                for lid, c in zip(op["lids"], op["couts"]):
+                    conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
+                    mean = torch.empty(c, device=dev, dtype=torch.float32)
+                    invstd = torch.empty(c, device=dev, dtype=torch.float32)
+                    zs = ChanSlice(acts[op["src"]], off, c)
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    K.bn_train_stats(zs, conv.bias.detach(), mean, invstd, bn.running_mean if track else None,
+                                     bn.running_var if track else None, bn.eps,
+                                     0.1 if bn.momentum is None else bn.momentum, bws)
+                    if track and bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                    K.bn_train_apply(zs, ChanSlice(get(op["dst"]), op["dst_c0"] + off, c), mean, invstd,
+                                     bn.weight.detach(), bn.bias.detach(), True)
+                    bnstat[lid] = (mean, invstd)
+                    off += c
             else:
                 feat = torch.empty((n, shapes[op["src"]][0]), device=dev, dtype=torch.float32)
                 K.gap_fwd(full(acts[op["src"]]), feat)
             if lane_ctx is not None:
                 lane_ctx.__exit__(None, None, None)
-                if op["kind"] == "conv" and len(op["lids"]) == 2:     # the reduce pair feeds the double-3x3 chain
+                # the reduce pair feeds the double-3x3 chain (with a training-mode BatchNorm its bn_train op completes it)
+                if (op["kind"] == "conv" and len(op["lids"]) == 2 and not op.get("bn_train")) or \
+                        (op["kind"] == "bn_train" and len(op["lids"]) == 2):
                     ev = torch.cuda.Event()
                     ev.record(lanes[0])
                     lanes[1].wait_event(ev)
@@ -422,7 +474,7 @@ class BNInception(nn.Module):
                 # inference: drop activations as soon as their last consumer has been launched
                 for name in [nm for nm, last in last_use.items() if last == i and nm != "data"]:
                     acts.pop(name, None)
-        saved = (plan, shapes, acts, argmax, tscale, wcat) if keep else None
+        saved = (plan, shapes, acts, argmax, tscale, bnstat) if keep else None
         return feat, saved
 
     # ------------------------------------------------------------------ backward executor
@@ -432,7 +484,8 @@ class BNInception(nn.Module):
         return self._ws
 
     def _run_backward(self, dfeat, saved):
-        plan, shapes, acts, argmax, tscale, wcat = saved
+        plan, shapes, acts, argmax, tscale, bnstat = saved
+        bn_grads = {}    # training-mode BatchNorm layers: layer id -> (dgamma, dbeta)
         n, dev = dfeat.shape[0], dfeat.device
         layout, total = self.flat_grad_layout()
         lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
@@ -469,6 +522,8 @@ class BNInception(nn.Module):
                         tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
                 if op.get("raw"):
                     ws_bytes = max(ws_bytes, K.channel_sum_workspace_bytes(n, op["cout"]))
+            elif op["kind"] == "bn_train":
+                ws_bytes = max(ws_bytes, 4 * K.bn_train_workspace_floats(n, op["c"]))
         ws = self._workspace(ws_bytes, dev)
         # all dgrad weight operands in two launches
         dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
@@ -552,6 +607,21 @@ class BNInception(nn.Module):
                     masked.setdefault(op["dst"], []).append((op["dst_c0"], op["dst_c0"] + c))
                 K.pool_bwd("avg", g, None, full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=False)
                 inited.add((op["src"], 0))
+            elif op["kind"] == "bn_train":
+                # batch-norm backward of the layer(s): the slice's gradient arrives untouched (NaN scales, see forward)
+                off = 0
+                for lid, c in zip(op["lids"], op["couts"]):
+                    bn = getattr(self, lid + "_bn")
+                    mean, invstd = bnstat[lid]
+                    dgamma = torch.empty(c, device=dev, dtype=torch.float32)
+                    dbeta = torch.empty(c, device=dev, dtype=torch.float32)
+                    K.bn_train_bwd(ChanSlice(grads[op["dst"]], op["dst_c0"] + off, c),
+                                   ChanSlice(acts[op["dst"]], op["dst_c0"] + off, c), ChanSlice(acts[op["src"]], off, c),
+                                   mean, invstd, bn.weight.detach(), dgamma, dbeta, ChanSlice(gbuf(op["src"]), off, c), ws,
+                                   True)
+                    bn_grads[lid] = (dgamma, dbeta)
+                    off += c
+                inited.add((op["src"], 0))
             else:
                 cout, cin, k, s, p = op["cout"], op["cin"], op["k"], op["s"], op["p"]
                 lids = op["lids"]
@@ -577,7 +647,7 @@ class BNInception(nn.Module):
                 else:
                     wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
                     run_wgrad = lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg)   # noqa: E731
-                if raw:
+                if raw and not op.get("bn_train"):
                     # the bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's backward
                     # (the wgrad kernel's bias column sums the pooled gradient, which differs at the image border)
                     g_pre = ChanSlice(grads[op["final"][0]], op["final"][1], cout)
@@ -638,4 +708,9 @@ class BNInception(nn.Module):
             wo, wn, bo, bn = lay[lid]
             out.append(flat[wo:wo + wn].view_as(conv.weight) if conv.weight.requires_grad else None)
             out.append(flat[bo:bo + bn] if conv.bias.requires_grad else None)
+        for lid in self._train_bn_ids():
+            bnm = getattr(self, lid + "_bn")
+            dgamma, dbeta = bn_grads[lid]
+            out.append(dgamma if bnm.weight.requires_grad else None)
+            out.append(dbeta if bnm.bias.requires_grad else None)
         return out

@@ -43,11 +43,11 @@ using namespace x6;
 // the straight LDS copy conflict-free for the ds_read_b128 fragment reads.
 //   mode 0 (forward operand): A[m][c][tap] = w[m][c][tap];  mode 1 (dgrad operand): A[m][c][tap] = w[c][m][tap]
 // Two sources (fused pair): output channel co < split comes from w0, the rest from w1.
-// Three launches: clear the amax tails, max |w| of every entry into its tail (XP_AMAX_BLOCKS workgroups per entry,
-// unsigned atomic max), then the packing proper, which derives the entry's power-of-two scale from that tail.
+// Three launches: clear the amax tails, max |w| of every entry into its tail (one workgroup per XP_ACHUNK source
+// elements, unsigned atomic max), then the packing proper, which derives the entry's power-of-two scale from that tail.
 constexpr int XP_MAX = 40;
 constexpr int XP_CHUNK = 4096;   // (slab, m, kpair) triples per block
-constexpr int XP_AMAX_BLOCKS = 8;
+constexpr int XP_ACHUNK = 8192;  // source elements per block of the amax launch
 struct X6PackTable {
     const float* w0[XP_MAX];
     const float* w1[XP_MAX];
@@ -57,18 +57,22 @@ struct X6PackTable {
     int srckk[XP_MAX];          // taps per channel of the SOURCE weight (== kk unless a tap subset is packed)
     unsigned tapmap[XP_MAX];    // srckk != kk: nibble t = source tap of packed tap t
     int blk0[XP_MAX + 1];
+    int ablk0[XP_MAX + 1];      // block ranges of the amax launch
     int count;
 };
 __global__ __launch_bounds__(64) void pack_x6_clear_tail_kernel(X6PackTable t) {
     for (int i = threadIdx.x; i < t.count * ATAIL; i += 64) t.out[i / ATAIL][t.rows_dw[i / ATAIL] + i % ATAIL] = 0u;
 }
 __global__ __launch_bounds__(256) void pack_x6_amax_kernel(X6PackTable t) {
-    const int ti = blockIdx.x / XP_AMAX_BLOCKS, part = blockIdx.x % XP_AMAX_BLOCKS;
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.ablk0[ti + 1]) ++ti;
     const long n0 = (long)t.split[ti] * t.cin[ti] * t.srckk[ti];                    // elements of w0
     const long n1 = (long)(t.cout[ti] - t.split[ti]) * t.cin[ti] * t.srckk[ti];     // elements of w1 (fused pair)
+    const long base = (long)((int)blockIdx.x - t.ablk0[ti]) * XP_ACHUNK;
+    long end = base + XP_ACHUNK;
+    if (end > n0 + n1) end = n0 + n1;
     float m = 0.f;
-    for (long i = (long)part * 256 + threadIdx.x; i < n0 + n1; i += 256 * XP_AMAX_BLOCKS)
-        m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : t.w1[ti][i - n0]));
+    for (long i = base + threadIdx.x; i < end; i += 256) m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : t.w1[ti][i - n0]));
     amax_emit(reinterpret_cast<float*>(t.out[ti] + t.rows_dw[ti]), m);
 }
 __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
@@ -112,10 +116,16 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
     }
 }
 // the three launches of a filled table (blk0[count] = blocks of the packing launch)
-int launch_pack(const X6PackTable& t, hipStream_t stream) {
+int launch_pack(X6PackTable& t, hipStream_t stream) {
     if (t.count == 0 || t.blk0[t.count] == 0) return SSN_OK;
+    int ablocks = 0;
+    for (int i = 0; i < t.count; ++i) {
+        t.ablk0[i] = ablocks;
+        ablocks += (int)(((long)t.cout[i] * t.cin[i] * t.srckk[i] + XP_ACHUNK - 1) / XP_ACHUNK);
+    }
+    t.ablk0[t.count] = ablocks;
     hipLaunchKernelGGL(pack_x6_clear_tail_kernel, dim3(1), dim3(64), 0, stream, t);
-    hipLaunchKernelGGL(pack_x6_amax_kernel, dim3((unsigned)(t.count * XP_AMAX_BLOCKS)), dim3(256), 0, stream, t);
+    hipLaunchKernelGGL(pack_x6_amax_kernel, dim3((unsigned)ablocks), dim3(256), 0, stream, t);
     hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)t.blk0[t.count]), dim3(256), 0, stream, t);
     return SSN_OK;
 }

@@ -43,7 +43,34 @@ __global__ __launch_bounds__(256) void frames_kernel(const uint8_t* src, float* 
     }
 }
 
+// RGBDiff input (SSN._get_diff, /root/reference/ssn_models.py:302-316, keep_rgb = False): every segment holds
+// new_length + 1 stacked RGB frames; the network sees the new_length differences of consecutive frames,
+//   out[g][x][c][hw] = in[g][x + 1][c][hw] - in[g][x][c][hw],   x < new_length
+// i.e. out[g][j] = in[g][j + plane] - in[g][j] with plane = C * HW floats and j < new_length * plane.
+__global__ __launch_bounds__(256) void frame_diff_kernel(const float* in, float* out, long per_seg_out, long per_seg_in,
+                                                         long plane, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long g = idx / per_seg_out, j = idx - g * per_seg_out;
+        const float* src = in + g * per_seg_in + j;
+        out[idx] = src[plane] - src[0];
+    }
+}
+
 }  // namespace
+
+extern "C" int ssn_frame_diff(const float* in, float* out, long n_segments, int new_length, int C, int HW,
+                              hipStream_t stream) {
+    SSN_CHECK_ARG(in && out && n_segments >= 0 && new_length >= 1 && C >= 1 && HW >= 1, "frame_diff: bad arguments");
+    const long plane = (long)C * HW;
+    const long total = n_segments * new_length * plane;
+    if (total == 0) return SSN_OK;
+    long blocks = (total + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 65535 * 4) blocks = 65535 * 4;
+    hipLaunchKernelGGL(frame_diff_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, new_length * plane,
+                       (new_length + 1) * plane, plane, total);
+    SSN_CHECK_LAUNCH("frame_diff");
+    return SSN_OK;
+}
 
 extern "C" int ssn_frames_crop_normalize(const unsigned char* src, float* dst, int n_img, int Hs, int Ws, int C,
                                          int crop_h, int crop_w, int n_crops, const int* off_x, const int* off_y,

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void stpp_reorg_kernel(const float* scores, in
         for (int c = threadIdx.x; c < act_len; c += 256) {
             float acc = 0.f;
             for (int r = a0; r < a1; ++r) acc += scores[(long)r * D + c];
-            out_act[(long)prop * act_len + c] = acc / (float)(a1 - a0);
+            // (a0 < 0: the range starts past the last row -- the reference's mean over an empty slice, NaN)
+            out_act[(long)prop * act_len + c] = a0 < 0 ? __builtin_nanf("") : acc / (float)(a1 - a0);
         }
     }
     for (int which = 0; which < 2; ++which) {
@@ -107,6 +108,10 @@ __global__ __launch_bounds__(256) void stpp_reorg_kernel(const float* scores, in
             for (int part = 0; part < n_parts; ++part) {
                 const int pl = ranges[((long)prop * n_parts + part) * 2];
                 const int pr = ranges[((long)prop * n_parts + part) * 2 + 1];
+                if (pl < 0) {            // starts past the last row: mean over an empty slice (NaN) in the reference
+                    tot += __builtin_nanf("");
+                    continue;
+                }
                 if (pr - pl < 1) continue;
                 float acc = 0.f;
                 for (int r = pl; r < pr; ++r) acc += scores[(long)r * D + base + part * len + c];

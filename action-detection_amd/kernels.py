@@ -386,6 +386,38 @@ def channel_sum(g, out, workspace):
              workspace.numel() * workspace.element_size(), _stream(lib, out))
 
 
+def bn_train_workspace_floats(n, c):
+    fn = _lib.get_lib().cdll.ssn_bn_train_workspace_floats
+    fn.restype = ctypes.c_long
+    return int(fn(int(n), int(c)))
+
+
+def bn_train_stats(z, conv_bias, mean, invstd, running_mean, running_var, eps, momentum, workspace):
+    """Batch statistics of the ChanSlice z (the convolution WITHOUT its bias) + running-statistics update."""
+    lib = _check(z, conv_bias, mean, invstd, running_mean, running_var, workspace)
+    h, w = z.hw
+    lib.call("ssn_bn_train_stats", _p(z), _p(conv_bias), _p(mean), _p(invstd), _p(running_mean), _p(running_var), z.n,
+             z.c, h * w, z.img_stride, float(eps), float(momentum), _p(workspace),
+             workspace.numel() * workspace.element_size(), _stream(lib, mean))
+
+
+def bn_train_apply(z, y, mean, invstd, gamma, beta, relu=True):
+    """y = relu?(gamma * (z - mean) * invstd + beta) on ChanSlices."""
+    lib = _check(z, y, mean, invstd, gamma, beta)
+    h, w = z.hw
+    lib.call("ssn_bn_train_apply", _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), int(bool(relu)), z.n, z.c,
+             h * w, z.img_stride, y.img_stride, _amax_out(y), _stream(lib, mean))
+
+
+def bn_train_bwd(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, workspace, relu=True):
+    """Backward of bn_train_apply(bn_train_stats(z)): dgamma, dbeta [C] and dz (ChanSlice)."""
+    lib = _check(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, workspace)
+    h, w = z.hw
+    lib.call("ssn_bn_train_bwd", _p(dy), _p(y), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), _p(dz),
+             int(bool(relu)), z.n, z.c, h * w, dy.img_stride, y.img_stride, z.img_stride, dz.img_stride, _p(workspace),
+             workspace.numel() * workspace.element_size(), _amax_out(dz), _stream(lib, mean))
+
+
 @_hbm_timed
 def gap_fwd(x, y):
     lib = _check(x, y)
@@ -479,6 +511,19 @@ def frames_crop_normalize(src, dst, crops, roll, invert_even, mean, std):
     lib.call("ssn_frames_crop_normalize", _p(src), _p(dst), n_img, hs, ws, c, ch, cw, nc,
              ctypes.cast(ox, ctypes.c_void_p), ctypes.cast(oy, ctypes.c_void_p), ctypes.cast(fl, ctypes.c_void_p),
              int(roll), int(invert_even), _p(mean), mean.numel(), _p(std), std.numel(), _stream(lib, src))
+
+
+def frame_diff(x, new_length, channels=3):
+    """RGBDiff input (SSN._get_diff): x [..., (new_length + 1) * channels * k, H, W] stacked frames per segment ->
+    [n_segments, new_length * channels, H, W] differences of consecutive frames."""
+    lib = _check(x)
+    h, w = x.shape[-2:]
+    per_in = (new_length + 1) * channels
+    assert x.numel() % (per_in * h * w) == 0
+    n_seg = x.numel() // (per_in * h * w)
+    out = torch.empty((n_seg, new_length * channels, h, w), device=x.device, dtype=torch.float32)
+    lib.call("ssn_frame_diff", _p(x), _p(out), n_seg, int(new_length), int(channels), h * w, _stream(lib, x))
+    return out
 
 
 def detections(act, comp, reg, rel_prop, top_k, include_bg, nms_thresh, regress):

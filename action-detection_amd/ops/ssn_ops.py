@@ -155,8 +155,19 @@ class STPPReorgainzed:
         n_out = proposal_ticks.size(0) if torch.is_tensor(proposal_ticks) else len(proposal_ticks)
         pt = proposal_ticks.cpu().numpy() if torch.is_tensor(proposal_ticks) else np.asarray(proposal_ticks)
         ranges, act = self.host_ranges(pt, scores.size(0))
-        if ranges.size and (ranges.max() > scores.size(0) or act.max() > scores.size(0) or act.min() < 0):
-            raise IndexError("proposal ticks reach outside the %d score rows" % scores.size(0))
+        # The reference slices with Python semantics (ops/ssn_ops.py:149,157): a range END past the last score row is
+        # clamped to it (the mean then runs over the rows that exist); a range that STARTS at or past the last row is a
+        # mean over nothing -- NaN, which the reference adds into the proposal's scores (marked (-1, -1) for the
+        # kernel).  Negative starts would count rows from the END in Python; nothing sensible, so they raise.
+        t_rows = scores.size(0)
+        if ranges.size:
+            live = ranges[..., 1] > ranges[..., 0]
+            if (act[:, 0] < 0).any() or (ranges[..., 0][live] < 0).any():
+                raise IndexError("proposal ticks start before the first of the %d score rows" % t_rows)
+            np.minimum(ranges[..., 1], t_rows, out=ranges[..., 1])
+            np.minimum(act[:, 1], t_rows, out=act[:, 1])
+            ranges[live & (ranges[..., 0] >= t_rows)] = -1
+            act[act[:, 0] >= t_rows] = -1
         sc = scaling if torch.is_tensor(scaling) else torch.as_tensor(np.asarray(scaling))
         sc = sc.to(device=dev, dtype=torch.float32).reshape(-1, 2).contiguous()
         out_act = torch.empty((n_out, self.act_len), device=dev, dtype=torch.float32)

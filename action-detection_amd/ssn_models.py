@@ -7,7 +7,8 @@ drops into the loops of ssn_train.py:205-253 and ssn_test.py:78-92.  Differences
 deliberate and documented in DESIGN.md:
   * BNInception is built for training and testing, InceptionV3 for testing (forward only); resnet/vgg raise;
   * the backbone is this repo's ``bninception.BNInception`` executor instead of ``model_zoo``;
-  * ``bn_mode`` other than 'frozen' raises at forward time;
+  * ``bn_mode`` 'partial' / 'full' run the training-mode BatchNorm kernels of csrc/bn_train.hip (batch statistics per
+    rank, like the per-replica statistics of the reference's DataParallel);
   * one host sync per forward (prop_type -> row indices) instead of the reference's three
     ``nonzero()`` syncs.
 """
@@ -87,7 +88,7 @@ class SSN(torch.nn.Module):
         if self.modality == 'Flow':
             self.base_model = self._construct_flow_model(self.base_model)
         elif self.modality == 'RGBDiff':
-            raise NotImplementedError("RGBDiff modality is outside the built hot path (SURVEY.md section 8f-4)")
+            self.base_model = self._construct_diff_model(self.base_model)
 
         self.prepare_bn()
 
@@ -232,6 +233,9 @@ class SSN(torch.nn.Module):
 
     def _backbone(self, input):
         sample_len = (3 if self.modality == "RGB" else 2) * self.new_length
+        if self.modality == 'RGBDiff':
+            sample_len = 3 * self.new_length
+            input = self._get_diff(input)
         x = input.reshape((-1, sample_len) + tuple(input.shape[-2:]))
         feat = self.base_model.features(x)
         return getattr(self.base_model, self.base_model.last_layer_name)(feat)
@@ -292,16 +296,37 @@ class SSN(torch.nn.Module):
         base_out = self._backbone(input)
         return self.test_fc(base_out), base_out
 
+    # ---- /root/reference/ssn_models.py:302-316
+    def _get_diff(self, input, keep_rgb=False):
+        """RGBDiff: every segment holds new_length + 1 stacked RGB frames; the backbone sees the new_length differences
+        of consecutive frames (one launch, csrc/frames.hip: ssn_frame_diff)."""
+        if keep_rgb:
+            raise NotImplementedError("keep_rgb=True is never used by the reference drivers")
+        from . import kernels as K
+        return K.frame_diff(input.contiguous().float(), self.new_length, 3)
+
+    # ---- /root/reference/ssn_models.py:345-376 (keep_rgb = False)
+    def _construct_diff_model(self, base_model, keep_rgb=False):
+        """First-conv surgery for RGB differences: as for flow, over 3 * new_length input channels.  (The reference's
+        own method subscripts a ``filter`` object -- a Python-2 idiom -- and only runs with ``filter`` shimmed to return
+        a list, which is how oracle/make_golden.py obtains the fixture this is tested against.)"""
+        if keep_rgb:
+            raise NotImplementedError("keep_rgb=True is never used by the reference drivers")
+        return SSN._first_conv_surgery(base_model, 3 * self.new_length)
+
     # ---- /root/reference/ssn_models.py:318-343
     def _construct_flow_model(self, base_model):
         """First-conv surgery for stacked optical flow: the RGB kernel averaged over its input channels and repeated
         over the 2 * new_length flow channels, bias kept; the new layer replaces the old one under the same name."""
+        return SSN._first_conv_surgery(base_model, 2 * self.new_length)
+
+    @staticmethod
+    def _first_conv_surgery(base_model, c_flow):
         name, old = next((n, m) for n, m in base_model.named_modules() if isinstance(m, nn.Conv2d))
         holder = base_model
         *path, leaf = name.split(".")
         for part in path:
             holder = getattr(holder, part)
-        c_flow = 2 * self.new_length
         has_bias = old.bias is not None
         new = nn.Conv2d(c_flow, old.out_channels, old.kernel_size, old.stride, old.padding, bias=has_bias)
         with torch.no_grad():

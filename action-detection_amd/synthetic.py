@@ -70,11 +70,13 @@ def make_batch(num_videos, modality="RGB", num_class=20, seed=0, input_size=224,
     rng = np.random.RandomState(seed)
     if new_length is None:
         new_length = 1 if modality == "RGB" else 5
-    c = 3 * new_length if modality == "RGB" else 2 * new_length
+    c = 3 * new_length if modality == "RGB" else (3 * (new_length + 1) if modality == "RGBDiff" else 2 * new_length)
     v, p, s = num_videos, prop_per_video, num_segments
     pix = rng.randint(0, 256, size=(v, p * s, c, input_size, input_size)).astype(np.float32)
     if modality == "RGB":
         mean = np.array([104, 117, 128] * new_length, np.float32)
+    elif modality == "RGBDiff":      # ssn_models.py:128-129: the RGB means repeated over the new_length + 1 stacked frames
+        mean = np.array([104, 117, 128] * (new_length + 1), np.float32)
     else:
         mean = np.full((c,), 128, np.float32)
     pix -= mean.reshape(1, 1, c, 1, 1)

@@ -175,6 +175,27 @@ int ssn_conv_pick_tile(int M, long P);
 /* tooling only: ablation switches for the conv kernel (tools/ablate_conv.py); 0 = normal operation */
 int ssn_conv_debug_flags(int flags);
 
+/* ------------------------------------------------------------------ backbone: training-mode BatchNorm2d
+ * bn_mode 'partial' (first BatchNorm2d) / 'full' (all) of ssn_models.py:95-105,156-174 (csrc/bn_train.hip): the
+ * layers SSN.train() leaves in training mode normalise with batch statistics, update running_mean / running_var
+ * (momentum, unbiased variance) and take the full batch-norm backward.  z is the convolution output WITHOUT the conv
+ * bias (it cancels in z - mean(z); conv_bias only enters the running mean).  workspace:
+ * ssn_bn_train_workspace_floats(N, C) floats.  Reductions are two-level, atomic-free, combined in double.
+ *   stats : mean[c], invstd[c] = 1/sqrt(biased var + eps) over (N, HW); running stats updated in place (or NULL)
+ *   apply : y = relu?(gamma * (z - mean) * invstd + beta)
+ *   bwd   : g = dy * (y > 0 | 1), dbeta = sum g, dgamma = sum g * xhat, dz = gamma * invstd * (g - dbeta/n - xhat * dgamma/n) */
+long ssn_bn_train_workspace_floats(int N, int C);
+int ssn_bn_train_stats(const float* z, const float* conv_bias, float* mean, float* invstd, float* running_mean,
+                       float* running_var, int N, int C, int HW, long z_img_stride, float eps, float momentum,
+                       void* workspace, size_t ws_bytes, hipStream_t stream);
+int ssn_bn_train_apply(const float* z, float* y, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, int relu, int N, int C, int HW, long z_img_stride, long y_img_stride,
+                       float* y_amax, hipStream_t stream);
+int ssn_bn_train_bwd(const float* dy, const float* y, const float* z, const float* mean, const float* invstd,
+                     const float* gamma, float* dgamma, float* dbeta, float* dz, int relu, int N, int C, int HW,
+                     long dy_img_stride, long y_img_stride, long z_img_stride, long dz_img_stride, void* workspace,
+                     size_t ws_bytes, float* dz_amax, hipStream_t stream);
+
 /* ------------------------------------------------------------------ backbone: pooling
  * Max / average pools of BN-Inception (ceil_mode output sizes computed by the caller, avg with
  * count_include_pad=True) and the global average pool before `fc` (ssn_models.py:266 -> backbone).
@@ -237,6 +258,10 @@ int ssn_stpp_reorg(const float* scores, int T, int D, const int* ranges, const i
  * on reg [n_pairs][2], in place. */
 int ssn_crop_mean(const float* x, float* y, int num_crop, int T, int D, hipStream_t stream);
 int ssn_reg_denorm(float* reg, long n_pairs, float mean0, float std0, float mean1, float std1, hipStream_t stream);
+
+/* RGBDiff input (SSN._get_diff, ssn_models.py:302-316, keep_rgb = False): in [n_segments][new_length + 1][C][HW] ->
+ * out [n_segments][new_length][C][HW], out[g][x] = in[g][x + 1] - in[g][x]. */
+int ssn_frame_diff(const float* in, float* out, long n_segments, int new_length, int C, int HW, hipStream_t stream);
 
 /* Input side (csrc/frames.hip): the arithmetic of the reference's transform chain after decoding / scaling --
  * GroupOverSample or crop + horizontal flip, Stack(roll), ToTorchFormatTensor(div=False), GroupNormalize

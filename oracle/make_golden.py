@@ -180,6 +180,89 @@ def golden_ssn(ref_models, ref_ops):
     np.savez_compressed(os.path.join(OUT, "ref_ssn.npz"), **out)
 
 
+def golden_ssn_bn(ref_models, ref_ops):
+    """bn_mode 'partial' / 'full' of the reference SSN (/root/reference/ssn_models.py:95-105,156-174): the first /
+    every BatchNorm2d normalises with batch statistics, updates its running statistics and gets gamma / beta gradients."""
+    out = {}
+    for mode in ("partial", "full"):
+        torch.manual_seed(0)
+        c, v, size = 20, 2, 32
+        m = ref_models.SSN(c, 2, 5, 2, "RGB", base_model="BNInception", dropout=0, stpp_cfg=(1, 1, 1), bn_mode=mode)
+        init_backbone_synthetic(m.base_model)
+        init_heads_synthetic(m)
+        m.train()
+        out["%s_training_bn" % mode] = np.array([n for n, mod in m.base_model.named_modules()
+                                                if isinstance(mod, torch.nn.BatchNorm2d) and mod.training])
+        batch = make_batch(v, "RGB", c, seed=3, input_size=size)
+        res = m(*batch)
+        act_l = torch.nn.CrossEntropyLoss()(res[0], res[1])
+        comp_l = ref_ops.CompletenessLoss()(res[2], res[3], 1, 7)
+        reg_l = ref_ops.ClassWiseRegressionLoss()(res[4], res[5], res[6])
+        loss = act_l + 0.1 * comp_l + 0.1 * reg_l
+        loss.backward()
+        for i, t in enumerate(res):
+            out["%s_out%d" % (mode, i)] = t.detach().numpy()
+        out["%s_losses" % mode] = np.array([act_l.item(), comp_l.item(), reg_l.item(), loss.item()], np.float64)
+        gn, names = [], []
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                gn.append([float(p.grad.double().norm()), float(p.grad.double().sum())])
+        out["%s_grad_names" % mode] = np.array(names)
+        out["%s_grad_stats" % mode] = np.array(gn)
+        bn1 = m.base_model.conv1_7x7_s2_bn
+        out["%s_bn1_running_mean" % mode] = bn1.running_mean.numpy().copy()
+        out["%s_bn1_running_var" % mode] = bn1.running_var.numpy().copy()
+        out["%s_bn1_dgamma" % mode] = bn1.weight.grad.numpy().copy()
+        out["%s_bn1_dbeta" % mode] = bn1.bias.grad.numpy().copy()
+        out["%s_conv1_dw" % mode] = m.base_model.conv1_7x7_s2.weight.grad.numpy().copy()
+        bn5 = m.base_model.inception_5b_1x1_bn
+        out["%s_bn5b_running_mean" % mode] = bn5.running_mean.numpy().copy()
+        out["%s_bn5b_running_var" % mode] = bn5.running_var.numpy().copy()
+        out["%s_bn1_batches" % mode] = np.array([int(bn1.num_batches_tracked), int(bn5.num_batches_tracked)])
+        pol = m.get_optim_policies()
+        out["%s_policy_sizes" % mode] = np.array([[len(g["params"]), sum(p.numel() for p in g["params"])] for g in pol])
+    np.savez_compressed(os.path.join(OUT, "ref_ssn_bn.npz"), **out)
+
+
+def golden_ssn_rgbdiff(ref_models, ref_ops):
+    """RGBDiff modality of the reference SSN (_get_diff + _construct_diff_model, ssn_models.py:302-316,345-376).
+    The reference's _construct_diff_model subscripts the result of ``filter`` (a Python-2 list); the shim below gives the
+    module a list-returning ``filter`` -- the fourth shim next to torchvision / model_zoo / .cuda(); no source edit."""
+    import builtins
+    ref_models.filter = lambda f, it: list(builtins.filter(f, it))
+    out = {}
+    torch.manual_seed(0)
+    c, v, size = 20, 2, 32
+    m = ref_models.SSN(c, 2, 5, 2, "RGBDiff", base_model="BNInception", dropout=0, stpp_cfg=(1, 1, 1))
+    init_backbone_synthetic(m.base_model)
+    init_heads_synthetic(m)
+    m.train()
+    batch = make_batch(v, "RGBDiff", c, seed=3, input_size=size)
+    res = m(*batch)
+    act_l = torch.nn.CrossEntropyLoss()(res[0], res[1])
+    comp_l = ref_ops.CompletenessLoss()(res[2], res[3], 1, 7)
+    reg_l = ref_ops.ClassWiseRegressionLoss()(res[4], res[5], res[6])
+    loss = act_l + 0.1 * comp_l + 0.1 * reg_l
+    loss.backward()
+    for i, t in enumerate(res):
+        out["out%d" % i] = t.detach().numpy()
+    out["losses"] = np.array([act_l.item(), comp_l.item(), reg_l.item(), loss.item()], np.float64)
+    gn, names = [], []
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gn.append([float(p.grad.double().norm()), float(p.grad.double().sum())])
+    out["grad_names"] = np.array(names)
+    out["grad_stats"] = np.array(gn)
+    out["conv1_weight_shape"] = np.array(m.base_model.conv1_7x7_s2.weight.shape)
+    out["conv1_dw"] = m.base_model.conv1_7x7_s2.weight.grad.numpy().copy()
+    out["diff_sample"] = m._get_diff(batch[0]).reshape(-1, 15, size, size)[:3].numpy().copy()
+    out["input_mean"] = np.array(m.input_mean)
+    out["state_keys"] = np.array(sorted(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "ref_ssn_rgbdiff.npz"), **out)
+
+
 def golden_binary(ref_binary, ref_ops):
     """BinaryClassifier (binary_model.py) on the stub backbone: train forward + CE loss + gradients, test path."""
     ref_binary.Identity = ref_ops.Identity      # the reference forgets to import it (NameError at dropout == 0)
@@ -385,7 +468,12 @@ def main():
     golden_stpp(ref_ops)
     golden_losses(ref_ops)
     golden_reorg(ref_ops)
-    golden_ssn(ref_models, ref_ops)
+    if not os.environ.get("GOLDEN_ONLY"):
+        golden_ssn(ref_models, ref_ops)
+    golden_ssn_bn(ref_models, ref_ops)
+    golden_ssn_rgbdiff(ref_models, ref_ops)
+    if os.environ.get("GOLDEN_ONLY") == "ssn_bn":
+        return
     import binary_model as ref_binary
     golden_binary(ref_binary, ref_ops)
     golden_proposal_io()

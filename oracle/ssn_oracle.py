@@ -499,7 +499,8 @@ class OracleSSN(nn.Module):
         self.stpp_cfg = stpp_cfg
         self.num_class = num_class
         # ssn_models.py:121-131 + :318-343 (flow: first conv gets 2*new_length input channels)
-        cin = 3 if modality == "RGB" else 2 * self.new_length
+        # (RGBDiff, :345-376 with keep_rgb = False: 3 * new_length channels of frame differences)
+        cin = 3 if modality == "RGB" else (3 if modality == "RGBDiff" else 2) * self.new_length
         if base_model == "InceptionV3":     # ssn_models.py:133-139
             self.base_model = OracleInceptionV3(in_channels=3)
             self.last_layer_name, first = "top_cls_fc", "conv_1a_3x3"
@@ -509,7 +510,7 @@ class OracleSSN(nn.Module):
         feat = getattr(self.base_model, self.last_layer_name).in_features
         # ssn_models.py:69-74
         setattr(self.base_model, self.last_layer_name, nn.Identity() if dropout == 0 else nn.Dropout(p=dropout))
-        if modality == "Flow":
+        if modality in ("Flow", "RGBDiff"):
             old = getattr(self.base_model, first)
             new = nn.Conv2d(cin, old.out_channels, old.kernel_size, old.stride, old.padding, bias=True)
             new.weight.data = old.weight.data.mean(dim=1, keepdim=True).expand(-1, cin, -1, -1).contiguous()
@@ -546,6 +547,11 @@ class OracleSSN(nn.Module):
 
     def forward(self, input, aug_scaling=None, target=None, reg_target=None, prop_type=None):
         sample_len = (3 if self.modality == "RGB" else 2) * self.new_length
+        if self.modality == "RGBDiff":
+            # ssn_models.py:302-316 (_get_diff, keep_rgb = False): differences of the new_length + 1 stacked frames
+            sample_len = 3 * self.new_length
+            v = input.reshape((-1, self.num_segments, self.new_length + 1, 3) + tuple(input.shape[-2:]))
+            input = v[:, :, 1:] - v[:, :, :-1]
         x = input.reshape((-1, sample_len) + tuple(input.shape[-2:]))
         base_out = getattr(self.base_model, self.last_layer_name)(self.base_model.features(x))
         if self.test_mode:
@@ -660,7 +666,8 @@ class OracleBinaryClassifier(nn.Module):
         super().__init__()
         self.modality, self.course_segment, self.test_mode = modality, course_segment, test_mode
         self.new_length = (1 if modality == "RGB" else 5) if new_length is None else new_length
-        cin = 3 if modality == "RGB" else 2 * self.new_length
+        # (RGBDiff, :345-376 with keep_rgb = False: 3 * new_length channels of frame differences)
+        cin = 3 if modality == "RGB" else (3 if modality == "RGBDiff" else 2) * self.new_length
         self.base_model = OracleBNInception(in_channels=3)
         feat = self.base_model.fc.in_features
         self.base_model.fc = nn.Identity() if dropout == 0 else nn.Dropout(p=dropout)      # :121-125

@@ -179,11 +179,15 @@ def _product_vs_golden(tag, device):
     np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["%s_losses" % tag], rtol=1e-4)
     total.backward()
     grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
-    for n, (norm, s) in zip([str(x) for x in g["%s_grad_names" % tag]], g["%s_grad_stats" % tag]):
-        # gradients: 3e-3 on the norms.  At 32^2 the 7x7-stage planes are single pixels, so one ReLU unit that two fp32
-        # implementations resolve differently (pre-activation within rounding of zero) moves a whole tensor by ~1e-3
-        # (profiles/r2_grad_flip_diag.txt: the reference's own fp32 CPU path is 2.4e-3 off float64 on one tensor at 224^2)
-        assert abs(float(grads[n].double().norm()) - norm) <= 3e-3 * norm + 1e-10, n
+    # gradient norms, as a distribution.  The loss is only piecewise smooth: a ReLU unit whose pre-activation is within
+    # rounding of zero takes different branches in two fp32 implementations, and at 32^2 -- the 7x7-stage planes are
+    # single pixels -- one such unit moves a whole tensor by 1e-3..1e-2 (profiles/r2_grad_flip_diag.txt: the reference's
+    # own fp32 CPU path is 2.4e-3 off float64 on one tensor at 224^2).  Which units flip is an accident of rounding; a
+    # wiring error moves the bulk.  So: the median within 3e-4, at most 5 % of the tensors beyond 3e-3, none beyond 3e-2.
+    names = [str(x) for x in g["%s_grad_names" % tag]]
+    e = torch.tensor([abs(float(grads[n].double().norm()) - norm) / (norm + 1e-12)
+                      for n, (norm, s) in zip(names, g["%s_grad_stats" % tag])])
+    assert e.median() < 3e-4 and e.max() < 3e-2 and int((e > 3e-3).sum()) <= max(3, len(e) // 20), (e.median(), e.max())
     # element-wise gradients: 5e-3 for the deepest chain (conv1: ~60 fp32 reductions in a different order on
     # each side; tests/test_model_gpu.py referees such differences against float64), 1e-3 / 1e-4 near the loss
     assert rel_err(m.base_model.conv1_7x7_s2.bias.grad, torch.from_numpy(g["%s_grad_conv1_b" % tag])) < 5e-3
@@ -236,3 +240,205 @@ def test_sharded_completeness_loss_averages_to_the_gathered_loss(backend):
             grads.append(p.grad.cpu() / world)
         assert abs(tot - float(full_loss)) < 1e-6 * max(1.0, abs(float(full_loss)))
         assert np.allclose(torch.cat(grads).numpy(), full_grad, rtol=1e-5, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bn_mode 'partial' / 'full' (/root/reference/ssn_models.py:95-105,156-174): fixture ref_ssn_bn.npz from the reference's
+# own SSN class -- outputs, losses, every gradient norm (BatchNorm gamma / beta included), running statistics after one
+# training forward, which BatchNorm2d modules stay in training mode, optimiser groups.
+def _bn_pair(mode, cls):
+    from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic, make_batch
+    torch.manual_seed(0)
+    m = cls(20, 2, 5, 2, "RGB", dropout=0, stpp_cfg=(1, 1, 1), bn_mode=mode)
+    init_backbone_synthetic(m.base_model)
+    init_heads_synthetic(m)
+    m.train()
+    return m, make_batch(2, "RGB", 20, seed=3, input_size=32)
+
+
+def _grad_norm_errors(grads, names, stats):
+    return torch.tensor([abs(float(grads[n].double().norm()) - norm) / (norm + 1e-12) for n, (norm, _) in zip(names, stats)])
+
+
+@pytest.mark.parametrize("mode", ["partial", "full"])
+def test_oracle_bn_modes_match_reference(mode):
+    g = load("ref_ssn_bn.npz")
+    m, batch = _bn_pair(mode, O.OracleSSN)
+    training = [n for n, mod in m.base_model.named_modules() if isinstance(mod, torch.nn.BatchNorm2d) and mod.training]
+    assert training == [str(x) for x in g["%s_training_bn" % mode]]
+    out = m(*batch)
+    for i, t in enumerate(out):
+        assert rel_err(t.float(), torch.from_numpy(g["%s_out%d" % (mode, i)]).float()) < 1e-6, i
+    total, a, c, r = O.ssn_total_loss(out, 2)
+    np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["%s_losses" % mode], rtol=1e-6)
+    total.backward()
+    grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
+    names = [str(n) for n in g["%s_grad_names" % mode]]
+    assert sorted(names) == sorted(grads)
+    assert _grad_norm_errors(grads, names, g["%s_grad_stats" % mode]).max() < 1e-4
+    bn1 = m.base_model.conv1_7x7_s2_bn
+    assert rel_err(bn1.running_mean, torch.from_numpy(g["%s_bn1_running_mean" % mode])) < 1e-6
+    assert rel_err(bn1.running_var, torch.from_numpy(g["%s_bn1_running_var" % mode])) < 1e-6
+
+
+def _product_bn_vs_golden(mode, device):
+    from action_detection_amd.ssn_models import SSN
+    g = load("ref_ssn_bn.npz")
+    m, batch = _bn_pair(mode, SSN)
+    m.to(device)
+    training = [n for n, mod in m.base_model.named_modules() if isinstance(mod, torch.nn.BatchNorm2d) and mod.training]
+    assert training == [str(x) for x in g["%s_training_bn" % mode]]
+    out = m(*[t.to(device) for t in batch])
+    for i, t in enumerate(out):
+        want = torch.from_numpy(g["%s_out%d" % (mode, i)])
+        if i % 2 == 1 or i == 6:
+            assert torch.equal(t.cpu(), want), i
+        else:
+            assert rel_err(t, want) < 1e-4, (i, rel_err(t, want))                 # logits: north-star tolerance
+    a = P.ActivityLoss()(out[0], out[1])
+    c = P.CompletenessLoss()(out[2], out[3], 1, 7)
+    r = P.ClassWiseRegressionLoss()(out[4], out[5], out[6])
+    total = a + 0.1 * c + 0.1 * r
+    np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["%s_losses" % mode], rtol=1e-4)
+    total.backward()
+    bn1, bn5 = m.base_model.conv1_7x7_s2_bn, m.base_model.inception_5b_1x1_bn
+    assert rel_err(bn1.running_mean, torch.from_numpy(g["%s_bn1_running_mean" % mode])) < 1e-5
+    assert rel_err(bn1.running_var, torch.from_numpy(g["%s_bn1_running_var" % mode])) < 1e-5
+    assert rel_err(bn5.running_mean, torch.from_numpy(g["%s_bn5b_running_mean" % mode])) < 1e-4
+    assert rel_err(bn5.running_var, torch.from_numpy(g["%s_bn5b_running_var" % mode])) < 1e-4
+    assert [int(bn1.num_batches_tracked), int(bn5.num_batches_tracked)] == g["%s_bn1_batches" % mode].tolist()
+    grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
+    names = [str(n) for n in g["%s_grad_names" % mode]]
+    assert sorted(names) == sorted(grads)
+    # The bias of a convolution in front of a training-mode BatchNorm has an exactly zero gradient (the batch mean absorbs
+    # it); both sides hold rounding noise there -- checked against the weight gradient's size, not against each other.
+    training_convs = [n[:-len("_bn")] for n in training]
+    stats = g["%s_grad_stats" % mode]
+    keep = [i for i, n in enumerate(names) if not any(n == "base_model.%s.bias" % c for c in training_convs)]
+    for c in training_convs:
+        gb, gw = grads["base_model.%s.bias" % c], grads["base_model.%s.weight" % c]
+        assert float(gb.double().norm()) < 1e-4 * float(gw.double().norm()) + 1e-12, c
+    names, stats = [names[i] for i in keep], stats[keep]
+    # gradient norms as a distribution (ReLU sign flips, see _product_vs_golden): the bulk within 1e-3, every tensor within 3e-2
+    e = _grad_norm_errors(grads, names, stats)
+    assert e.median() < 1e-3 and e.max() < 3e-2 and int((e > 5e-3).sum()) <= max(3, len(e) // 20), (e.median(), e.max())
+    assert rel_err(bn1.weight.grad, torch.from_numpy(g["%s_bn1_dgamma" % mode])) < 5e-3
+    assert rel_err(bn1.bias.grad, torch.from_numpy(g["%s_bn1_dbeta" % mode])) < 5e-3
+    # (element-wise, the deepest chain at 32^2: the same ReLU-flip sensitivity as the norms above, hence their 3e-2 cap)
+    assert rel_err(m.base_model.conv1_7x7_s2.weight.grad, torch.from_numpy(g["%s_conv1_dw" % mode])) < 3e-2
+    pol = m.get_optim_policies()
+    assert [[len(x["params"]), sum(p.numel() for p in x["params"])] for x in pol] == g["%s_policy_sizes" % mode].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["partial", "full"])
+def test_product_bn_modes_match_reference_gpu(mode, hip_library):
+    _product_bn_vs_golden(mode, "cuda:0")
+
+
+@pytest.mark.slow_emu
+@pytest.mark.skipif(os.environ.get("SSN_SLOW") != "1", reason="~10 min through the host emulator; set SSN_SLOW=1")
+@pytest.mark.parametrize("mode", ["partial", "full"])
+def test_product_bn_modes_match_reference_emulated(mode, emu):
+    _product_bn_vs_golden(mode, "cpu")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RGBDiff modality (/root/reference/ssn_models.py:302-316,345-376): fixture ref_ssn_rgbdiff.npz from the reference's own
+# class (its Python-2 `filter(...)[0]` shimmed, oracle/make_golden.py).
+def _rgbdiff_pair(cls):
+    from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic, make_batch
+    torch.manual_seed(0)
+    m = cls(20, 2, 5, 2, "RGBDiff", dropout=0, stpp_cfg=(1, 1, 1))
+    init_backbone_synthetic(m.base_model)
+    init_heads_synthetic(m)
+    m.train()
+    return m, make_batch(2, "RGBDiff", 20, seed=3, input_size=32)
+
+
+def test_oracle_rgbdiff_matches_reference():
+    g = load("ref_ssn_rgbdiff.npz")
+    m, batch = _rgbdiff_pair(O.OracleSSN)
+    assert list(m.base_model.conv1_7x7_s2.weight.shape) == g["conv1_weight_shape"].tolist() == [64, 15, 7, 7]
+    out = m(*batch)
+    for i, t in enumerate(out):
+        assert rel_err(t.float(), torch.from_numpy(g["out%d" % i]).float()) < 1e-6, i
+    total, a, c, r = O.ssn_total_loss(out, 2)
+    np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["losses"], rtol=1e-6)
+    total.backward()
+    grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(names) == sorted(grads)
+    assert _grad_norm_errors(grads, names, g["grad_stats"]).max() < 1e-4
+
+
+def test_frame_diff_kernel(backend):
+    """ssn_frame_diff == SSN._get_diff of the reference (bit-exact: one fp32 subtraction per element)."""
+    g = load("ref_ssn_rgbdiff.npz")
+    from action_detection_amd import kernels as K
+    from action_detection_amd.synthetic import make_batch
+    x = make_batch(2, "RGBDiff", 20, seed=3, input_size=32)[0]
+    d = K.frame_diff(backend.put(x), 5, 3)
+    assert tuple(d.shape) == (2 * 8 * 9, 15, 32, 32)
+    assert torch.equal(d[:3].cpu(), torch.from_numpy(g["diff_sample"]))
+    v = x.reshape(-1, 9, 6, 3, 32, 32)
+    assert torch.equal(d.cpu(), (v[:, :, 1:] - v[:, :, :-1]).reshape(-1, 15, 32, 32))
+
+
+def _product_rgbdiff_vs_golden(device):
+    from action_detection_amd.ssn_models import SSN
+    g = load("ref_ssn_rgbdiff.npz")
+    m, batch = _rgbdiff_pair(SSN)
+    assert list(m.base_model.conv1_7x7_s2.weight.shape) == [64, 15, 7, 7] and list(m.input_mean) == g["input_mean"].tolist()
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    m.to(device)
+    out = m(*[t.to(device) for t in batch])
+    for i, t in enumerate(out):
+        want = torch.from_numpy(g["out%d" % i])
+        if i % 2 == 1 or i == 6:
+            assert torch.equal(t.cpu(), want), i
+        else:
+            assert rel_err(t, want) < 1e-4, (i, rel_err(t, want))
+    a = P.ActivityLoss()(out[0], out[1])
+    c = P.CompletenessLoss()(out[2], out[3], 1, 7)
+    r = P.ClassWiseRegressionLoss()(out[4], out[5], out[6])
+    total = a + 0.1 * c + 0.1 * r
+    np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["losses"], rtol=1e-4)
+    total.backward()
+    grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
+    names = [str(n) for n in g["grad_names"]]
+    e = _grad_norm_errors(grads, names, g["grad_stats"])
+    assert e.median() < 3e-4 and e.max() < 3e-2 and int((e > 3e-3).sum()) <= max(3, len(e) // 20), (e.median(), e.max())
+    assert rel_err(m.base_model.conv1_7x7_s2.weight.grad, torch.from_numpy(g["conv1_dw"])) < 5e-3
+
+
+@pytest.mark.gpu
+def test_product_rgbdiff_matches_reference_gpu(hip_library):
+    _product_rgbdiff_vs_golden("cuda:0")
+
+
+@pytest.mark.slow_emu
+@pytest.mark.skipif(os.environ.get("SSN_SLOW") != "1", reason="~10 min through the host emulator; set SSN_SLOW=1")
+def test_product_rgbdiff_matches_reference_emulated(emu):
+    _product_rgbdiff_vs_golden("cpu")
+
+
+def test_product_reorg_clamps_range_ends_like_python_slices(backend):
+    """A proposal whose ticks run past the last score row: the reference's ``raw_scores[pl:pr]`` (ops/ssn_ops.py:149,157)
+    clamps the END of the slice to the rows that exist, and a slice that starts past the last row is empty (mean = NaN); so
+    does the product (negative starts, which Python would count from the end, raise)."""
+    rng = np.random.RandomState(5)
+    t, cfg = 40, (1, (1, 2), 1)
+    mod = P.STPPReorgainzed(21 + 20 * 5 + 40 * 5, 21, 20, 40, True, True, stpp_cfg=cfg)
+    scores = rng.standard_normal((t, mod.feat_dim)).astype(np.float32)
+    ticks = np.array([[30, 34, 39, 47], [20, 36, 44, 52], [0, 3, 9, 12]], np.int64)     # ends beyond row 40
+    scaling = rng.uniform(0, 1, (3, 2))
+    want = O.stpp_reorganized(scores, ticks, scaling, 21, 20, 40, stpp_cfg=cfg)
+    got = mod.forward(backend.put(torch.from_numpy(scores)), torch.from_numpy(ticks), scaling)
+    for g_, w_ in zip(got, want):
+        g_, w_ = g_.cpu().numpy(), np.asarray(w_)
+        assert np.array_equal(np.isnan(g_), np.isnan(w_))
+        np.testing.assert_allclose(np.nan_to_num(g_), np.nan_to_num(w_), rtol=1e-5, atol=1e-6)
+    assert np.isnan(want[1][1]).any() and not np.isnan(want[1][0]).any()      # second proposal: a part starts at row 40 = T
+    with pytest.raises(IndexError):
+        mod.forward(backend.put(torch.from_numpy(scores)), torch.from_numpy(np.array([[-3, 1, 4, 7]], np.int64)), scaling[:1])

@@ -690,3 +690,39 @@ def test_conv_x6_dgrad_s2(backend):
         ref = torch.where(torch.isnan(m), tot, torch.where(act[:, 5:].double() > 0, tot * m, torch.zeros_like(tot)))
         assert rel_err(wide[:, 5:], ref) < 2e-6, ("dgrad s2 acc+mask", n, cin, h, cout, tile)
         assert torch.equal(wide[:, :5].cpu(), prev[:, :5])
+
+
+def test_bn_train(backend):
+    """Training-mode BatchNorm2d + ReLU (bn_mode 'partial' / 'full'): statistics, running-stat update, output and the full
+    backward against torch autograd in float64, on channel slices, with a large per-channel offset (|mean| >> sigma)."""
+    g = torch.Generator().manual_seed(93)
+    for (n, c, h, off) in ([(4, 20, 14, 50.0), (33, 7, 5, 0.0), (2, 64, 28, 3.0)] if backend.is_gpu else [(3, 5, 6, 50.0), (33, 3, 2, 0.0)]):
+        z0 = torch.randn(n, c, h, h, generator=g) * (torch.rand(1, c, 1, 1, generator=g) + 0.5) + off * torch.randn(1, c, 1, 1, generator=g)
+        bias = torch.randn(c, generator=g)
+        gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+        gy = torch.randn(n, c, h, h, generator=g)
+        bn = torch.nn.BatchNorm2d(c, eps=1e-5).double()
+        bn.weight.data.copy_(gamma), bn.bias.data.copy_(beta)
+        bn.running_mean.normal_(generator=g), bn.running_var.uniform_(0.5, 1.5, generator=g)
+        rm0, rv0 = bn.running_mean.clone().float(), bn.running_var.clone().float()
+        zin = (z0.double() + bias.double().view(1, c, 1, 1)).requires_grad_()
+        yref = torch.relu(bn(zin))
+        yref.backward(gy.double())
+        # HIP path on slices of wider tensors
+        zw = backend.put(torch.zeros(n, c + 3, h, h)); zw[:, 3:] = backend.put(z0)
+        yw = backend.put(torch.zeros(n, c + 2, h, h))
+        dyw = backend.put(torch.zeros(n, c + 1, h, h)); dyw[:, 1:] = backend.put(gy)
+        dzw = backend.put(torch.zeros(n, c + 4, h, h))
+        zs, ys, dys, dzs = K.ChanSlice(zw, 3, c), K.ChanSlice(yw, 2, c), K.ChanSlice(dyw, 1, c), K.ChanSlice(dzw, 4, c)
+        mean, invstd = backend.put(torch.empty(c)), backend.put(torch.empty(c))
+        rm, rv = backend.put(rm0.clone()), backend.put(rv0.clone())
+        ws = backend.put(torch.empty(K.bn_train_workspace_floats(n, c)))
+        K.bn_train_stats(zs, backend.put(bias), mean, invstd, rm, rv, 1e-5, 0.1, ws)
+        K.bn_train_apply(zs, ys, mean, invstd, backend.put(gamma), backend.put(beta), True)
+        assert rel_err(yw[:, 2:], yref) < 2e-6, (n, c, h, "y")
+        assert rel_err(rm, bn.running_mean) < 1e-6 and rel_err(rv, bn.running_var) < 1e-6
+        dgamma, dbeta = backend.put(torch.empty(c)), backend.put(torch.empty(c))
+        K.bn_train_bwd(dys, ys, zs, mean, invstd, backend.put(gamma), dgamma, dbeta, dzs, ws, True)
+        assert rel_err(dgamma, bn.weight.grad) < 1e-5 and rel_err(dbeta, bn.bias.grad) < 1e-5
+        assert rel_err(dzw[:, 4:], zin.grad) < 1e-5, (n, c, h, "dz")
+        assert float(dzw[:, :4].abs().max()) == 0.0 and float(yw[:, :2].abs().max()) == 0.0
