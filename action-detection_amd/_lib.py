@@ -42,15 +42,15 @@ _SIGS = {
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
     "ssn_conv_wgrad_x6": "ppppiiiililiiiplippp",
     "ssn_wgrad_reduce": "pppiiip",
-    "ssn_conv_x6_pack_weights_multi": "ippppppppp",
-    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiippp",
+    "ssn_conv_x6_pack_weights_multi": "ippppppppppp",
+    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiippip",
     "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiippp",
     "ssn_conv_x6_fwd_rect": "pppppiiiiliiiliiiiiiippp",
     "ssn_conv_x6_pack_dgrad_s2": "ppiip",
     "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiippp",
     "ssn_conv_x6_pack_weights_rect": "ppiiiip",
     "ssn_pool_fwd": "ipppiiiiliiliiipp",
-    "ssn_pool_bwd": "ipppiiiiliiliiiiplppp",
+    "ssn_pool_bwd": "ipppiiiiliiliiiiplpplpp",
     "ssn_avgpool_affine_fwd": "ppppiiiiiliiliiipp",
     "ssn_channel_sum": "ppiiilpup",
     "ssn_tensor_amax": "plpp",

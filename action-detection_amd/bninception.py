@@ -104,6 +104,8 @@ class BNInception(nn.Module):
         # csrc/conv_x6.hip); "f32": exact-f32 MFMA
         self.conv_precision = "split"
         self.wgrad_x6 = True          # weight gradients on the split kernel too (False: exact-f32 MFMA wgrad; bisecting aid)
+        # the pool projection of a block rides in the launch of its reduce pair (see _move_avg_pools); False = own launch
+        self.merge_projection = os.environ.get("SSN_MERGE_PROJ", "1") != "0"
         # average-pool branches: pool BEHIND the 1x1 projection (see _move_avg_pools); False = the manifest's order
         self.pool_after_projection = os.environ.get("SSN_POOL_ORDER", "") != "manifest"
 
@@ -136,40 +138,30 @@ class BNInception(nn.Module):
         them -- 'full' -- there, /root/reference/ssn_models.py:95-105,156-174); forward order."""
         return [lid for lid in self._conv_ids if getattr(self, lid + "_bn").training]
 
-    def flat_grad_layout(self):
+    def flat_grad_layout(self, plan=None):
         """[(layer id, weight offset, weight numel, bias offset, bias numel)], total.
 
-        Forward layer order, except that the two 1x1 "reduce" convolutions of a block (which the executor
-        runs as ONE fused launch) sit as [w_3x3_reduce | w_double_3x3_reduce | b_3x3_reduce | b_double_...], so
-        the fused wgrad writes both weight gradients (and both bias gradients) as one contiguous matrix.
+        Forward (plan) order; the convolutions of ONE fused launch -- the two 1x1 "reduce" convolutions of a block,
+        plus the block's pool projection when it rides along -- sit as [w_a | w_b | (w_p) | b_a | b_b | (b_p)], so
+        the fused wgrad writes all weight gradients (and all bias gradients) as one contiguous matrix.
         """
+        if plan is None:
+            plan, _ = self._plan(torch.zeros(1, getattr(self, self._conv_ids[0]).in_channels, self.input_size_hint,
+                                             self.input_size_hint))
         off, lay = 0, []
-        ids = list(self._conv_ids)
-        i = 0
-        while i < len(ids):
-            lid = ids[i]
-            mate = lid.replace("_3x3_reduce", "_double_3x3_reduce")
-            if lid.endswith("_3x3_reduce") and "double" not in lid and mate in ids and lid.startswith("inception_"):
-                a, b = getattr(self, lid), getattr(self, mate)
-                wa, wb, ba, bb = a.weight.numel(), b.weight.numel(), a.bias.numel(), b.bias.numel()
-                lay.append((lid, off, wa, off + wa + wb, ba))
-                lay.append((mate, off + wa, wb, off + wa + wb + ba, bb))
-                off += wa + wb + ba + bb
-                # the conv between them in forward order (<block>_3x3) follows the pair
-                mid = ids[i + 1]
-                assert ids[i + 2] == mate, (lid, ids[i + 1], ids[i + 2])
-                conv = getattr(self, mid)
-                wn, bn = conv.weight.numel(), conv.bias.numel()
-                lay.append((mid, off, wn, off + wn, bn))
-                off += wn + bn
-                i += 3
+        for op in plan:
+            if op["kind"] != "conv":
                 continue
-            conv = getattr(self, lid)
-            wn, bn = conv.weight.numel(), conv.bias.numel()
-            lay.append((lid, off, wn, off + wn, bn))
-            off += wn + bn
-            i += 1
-        return lay, off
+            convs = [getattr(self, lid) for lid in op["lids"]]
+            wo = off
+            for lid, conv in zip(op["lids"], convs):
+                lay.append([lid, wo, conv.weight.numel(), None, conv.bias.numel()])
+                wo += conv.weight.numel()
+            for ent, conv in zip(lay[-len(convs):], convs):
+                ent[3] = wo
+                wo += conv.bias.numel()
+            off = wo
+        return [tuple(e) for e in lay], off
 
     def features(self, x):
         if x.dim() != 4:
@@ -237,7 +229,7 @@ class BNInception(nn.Module):
                 plan.append(dict(kind="gap", lid=lid, src=src, dst=dst))
         train_bn = set(self._train_bn_ids())
         if self.pool_after_projection and not train_bn:
-            plan = self._move_avg_pools(plan, shapes)
+            plan = self._move_avg_pools(plan, shapes, merge=self.conv_precision == "split" and self.merge_projection)
         if train_bn:
             plan = self._split_train_bn(plan, shapes, train_bn)
         return plan, shapes
@@ -261,13 +253,15 @@ class BNInception(nn.Module):
         return out
 
     @staticmethod
-    def _move_avg_pools(plan, shapes):
+    def _move_avg_pools(plan, shapes, merge=False):
         """<block>_pool (3x3 / s1 / p1 average, count_include_pad) -> <block>_pool_proj (1x1) + BN + ReLU is evaluated
         as  relu(scale * avgpool(conv1x1_nobias(x)) + shift): a 1x1 convolution commutes with a zero-padded average
         pool (both linear, the bias / folded BN shift is added after the pool either way).  The pool then runs on the
         projection's 32-128 output channels instead of the block's 192-1056 input channels (4-8x less HBM traffic in
         forward and backward), applies the affine + ReLU itself, and the projection joins the other 1x1 convolutions
-        that read the block input directly."""
+        that read the block input directly.  With `merge` it becomes part of the block's fused reduce launch: output
+        channels [ca + cb, ca + cb + cp) of the "<block>_reduce" tensor, marked raw (no affine, no ReLU) -- the block input is
+        then read (forward, wgrad) and its gradient written (dgrad) by two launches instead of three."""
         out, i = [], 0
         while i < len(plan):
             op = plan[i]
@@ -278,10 +272,21 @@ class BNInception(nn.Module):
                     and sum(1 for q in plan if q["src"] == op["dst"]) == 1):
                 z = nxt["lids"][0] + "_z"
                 cout = nxt["cout"]
+                pair = next((q for q in out if q["kind"] == "conv" and len(q["lids"]) == 2 and q["src"] == op["src"]
+                             and q.get("src_c0", 0) == 0 and q["k"] == 1 and not q.get("raw")), None) if merge else None
+                if pair is not None:
+                    c0 = pair["cout"]
+                    pair.update(lids=pair["lids"] + nxt["lids"], couts=pair["couts"] + [cout], cout=c0 + cout,
+                                raw_from=c0, proj_final=(nxt["dst"], nxt["dst_c0"]))
+                    shapes[pair["dst"]] = (c0 + cout,) + tuple(shapes[pair["dst"]][1:])
+                    out.append(dict(kind="pool_aff", lid=op["lid"], conv=nxt["lids"][0], src=pair["dst"], src_c0=c0,
+                                    dst=nxt["dst"], dst_c0=nxt["dst_c0"], c=cout, k=3, s=1, p=1))
+                    i += 2
+                    continue
                 shapes[z] = (cout, shapes[op["src"]][1], shapes[op["src"]][2])
                 out.append(dict(nxt, src=op["src"], src_c0=0, dst=z, dst_c0=0, raw=True,
                                 final=(nxt["dst"], nxt["dst_c0"])))
-                out.append(dict(kind="pool_aff", lid=op["lid"], conv=nxt["lids"][0], src=z, dst=nxt["dst"],
+                out.append(dict(kind="pool_aff", lid=op["lid"], conv=nxt["lids"][0], src=z, src_c0=0, dst=nxt["dst"],
                                 dst_c0=nxt["dst_c0"], c=cout, k=3, s=1, p=1))
                 i += 2
                 continue
@@ -331,6 +336,8 @@ class BNInception(nn.Module):
             if op["kind"] != "conv":
                 continue
             shift_of[op["lids"][0]] = shift_flat[soff:soff + op["cout"]]
+            for lid_, o_ in zip(op["lids"], [sum(op["couts"][:q]) for q in range(len(op["lids"]))]):
+                shift_of.setdefault(lid_, shift_flat[soff + o_:soff + o_ + getattr(self, lid_).out_channels])
             off = 0
             # (a projection whose pool runs behind it: its BN affine belongs to the slice the POOL writes)
             aff_dst, aff_c0 = op.get("final", (op["dst"], op["dst_c0"]))
@@ -342,9 +349,13 @@ class BNInception(nn.Module):
                 continue
             for lid, c in zip(op["lids"], op["couts"]):
                 conv, bn = getattr(self, lid), getattr(self, lid + "_bn")
+                if "raw_from" in op and off >= op["raw_from"]:
+                    # the projection riding in the reduce launch: its BN affine belongs to the slice its POOL writes
+                    sdst = scale_slice(op["proj_final"][0], op["proj_final"][1], c)
+                else:
+                    sdst = scale_slice(aff_dst, aff_c0 + off, c)
                 for lst, v in zip(fold, (conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
-                                         bn.running_var, bn.eps, scale_slice(aff_dst, aff_c0 + off, c),
-                                         shift_flat[soff + off:soff + off + c])):
+                                         bn.running_var, bn.eps, sdst, shift_flat[soff + off:soff + off + c])):
                     lst.append(v)
                 off += c
             soff += op["cout"]
@@ -353,7 +364,8 @@ class BNInception(nn.Module):
         conv_ops = [op for op in plan if op["kind"] == "conv"]
         for op in conv_ops:      # which matrix path each layer takes (bf16 3-way split, or exact f32 MFMA)
             op["x6"] = (self.conv_precision == "split" and op["k"] in (1, 3)
-                        and x6_wins("fwd", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1]))
+                        and ("raw_from" in op       # (rows without affine / ReLU: split kernel only)
+                             or x6_wins("fwd", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
         packed_fwd = {}
         for x6 in (False, True):
             ops = [op for op in conv_ops if op["x6"] == x6]
@@ -379,8 +391,8 @@ class BNInception(nn.Module):
 
         def lane_of(op):
             lid = op["lids"][0] if op["kind"] == "conv" else op["lid"]
-            if op["kind"] == "conv" and op.get("raw"):
-                return 2
+            if op["kind"] == "conv" and op.get("raw") and not op.get("bn_train"):
+                return 2          # a projection in front of its pool (the convolution of a bn_train pair stays with its op)
             if "_double_3x3_1" in lid or "_double_3x3_2" in lid:
                 return 1
             if lid.endswith("_pool") or lid.endswith("_pool_proj"):
@@ -422,7 +434,8 @@ class BNInception(nn.Module):
                 if op["x6"]:
                     self._timed("conv_fwd_x6", op["lids"][0], flops,
                                 lambda: K.conv_x6_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
-                                                      not raw, tuned_tile("fwd6", n, cin, cout, k, s, hin)))
+                                                      not raw, tuned_tile("fwd6", n, cin, cout, k, s, hin),
+                                                      raw_from=op.get("raw_from", 0)))
                 else:
                     self._timed("conv_fwd_f32", op["lids"][0], flops,
                                 lambda: K.conv_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
@@ -438,7 +451,8 @@ class BNInception(nn.Module):
                 K.pool_fwd(op["pool"], full(acts[op["src"]]), out, am, op["k"], op["s"], op["p"])
             elif op["kind"] == "pool_aff":
                 c = op["c"]
-                K.avgpool_affine_fwd(full(acts[op["src"]]), ChanSlice(get(op["dst"]), op["dst_c0"], c),
+                K.avgpool_affine_fwd(ChanSlice(acts[op["src"]], op.get("src_c0", 0), c),
+                                     ChanSlice(get(op["dst"]), op["dst_c0"], c),
                                      scale_slice(op["dst"], op["dst_c0"], c), shift_of[op["conv"]], True,
                                      op["k"], op["s"], op["p"])
             elif op["kind"] == "bn_train":
@@ -465,11 +479,13 @@ class BNInception(nn.Module):
             if lane_ctx is not None:
                 lane_ctx.__exit__(None, None, None)
                 # the reduce pair feeds the double-3x3 chain (with a training-mode BatchNorm its bn_train op completes it)
-                if (op["kind"] == "conv" and len(op["lids"]) == 2 and not op.get("bn_train")) or \
-                        (op["kind"] == "bn_train" and len(op["lids"]) == 2):
+                if (op["kind"] == "conv" and len(op["lids"]) >= 2 and not op.get("bn_train")) or \
+                        (op["kind"] == "bn_train" and len(op["lids"]) >= 2):
                     ev = torch.cuda.Event()
                     ev.record(lanes[0])
                     lanes[1].wait_event(ev)
+                    if "raw_from" in op:            # ... and, with the projection on board, the pool behind it
+                        lanes[2].wait_event(ev)
             if not keep and lanes is None:
                 # inference: drop activations as soon as their last consumer has been launched
                 for name in [nm for nm, last in last_use.items() if last == i and nm != "data"]:
@@ -487,7 +503,7 @@ class BNInception(nn.Module):
         plan, shapes, acts, argmax, tscale, bnstat = saved
         bn_grads = {}    # training-mode BatchNorm layers: layer id -> (dgamma, dbeta)
         n, dev = dfeat.shape[0], dfeat.device
-        layout, total = self.flat_grad_layout()
+        layout, total = self.flat_grad_layout(plan)
         lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
         flat = torch.empty(total, device=dev, dtype=torch.float32)
         grads = {}
@@ -520,7 +536,7 @@ class BNInception(nn.Module):
                     ws_bytes = max(ws_bytes, K.wgrad_workspace_bytes(
                         n, op["cin"], op["cout"], shapes[op["dst"]][1], shapes[op["dst"]][2], op["k"],
                         tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
-                if op.get("raw"):
+                if op.get("raw") or "raw_from" in op:
                     ws_bytes = max(ws_bytes, K.channel_sum_workspace_bytes(n, op["cout"]))
             elif op["kind"] == "bn_train":
                 ws_bytes = max(ws_bytes, 4 * K.bn_train_workspace_floats(n, op["c"]))
@@ -530,7 +546,8 @@ class BNInception(nn.Module):
         dg_layout = {op["lids"][0]: K.dgrad_layout(op["k"], op["s"], op["p"], shapes[op["src"]][1],
                                                    shapes[op["src"]][2]) for op in dg_ops}
         dg_x6 = {op["lids"][0]: (self.conv_precision == "split" and op["k"] in (1, 3) and op["s"] == 1
-                                 and x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1]))
+                                 and ("raw_from" in op or x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"],
+                                                                  shapes[op["src"]][1])))
                  for op in dg_ops}
         # 3x3 / stride-2 layers: four parity-class stride-1 launches on the x6 kernel (no tap that does not contribute)
         dg_s2 = {op["lids"][0]: (self.conv_precision == "split" and dg_layout[op["lids"][0]] == 2 and len(op["lids"]) == 1)
@@ -594,7 +611,8 @@ class BNInception(nn.Module):
                 my, ms = mask_args(idx, op, c)
                 K.pool_bwd(op["pool"], ChanSlice(grads[op["dst"]], op["dst_c0"], c), argmax.get(op["lid"]),
                            full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=key in inited,
-                           mask_y=my, mask_scale=ms)
+                           mask_y=my, mask_scale=ms,
+                           pool_y=ChanSlice(acts[op["dst"]], op["dst_c0"], c) if op["pool"] == "max" else None)
                 inited.add(key)
             elif op["kind"] == "pool_aff":
                 # y = relu(scale * avgpool(z) + shift): finish the slice's ReLU/BN backward if no later launch did, then
@@ -605,8 +623,9 @@ class BNInception(nn.Module):
                     K.relu_bn_bwd(g, ChanSlice(acts[op["dst"]], op["dst_c0"], c),
                                   tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + c])
                     masked.setdefault(op["dst"], []).append((op["dst_c0"], op["dst_c0"] + c))
-                K.pool_bwd("avg", g, None, full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=False)
-                inited.add((op["src"], 0))
+                K.pool_bwd("avg", g, None, ChanSlice(gbuf(op["src"]), op.get("src_c0", 0), c), op["k"], op["s"], op["p"],
+                           accumulate=False)
+                inited.add((op["src"], op.get("src_c0", 0)))
             elif op["kind"] == "bn_train":
                 # batch-norm backward of the layer(s): the slice's gradient arrives untouched (NaN scales, see forward)
                 off = 0
@@ -627,12 +646,14 @@ class BNInception(nn.Module):
                 lids = op["lids"]
                 g = ChanSlice(grads[op["dst"]], op["dst_c0"], cout)
                 raw = bool(op.get("raw"))       # bias-free, affine-free projection in front of a pool: nothing to undo
-                if not raw and not is_masked(op["dst"], op["dst_c0"], cout):
-                    K.relu_bn_bwd(g, ChanSlice(acts[op["dst"]], op["dst_c0"], cout),
-                                  tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + cout])
+                c_aff = op.get("raw_from", cout)    # (a projection riding in the reduce launch: its channels are raw)
+                if not raw and not is_masked(op["dst"], op["dst_c0"], c_aff):
+                    K.relu_bn_bwd(ChanSlice(grads[op["dst"]], op["dst_c0"], c_aff),
+                                  ChanSlice(acts[op["dst"]], op["dst_c0"], c_aff),
+                                  tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + c_aff])
                 wo, wn, bo, bn = lay[lids[0]]
-                if len(lids) == 2:      # fused pair: [wA | wB] and [bA | bB] are contiguous in the flat layout
-                    wo2, wn2, bo2, bn2 = lay[lids[1]]
+                for extra in lids[1:]:   # fused launch: [wA | wB | (wP)] and [bA | bB | (bP)] are contiguous in the flat layout
+                    wo2, wn2, bo2, bn2 = lay[extra]
                     assert wo2 == wo + wn and bo2 == bo + bn
                     wn, bn = wn + wn2, bn + bn2
                 dw = flat[wo:wo + wn].view(cout, cin, k, k)
@@ -647,15 +668,18 @@ class BNInception(nn.Module):
                 else:
                     wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
                     run_wgrad = lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg)   # noqa: E731
-                if raw and not op.get("bn_train"):
-                    # the bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's backward
-                    # (the wgrad kernel's bias column sums the pooled gradient, which differs at the image border)
-                    g_pre = ChanSlice(grads[op["final"][0]], op["final"][1], cout)
+                if (raw and not op.get("bn_train")) or "raw_from" in op:
+                    # the (projection's) bias sits behind the pool: its gradient is the sum of the gradient BEFORE the
+                    # pool's backward (the wgrad kernel's bias column sums the pooled gradient, which differs at the border)
+                    fin = op["proj_final"] if "raw_from" in op else op["final"]
+                    cp = cout - op.get("raw_from", 0)
+                    g_pre = ChanSlice(grads[fin[0]], fin[1], cp)
+                    db_proj = db[op.get("raw_from", 0):]
                     inner_wgrad = run_wgrad
 
                     def run_wgrad():
                         inner_wgrad()
-                        K.channel_sum(g_pre, db, ws)
+                        K.channel_sum(g_pre, db_proj, ws)
                 wfam = "conv_wgrad_x6" if wg_x6[lids[0]] else "conv_wgrad_f32"
                 if use_side:
                     ready = torch.cuda.Event()

@@ -34,17 +34,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, uin
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-// ch[0,BM) = inv * scale (inv if none), ch[BM,2BM) = shift (0), ch[2BM,3BM) = mask scale (NaN: pass through).  All
+// ch[0,BM) = inv * scale (inv if none), ch[BM,2BM) = shift (0), ch[2BM,3BM) = mask scale (NaN: pass through),
+// ch[3BM,4BM) = the ReLU floor (0, or -inf for rows that take no ReLU).  Rows m >= raw_from are "raw": no affine and no
+// ReLU whatever scale / relu say (the bias-free pool projection that rides in the same launch as the reduce pair).  All
 // threads of the workgroup call this between two barriers (LDS is free once the main loop has ended).
 template <int BM, int NT>
 __device__ __forceinline__ void epi_stage_channels(float* ch, const float* scale, const float* shift,
-                                                   const float* mask_scale, int m0, int M, int tid, float inv = 1.f) {
+                                                   const float* mask_scale, int m0, int M, int tid, float inv = 1.f,
+                                                   int relu = 0, int raw_from = 0x7fffffff) {
     for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         const bool ok = m < M;
-        ch[r] = (ok && scale) ? scale[m] * inv : inv;
-        ch[BM + r] = (ok && scale) ? shift[m] : 0.f;
+        const bool aff = ok && scale && m < raw_from;
+        ch[r] = aff ? scale[m] * inv : inv;
+        ch[BM + r] = aff ? shift[m] : 0.f;
         ch[2 * BM + r] = (ok && mask_scale) ? mask_scale[m] : __builtin_nanf("");
+        ch[3 * BM + r] = (relu && m < raw_from) ? 0.f : -__builtin_inff();
     }
 }
 
@@ -71,7 +76,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                 for (int r = 0; r < 16; ++r) {
                     const int sr = srow(i, r);
                     float v = acc[i][j][r] * ch[sr + 4 * lh] + ch[BM + sr + 4 * lh];
-                    if (e.relu) v = fmaxf(v, 0.f);
+                    if (e.relu) v = fmaxf(v, ch[3 * BM + sr + 4 * lh]);
                     cmax = fmaxf(cmax, fabsf(v));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
                                                           sr < mlim ? yoff[j] : EPI_OOB, (uint32_t)sr * e.howo4, 0);
@@ -105,7 +110,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                 const int r = (g & 1) * 8 + q;
                 const int sr = srow(i, r);
                 float v = acc[i][j][r] * ch[sr + 4 * lh] + ch[BM + sr + 4 * lh];
-                if (e.relu) v = fmaxf(v, 0.f);
+                if (e.relu) v = fmaxf(v, ch[3 * BM + sr + 4 * lh]);
                 v += old[b][q];
                 const float sc = ch[2 * BM + sr + 4 * lh];
                 v = (sc != sc) ? v : (mk[b][q] > 0.f ? v * sc : 0.f);   // NaN marks a channel that is not a ReLU output

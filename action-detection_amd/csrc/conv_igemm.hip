@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     // ---- epilogue: folded BN affine + ReLU (fwd) or accumulate + fused ReLU/BN backward (dgrad); conv_epilogue.h ----
     __syncthreads();
     float* ch = lds;
-    epi_stage_channels<BM, 256>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid);
+    epi_stage_channels<BM, 256>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid, 1.f, p.relu);
     __syncthreads();
     EpiArgs e;
     e.y = p.y;

@@ -42,7 +42,8 @@ using namespace x6;
 // khalf holds f16 k = 8 * khalf + 0..7 of that plane; it is stored at chunk position c ^ ((m >> 2) & 3), which makes
 // the straight LDS copy conflict-free for the ds_read_b128 fragment reads.
 //   mode 0 (forward operand): A[m][c][tap] = w[m][c][tap];  mode 1 (dgrad operand): A[m][c][tap] = w[c][m][tap]
-// Two sources (fused pair): output channel co < split comes from w0, the rest from w1.
+// Up to three sources (fused launches: the reduce pair, or the pair plus the pool projection): output channel
+// co < split comes from w0, split <= co < split2 from w1, the rest from w2.
 // Three launches: clear the amax tails, max |w| of every entry into its tail (one workgroup per XP_ACHUNK source
 // elements, unsigned atomic max), then the packing proper, which derives the entry's power-of-two scale from that tail.
 constexpr int XP_MAX = 40;
@@ -51,9 +52,10 @@ constexpr int XP_ACHUNK = 8192;  // source elements per block of the amax launch
 struct X6PackTable {
     const float* w0[XP_MAX];
     const float* w1[XP_MAX];
+    const float* w2[XP_MAX];
     uint32_t* out[XP_MAX];
     long rows_dw[XP_MAX];       // dwords of the packed rows; the tail starts there
-    int cout[XP_MAX], cin[XP_MAX], kk[XP_MAX], mode[XP_MAX], split[XP_MAX];   // kk = taps per channel (kh * kw)
+    int cout[XP_MAX], cin[XP_MAX], kk[XP_MAX], mode[XP_MAX], split[XP_MAX], split2[XP_MAX];   // kk = taps per channel (kh * kw)
     int srckk[XP_MAX];          // taps per channel of the SOURCE weight (== kk unless a tap subset is packed)
     unsigned tapmap[XP_MAX];    // srckk != kk: nibble t = source tap of packed tap t
     int blk0[XP_MAX + 1];
@@ -66,13 +68,16 @@ __global__ __launch_bounds__(64) void pack_x6_clear_tail_kernel(X6PackTable t) {
 __global__ __launch_bounds__(256) void pack_x6_amax_kernel(X6PackTable t) {
     int ti = 0;
     while (ti + 1 < t.count && (int)blockIdx.x >= t.ablk0[ti + 1]) ++ti;
-    const long n0 = (long)t.split[ti] * t.cin[ti] * t.srckk[ti];                    // elements of w0
-    const long n1 = (long)(t.cout[ti] - t.split[ti]) * t.cin[ti] * t.srckk[ti];     // elements of w1 (fused pair)
+    const long per = (long)t.cin[ti] * t.srckk[ti];
+    const long n0 = (long)t.split[ti] * per;                          // elements of w0
+    const long n1 = (long)(t.split2[ti] - t.split[ti]) * per;         // ... of w1 (fused pair)
+    const long n2 = (long)(t.cout[ti] - t.split2[ti]) * per;          // ... of w2 (pair + pool projection)
     const long base = (long)((int)blockIdx.x - t.ablk0[ti]) * XP_ACHUNK;
     long end = base + XP_ACHUNK;
-    if (end > n0 + n1) end = n0 + n1;
+    if (end > n0 + n1 + n2) end = n0 + n1 + n2;
     float m = 0.f;
-    for (long i = base + threadIdx.x; i < end; i += 256) m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : t.w1[ti][i - n0]));
+    for (long i = base + threadIdx.x; i < end; i += 256)
+        m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : (i < n0 + n1 ? t.w1[ti][i - n0] : t.w2[ti][i - n0 - n1])));
     amax_emit(reinterpret_cast<float*>(t.out[ti] + t.rows_dw[ti]), m);
 }
 __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
@@ -99,8 +104,8 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
             float x = 0.f;
             if (c < C) {
                 const int co = mode ? c : m, ci = mode ? m : c;
-                const float* src = co < t.split[ti] ? t.w0[ti] : t.w1[ti];
-                const int cor = co < t.split[ti] ? co : co - t.split[ti];
+                const float* src = co < t.split[ti] ? t.w0[ti] : (co < t.split2[ti] ? t.w1[ti] : t.w2[ti]);
+                const int cor = co < t.split[ti] ? co : (co < t.split2[ti] ? co - t.split[ti] : co - t.split2[ti]);
                 const int stap = t.srckk[ti] == KK ? tap : (int)((t.tapmap[ti] >> (4 * tap)) & 15u);
                 x = src[((long)cor * Cin + ci) * t.srckk[ti] + stap];
             }
@@ -163,7 +168,9 @@ int launch_cfg(X6Args& a, hipStream_t stream) {
 //   0 128x128, 1 64x128, 2 96x128, 3 64x64, 4 32x128, 5 128x128 (1x4 waves), 6 64x128 (1x4 waves), 7 128x64
 // 8-15: 8-wave ping-pong workgroups (two groups side by side along the pixel axis):
 //   8 128x256, 9 64x256, 10 96x256, 11 64x128, 12 160x256, 13 128x128, 14 64x256 (1x4 waves), 15 128x256 (1x4 waves)
-// 16-17: 4-wave workgroups with 128x64 / 96x64 register tiles per wave, one workgroup per CU:   16 128x256, 17 96x256, 18 160x256, 19 192x256
+// 16-19: 4-wave workgroups with 128x64 .. 192x64 register tiles per wave, one workgroup per CU:   16 128x256, 17 96x256, 18 160x256, 19 192x256
+// 20-21: tall tiles that cover the 160-192 output channels of the 14x14 stage in ONE m-tile at two workgroups per CU:
+//   20 192x128 (1x4 waves), 21 160x128 (1x4 waves)
 template <int KH, int KW, int S, int MODE>
 int launch_tile(X6Args& a, int cfg, hipStream_t stream) {
     switch (cfg) {
@@ -187,6 +194,8 @@ int launch_tile(X6Args& a, int cfg, hipStream_t stream) {
         case 17: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 3, 2>(a, stream);
         case 18: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 5, 2>(a, stream);
         case 19: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 6, 2>(a, stream);
+        case 20: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 6, 1>(a, stream);
+        case 21: return launch_cfg<KH, KW, S, MODE, 1, 1, 4, 5, 1>(a, stream);
     }
     ssn_set_error("conv_x6: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -264,9 +273,10 @@ extern "C" long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int tran
 
 // Scale + split + pack `count` weights (HOST arrays, one entry per layer; see ssn_conv_pack_weights_multi for w1/split).
 extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1,
-                                              float* const* out, const int* cout, const int* cin, const int* ksize,
-                                              const int* mode, const int* split, hipStream_t stream) {
-    SSN_CHECK_ARG(count >= 0 && (count == 0 || (w0 && w1 && out && cout && cin && ksize && mode && split)),
+                                              const float* const* w2, float* const* out, const int* cout,
+                                              const int* cin, const int* ksize, const int* mode, const int* split,
+                                              const int* split2, hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (w0 && w1 && w2 && out && cout && cin && ksize && mode && split && split2)),
                   "conv x6 pack: bad arguments");
     for (int base = 0; base < count; base += XP_MAX) {
         X6PackTable t;
@@ -276,9 +286,13 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
             const int j = base + i;
             SSN_CHECK_ARG(ksize[j] == 1 || ksize[j] == 3, "conv x6 pack: ksize %d unsupported", ksize[j]);
             SSN_CHECK_ARG(mode[j] == 0 || mode[j] == 1, "conv x6 pack: mode %d", mode[j]);
-            SSN_CHECK_ARG(w0[j] && out[j] && (w1[j] || split[j] >= cout[j]), "conv x6 pack: null pointer");
+            SSN_CHECK_ARG(w0[j] && out[j] && (w1[j] || split[j] >= cout[j]) && (w2[j] || split2[j] >= cout[j]) &&
+                              split[j] <= split2[j],
+                          "conv x6 pack: null pointer / bad splits");
             t.w0[i] = w0[j];
             t.w1[i] = w1[j];
+            t.w2[i] = w2[j];
+            t.split2[i] = split2[j];
             t.out[i] = (uint32_t*)out[j];
             t.cout[i] = cout[j];
             t.cin[i] = cin[j];
@@ -308,6 +322,8 @@ extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cou
     t.count = 1;
     t.w0[0] = w;
     t.w1[0] = nullptr;
+    t.w2[0] = nullptr;
+    t.split2[0] = cout;
     t.out[0] = (uint32_t*)out;
     t.cout[0] = cout;
     t.cin[0] = cin;
@@ -345,6 +361,8 @@ extern "C" int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, i
             }
         t.w0[cls] = w;
         t.w1[cls] = nullptr;
+        t.w2[cls] = nullptr;
+        t.split2[cls] = cout;
         t.out[cls] = (uint32_t*)out + off;
         t.cout[cls] = cout;
         t.cin[cls] = cin;
@@ -367,7 +385,7 @@ extern "C" int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, i
 extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                                float* y, int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                                long y_img_stride, int ksize, int stride, int pad, int relu, int x_guard_bytes,
-                               int tile_cfg, const float* x_amax, float* y_amax, hipStream_t stream) {
+                               int tile_cfg, const float* x_amax, float* y_amax, int raw_from, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv x6 fwd: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 fwd: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv x6 fwd: stride %d unsupported", stride);
@@ -379,6 +397,7 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
     a.scale = scale;
     a.shift = shift;
     a.relu = relu;
+    a.raw_from = raw_from > 0 ? raw_from : 0x7fffffff;    // <= 0: every output row takes the affine / ReLU
     a.accumulate = 0;
     a.mask_y = nullptr;
     a.mask_scale = nullptr;
@@ -407,6 +426,7 @@ extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float*
     a.scale = nullptr;
     a.shift = nullptr;
     a.relu = 0;
+    a.raw_from = 0x7fffffff;
     a.accumulate = accumulate;
     a.mask_y = mask_scale ? mask_y : nullptr;
     a.mask_scale = mask_y ? mask_scale : nullptr;

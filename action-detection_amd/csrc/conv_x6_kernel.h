@@ -34,6 +34,7 @@ struct X6Args {
     int P;
     int pad_h, pad_w;
     int relu, accumulate;
+    int raw_from;         // output rows >= raw_from take no affine and no ReLU (conv_epilogue.h); M or more: none
     const float* mask_y;
     const float* mask_scale;
     long mask_img_stride;
@@ -81,7 +82,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 template <int KH, int KW, int S, int MODE, bool WIDE, int NG, int WM, int WN, int TM, int TN>
 // big register tiles (TM * TN >= 6, e.g. 128 x 64 per wave) run one wave per SIMD with up to 512 VGPRs: a third of the
 // LDS traffic per MFMA of the 1 x 4-wave tiles, the software pipeline hides the LDS round trip without a partner wave
-__global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void conv_x6_kernel(X6Args p) {
+__global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 : 2) void conv_x6_kernel(X6Args p) {
     constexpr int NW = 4 * NG;              // waves per workgroup
     constexpr int NT = 64 * NW;
     constexpr int BM = WM * TM * 32;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6) ? 1 : 2) void c
     // ---- epilogue: BN affine + ReLU (forward), or accumulate + fused ReLU/BN backward (dgrad) ----
     __syncthreads();
     float* ch = reinterpret_cast<float*>(lds);
-    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid, inv);
+    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid, inv, p.relu, p.raw_from);
     __syncthreads();
     EpiArgs e;
     e.y = p.y;

@@ -166,7 +166,8 @@ def pack_weights(w, transposed, out=None):
 
 
 def pack_weights_multi(entries, x6=False):
-    """entries: list of (weights, mode) with weights = [w] or [wA, wB] (fused pair, concatenated output channels).
+    """entries: list of (weights, mode) with weights = [w], [wA, wB] (fused pair) or -- x6 only -- [wA, wB, wC]
+    (concatenated output channels).
 
     Returns one packed tensor per entry (views of a single flat buffer); ceil(len / 40) launches in total.
     x6=True: scale + split every weight into two f16 planes for the conv_x6 kernels (modes 0/1, ksize 1/3 only).
@@ -192,9 +193,17 @@ def pack_weights_multi(entries, x6=False):
     a_cout, a_cin, a_ks = ia(couts), ia(cins), ia(kss)
     a_mode = ia([m for _, m in entries])
     a_split = ia([ws[0].shape[0] if len(ws) > 1 else co for (ws, _), co in zip(entries, couts)])
-    lib.call("ssn_conv_x6_pack_weights_multi" if x6 else "ssn_conv_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(po),
-             ctypes.addressof(a_cout), ctypes.addressof(a_cin), ctypes.addressof(a_ks), ctypes.addressof(a_mode),
-             ctypes.addressof(a_split), _stream(lib, first))
+    if x6:
+        w2 = _ptr_array([ws[2] if len(ws) > 2 else None for ws, _ in entries])
+        a_split2 = ia([ws[0].shape[0] + ws[1].shape[0] if len(ws) > 2 else co for (ws, _), co in zip(entries, couts)])
+        lib.call("ssn_conv_x6_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(w2),
+                 ctypes.addressof(po), ctypes.addressof(a_cout), ctypes.addressof(a_cin), ctypes.addressof(a_ks),
+                 ctypes.addressof(a_mode), ctypes.addressof(a_split), ctypes.addressof(a_split2), _stream(lib, first))
+    else:
+        assert all(len(ws) <= 2 for ws, _ in entries)
+        lib.call("ssn_conv_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(po),
+                 ctypes.addressof(a_cout), ctypes.addressof(a_cin), ctypes.addressof(a_ks), ctypes.addressof(a_mode),
+                 ctypes.addressof(a_split), _stream(lib, first))
     return outs
 
 
@@ -224,8 +233,9 @@ def guarded_empty(shape, device, guard_floats=64):
     return flat[guard_floats:].view(*shape)
 
 
-def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1):
-    """conv_fwd on the f16 matrix cores (2-way split, fp32-class accuracy).  w_packed: pack_weights_multi(x6=True)."""
+def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1, raw_from=0):
+    """conv_fwd on the f16 matrix cores (2-way split, fp32-class accuracy).  w_packed: pack_weights_multi(x6=True).
+    raw_from > 0: output channels >= raw_from take neither the affine nor the ReLU."""
     lib = _check(x, w_packed, scale, shift, y)
     h, wd = x.hw
     ho, wo = y.hw
@@ -233,7 +243,7 @@ def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, til
     xa = _amax_in(x)
     lib.call("ssn_conv_x6_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
              x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), guard_bytes(x), tile_cfg,
-             _p(xa), _amax_out(y), _stream(lib, w_packed))
+             _p(xa), _amax_out(y), int(raw_from), _stream(lib, w_packed))
 
 
 def pack_weights_rect(w):
@@ -356,13 +366,15 @@ def pool_fwd(kind, x, y, argmax, ksize, stride, pad):
              y.img_stride, ksize, stride, pad, _amax_out(y), _stream(lib, x))
 
 
-def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, mask_scale=None):
-    lib = _check(dy, dx, argmax, mask_y, mask_scale)
+def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, mask_scale=None, pool_y=None):
+    """pool_y (optional, max pools with a mask): the pooled output of the forward pass; see ssn_pool_bwd."""
+    lib = _check(dy, dx, argmax, mask_y, mask_scale, pool_y)
     h, w = dx.hw
     ho, wo = dy.hw
     lib.call("ssn_pool_bwd", int(kind == "max"), _p(dy), _p(argmax), _p(dx), dx.n, dx.c, h, w, dx.img_stride, ho,
              wo, dy.img_stride, ksize, stride, pad, int(accumulate), _p(mask_y),
-             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _amax_out(dx), _stream(lib, dx))
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _p(pool_y),
+             pool_y.img_stride if pool_y is not None else 0, _amax_out(dx), _stream(lib, dx))
 
 
 def avgpool_affine_fwd(x, y, scale, shift, relu, ksize, stride, pad):

@@ -120,13 +120,17 @@ int ssn_tensor_amax(const float* x, long n, float* slot, hipStream_t stream);
 long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int transposed);
 void ssn_conv_x6_debug_trace(unsigned long long* per_block_8_words); /* tooling only; NULL = off */
 void ssn_conv_x6_debug_flags(int flags);   /* tooling only (tools/ablate_x6.py); 0 = normal operation */
-int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1, float* const* out,
-                                   const int* cout, const int* cin, const int* ksize, const int* mode,
-                                   const int* split, hipStream_t stream);
+/* (w0 / w1 / w2, split, split2: up to three sources per entry -- output channels [0, split) from w0, [split, split2)
+ * from w1, the rest from w2; split = split2 = cout for a single source.  raw_from (ssn_conv_x6_fwd, > 0): output
+ * channels >= raw_from take neither the affine nor the ReLU -- the bias-free pool projection that shares a launch
+ * with the reduce pair of its Inception block.) */
+int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1, const float* const* w2,
+                                   float* const* out, const int* cout, const int* cin, const int* ksize,
+                                   const int* mode, const int* split, const int* split2, hipStream_t stream);
 int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
                     int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo, long y_img_stride,
                     int ksize, int stride, int pad, int relu, int x_guard_bytes, int tile_cfg, const float* x_amax,
-                    float* y_amax, hipStream_t stream);
+                    float* y_amax, int raw_from, hipStream_t stream);
 int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                       long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                       int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
@@ -206,7 +210,10 @@ int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, in
 int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H, int W,
                  long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride, int pad,
                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                 float* dx_amax, hipStream_t stream);
+                 const float* pool_y, long pool_y_img_stride, float* dx_amax, hipStream_t stream);
+/* (pool_y, optional, max pooling with mask_y / mask_scale and accumulate == 0: the pooled output of the forward pass; the
+ * ReLU mask is then taken from it -- a routed gradient's pixel equals its window's maximum -- instead of from mask_y,
+ * which is 4x larger for the stride-2 pools.  Same result bit for bit.) */
 /* y = relu?(scale[c] * avgpool(x) + shift[c]) (average pools only): the pool-projection branch of an Inception block
  * (<block>_pool -> <block>_pool_proj + BN + ReLU) evaluated as avgpool(conv1x1(x)) -- identical to conv1x1(avgpool(x))
  * for zero padding with count_include_pad -- so that the pool touches the projection's output channels only. */

@@ -21,6 +21,9 @@ def pytest_configure(config):
 def emu_library():
     """Host-emulation build of the product's .hip sources (tests/emu) -- CPU tier only."""
     from action_detection_amd import _lib
+    prebuilt = os.environ.get("SSN_EMU_LIB")      # a library built elsewhere (EMU_OUT of build_emu.sh)
+    if prebuilt:
+        return _lib.SsnLibrary(prebuilt, is_emulator=True)
     subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL)
     return _lib.SsnLibrary(os.path.join(ROOT, "tests", "emu", "libssn_emu.so"), is_emulator=True)
 

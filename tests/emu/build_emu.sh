@@ -5,10 +5,11 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/../../action-detection_amd/csrc"
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
-OUT="$HERE/libssn_emu.so"
+OUT="${EMU_OUT:-$HERE/libssn_emu.so}"      # EMU_OUT / EMU_OBJ: build into another place (a second build while tests run)
+OBJ="${EMU_OBJ:-$HERE}"
 OBJS=()
 for f in "$SRC"/*.hip "$HERE/emu_globals.cpp"; do
-  o="$HERE/.obj_$(basename "$f").o"
+  o="$OBJ/.obj_$(basename "$f").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ "$SRC/ssn_common.h" -nt "$o" ] || [ "$SRC/conv_epilogue.h" -nt "$o" ] || [ "$SRC/conv_x6_kernel.h" -nt "$o" ]; then
     "$CXX" -x c++ -std=c++17 -O1 -fPIC -w -I "$HERE" -I "$SRC" -c "$f" -o "$o" &
   fi

@@ -147,6 +147,31 @@ def test_pools(backend):
             assert rel_err(dx.cpu() - 1.0, x.grad) < 1e-6, (kind, h, "bwd")
 
 
+def test_maxpool_backward_mask_from_pooled_output(backend):
+    """The fused ReLU/BN backward of a max pool's input: taking the mask from the pooled OUTPUT (pool_y) is bit-identical to
+    taking it from the 4x larger input activation (mask_y), NaN-scale channels pass through in both forms."""
+    g = torch.Generator().manual_seed(41)
+    for h, k, s, p in (((112, 3, 2, 0), (28, 3, 2, 0), (14, 3, 2, 0)) if backend.is_gpu else ((16, 3, 2, 0), (12, 3, 2, 0), (7, 3, 2, 0), (6, 3, 1, 1))):
+        n, c = 2, 8
+        x = torch.relu(torch.randn(n, c, h, h, generator=g))
+        ho = F.max_pool2d(x, k, s, p, ceil_mode=True).shape[2]
+        xd = backend.put(x)
+        y = backend.put(torch.zeros(n, c + 2, ho, ho))
+        am = backend.put(torch.zeros(n, c, ho, ho, dtype=torch.uint8))
+        K.pool_fwd("max", K.full(xd), K.ChanSlice(y, 2, c), am, k, s, p)
+        gy = backend.put(torch.randn(n, c, ho, ho, generator=g))
+        scale = torch.rand(c, generator=g) + 0.5
+        scale[1] = -scale[1]
+        scale[3] = float("nan")
+        sc = backend.put(scale)
+        dx_a, dx_b = backend.put(torch.zeros(n, c, h, h)), backend.put(torch.zeros(n, c, h, h))
+        K.pool_bwd("max", K.full(gy), am, K.full(dx_a), k, s, p, False, mask_y=K.full(xd), mask_scale=sc)
+        K.pool_bwd("max", K.full(gy), am, K.full(dx_b), k, s, p, False, mask_y=K.full(xd), mask_scale=sc,
+                   pool_y=K.ChanSlice(y, 2, c))
+        assert torch.equal(dx_a.cpu(), dx_b.cpu()), (h, k, s)
+        assert float(dx_a.abs().max()) > 0
+
+
 def test_avgpool_behind_projection(backend):
     """The pool-projection branch with the pool moved behind the 1x1 convolution (ssn_avgpool_affine_fwd,
     ssn_channel_sum): relu(scale * avgpool(conv1x1(x)) + shift) equals torch's relu(bn(conv1x1(avgpool(x)) + bias)) in
@@ -726,3 +751,32 @@ def test_bn_train(backend):
         assert rel_err(dgamma, bn.weight.grad) < 1e-5 and rel_err(dbeta, bn.bias.grad) < 1e-5
         assert rel_err(dzw[:, 4:], zin.grad) < 1e-5, (n, c, h, "dz")
         assert float(dzw[:, :4].abs().max()) == 0.0 and float(yw[:, :2].abs().max()) == 0.0
+
+
+def test_conv_split_three_sources_and_raw_rows(backend):
+    """The fused launch on a block input: reduce pair + pool projection = one convolution with three weight sources whose
+    last output channels are raw (no affine, no ReLU); forward, and the dgrad operand packed from the same three sources."""
+    g = torch.Generator().manual_seed(94)
+    n, cin, h = (3, 192, 28) if backend.is_gpu else (1, 24, 6)
+    ca, cb, cp = (64, 64, 32) if backend.is_gpu else (32, 32, 32)
+    x = torch.randn(n, cin, h, h, generator=g)
+    ws = [torch.randn(c, cin, 1, 1, generator=g) * 0.1 for c in (ca, cb, cp)]
+    cout = ca + cb + cp
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    ref = F.conv2d(x.double(), torch.cat(ws).double())
+    want = ref.clone()
+    want[:, :ca + cb] = torch.relu(ref[:, :ca + cb] * scale[:ca + cb].double().view(1, -1, 1, 1)
+                                   + shift[:ca + cb].double().view(1, -1, 1, 1))
+    wd = [backend.put(w) for w in ws]
+    wp, wt = K.pack_weights_multi([(wd, 0), (wd, 1)], x6=True)
+    for tile in (-1, 3, 2):
+        y = backend.put(torch.zeros(n, cout, h, h))
+        K.conv_x6_fwd(K.full(backend.put(x)), wp, backend.put(scale), backend.put(shift), K.full(y), 1, 1, 0, True, tile,
+                      raw_from=ca + cb)
+        assert rel_err(y, want) < 2e-5, tile
+        assert float(y[:, ca + cb:].min()) < 0          # the raw rows keep their negative values
+    gy = torch.randn(n, cout, h, h, generator=g)
+    dx = backend.put(torch.zeros(n, cin, h, h))
+    K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), 1, 0, False)
+    dref = torch.nn.grad.conv2d_input(x.shape, torch.cat(ws).double(), gy.double())
+    assert rel_err(dx, dref) < 5e-5

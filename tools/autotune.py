@@ -66,8 +66,8 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     flops = 2.0 * n * ho * ho * cout * cin * k * k
     res = {}
     for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]),
-                       ("wgrad", [0, 1, 2, 3, 4, 5, 6]), ("fwd6", list(range(20))),
-                       ("dgrad6", list(range(20))), ("wgrad6", list(range(12)))):
+                       ("wgrad", [0, 1, 2, 3, 4, 5, 6]), ("fwd6", list(range(22))),
+                       ("dgrad6", list(range(22))), ("wgrad6", list(range(12)))):
         if only and kind not in only:
             continue
         if (kind in ("dgrad", "fwd6") and k == 7) or (kind == "dgrad6" and (k == 7 or s != 1)):
