@@ -50,7 +50,7 @@ _SIGS = {
     "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiippp",
     "ssn_conv_x6_pack_weights_rect": "ppiiiip",
     "ssn_pool_fwd": "ipppiiiiliiliiipp",
-    "ssn_pool_bwd": "ipppiiiiliiliiiiplpplpp",
+    "ssn_pool_bwd": "ipppiiiiliiliiiiplppp",
     "ssn_avgpool_affine_fwd": "ppppiiiiiliiliiipp",
     "ssn_channel_sum": "ppiiilpup",
     "ssn_tensor_amax": "plpp",

@@ -538,8 +538,6 @@ class BNInception(nn.Module):
                         tuned_tile("wgrad", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
                 if op.get("raw") or "raw_from" in op:
                     ws_bytes = max(ws_bytes, K.channel_sum_workspace_bytes(n, op["cout"]))
-            elif op["kind"] == "bn_train":
-                ws_bytes = max(ws_bytes, 4 * K.bn_train_workspace_floats(n, op["c"]))
         ws = self._workspace(ws_bytes, dev)
         # all dgrad weight operands in two launches
         dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
@@ -611,8 +609,7 @@ class BNInception(nn.Module):
                 my, ms = mask_args(idx, op, c)
                 K.pool_bwd(op["pool"], ChanSlice(grads[op["dst"]], op["dst_c0"], c), argmax.get(op["lid"]),
                            full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=key in inited,
-                           mask_y=my, mask_scale=ms,
-                           pool_y=ChanSlice(acts[op["dst"]], op["dst_c0"], c) if op["pool"] == "max" else None)
+                           mask_y=my, mask_scale=ms)
                 inited.add(key)
             elif op["kind"] == "pool_aff":
                 # y = relu(scale * avgpool(z) + shift): finish the slice's ReLU/BN backward if no later launch did, then
@@ -627,8 +624,10 @@ class BNInception(nn.Module):
                            accumulate=False)
                 inited.add((op["src"], op.get("src_c0", 0)))
             elif op["kind"] == "bn_train":
-                # batch-norm backward of the layer(s): the slice's gradient arrives untouched (NaN scales, see forward)
+                # batch-norm backward of the layer(s): the slice's gradient arrives untouched (NaN scales, see forward).
+                # Its reductions get their own scratch: `ws` belongs to the weight-gradient chain on the side stream.
                 off = 0
+                bws = torch.empty(K.bn_train_workspace_floats(n, op["c"]), device=dev, dtype=torch.float32)
                 for lid, c in zip(op["lids"], op["couts"]):
                     bn = getattr(self, lid + "_bn")
                     mean, invstd = bnstat[lid]
@@ -636,7 +635,7 @@ class BNInception(nn.Module):
                     dbeta = torch.empty(c, device=dev, dtype=torch.float32)
                     K.bn_train_bwd(ChanSlice(grads[op["dst"]], op["dst_c0"] + off, c),
                                    ChanSlice(acts[op["dst"]], op["dst_c0"] + off, c), ChanSlice(acts[op["src"]], off, c),
-                                   mean, invstd, bn.weight.detach(), dgamma, dbeta, ChanSlice(gbuf(op["src"]), off, c), ws,
+                                   mean, invstd, bn.weight.detach(), dgamma, dbeta, ChanSlice(gbuf(op["src"]), off, c), bws,
                                    True)
                     bn_grads[lid] = (dgamma, dbeta)
                     off += c

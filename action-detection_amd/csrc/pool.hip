@@ -109,12 +109,6 @@ struct PoolBwdArgs {
     const float* mask_y;      // optional fused ReLU+BN backward of the tensor dx is the gradient of
     const float* mask_scale;
     long mask_img_stride;
-    // max pooling only, optional: the pooled OUTPUT of the forward pass ([N][C][Ho][Wo] channel slice).  The mask of the
-    // fused ReLU backward is (x > 0) at the input pixel, and a gradient only ever reaches a pixel that IS the maximum of its
-    // window, where x equals the pooled value: testing pool_y[window] > 0 per routed gradient is the same predicate, read from a
-    // tensor (stride^2 = 4 times) smaller than x -- the 925 MB conv1 output is then not read at all in the backward of pool1.
-    const float* pool_y;
-    long pool_y_img_stride;
     long total;  // N*C*H*W
     uint32_t dy_bytes, idx_bytes;
     float* amax;   // amax slot of dx's tensor (nullptr: not tracked)
@@ -146,10 +140,6 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
         if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
         float gv[NWIN * NWIN];
         unsigned iv[NWIN * NWIN];
-        const bool use_py = MAX && p.pool_y && p.mask_scale;
-        const float psc = use_py ? p.mask_scale[c] : 0.f;
-        const bool py_mask = use_py && !(psc != psc);      // NaN scale: the channel is not a ReLU output, nothing to mask
-        const float* pyb = use_py ? p.pool_y + (long)n * p.pool_y_img_stride + (long)c * howo : nullptr;
 #pragma unroll
         for (int a = 0; a < NWIN; ++a)
 #pragma unroll
@@ -159,7 +149,6 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
                 const uint32_t e = (uint32_t)(ho * p.Wo + wo);
                 gv[a * NWIN + b] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(dyr, in ? dybase + e * 4u : POOL_OOB, 0, 0));
-                if (py_mask && in && !(pyb[e] > 0.f)) gv[a * NWIN + b] = 0.f;   // the routed pixel's ReLU is off
                 if (MAX)
                     iv[a * NWIN + b] = __builtin_amdgcn_raw_buffer_load_b8(ixr, in ? ixbase + e : POOL_OOB, 0, 0);
             }
@@ -182,9 +171,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdArgs p) {
                 }
             }
         float* dst = p.dx + (long)n * p.dx_img_stride + rem;
-        if (py_mask) g *= psc;   // (mask already applied per window; accumulate is excluded by the host for this form)
         if (p.accumulate) g += *dst;
-        if (p.mask_y && !use_py) {
+        if (p.mask_y) {
             const float sc = p.mask_scale[c];
             g = (sc != sc) ? g : (p.mask_y[(long)n * p.mask_img_stride + rem] > 0.f ? g * sc : 0.f);
         }
@@ -390,10 +378,6 @@ __global__ __launch_bounds__(256) void pool_max2_bwd_vec_kernel(PoolBwdArgs p, F
         const int wi0 = (int)q * 4, wq = (int)q * 2;
         const uint32_t dybase = (uint32_t)(((long)n * p.dy_img_stride + (long)c * howo) * 4);
         const uint32_t ixbase = (uint32_t)(((long)n * p.C + c) * howo);
-        const bool use_py = p.pool_y && p.mask_scale;
-        const float psc = use_py ? p.mask_scale[c] : 0.f;
-        const bool py_mask = use_py && !(psc != psc);      // NaN scale: not a ReLU output, nothing to mask
-        const float* pyb = use_py ? p.pool_y + (long)n * p.pool_y_img_stride + (long)c * howo : nullptr;
         // output rows: a = 0 -> ho = hi / 2 (window row r = hi - 2 ho = 0 or 1); a = 1 -> ho = hi / 2 - 1 (r = 2, even hi)
         float g[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -410,20 +394,11 @@ __global__ __launch_bounds__(256) void pool_max2_bwd_vec_kernel(PoolBwdArgs p, F
             const pu32x2 gm = __builtin_amdgcn_raw_buffer_load_b64(dyr, rowin ? dybase + e0 * 4u : POOL_OOB, 0, 0);
             const uint32_t im = __builtin_amdgcn_raw_buffer_load_b16(ixr, rowin ? ixbase + e0 : POOL_OOB, 0, 0);
             const uint32_t g0u = gm[0], g1u = gm[1];
-            float g0 = __builtin_bit_cast(float, g0u), g1 = __builtin_bit_cast(float, g1u);
-            float glm = gl;
-            if (py_mask) {     // ReLU mask of the routed pixel = sign of the pooled value of its window
-                if (left && !(pyb[e0 - 1u] > 0.f)) glm = 0.f;
-                if (rowin) {
-                    const float2 py = *reinterpret_cast<const float2*>(pyb + e0);
-                    if (!(py.x > 0.f)) g0 = 0.f;
-                    if (!(py.y > 0.f)) g1 = 0.f;
-                }
-            }
+            const float g0 = __builtin_bit_cast(float, g0u), g1 = __builtin_bit_cast(float, g1u);
             const uint32_t i0 = im & 0xFFu, i1 = (im >> 8) & 0xFFu;
             const uint32_t rb = (uint32_t)(r * 3);
             // pixel wi0 + d is tap s = wi0 + d - 2 wo of window wo
-            g[0] += (left && il == rb + 2u) ? glm : 0.f;       // wo = wq - 1, s = 2
+            g[0] += (left && il == rb + 2u) ? gl : 0.f;        // wo = wq - 1, s = 2
             g[0] += (rowin && i0 == rb + 0u) ? g0 : 0.f;       // wo = wq,     s = 0
             g[1] += (rowin && i0 == rb + 1u) ? g0 : 0.f;       //              s = 1
             g[2] += (rowin && i0 == rb + 2u) ? g0 : 0.f;       //              s = 2
@@ -431,16 +406,12 @@ __global__ __launch_bounds__(256) void pool_max2_bwd_vec_kernel(PoolBwdArgs p, F
             g[3] += (rowin && i1 == rb + 1u) ? g1 : 0.f;       //              s = 1
         }
         const long o = (long)n * p.dx_img_stride + (long)c * p.H * p.W + (long)hi * p.W + wi0;
-        if (py_mask) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] *= psc;
-        }
         if (p.accumulate) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p.dx + o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] += t[e];
         }
-        if (p.mask_y && !use_py) {
+        if (p.mask_y) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p.mask_y + (long)n * p.mask_img_stride + (long)c * p.H * p.W +
                                                             (long)hi * p.W + wi0);
             const float sc = p.mask_scale[c];
@@ -607,16 +578,10 @@ extern "C" int ssn_avgpool_affine_fwd(const float* x, float* y, const float* sca
 extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H,
                             int W, long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride,
                             int pad, int accumulate, const float* mask_y, long mask_img_stride,
-                            const float* mask_scale, const float* pool_y, long pool_y_img_stride, float* dx_amax,
-                            hipStream_t stream) {
+                            const float* mask_scale, float* dx_amax, hipStream_t stream) {
     SSN_CHECK_ARG(dy && dx && (!is_max || argmax), "pool_bwd: null pointer");
     PoolBwdArgs a;
     a.amax = dx_amax;
-    // the pooled-output form of the mask: max pooling, first writer of dx (a later read-modify-write would need the mask of
-    // the SUM), pooled rows 8-byte aligned for the vector kernel
-    a.pool_y = (is_max && pool_y && mask_y && mask_scale && !accumulate && ((uintptr_t)pool_y % 8 == 0) &&
-                pool_y_img_stride % 2 == 0 && (Ho * Wo) % 2 == 0 && Wo % 2 == 0) ? pool_y : nullptr;
-    a.pool_y_img_stride = pool_y_img_stride;
     a.dy = dy;
     a.idx = (const uint8_t*)argmax;
     a.dx = dx;

@@ -366,15 +366,13 @@ def pool_fwd(kind, x, y, argmax, ksize, stride, pad):
              y.img_stride, ksize, stride, pad, _amax_out(y), _stream(lib, x))
 
 
-def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, mask_scale=None, pool_y=None):
-    """pool_y (optional, max pools with a mask): the pooled output of the forward pass; see ssn_pool_bwd."""
-    lib = _check(dy, dx, argmax, mask_y, mask_scale, pool_y)
+def pool_bwd(kind, dy, argmax, dx, ksize, stride, pad, accumulate, mask_y=None, mask_scale=None):
+    lib = _check(dy, dx, argmax, mask_y, mask_scale)
     h, w = dx.hw
     ho, wo = dy.hw
     lib.call("ssn_pool_bwd", int(kind == "max"), _p(dy), _p(argmax), _p(dx), dx.n, dx.c, h, w, dx.img_stride, ho,
              wo, dy.img_stride, ksize, stride, pad, int(accumulate), _p(mask_y),
-             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _p(pool_y),
-             pool_y.img_stride if pool_y is not None else 0, _amax_out(dx), _stream(lib, dx))
+             mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), _amax_out(dx), _stream(lib, dx))
 
 
 def avgpool_affine_fwd(x, y, scale, shift, relu, ksize, stride, pad):

@@ -210,10 +210,7 @@ int ssn_pool_fwd(int is_max, const float* x, float* y, unsigned char* argmax, in
 int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* argmax, float* dx, int N, int C, int H, int W,
                  long dx_img_stride, int Ho, int Wo, long dy_img_stride, int ksize, int stride, int pad,
                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                 const float* pool_y, long pool_y_img_stride, float* dx_amax, hipStream_t stream);
-/* (pool_y, optional, max pooling with mask_y / mask_scale and accumulate == 0: the pooled output of the forward pass; the
- * ReLU mask is then taken from it -- a routed gradient's pixel equals its window's maximum -- instead of from mask_y,
- * which is 4x larger for the stride-2 pools.  Same result bit for bit.) */
+                 float* dx_amax, hipStream_t stream);
 /* y = relu?(scale[c] * avgpool(x) + shift[c]) (average pools only): the pool-projection branch of an Inception block
  * (<block>_pool -> <block>_pool_proj + BN + ReLU) evaluated as avgpool(conv1x1(x)) -- identical to conv1x1(avgpool(x))
  * for zero padding with count_include_pad -- so that the pool touches the projection's output channels only. */

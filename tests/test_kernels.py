@@ -147,31 +147,6 @@ def test_pools(backend):
             assert rel_err(dx.cpu() - 1.0, x.grad) < 1e-6, (kind, h, "bwd")
 
 
-def test_maxpool_backward_mask_from_pooled_output(backend):
-    """The fused ReLU/BN backward of a max pool's input: taking the mask from the pooled OUTPUT (pool_y) is bit-identical to
-    taking it from the 4x larger input activation (mask_y), NaN-scale channels pass through in both forms."""
-    g = torch.Generator().manual_seed(41)
-    for h, k, s, p in (((112, 3, 2, 0), (28, 3, 2, 0), (14, 3, 2, 0)) if backend.is_gpu else ((16, 3, 2, 0), (12, 3, 2, 0), (7, 3, 2, 0), (6, 3, 1, 1))):
-        n, c = 2, 8
-        x = torch.relu(torch.randn(n, c, h, h, generator=g))
-        ho = F.max_pool2d(x, k, s, p, ceil_mode=True).shape[2]
-        xd = backend.put(x)
-        y = backend.put(torch.zeros(n, c + 2, ho, ho))
-        am = backend.put(torch.zeros(n, c, ho, ho, dtype=torch.uint8))
-        K.pool_fwd("max", K.full(xd), K.ChanSlice(y, 2, c), am, k, s, p)
-        gy = backend.put(torch.randn(n, c, ho, ho, generator=g))
-        scale = torch.rand(c, generator=g) + 0.5
-        scale[1] = -scale[1]
-        scale[3] = float("nan")
-        sc = backend.put(scale)
-        dx_a, dx_b = backend.put(torch.zeros(n, c, h, h)), backend.put(torch.zeros(n, c, h, h))
-        K.pool_bwd("max", K.full(gy), am, K.full(dx_a), k, s, p, False, mask_y=K.full(xd), mask_scale=sc)
-        K.pool_bwd("max", K.full(gy), am, K.full(dx_b), k, s, p, False, mask_y=K.full(xd), mask_scale=sc,
-                   pool_y=K.ChanSlice(y, 2, c))
-        assert torch.equal(dx_a.cpu(), dx_b.cpu()), (h, k, s)
-        assert float(dx_a.abs().max()) > 0
-
-
 def test_avgpool_behind_projection(backend):
     """The pool-projection branch with the pool moved behind the 1x1 convolution (ssn_avgpool_affine_fwd,
     ssn_channel_sum): relu(scale * avgpool(conv1x1(x)) + shift) equals torch's relu(bn(conv1x1(avgpool(x)) + bias)) in
