@@ -84,6 +84,7 @@ _SIGS = {
     "ssn_bn_fold_multi": "ipppppppppp",
     "ssn_sumsq": "plpipp",
     "ssn_scale": "plpfp",
+    "ssn_add_inplace": "pplp",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double,
        "u": ctypes.c_ulonglong}

@@ -57,23 +57,52 @@ def x6_wins(kind, cin, cout, k, s, hin):
 
 
 class _BackboneFn(torch.autograd.Function):
+    """The whole backbone as one autograd node.  A batch whose largest activation tensor would exceed what one kernel operand
+    can address (32-bit buffer offsets: 2 GiB, 668 frames of 224 x 224) runs as consecutive sub-batches -- forward and backward
+    per sub-batch, the flat conv-gradient buffers summed (ssn_add_inplace) -- with the same results as one pass (frozen
+    BatchNorm: the images are independent)."""
+
     @staticmethod
     def forward(ctx, x, net, *params):
         need_grad = any(ctx.needs_input_grad)
-        feat, saved = net._run_forward(x, keep=need_grad)
+        bounds = net._chunk_bounds(x)
+        if len(bounds) > 2 and net._train_bn_ids():
+            raise NotImplementedError("a batch of %d frames needs chunked execution (2 GiB per kernel operand), which would change "
+                                      "the batch statistics of the training-mode BatchNorm layers; use a smaller batch" % x.shape[0])
+        feats, saved = [], []
+        for i0, i1 in zip(bounds[:-1], bounds[1:]):
+            f, s = net._run_forward(x[i0:i1], keep=need_grad)
+            feats.append(f)
+            saved.append(s)
         ctx.net = net
-        ctx.saved = saved
+        ctx.saved = saved if need_grad else None
+        ctx.bounds = bounds
         ctx.n_params = len(params)
-        return feat
+        return feats[0] if len(feats) == 1 else torch.cat(feats)
 
     @staticmethod
     def backward(ctx, dfeat):
-        net, saved = ctx.net, ctx.saved
+        net, saved, bounds = ctx.net, ctx.saved, ctx.bounds
         ctx.saved = None
         if saved is None:
             raise RuntimeError("backbone forward ran without grad bookkeeping")
-        grads = net._run_backward(dfeat.contiguous(), saved)
-        return (None, None) + tuple(grads)
+        dfeat = dfeat.contiguous()
+        if len(saved) == 1:
+            grads, _ = net._run_backward(dfeat, saved[0])
+            return (None, None) + tuple(grads)
+        # sub-batches: per-chunk backward without the gradient-ready hook, one summed flat buffer, then the hook once
+        total = None
+        for k, (i0, i1) in enumerate(zip(bounds[:-1], bounds[1:])):
+            grads, flat = net._run_backward(dfeat[i0:i1], saved[k], hook=False)
+            saved[k] = None
+            if total is None:
+                total, out = flat, grads          # the returned views alias the first chunk's buffer, which takes the sum
+            else:
+                K.add_(total, flat)
+        if net.grad_ready_hook is not None:
+            net.grad_ready_hook.range_ready(total, 0, total.numel())
+            net.grad_ready_hook.finish()
+        return (None, None) + tuple(out)
 
 
 class BNInception(nn.Module):
@@ -162,6 +191,18 @@ class BNInception(nn.Module):
                 wo += conv.bias.numel()
             off = wo
         return [tuple(e) for e in lay], off
+
+    max_operand_bytes = (1 << 31) - (1 << 20)     # what a raw buffer descriptor addresses, less the guard floats
+
+    def _chunk_bounds(self, x):
+        """[0, n1, ..., N]: sub-batches whose largest activation tensor stays below max_operand_bytes (one chunk = all of
+        it for the batches of the reference's configurations)."""
+        _, shapes = self._manifest(x)
+        per_image = 4 * max(c * h * w for c, h, w in dict(shapes).values())
+        per_image = max(per_image, 4 * x.shape[1] * x.shape[2] * x.shape[3])
+        n, cap = x.shape[0], max(1, self.max_operand_bytes // per_image)
+        parts = (n + cap - 1) // cap
+        return [round(i * n / parts) for i in range(parts + 1)] if n else [0, 0]
 
     def features(self, x):
         if x.dim() != 4:
@@ -499,7 +540,7 @@ class BNInception(nn.Module):
             self._ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
         return self._ws
 
-    def _run_backward(self, dfeat, saved):
+    def _run_backward(self, dfeat, saved, hook=True):
         plan, shapes, acts, argmax, tscale, bnstat = saved
         bn_grads = {}    # training-mode BatchNorm layers: layer id -> (dgamma, dbeta)
         n, dev = dfeat.shape[0], dfeat.device
@@ -713,7 +754,7 @@ class BNInception(nn.Module):
                     inited.add(key)
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
-                if self.grad_ready_hook is not None and closes_block:
+                if hook and self.grad_ready_hook is not None and closes_block:
                     # the first conv of a block (forward order) closes that block's contiguous range
                     if use_side:
                         main.wait_stream(side)    # the block's wgrads must have landed before the all-reduce
@@ -721,7 +762,7 @@ class BNInception(nn.Module):
                     pending_end = wo
         if use_side:
             main.wait_stream(side)
-        if self.grad_ready_hook is not None:
+        if hook and self.grad_ready_hook is not None:
             if pending_end > 0:
                 self.grad_ready_hook.range_ready(flat, 0, pending_end)
             self.grad_ready_hook.finish()
@@ -736,4 +777,4 @@ class BNInception(nn.Module):
             dgamma, dbeta = bn_grads[lid]
             out.append(dgamma if bnm.weight.requires_grad else None)
             out.append(dbeta if bnm.bias.requires_grad else None)
-        return out
+        return out, flat

@@ -246,6 +246,11 @@ __global__ __launch_bounds__(256) void scale_kernel(float* x, long n, const floa
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= c;
 }
 
+// dst += src (the flat conv-gradient buffers of the sub-batches of one backward, see bninception.py: chunked execution)
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* dst, const float* src, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] += src[i];
+}
+
 inline unsigned grid_for(long total, int cap = 4096) {
     long b = (total + 255) / 256;
     if (b > cap) b = cap;
@@ -399,6 +404,14 @@ extern "C" int ssn_sumsq(const float* x, long n, float* out, int accumulate, flo
 }
 
 // x *= coef  (coef read from device memory when coef_dev != nullptr, e.g. a clip coefficient)
+extern "C" int ssn_add_inplace(float* dst, const float* src, long n, hipStream_t stream) {
+    SSN_CHECK_ARG(dst && src && n >= 0, "add_inplace: bad arguments");
+    if (n == 0) return SSN_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, src, n);
+    SSN_CHECK_LAUNCH("add_inplace");
+    return SSN_OK;
+}
+
 extern "C" int ssn_scale(float* x, long n, const float* coef_dev, float coef, hipStream_t stream) {
     SSN_CHECK_ARG(x, "scale: null pointer");
     if (n == 0) return SSN_OK;

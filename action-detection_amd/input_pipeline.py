@@ -56,3 +56,96 @@ class GpuFrameTransform(object):
     def crop(self, frames, off_w, off_h, flip):
         """One crop (+ optional flip) of every frame: the tail of the training chain -> [n_img * C, crop_h, crop_w]."""
         return self._run(frames, [(off_w, off_h, flip)]).reshape(-1, self.crop_h, self.crop_w)
+
+
+class TrainingBatchPrefetcher(object):
+    """Keeps the GPU fed during training.
+
+    The reference's loader workers produce finished fp32 tensors and the training loop uploads them synchronously
+    (``ssn_train.py:205-208``; its ``Data`` meter is that wait, 4 bytes per pixel over PCIe).  Here the workers stop after
+    the PIL part -- decode, scale-jittered crop + resize, flip -- and hand over the uint8 frames; a background thread stages
+    batch i + 1 in pinned memory, a side HIP stream uploads it (1 byte per pixel) and runs the ``Stack(roll) ->
+    ToTorchFormatTensor(div=False) -> GroupNormalize`` tail as one launch (``ssn_frames_crop_normalize``) while the compute
+    stream is busy with batch i; ``next()`` only makes the compute stream wait on that batch's event.
+
+    ``source``: iterable of ``(frames, scaling, target, reg_target, prop_type)`` with ``frames`` uint8
+    ``[videos, images per video, H, W, C]`` (numpy or torch, already at the network's input size); ``transform``: a
+    ``GpuFrameTransform`` for the same device.  Yields ``(input [videos, images * C, H, W] fp32, scaling, target, reg_target,
+    prop_type)`` on the device -- the five arguments of ``SSN.forward``.  ``depth`` batches are in flight (>= 2).  On a
+    non-HIP device (the host emulator of the tests) it degrades to a synchronous loop with the same results.
+    """
+
+    def __init__(self, source, transform, depth=2):
+        import queue
+        import threading
+        self.transform = transform
+        self.device = transform.mean.device
+        self.cuda = self.device.type == "cuda"
+        self.depth = max(2, int(depth))
+        self._source = iter(source)
+        self._slots = [dict(pinned=None, dev=None, uploaded=None) for _ in range(self.depth)]
+        self._q = queue.Queue(maxsize=self.depth)
+        self._stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._stop = False
+        self._thread = threading.Thread(target=self._produce, daemon=True)
+        self._thread.start()
+
+    # -- producer thread: stage, upload, transform ------------------------------------------------------------------
+    def _produce(self):
+        try:
+            i = 0
+            for item in self._source:
+                if self._stop:
+                    break
+                slot = self._slots[i % self.depth]
+                i += 1
+                self._q.put(("ok", self._stage(slot, item)))     # blocks while `depth` batches are waiting
+            self._q.put(("end", None))
+        except BaseException as e:      # surfaced on the consumer's thread
+            self._q.put(("err", e))
+
+    def _stage(self, slot, item):
+        frames, scaling, target, reg_target, prop_type = item
+        frames = torch.as_tensor(frames)
+        if frames.dtype != torch.uint8 or frames.dim() != 5:
+            raise ValueError("frames: uint8 [videos, images, H, W, C]")
+        v, n_img, h, w, c = frames.shape
+        small = [torch.as_tensor(t) for t in (scaling, target, reg_target, prop_type)]
+        if not self.cuda:
+            out = self.transform.crop(frames.reshape(v * n_img, h, w, c), 0, 0, False)
+            return (out.reshape(v, n_img * c, h, w),) + tuple(t.to(self.device) for t in small), None
+        if slot["pinned"] is None or slot["pinned"].shape != frames.shape:
+            slot["pinned"] = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
+            slot["dev"] = torch.empty(frames.shape, dtype=torch.uint8, device=self.device)
+        if slot["uploaded"] is not None:
+            slot["uploaded"].synchronize()      # the upload that last read this pinned buffer (`depth` batches ago) is done
+        slot["pinned"].copy_(frames)
+        with torch.cuda.stream(self._stream):
+            slot["dev"].copy_(slot["pinned"], non_blocking=True)    # (the device buffer is only touched on this stream)
+            slot["uploaded"] = torch.cuda.Event()
+            slot["uploaded"].record(self._stream)
+            out = self.transform.crop(slot["dev"].reshape(v * n_img, h, w, c), 0, 0, False).reshape(v, n_img * c, h, w)
+            rest = tuple(t.pin_memory().to(self.device, non_blocking=True) for t in small)
+            ready = torch.cuda.Event()
+            ready.record(self._stream)
+        return (out,) + rest, ready
+
+    # -- consumer ------------------------------------------------------------------------------------------------------
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        kind, payload = self._q.get()
+        if kind == "end":
+            raise StopIteration
+        if kind == "err":
+            raise payload
+        batch, ready = payload
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            for t in batch:
+                t.record_stream(torch.cuda.current_stream(self.device))   # allocated on the side stream, used here
+        return batch
+
+    def close(self):
+        self._stop = True

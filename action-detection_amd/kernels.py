@@ -671,6 +671,13 @@ def sumsq(x, out, accumulate, workspace):
     lib.call("ssn_sumsq", _p(x), x.numel(), _p(out), int(accumulate), _p(workspace), _stream(lib, x))
 
 
+def add_(dst, src):
+    """dst += src (flat fp32 buffers of equal length)."""
+    lib = _check(dst, src)
+    assert dst.numel() == src.numel()
+    lib.call("ssn_add_inplace", _p(dst), _p(src), dst.numel(), _stream(lib, dst))
+
+
 def scale_(x, coef_dev=None, coef=1.0):
     lib = _check(x, coef_dev)
     lib.call("ssn_scale", _p(x), x.numel(), _p(coef_dev), float(coef), _stream(lib, x))

@@ -339,6 +339,9 @@ int ssn_sgd_step_multi(int count, float* const* w, const float* const* grad, flo
 /* clip_grad_norm support (ssn_train.py:245-249): out[0] (+)= sum(x^2); workspace >= 1024 floats. */
 int ssn_sumsq(const float* x, long n, float* out, int accumulate, float* workspace, hipStream_t stream);
 int ssn_scale(float* x, long n, const float* coef_dev, float coef, hipStream_t stream);
+/* dst[i] += src[i]: sums the conv-gradient buffers of the sub-batches when one backward is executed in chunks (a batch
+ * whose activations exceed the 2 GiB a kernel operand can address; DataParallel's reduce of replica gradients). */
+int ssn_add_inplace(float* dst, const float* src, long n, hipStream_t stream);
 
 #ifdef __cplusplus
 }

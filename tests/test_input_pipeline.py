@@ -35,3 +35,36 @@ def test_oversample_rgb_and_flow_bit_exact(backend):
     one = tf.crop(backend.put(torch.from_numpy(frames)), offs[3][0], offs[3][1], True)
     allc = tf.oversample(backend.put(torch.from_numpy(frames))).reshape(10, 9, 24, 24)
     assert torch.equal(one.cpu(), allc[7].cpu())
+
+
+def test_training_batch_prefetcher(backend):
+    """uint8 frames -> the five arguments of SSN.forward, batch after batch, equal to the synchronous transform chain (on the
+    GPU: staged through pinned memory and a side stream while the consumer works on the previous batch)."""
+    from action_detection_amd.input_pipeline import TrainingBatchPrefetcher
+    rs = np.random.RandomState(11)
+    dev = backend.device
+    tf = GpuFrameTransform(16, [104, 117, 128], [1], roll=True, device=dev)
+    items = []
+    for _ in range(5):
+        frames = rs.randint(0, 256, size=(2, 6, 16, 16, 3)).astype(np.uint8)
+        items.append((frames, rs.rand(2, 8, 2).astype(np.float32), rs.randint(0, 5, (2, 8)), rs.randn(2, 8, 2).astype(np.float32),
+                      np.tile(np.array([0, 1, 1, 1, 1, 1, 1, 2]), (2, 1))))
+    seen = 0
+    for got, want in zip(TrainingBatchPrefetcher(iter(items), tf, depth=2), items):
+        inp, scaling, target, reg_target, prop_type = got
+        ref = O.oversample_transform([f for f in want[0].reshape(12, 16, 16, 3)], 16, 16, [104, 117, 128], [1], True, False)
+        ref = ref.reshape(10, 12 * 3, 16, 16)[4].reshape(2, 18, 16, 16)      # crop 4 = the centre crop = the whole 16x16 frame
+        assert inp.shape == (2, 18, 16, 16) and torch.equal(inp.cpu(), ref)
+        assert torch.equal(scaling.cpu(), torch.from_numpy(want[1])) and torch.equal(target.cpu(), torch.from_numpy(want[2]))
+        assert torch.equal(prop_type.cpu(), torch.from_numpy(want[4])) and str(inp.device).startswith(str(dev)[:4])
+        seen += 1
+    assert seen == 5
+
+    def broken():
+        yield items[0]
+        raise RuntimeError("decoder died")
+    it = TrainingBatchPrefetcher(broken(), tf)
+    next(it)
+    import pytest
+    with pytest.raises(RuntimeError):
+        next(it)

@@ -155,3 +155,30 @@ def test_no_cpu_fallback(hip_library):
     m, _ = build("RGB", (1, 1, 1))
     with pytest.raises(RuntimeError):
         m.cpu()(*make_batch(2, "RGB", 20, seed=8, input_size=32))
+
+
+def test_chunked_execution_matches_single_pass(hip_library):
+    """A batch above the 2 GiB a kernel operand can address runs as sub-batches (forward + backward per chunk, flat conv
+    gradients summed): same features and parameter gradients as one pass.  (The limit is lowered instead of using 700 frames.)"""
+    from action_detection_amd.bninception import BNInception
+    torch.manual_seed(0)
+    m = BNInception()
+    init_backbone_synthetic(m)
+    m.eval().cuda()
+    x = (torch.randn(7, 3, 224, 224) * 50).cuda()
+    w = torch.randn(7, 1024, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        f = m.features(x)
+        (f * w).sum().backward()
+        return f.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    f1, g1 = run()
+    assert len(m._chunk_bounds(x)) == 2
+    m.max_operand_bytes = 3 * 4 * 64 * 112 * 112 + 4096           # three images of the largest activation per chunk
+    assert m._chunk_bounds(x) == [0, 2, 5, 7]
+    f3, g3 = run()
+    assert torch.equal(f1, f3)                                     # per-image results do not depend on the batch they run in
+    for n in g1:
+        assert rel_err(g3[n], g1[n]) < 2e-5, (n, rel_err(g3[n], g1[n]))   # (sums over 7 images in a different order)
