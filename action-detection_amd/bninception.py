@@ -267,13 +267,55 @@ class BNInception(nn.Module):
                                  k=k, s=s, p=p))
             else:
                 _, lid, src, dst = op
-                plan.append(dict(kind="gap", lid=lid, src=src, dst=dst))
+                plan.append(dict(kind="gap", lid=lid, src=src, dst=dst, c=shapes[src][0]))
         train_bn = set(self._train_bn_ids())
         if self.pool_after_projection and not train_bn:
-            plan = self._move_avg_pools(plan, shapes, merge=self.conv_precision == "split" and self.merge_projection)
+            merge = self.conv_precision == "split" and self.merge_projection
+            plan = self._move_avg_pools(plan, shapes, merge=merge)
+            if merge:
+                plan = self._merge_block_heads(plan, shapes)
         if train_bn:
             plan = self._split_train_bn(plan, shapes, train_bn)
         return plan, shapes
+
+    @staticmethod
+    def _merge_block_heads(plan, shapes):
+        """ONE launch on an Inception block input: the block's 1x1 branch joins its fused reduce (+ projection) launch.  The
+        1x1 branch must land at the head of the block-output tensor, the reduce rows in a tensor of their own -- so the reduce
+        tensor moves INTO the block-output allocation, behind the block's own channels: output rows >= row_split are stored
+        row_gap channels further up (conv_epilogue.h), the dgrad / wgrad of the launch read the gradient tensor with the same
+        displacement (k_split / k_gap, g_row_split / g_row_gap).  The block input is then read once per pass and its gradient
+        has a single writer (no read-modify-write, the producer's ReLU/BN backward fused into that one store)."""
+        out, moved = [], {}       # moved: reduce tensor -> (block-output tensor, channel offset)
+        for op in plan:
+            if (op["kind"] == "conv" and len(op["lids"]) == 1 and op["lids"][0].endswith("_1x1") and op["k"] == 1
+                    and op["dst_c0"] == 0 and not op.get("raw")):
+                pair = next((q for q in plan if q["kind"] == "conv" and len(q["lids"]) >= 2 and q["src"] == op["src"]
+                             and q.get("src_c0", 0) == op.get("src_c0", 0) and q["k"] == 1 and q["dst_c0"] == 0), None)
+                if pair is not None and op["cout"] % 32 == 0 and shapes[op["dst"]][0] % 32 == 0:
+                    blk, cblk, c1 = op["dst"], shapes[op["dst"]][0], op["cout"]
+                    moved[pair["dst"]] = (blk, cblk)
+                    merged = dict(pair, lids=op["lids"] + pair["lids"], couts=[c1] + pair["couts"], cout=c1 + pair["cout"],
+                                  dst=blk, dst_c0=0, row_split=c1, row_gap=cblk - c1, block_channels=cblk, merged_from=pair)
+                    if "raw_from" in pair:
+                        merged["raw_from"] = c1 + pair["raw_from"]
+                    shapes[blk] = (cblk + pair["cout"],) + tuple(shapes[blk][1:])
+                    out.append(merged)
+                    continue
+            out.append(op)
+        res = []
+        for op in out:
+            if any(op is m.get("merged_from") for m in out if "merged_from" in m):
+                continue          # the reduce launch now lives in its block's head launch
+            if op.get("src") in moved:
+                blk, c0 = moved[op["src"]]
+                op = dict(op, src=blk, src_c0=op.get("src_c0", 0) + c0)
+            res.append(op)
+        for m in res:
+            m.pop("merged_from", None)
+        for name in moved:
+            shapes.pop(name, None)
+        return res
 
     @staticmethod
     def _split_train_bn(plan, shapes, train_bn):
@@ -393,8 +435,8 @@ class BNInception(nn.Module):
                 if "raw_from" in op and off >= op["raw_from"]:
                     # the projection riding in the reduce launch: its BN affine belongs to the slice its POOL writes
                     sdst = scale_slice(op["proj_final"][0], op["proj_final"][1], c)
-                else:
-                    sdst = scale_slice(aff_dst, aff_c0 + off, c)
+                else:     # (rows behind the split of a block-head launch live row_gap channels further up the tensor)
+                    sdst = scale_slice(aff_dst, aff_c0 + off + (op["row_gap"] if off >= op.get("row_split", 1 << 30) else 0), c)
                 for lst, v in zip(fold, (conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                          bn.running_var, bn.eps, sdst, shift_flat[soff + off:soff + off + c])):
                     lst.append(v)
@@ -405,7 +447,7 @@ class BNInception(nn.Module):
         conv_ops = [op for op in plan if op["kind"] == "conv"]
         for op in conv_ops:      # which matrix path each layer takes (bf16 3-way split, or exact f32 MFMA)
             op["x6"] = (self.conv_precision == "split" and op["k"] in (1, 3)
-                        and ("raw_from" in op       # (rows without affine / ReLU: split kernel only)
+                        and ("raw_from" in op or "row_gap" in op      # (raw rows / displaced rows: split kernel only)
                              or x6_wins("fwd", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
         packed_fwd = {}
         for x6 in (False, True):
@@ -466,7 +508,9 @@ class BNInception(nn.Module):
                 raw = bool(op.get("raw"))      # no affine / ReLU here: the pool behind this projection applies them
                 shift = None if raw else shift_of[op["lids"][0]]
                 wp = packed_fwd[op["lids"][0]]
-                scale = None if raw else scale_slice(op["dst"], op["dst_c0"], cout)
+                # (per-channel vector of the destination tensor from the slice's first channel; a block-head launch reaches
+                #  row_gap channels further up for its rows behind the split, like its stores)
+                scale = None if raw else scale_slice(op["dst"], op["dst_c0"], cout + op.get("row_gap", 0))
                 ho = shapes[op["dst"]][1]
                 hin = shapes[op["src"]][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
@@ -476,7 +520,8 @@ class BNInception(nn.Module):
                     self._timed("conv_fwd_x6", op["lids"][0], flops,
                                 lambda: K.conv_x6_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
                                                       not raw, tuned_tile("fwd6", n, cin, cout, k, s, hin),
-                                                      raw_from=op.get("raw_from", 0)))
+                                                      raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0),
+                                                      row_gap=op.get("row_gap", 0)))
                 else:
                     self._timed("conv_fwd_f32", op["lids"][0], flops,
                                 lambda: K.conv_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
@@ -489,7 +534,7 @@ class BNInception(nn.Module):
                     _, ho, wo = shapes[op["dst"]]
                     am = torch.empty((n, c, ho, wo), device=dev, dtype=torch.uint8)
                     argmax[op["lid"]] = am
-                K.pool_fwd(op["pool"], full(acts[op["src"]]), out, am, op["k"], op["s"], op["p"])
+                K.pool_fwd(op["pool"], ChanSlice(acts[op["src"]], 0, c), out, am, op["k"], op["s"], op["p"])
             elif op["kind"] == "pool_aff":
                 c = op["c"]
                 K.avgpool_affine_fwd(ChanSlice(acts[op["src"]], op.get("src_c0", 0), c),
@@ -515,8 +560,8 @@ class BNInception(nn.Module):
                     bnstat[lid] = (mean, invstd)
                     off += c
             else:
-                feat = torch.empty((n, shapes[op["src"]][0]), device=dev, dtype=torch.float32)
-                K.gap_fwd(full(acts[op["src"]]), feat)
+                feat = torch.empty((n, op["c"]), device=dev, dtype=torch.float32)
+                K.gap_fwd(ChanSlice(acts[op["src"]], 0, op["c"]), feat)
             if lane_ctx is not None:
                 lane_ctx.__exit__(None, None, None)
                 # the reduce pair feeds the double-3x3 chain (with a training-mode BatchNorm its bn_train op completes it)
@@ -565,9 +610,9 @@ class BNInception(nn.Module):
         for op in plan:
             if op["kind"] == "conv":
                 hin, win = shapes[op["src"]][1], shapes[op["src"]][2]
-                x6 = (self.conv_precision == "split" and self.wgrad_x6 and op["src"] != "data"
+                x6 = (self.conv_precision == "split" and op["src"] != "data"
                       and K.wgrad_x6_supported(op["k"], op["s"], op["p"], hin, win)
-                      and x6_wins("wgrad", op["cin"], op["cout"], op["k"], op["s"], hin))
+                      and ("row_gap" in op or (self.wgrad_x6 and x6_wins("wgrad", op["cin"], op["cout"], op["k"], op["s"], hin))))
                 wg_x6[op["lids"][0]] = x6
                 if x6:
                     ws_bytes = max(ws_bytes, K.wgrad_x6_workspace_bytes(
@@ -585,8 +630,8 @@ class BNInception(nn.Module):
         dg_layout = {op["lids"][0]: K.dgrad_layout(op["k"], op["s"], op["p"], shapes[op["src"]][1],
                                                    shapes[op["src"]][2]) for op in dg_ops}
         dg_x6 = {op["lids"][0]: (self.conv_precision == "split" and op["k"] in (1, 3) and op["s"] == 1
-                                 and ("raw_from" in op or x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"],
-                                                                  shapes[op["src"]][1])))
+                                 and ("raw_from" in op or "row_gap" in op
+                                      or x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
                  for op in dg_ops}
         # 3x3 / stride-2 layers: four parity-class stride-1 launches on the x6 kernel (no tap that does not contribute)
         dg_s2 = {op["lids"][0]: (self.conv_precision == "split" and dg_layout[op["lids"][0]] == 2 and len(op["lids"]) == 1)
@@ -642,14 +687,14 @@ class BNInception(nn.Module):
             op = plan[idx]
             if op["kind"] == "gap":
                 key = (op["src"], 0)
-                K.gap_bwd(dfeat, full(gbuf(op["src"])), accumulate=key in inited)
+                K.gap_bwd(dfeat, ChanSlice(gbuf(op["src"]), 0, op["c"]), accumulate=key in inited)
                 inited.add(key)
             elif op["kind"] == "pool":
                 c = op["c"]
                 key = (op["src"], 0)
                 my, ms = mask_args(idx, op, c)
                 K.pool_bwd(op["pool"], ChanSlice(grads[op["dst"]], op["dst_c0"], c), argmax.get(op["lid"]),
-                           full(gbuf(op["src"])), op["k"], op["s"], op["p"], accumulate=key in inited,
+                           ChanSlice(gbuf(op["src"]), 0, c), op["k"], op["s"], op["p"], accumulate=key in inited,
                            mask_y=my, mask_scale=ms)
                 inited.add(key)
             elif op["kind"] == "pool_aff":
@@ -686,11 +731,18 @@ class BNInception(nn.Module):
                 lids = op["lids"]
                 g = ChanSlice(grads[op["dst"]], op["dst_c0"], cout)
                 raw = bool(op.get("raw"))       # bias-free, affine-free projection in front of a pool: nothing to undo
-                c_aff = op.get("raw_from", cout)    # (a projection riding in the reduce launch: its channels are raw)
-                if not raw and not is_masked(op["dst"], op["dst_c0"], c_aff):
-                    K.relu_bn_bwd(ChanSlice(grads[op["dst"]], op["dst_c0"], c_aff),
-                                  ChanSlice(acts[op["dst"]], op["dst_c0"], c_aff),
-                                  tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + c_aff])
+                # channel ranges of the destination tensor whose ReLU / frozen-BN backward is still due (the raw rows of a
+                # projection riding along have none; a block-head launch has its rows behind the split row_gap channels up)
+                c_aff, gap, split = op.get("raw_from", cout), op.get("row_gap", 0), op.get("row_split", cout)
+                ranges = [(0, min(split, c_aff))] + ([(split + gap, c_aff - split)] if c_aff > split else [])
+                if "row_gap" in op:      # (finer: the reduce rows are finalised per consuming convolution)
+                    offs = [sum(op["couts"][:q]) for q in range(len(lids))]
+                    ranges = [(o_ + (gap if o_ >= split else 0), c_) for o_, c_ in zip(offs, op["couts"]) if o_ < c_aff]
+                for r0, rc in ([] if raw else ranges):
+                    if not is_masked(op["dst"], op["dst_c0"] + r0, rc):
+                        K.relu_bn_bwd(ChanSlice(grads[op["dst"]], op["dst_c0"] + r0, rc),
+                                      ChanSlice(acts[op["dst"]], op["dst_c0"] + r0, rc),
+                                      tscale[op["dst"]][op["dst_c0"] + r0:op["dst_c0"] + r0 + rc])
                 wo, wn, bo, bn = lay[lids[0]]
                 for extra in lids[1:]:   # fused launch: [wA | wB | (wP)] and [bA | bB | (bP)] are contiguous in the flat layout
                     wo2, wn2, bo2, bn2 = lay[extra]
@@ -704,7 +756,8 @@ class BNInception(nn.Module):
                 xin = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 if wg_x6[lids[0]]:
                     wcfg = tuned_tile("wgrad6", n, cin, cout, k, s, hin)
-                    run_wgrad = lambda: K.conv_wgrad_x6(g, xin, dw, db, k, p, ws, wcfg)   # noqa: E731
+                    run_wgrad = lambda: K.conv_wgrad_x6(g, xin, dw, db, k, p, ws, wcfg,   # noqa: E731
+                                                        g_row_split=op.get("row_split", 0), g_row_gap=op.get("row_gap", 0))
                 else:
                     wcfg = tuned_tile("wgrad", n, cin, cout, k, s, hin)
                     run_wgrad = lambda: K.conv_wgrad(g, xin, dw, db, k, s, p, ws, wcfg)   # noqa: E731
@@ -745,7 +798,8 @@ class BNInception(nn.Module):
                         self._timed("conv_dgrad_x6", lids[0], flops,
                                     lambda: K.conv_x6_dgrad(g, wt, dx, k, p, acc_flag,
                                                             tuned_tile("dgrad6", n, cin, cout, k, s, hin),
-                                                            mask_y=my, mask_scale=ms))
+                                                            mask_y=my, mask_scale=ms, k_split=op.get("row_split", 0),
+                                                            k_gap=op.get("row_gap", 0)))
                     else:
                         self._timed("conv_dgrad_f32", lids[0], flops,
                                     lambda: K.conv_dgrad(g, wt, dx, k, s, p, accumulate=acc_flag,

@@ -28,6 +28,10 @@ struct EpiArgs {
     int M;
     int relu, accumulate;
     float* amax;           // nullptr: the output tensor is not tracked
+    // Output rows m >= row_split are stored row_gap channels further up the tensor (both multiples of 32, so a 32-row MFMA
+    // tile never straddles the split): the fused launch on an Inception block input writes the block's 1x1 branch to the head
+    // of the block-output tensor and the reduce / projection rows behind the block's own channels.  No split: INT_MAX, 0.
+    int row_split, row_gap;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, uint32_t bytes) {
@@ -41,12 +45,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(const void* base, uin
 template <int BM, int NT>
 __device__ __forceinline__ void epi_stage_channels(float* ch, const float* scale, const float* shift,
                                                    const float* mask_scale, int m0, int M, int tid, float inv = 1.f,
-                                                   int relu = 0, int raw_from = 0x7fffffff) {
+                                                   int relu = 0, int raw_from = 0x7fffffff, int row_split = 0x7fffffff,
+                                                   int row_gap = 0) {
     for (int r = tid; r < BM; r += NT) {
         const int m = m0 + r;
         const bool ok = m < M;
         const bool aff = ok && scale && m < raw_from;
-        ch[r] = aff ? scale[m] * inv : inv;
+        // `scale` is indexed by the output CHANNEL (it is the per-tensor vector the backward masks read too), i.e. displaced
+        // like the stores of rows >= row_split; `shift` by the launch's own row
+        ch[r] = aff ? scale[m + (m >= row_split ? row_gap : 0)] * inv : inv;
         ch[BM + r] = aff ? shift[m] : 0.f;
         ch[2 * BM + r] = (ok && mask_scale) ? mask_scale[m] : __builtin_nanf("");
         ch[3 * BM + r] = (relu && m < raw_from) ? 0.f : -__builtin_inff();
@@ -62,6 +69,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
     const __amdgpu_buffer_rsrc_t yrsrc = epi_rsrc(e.y, e.y_bytes);
     const int mlim = e.M - m0 - 4 * lh;   // rows srow (without the lane-half term) below this are inside the tensor
     auto srow = [&](int i, int r) { return row0 + i * 32 + (r & 3) + 8 * (r >> 2); };
+    // wave-uniform channel displacement of MFMA tile i (see EpiArgs::row_split)
+    auto gap = [&](int i) { return (m0 + row0 + i * 32 >= e.row_split) ? e.row_gap : 0; };
     // amax of what is stored: rows past the tensor compute exact zeros (zero weight rows, shift staged as 0), so only
     // the pixel columns that do not exist have to be kept out
     float vmax = 0.f;
@@ -79,7 +88,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
                     if (e.relu) v = fmaxf(v, ch[3 * BM + sr + 4 * lh]);
                     cmax = fmaxf(cmax, fabsf(v));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrsrc,
-                                                          sr < mlim ? yoff[j] : EPI_OOB, (uint32_t)sr * e.howo4, 0);
+                                                          sr < mlim ? yoff[j] : EPI_OOB, (uint32_t)(sr + gap(i)) * e.howo4, 0);
                 }
             vmax = fmaxf(vmax, yoff[j] != EPI_OOB ? cmax : 0.f);
         }

@@ -329,6 +329,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     e.relu = p.relu;
     e.accumulate = p.accumulate;
     e.amax = p.y_amax;
+    e.row_split = 0x7fffffff;
+    e.row_gap = 0;
     uint32_t yoff[TN], moff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

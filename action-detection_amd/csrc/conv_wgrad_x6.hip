@@ -37,6 +37,7 @@ struct WgX6Args {
     float* part;     // [splits][M][ldp]
     const float* g_amax;   // amax slots of the tensors g and x belong to (required)
     const float* x_amax;
+    int g_row_split, g_row_gap;   // rows m >= g_row_split of G sit g_row_gap channels further up its tensor (fused block-input launch)
     int N, Cin, H, W;
     long x_img_stride;
     int M;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
 #pragma unroll
     for (int i = 0; i < NAR; ++i) {
         const int r = row0 + 64 * i, m = m0 + r;
-        a_const[i] = (r < BM && m < p.M) ? (uint32_t)(m * HW) * 4u : OOB;
+        a_const[i] = (r < BM && m < p.M) ? (uint32_t)((m + (m >= p.g_row_split ? p.g_row_gap : 0)) * HW) * 4u : OOB;
     }
     uint32_t b_const[NBR];   // byte offset of (c, r, s) relative to the pixel (guard included), or OOB
     int b_dh[NBR], b_dw[NBR];   // tap displacement (r - pad, s - pad)
@@ -400,7 +401,7 @@ extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int 
 extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                                  long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
                                  void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
-                                 hipStream_t stream) {
+                                 int g_row_split, int g_row_gap, hipStream_t stream) {
     SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
     SSN_CHECK_ARG(g_amax && x_amax, "conv wgrad x6: the amax slots of both operand tensors are required");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv wgrad x6: ksize %d unsupported", ksize);
@@ -414,6 +415,9 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.part = (float*)workspace;
     a.g_amax = g_amax;
     a.x_amax = x_amax;
+    SSN_CHECK_ARG(g_row_gap >= 0 && (g_row_gap == 0 || (g_row_split > 0 && g_row_split < Cout)), "conv wgrad x6: bad row split");
+    a.g_row_split = g_row_gap ? g_row_split : 0x7fffffff;
+    a.g_row_gap = g_row_gap;
     a.N = N;
     a.Cin = Cin;
     a.H = H;
@@ -428,7 +432,7 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.pad = pad;
     a.div_hw = make_fastdiv((uint32_t)a.HWp);
     a.div_w = make_fastdiv((uint32_t)W);
-    const long gb = ((long)(N - 1) * g_img_stride + (long)Cout * H * W) * 4;
+    const long gb = ((long)(N - 1) * g_img_stride + (long)(Cout + g_row_gap) * H * W) * 4;
     const long xb = ((long)(N - 1) * x_img_stride + (long)Cin * H * W) * 4;
     SSN_CHECK_ARG(gb < (1l << 31) && xb < (1l << 31) - 512, "conv wgrad x6: operand larger than 2 GiB (buffer addressing)");
     a.g_bytes = (uint32_t)gb;

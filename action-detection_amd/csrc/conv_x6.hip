@@ -42,8 +42,8 @@ using namespace x6;
 // khalf holds f16 k = 8 * khalf + 0..7 of that plane; it is stored at chunk position c ^ ((m >> 2) & 3), which makes
 // the straight LDS copy conflict-free for the ds_read_b128 fragment reads.
 //   mode 0 (forward operand): A[m][c][tap] = w[m][c][tap];  mode 1 (dgrad operand): A[m][c][tap] = w[c][m][tap]
-// Up to three sources (fused launches: the reduce pair, or the pair plus the pool projection): output channel
-// co < split comes from w0, split <= co < split2 from w1, the rest from w2.
+// Up to four sources (fused launches on an Inception block input: 1x1 branch, reduce pair, pool projection): output
+// channel co < split comes from w0, split <= co < split2 from w1, split2 <= co < split3 from w2, the rest from w3.
 // Three launches: clear the amax tails, max |w| of every entry into its tail (one workgroup per XP_ACHUNK source
 // elements, unsigned atomic max), then the packing proper, which derives the entry's power-of-two scale from that tail.
 constexpr int XP_MAX = 40;
@@ -53,9 +53,10 @@ struct X6PackTable {
     const float* w0[XP_MAX];
     const float* w1[XP_MAX];
     const float* w2[XP_MAX];
+    const float* w3[XP_MAX];
     uint32_t* out[XP_MAX];
     long rows_dw[XP_MAX];       // dwords of the packed rows; the tail starts there
-    int cout[XP_MAX], cin[XP_MAX], kk[XP_MAX], mode[XP_MAX], split[XP_MAX], split2[XP_MAX];   // kk = taps per channel (kh * kw)
+    int cout[XP_MAX], cin[XP_MAX], kk[XP_MAX], mode[XP_MAX], split[XP_MAX], split2[XP_MAX], split3[XP_MAX];   // kk = kh * kw
     int srckk[XP_MAX];          // taps per channel of the SOURCE weight (== kk unless a tap subset is packed)
     unsigned tapmap[XP_MAX];    // srckk != kk: nibble t = source tap of packed tap t
     int blk0[XP_MAX + 1];
@@ -71,13 +72,15 @@ __global__ __launch_bounds__(256) void pack_x6_amax_kernel(X6PackTable t) {
     const long per = (long)t.cin[ti] * t.srckk[ti];
     const long n0 = (long)t.split[ti] * per;                          // elements of w0
     const long n1 = (long)(t.split2[ti] - t.split[ti]) * per;         // ... of w1 (fused pair)
-    const long n2 = (long)(t.cout[ti] - t.split2[ti]) * per;          // ... of w2 (pair + pool projection)
+    const long n2 = (long)(t.split3[ti] - t.split2[ti]) * per;        // ... of w2
+    const long n3 = (long)(t.cout[ti] - t.split3[ti]) * per;          // ... of w3
     const long base = (long)((int)blockIdx.x - t.ablk0[ti]) * XP_ACHUNK;
     long end = base + XP_ACHUNK;
-    if (end > n0 + n1 + n2) end = n0 + n1 + n2;
+    if (end > n0 + n1 + n2 + n3) end = n0 + n1 + n2 + n3;
     float m = 0.f;
     for (long i = base + threadIdx.x; i < end; i += 256)
-        m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : (i < n0 + n1 ? t.w1[ti][i - n0] : t.w2[ti][i - n0 - n1])));
+        m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : (i < n0 + n1 ? t.w1[ti][i - n0] : (i < n0 + n1 + n2 ? t.w2[ti][i - n0 - n1]
+                                                                                     : t.w3[ti][i - n0 - n1 - n2]))));
     amax_emit(reinterpret_cast<float*>(t.out[ti] + t.rows_dw[ti]), m);
 }
 __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
@@ -104,8 +107,9 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
             float x = 0.f;
             if (c < C) {
                 const int co = mode ? c : m, ci = mode ? m : c;
-                const float* src = co < t.split[ti] ? t.w0[ti] : (co < t.split2[ti] ? t.w1[ti] : t.w2[ti]);
-                const int cor = co < t.split[ti] ? co : (co < t.split2[ti] ? co - t.split[ti] : co - t.split2[ti]);
+                const float* src = co < t.split[ti] ? t.w0[ti] : (co < t.split2[ti] ? t.w1[ti] : (co < t.split3[ti] ? t.w2[ti] : t.w3[ti]));
+                const int cor = co < t.split[ti] ? co : (co < t.split2[ti] ? co - t.split[ti]
+                                                         : (co < t.split3[ti] ? co - t.split2[ti] : co - t.split3[ti]));
                 const int stap = t.srckk[ti] == KK ? tap : (int)((t.tapmap[ti] >> (4 * tap)) & 15u);
                 x = src[((long)cor * Cin + ci) * t.srckk[ti] + stap];
             }
@@ -213,7 +217,17 @@ long x6_packed_dwords(int Cout, int Cin, int ksize, int transposed) {
 }
 
 int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, int C, int H, int W, long xs, int M,
-              int Ho, int Wo, long ys, int ksize, int pad, const float* x_amax, float* y_amax, const char* what) {
+              int Ho, int Wo, long ys, int ksize, int pad, const float* x_amax, float* y_amax, int row_split, int row_gap,
+              int k_split, int k_gap, const char* what) {
+    if ((row_gap && (row_split % 32 || row_gap % 32 || row_split <= 0 || row_split >= M)) ||
+        (k_gap && (k_split % 16 || k_gap % 16 || k_split <= 0 || k_split >= C || C % 16))) {
+        ssn_set_error("%s: a row split must be a multiple of 32 inside (0, M), a channel split a multiple of 16 inside (0, C)", what);
+        return SSN_ERR_ARG;
+    }
+    a.row_split = row_gap ? row_split : 0x7fffffff;
+    a.row_gap = row_gap;
+    a.k_split = k_split;
+    a.k_gap = k_gap;
     if (!x_amax) {
         ssn_set_error("%s: the source tensor's amax slot is required (operand scaling of the f16 split)", what);
         return SSN_ERR_ARG;
@@ -238,7 +252,7 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
     a.ngroups = (C + 15) / 16;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
-    const long xb = ((long)(N - 1) * xs + (long)C * H * W) * 4;
+    const long xb = ((long)(N - 1) * xs + (long)(C + k_gap) * H * W) * 4;
     const long ab = (long)a.ngroups * ksize * ksize * M * APITCH * 4;   // packed rows (the amax tail follows them)
     if (!(xb < (1l << 31) && ab < (1l << 31) && (long)N * Ho * Wo < (1l << 31))) {
         ssn_set_error("%s: operand larger than 2 GiB (buffer addressing)", what);
@@ -249,7 +263,7 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
     a.sub_a = a.sub_b = a.sub_W = a.sub_HW = 0;
     a.x_bytes = (uint32_t)xb;
     a.a_bytes = (uint32_t)ab;
-    const long yb = ((long)(N - 1) * ys + (long)M * Ho * Wo) * 4;
+    const long yb = ((long)(N - 1) * ys + (long)(M + row_gap) * Ho * Wo) * 4;
     if (!(yb < (1l << 31))) {
         ssn_set_error("%s: output larger than 2 GiB (buffer addressing)", what);
         return SSN_ERR_ARG;
@@ -273,10 +287,11 @@ extern "C" long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int tran
 
 // Scale + split + pack `count` weights (HOST arrays, one entry per layer; see ssn_conv_pack_weights_multi for w1/split).
 extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1,
-                                              const float* const* w2, float* const* out, const int* cout,
-                                              const int* cin, const int* ksize, const int* mode, const int* split,
-                                              const int* split2, hipStream_t stream) {
-    SSN_CHECK_ARG(count >= 0 && (count == 0 || (w0 && w1 && w2 && out && cout && cin && ksize && mode && split && split2)),
+                                              const float* const* w2, const float* const* w3, float* const* out,
+                                              const int* cout, const int* cin, const int* ksize, const int* mode,
+                                              const int* split, const int* split2, const int* split3, hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (w0 && w1 && w2 && w3 && out && cout && cin && ksize && mode && split &&
+                                                split2 && split3)),
                   "conv x6 pack: bad arguments");
     for (int base = 0; base < count; base += XP_MAX) {
         X6PackTable t;
@@ -287,12 +302,14 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
             SSN_CHECK_ARG(ksize[j] == 1 || ksize[j] == 3, "conv x6 pack: ksize %d unsupported", ksize[j]);
             SSN_CHECK_ARG(mode[j] == 0 || mode[j] == 1, "conv x6 pack: mode %d", mode[j]);
             SSN_CHECK_ARG(w0[j] && out[j] && (w1[j] || split[j] >= cout[j]) && (w2[j] || split2[j] >= cout[j]) &&
-                              split[j] <= split2[j],
+                              (w3[j] || split3[j] >= cout[j]) && split[j] <= split2[j] && split2[j] <= split3[j],
                           "conv x6 pack: null pointer / bad splits");
             t.w0[i] = w0[j];
             t.w1[i] = w1[j];
             t.w2[i] = w2[j];
+            t.w3[i] = w3[j];
             t.split2[i] = split2[j];
+            t.split3[i] = split3[j];
             t.out[i] = (uint32_t*)out[j];
             t.cout[i] = cout[j];
             t.cin[i] = cin[j];
@@ -322,8 +339,8 @@ extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cou
     t.count = 1;
     t.w0[0] = w;
     t.w1[0] = nullptr;
-    t.w2[0] = nullptr;
-    t.split2[0] = cout;
+    t.w2[0] = t.w3[0] = nullptr;
+    t.split2[0] = t.split3[0] = cout;
     t.out[0] = (uint32_t*)out;
     t.cout[0] = cout;
     t.cin[0] = cin;
@@ -361,8 +378,8 @@ extern "C" int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, i
             }
         t.w0[cls] = w;
         t.w1[cls] = nullptr;
-        t.w2[cls] = nullptr;
-        t.split2[cls] = cout;
+        t.w2[cls] = t.w3[cls] = nullptr;
+        t.split2[cls] = t.split3[cls] = cout;
         t.out[cls] = (uint32_t*)out + off;
         t.cout[cls] = cout;
         t.cin[cls] = cin;
@@ -385,13 +402,14 @@ extern "C" int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, i
 extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift,
                                float* y, int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                                long y_img_stride, int ksize, int stride, int pad, int relu, int x_guard_bytes,
-                               int tile_cfg, const float* x_amax, float* y_amax, int raw_from, hipStream_t stream) {
+                               int tile_cfg, const float* x_amax, float* y_amax, int raw_from, int row_split,
+                               int row_gap, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv x6 fwd: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 fwd: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv x6 fwd: stride %d unsupported", stride);
     X6Args a;
     int rc = fill_args(a, x, (const uint32_t*)w_packed, y, N, Cin, H, W, x_img_stride, Cout, Ho, Wo, y_img_stride,
-                       ksize, pad, x_amax, y_amax, "conv x6 fwd");
+                       ksize, pad, x_amax, y_amax, row_split, row_gap, 0, 0, "conv x6 fwd");
     if (rc != SSN_OK) return rc;
     a.x_guard = x_guard_bytes;
     a.scale = scale;
@@ -414,13 +432,13 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
 extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                                  long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                                 int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax,
-                                 hipStream_t stream) {
+                                 int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, int k_split,
+                                 int k_gap, hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 dgrad: ksize %d unsupported", ksize);
     X6Args a;
     int rc = fill_args(a, dy, (const uint32_t*)wt_packed, dx, N, Cout, Ho, Wo, dy_img_stride, Cin, H, W,
-                       dx_img_stride, ksize, pad, dy_amax, dx_amax, "conv x6 dgrad");
+                       dx_img_stride, ksize, pad, dy_amax, dx_amax, 0, 0, k_split, k_gap, "conv x6 dgrad");
     if (rc != SSN_OK) return rc;
     a.x_guard = dy_guard_bytes;
     a.scale = nullptr;

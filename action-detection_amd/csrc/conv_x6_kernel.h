@@ -35,6 +35,8 @@ struct X6Args {
     int pad_h, pad_w;
     int relu, accumulate;
     int raw_from;         // output rows >= raw_from take no affine and no ReLU (conv_epilogue.h); M or more: none
+    int row_split, row_gap;   // forward: output rows >= row_split are stored row_gap channels further up (conv_epilogue.h)
+    int k_split, k_gap;       // gather source: channels >= k_split sit k_gap channels further up its tensor (multiples of 16)
     const float* mask_y;
     const float* mask_scale;
     long mask_img_stride;
@@ -200,6 +202,10 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
     uint32_t pf_x = (uint32_t)(WIDE ? wave * RPP : krow0) * hw_bytes;        // + 16 channels per group
     uint32_t pf_a = 0;                                                       // + a_step per slab
     const uint32_t row_wrap = (uint32_t)(p.W - KW) * 4u, group_step = 16u * hw_bytes;
+    // a gap in the channel axis of the gather source (the dgrad of a fused block-input launch reads the gradient of the 1x1
+    // branch at the head of the block-output gradient and the reduce / projection gradients behind the block's channels)
+    const int gap_left = p.k_gap ? p.ngroups - p.k_split / 16 : -(1 << 30);   // value of pf_left when the gap is crossed
+    const uint32_t gap_bytes = (uint32_t)p.k_gap * hw_bytes;
     uint32_t d_vo, d_so, d_aso, d_dead;
     uint32_t *d_b, *d_a;
     bool d_tail;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
         pf_a += a_step;
         if (KK == 1) {
             pf_x += group_step;
-            --pf_left;
+            if (--pf_left == gap_left) pf_x += gap_bytes;
         } else {
             pf_d += 4u;
             if (++pf_col == KW) {
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
                 pf_tap = 0;
                 pf_d = 0;
                 pf_x += group_step;
-                --pf_left;
+                if (--pf_left == gap_left) pf_x += gap_bytes;
             }
         }
     };
@@ -479,7 +485,8 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
     // ---- epilogue: BN affine + ReLU (forward), or accumulate + fused ReLU/BN backward (dgrad) ----
     __syncthreads();
     float* ch = reinterpret_cast<float*>(lds);
-    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid, inv, p.relu, p.raw_from);
+    epi_stage_channels<BM, NT>(ch, p.scale, p.shift, p.mask_scale, m0, p.M, tid, inv, p.relu, p.raw_from, p.row_split,
+                               p.row_gap);
     __syncthreads();
     EpiArgs e;
     e.y = p.y;
@@ -491,6 +498,8 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
     e.relu = p.relu;
     e.accumulate = p.accumulate;
     e.amax = p.y_amax;
+    e.row_split = p.row_split;
+    e.row_gap = p.row_gap;
     uint32_t yoff[TN], moff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {

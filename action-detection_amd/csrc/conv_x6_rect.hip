@@ -98,7 +98,8 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         a.pad_h = 0;
         a.pad_w = 0;
         a.relu = 0;
-        a.raw_from = 0x7fffffff;
+        a.raw_from = a.row_split = 0x7fffffff;
+        a.row_gap = a.k_split = a.k_gap = 0;
         a.accumulate = accumulate;
         a.mask_y = mask_scale ? mask_y : nullptr;
         a.mask_scale = mask_y ? mask_scale : nullptr;
@@ -168,7 +169,8 @@ extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const
     a.pad_h = pad_h;
     a.pad_w = pad_w;
     a.relu = relu;
-    a.raw_from = 0x7fffffff;
+    a.raw_from = a.row_split = 0x7fffffff;
+    a.row_gap = a.k_split = a.k_gap = 0;
     a.accumulate = 0;
     a.mask_y = nullptr;
     a.mask_scale = nullptr;

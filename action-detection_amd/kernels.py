@@ -167,7 +167,7 @@ def pack_weights(w, transposed, out=None):
 
 def pack_weights_multi(entries, x6=False):
     """entries: list of (weights, mode) with weights = [w], [wA, wB] (fused pair) or -- x6 only -- [wA, wB, wC]
-    (concatenated output channels).
+    ... [wA, wB, wC, wD] (concatenated output channels).
 
     Returns one packed tensor per entry (views of a single flat buffer); ceil(len / 40) launches in total.
     x6=True: scale + split every weight into two f16 planes for the conv_x6 kernels (modes 0/1, ksize 1/3 only).
@@ -194,11 +194,16 @@ def pack_weights_multi(entries, x6=False):
     a_mode = ia([m for _, m in entries])
     a_split = ia([ws[0].shape[0] if len(ws) > 1 else co for (ws, _), co in zip(entries, couts)])
     if x6:
+        assert all(len(ws) <= 4 for ws, _ in entries)
         w2 = _ptr_array([ws[2] if len(ws) > 2 else None for ws, _ in entries])
-        a_split2 = ia([ws[0].shape[0] + ws[1].shape[0] if len(ws) > 2 else co for (ws, _), co in zip(entries, couts)])
+        w3 = _ptr_array([ws[3] if len(ws) > 3 else None for ws, _ in entries])
+        cum = lambda ws, k: sum(w.shape[0] for w in ws[:k])   # noqa: E731
+        a_split2 = ia([cum(ws, 2) if len(ws) > 2 else co for (ws, _), co in zip(entries, couts)])
+        a_split3 = ia([cum(ws, 3) if len(ws) > 3 else co for (ws, _), co in zip(entries, couts)])
         lib.call("ssn_conv_x6_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(w2),
-                 ctypes.addressof(po), ctypes.addressof(a_cout), ctypes.addressof(a_cin), ctypes.addressof(a_ks),
-                 ctypes.addressof(a_mode), ctypes.addressof(a_split), ctypes.addressof(a_split2), _stream(lib, first))
+                 ctypes.addressof(w3), ctypes.addressof(po), ctypes.addressof(a_cout), ctypes.addressof(a_cin),
+                 ctypes.addressof(a_ks), ctypes.addressof(a_mode), ctypes.addressof(a_split), ctypes.addressof(a_split2),
+                 ctypes.addressof(a_split3), _stream(lib, first))
     else:
         assert all(len(ws) <= 2 for ws, _ in entries)
         lib.call("ssn_conv_pack_weights_multi", n, ctypes.addressof(w0), ctypes.addressof(w1), ctypes.addressof(po),
@@ -233,9 +238,10 @@ def guarded_empty(shape, device, guard_floats=64):
     return flat[guard_floats:].view(*shape)
 
 
-def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1, raw_from=0):
+def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, tile_cfg=-1, raw_from=0, row_split=0, row_gap=0):
     """conv_fwd on the f16 matrix cores (2-way split, fp32-class accuracy).  w_packed: pack_weights_multi(x6=True).
-    raw_from > 0: output channels >= raw_from take neither the affine nor the ReLU."""
+    raw_from > 0: output channels >= raw_from take neither the affine nor the ReLU.  row_gap > 0: output channels >= row_split
+    are stored row_gap channels further up y's tensor (y: the ChanSlice of the first row_split channels' home)."""
     lib = _check(x, w_packed, scale, shift, y)
     h, wd = x.hw
     ho, wo = y.hw
@@ -243,7 +249,7 @@ def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, til
     xa = _amax_in(x)
     lib.call("ssn_conv_x6_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
              x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), guard_bytes(x), tile_cfg,
-             _p(xa), _amax_out(y), int(raw_from), _stream(lib, w_packed))
+             _p(xa), _amax_out(y), int(raw_from), int(row_split), int(row_gap), _stream(lib, w_packed))
 
 
 def pack_weights_rect(w):
@@ -267,8 +273,9 @@ def conv_x6_fwd_rect(x, w_packed, scale, shift, y, kh, kw, pad_h, pad_w, relu=Tr
              _p(xa), _amax_out(y), _stream(lib, w_packed))
 
 
-def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
-    """Stride-1 conv_dgrad on the f16 matrix cores.  wt: pack_weights_multi([... mode 1], x6=True)."""
+def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None, k_split=0, k_gap=0):
+    """Stride-1 conv_dgrad on the f16 matrix cores.  wt: pack_weights_multi([... mode 1], x6=True).
+    k_gap > 0: channels >= k_split of dy sit k_gap channels further up its tensor (dy.c counts the channels read)."""
     lib = _check(dy, wt, dx, mask_y, mask_scale)
     assert wt.numel() >= packed_floats(dy.c, dx.c, ksize, True, True)
     ho, wo = dy.hw
@@ -277,7 +284,7 @@ def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, 
     lib.call("ssn_conv_x6_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, ksize, pad, int(accumulate), _p(mask_y),
              mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), guard_bytes(dy), tile_cfg,
-             _p(ga), _amax_out(dx), _stream(lib, wt))
+             _p(ga), _amax_out(dx), int(k_split), int(k_gap), _stream(lib, wt))
 
 
 def pack_dgrad_s2(w):
@@ -347,15 +354,16 @@ def wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg=-1):
     return int(_lib.get_lib().cdll.ssn_conv_wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg))
 
 
-def conv_wgrad_x6(g, x, dw, db, ksize, pad, workspace, tile_cfg=-1):
-    """conv_wgrad on the f16 matrix cores (stride 1, same size).  x needs >= 256 readable bytes in front of it."""
+def conv_wgrad_x6(g, x, dw, db, ksize, pad, workspace, tile_cfg=-1, g_row_split=0, g_row_gap=0):
+    """conv_wgrad on the f16 matrix cores (stride 1, same size).  x needs >= 256 readable bytes in front of it.
+    g_row_gap > 0: rows >= g_row_split of g sit g_row_gap channels further up its tensor (g.c counts the rows read)."""
     lib = _check(g, x, dw, db, workspace)
     h, w = x.hw
     assert g.hw == x.hw
     ga, xa = _amax_in(g), _amax_in(x)
     lib.call("ssn_conv_wgrad_x6", _p(g), _p(x), _p(dw), _p(db), x.n, x.c, h, w, x.img_stride, g.c, g.img_stride,
              ksize, pad, guard_bytes(x), _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg,
-             _p(ga), _p(xa), _stream(lib, dw))
+             _p(ga), _p(xa), int(g_row_split), int(g_row_gap), _stream(lib, dw))
 
 
 def pool_fwd(kind, x, y, argmax, ksize, stride, pad):

@@ -120,21 +120,27 @@ int ssn_tensor_amax(const float* x, long n, float* slot, hipStream_t stream);
 long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int transposed);
 void ssn_conv_x6_debug_trace(unsigned long long* per_block_8_words); /* tooling only; NULL = off */
 void ssn_conv_x6_debug_flags(int flags);   /* tooling only (tools/ablate_x6.py); 0 = normal operation */
-/* (w0 / w1 / w2, split, split2: up to three sources per entry -- output channels [0, split) from w0, [split, split2)
- * from w1, the rest from w2; split = split2 = cout for a single source.  raw_from (ssn_conv_x6_fwd, > 0): output
- * channels >= raw_from take neither the affine nor the ReLU -- the bias-free pool projection that shares a launch
- * with the reduce pair of its Inception block.) */
+/* The fused launch on an Inception block input (1x1 branch + reduce pair + pool projection = ONE convolution):
+ *  - w0..w3, split..split3: up to four weight sources per entry -- output channels [0, split) from w0, [split, split2)
+ *    from w1, [split2, split3) from w2, the rest from w3; all splits = cout for a single source;
+ *  - raw_from (fwd, > 0): output channels >= raw_from take neither the affine nor the ReLU (the bias-free projection);
+ *  - row_split / row_gap (fwd; multiples of 32, 0 = none): output channels >= row_split are stored row_gap channels further
+ *    up y's tensor (the 1x1 branch goes to the head of the block output, the rest behind the block's own channels);
+ *  - k_split / k_gap (dgrad; multiples of 16): the same displacement on the channel axis of dy;
+ *  - g_row_split / g_row_gap (wgrad): ... and on the rows of g. */
 int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1, const float* const* w2,
-                                   float* const* out, const int* cout, const int* cin, const int* ksize,
-                                   const int* mode, const int* split, const int* split2, hipStream_t stream);
+                                   const float* const* w3, float* const* out, const int* cout, const int* cin,
+                                   const int* ksize, const int* mode, const int* split, const int* split2,
+                                   const int* split3, hipStream_t stream);
 int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
                     int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo, long y_img_stride,
                     int ksize, int stride, int pad, int relu, int x_guard_bytes, int tile_cfg, const float* x_amax,
-                    float* y_amax, int raw_from, hipStream_t stream);
+                    float* y_amax, int raw_from, int row_split, int row_gap, hipStream_t stream);
 int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                       long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                       int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
-                      int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, hipStream_t stream);
+                      int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, int k_split, int k_gap,
+                      hipStream_t stream);
 
 /* Rectangular taps (csrc/conv_x6_rect.hip): the forward convolutions of the Inception-v3 backbone the reference's
  * tester runs on ActivityNet (ssn_models.py:133-139): kh x kw in {5x5, 1x7, 7x1, 1x3, 3x1}, stride 1, per-axis
@@ -165,7 +171,7 @@ long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int H, int W, i
 int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                       long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
                       void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
-                      hipStream_t stream);
+                      int g_row_split, int g_row_gap, hipStream_t stream);
 /* second pass of both wgrad kernels: dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] */
 int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
 

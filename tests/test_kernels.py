@@ -755,3 +755,50 @@ def test_conv_split_three_sources_and_raw_rows(backend):
     K.conv_x6_dgrad(K.full(backend.put(gy)), wt, K.full(dx), 1, 0, False)
     dref = torch.nn.grad.conv2d_input(x.shape, torch.cat(ws).double(), gy.double())
     assert rel_err(dx, dref) < 5e-5
+
+
+def test_conv_split_block_input_launch(backend):
+    """The ONE launch on an Inception block input: 1x1 branch + reduce pair + pool projection as a convolution with four
+    weight sources whose first rows live at the head of the block-output tensor and whose other rows behind the block's own
+    channels (row gap in forward, channel gap in dgrad, row gap on G in wgrad); the last rows raw."""
+    g = torch.Generator().manual_seed(95)
+    n, cin, h = (3, 192, 28) if backend.is_gpu else (1, 32, 6)
+    c1, ca, cb, cp, cblk = (64, 64, 64, 32, 256) if backend.is_gpu else (32, 32, 32, 32, 160)
+    m, cr = c1 + ca + cb + cp, ca + cb + cp
+    gapc = cblk - c1
+    x = torch.randn(n, cin, h, h, generator=g)
+    ws = [torch.randn(c, cin, 1, 1, generator=g) * 0.1 for c in (c1, ca, cb, cp)]
+    wcat = torch.cat(ws).double()
+    scale, shift = torch.rand(m, generator=g) + 0.5, torch.randn(m, generator=g) * 0.2
+    ref = F.conv2d(x.double(), wcat)
+    aff = c1 + ca + cb
+    want = ref.clone()
+    want[:, :aff] = torch.relu(ref[:, :aff] * scale[:aff].double().view(1, -1, 1, 1) + shift[:aff].double().view(1, -1, 1, 1))
+    wd = [backend.put(w) for w in ws]
+    wp, wt = K.pack_weights_multi([(wd, 0), (wd, 1)], x6=True)
+    xd = K.guarded_empty(x.shape, backend.put(torch.zeros(1)).device)
+    xd.copy_(backend.put(x))
+    for tile in (-1, 3, 2):
+        t = backend.put(torch.full((n, cblk + cr, h, h), 7.0))
+        tscale = torch.full((cblk + cr,), float("nan"))       # per-CHANNEL scales of the wide tensor; shifts go by row
+        tscale[:c1], tscale[cblk:] = scale[:c1], scale[c1:]
+        K.conv_x6_fwd(K.full(xd), wp, backend.put(tscale), backend.put(shift), K.ChanSlice(t, 0, m), 1, 1, 0, True, tile,
+                      raw_from=aff, row_split=c1, row_gap=gapc)
+        assert rel_err(t[:, :c1], want[:, :c1]) < 2e-5 and rel_err(t[:, cblk:], want[:, c1:]) < 2e-5, tile
+        assert (t[:, c1:cblk] == 7.0).all(), "wrote into the block's other branches"
+    # dgrad: the gradient tensor has the same layout
+    gy = torch.randn(n, m, h, h, generator=g)
+    gt = K.guarded_empty((n, cblk + cr, h, h), xd.device)
+    gt.fill_(float("nan"))                      # the channels between the two ranges must never be read
+    gt[:, :c1] = backend.put(gy[:, :c1])
+    gt[:, cblk:] = backend.put(gy[:, c1:])
+    K.attach_amax(gt, K.tensor_amax(backend.put(gy)))
+    dx = backend.put(torch.zeros(n, cin, h, h))
+    K.conv_x6_dgrad(K.ChanSlice(gt, 0, m), wt, K.full(dx), 1, 0, False, k_split=c1, k_gap=gapc)
+    assert rel_err(dx, torch.nn.grad.conv2d_input(x.shape, wcat, gy.double())) < 5e-5
+    # wgrad
+    dw, db = backend.put(torch.empty(m, cin, 1, 1)), backend.put(torch.empty(m))
+    wsz = backend.put(torch.empty(K.wgrad_x6_workspace_bytes(n, cin, m, h, h, 1, -1) // 4))
+    K.conv_wgrad_x6(K.ChanSlice(gt, 0, m), K.full(xd), dw, db, 1, 0, wsz, -1, g_row_split=c1, g_row_gap=gapc)
+    assert rel_err(dw, torch.nn.grad.conv2d_weight(x.double(), wcat.shape, gy.double())) < 5e-5
+    assert rel_err(db, gy.double().sum(dim=(0, 2, 3))) < 5e-5
