@@ -25,7 +25,8 @@ out_path = os.path.join(ROOT, "action-detection_amd", "tuned_tiles.json")
 shapes = {}
 for cin0 in (3, 10):
     # the executor's launch plan (fused reduce convolutions included), not the raw manifest
-    plan, t = BNInception(in_channels=cin0)._plan(torch.zeros(1, cin0, 224, 224))
+    # (.eval(): the frozen-BatchNorm plan of SSN's default bn_mode -- with the fused block-input launches)
+    plan, t = BNInception(in_channels=cin0).eval()._plan(torch.zeros(1, cin0, 224, 224))
     for op in plan:
         if op["kind"] == "conv":
             shapes[(op["cin"], op["cout"], op["k"], op["s"], op["p"], t[op["src"]][1], t[op["dst"]][1])] = \
