@@ -85,6 +85,9 @@ _SIGS = {
     "ssn_sumsq": "plpipp",
     "ssn_scale": "plpfp",
     "ssn_add_inplace": "pplp",
+    "ssn_space_to_depth2": "ppiiiipp",
+    "ssn_s2d_weights": "ppiiip",
+    "ssn_s2d_weights_bwd": "ppiiip",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double,
        "u": ctypes.c_ulonglong}

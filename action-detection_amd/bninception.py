@@ -135,6 +135,8 @@ class BNInception(nn.Module):
         self.wgrad_x6 = True          # weight gradients on the split kernel too (False: exact-f32 MFMA wgrad; bisecting aid)
         # the pool projection of a block rides in the launch of its reduce pair (see _move_avg_pools); False = own launch
         self.merge_projection = os.environ.get("SSN_MERGE_PROJ", "1") != "0"
+        # the 7x7 / stride-2 stem through its space-to-depth form on the split kernels (False: exact-f32 MFMA kernel)
+        self.stem_s2d = os.environ.get("SSN_STEM_S2D", "1") != "0"
         # average-pool branches: pool BEHIND the 1x1 projection (see _move_avg_pools); False = the manifest's order
         self.pool_after_projection = os.environ.get("SSN_POOL_ORDER", "") != "manifest"
 
@@ -445,13 +447,21 @@ class BNInception(nn.Module):
         K.bn_fold_multi(*fold)
         # all forward weight operands in two launches (fused pairs read both sources directly: no concatenation)
         conv_ops = [op for op in plan if op["kind"] == "conv"]
-        for op in conv_ops:      # which matrix path each layer takes (bf16 3-way split, or exact f32 MFMA)
+        for op in conv_ops:      # the stem: 7x7 / stride 2 / pad 3 on the caller's frames, even size
+            op["s2d"] = (self.conv_precision == "split" and self.stem_s2d and op["src"] == "data" and len(op["lids"]) == 1
+                         and (op["k"], op["s"], op["p"]) == (7, 2, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                         and not op.get("raw"))
+        for op in conv_ops:      # which matrix path each layer takes (f16 2-way split, or exact f32 MFMA)
             op["x6"] = (self.conv_precision == "split" and op["k"] in (1, 3)
                         and ("raw_from" in op or "row_gap" in op      # (raw rows / displaced rows: split kernel only)
                              or x6_wins("fwd", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
         packed_fwd = {}
+        for op in conv_ops:
+            if op["s2d"]:
+                acts["data_s2d"] = K.space_to_depth2(x)
+                packed_fwd[op["lids"][0]] = K.pack_weights_rect(K.s2d_weights(getattr(self, op["lids"][0]).weight.detach()))
         for x6 in (False, True):
-            ops = [op for op in conv_ops if op["x6"] == x6]
+            ops = [op for op in conv_ops if op["x6"] == x6 and not op["s2d"]]
             packed_fwd.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
                 [([getattr(self, lid).weight.detach() for lid in op["lids"]], 0) for op in ops], x6=x6)))
 
@@ -516,7 +526,12 @@ class BNInception(nn.Module):
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
                 src_slice = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 dst_slice = ChanSlice(get(op["dst"]), op["dst_c0"], cout)
-                if op["x6"]:
+                if op["s2d"]:
+                    xs = acts["data_s2d"]
+                    self._timed("conv_fwd_x6", op["lids"][0], flops,
+                                lambda: K.conv_x6_fwd_rect(full(xs), wp, scale, shift, dst_slice, 4, 4, 2, 2, True,
+                                                           tuned_tile("fwd6s2d", n, cin, cout, k, s, hin)))
+                elif op["x6"]:
                     self._timed("conv_fwd_x6", op["lids"][0], flops,
                                 lambda: K.conv_x6_fwd(src_slice, wp, scale, shift, dst_slice, k, s, p,
                                                       not raw, tuned_tile("fwd6", n, cin, cout, k, s, hin),
@@ -610,6 +625,10 @@ class BNInception(nn.Module):
         for op in plan:
             if op["kind"] == "conv":
                 hin, win = shapes[op["src"]][1], shapes[op["src"]][2]
+                if op.get("s2d"):
+                    ws_bytes = max(ws_bytes, K.wgrad_x6_workspace_bytes(
+                        n, 4 * op["cin"], op["cout"], hin // 2, win // 2, 4,
+                        tuned_tile("wgrad6s2d", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
                 x6 = (self.conv_precision == "split" and op["src"] != "data"
                       and K.wgrad_x6_supported(op["k"], op["s"], op["p"], hin, win)
                       and ("row_gap" in op or (self.wgrad_x6 and x6_wins("wgrad", op["cin"], op["cout"], op["k"], op["s"], hin))))
@@ -754,7 +773,17 @@ class BNInception(nn.Module):
                 hin = shapes[op["src"]][1]
                 flops = 2.0 * n * ho * ho * cout * cin * k * k
                 xin = ChanSlice(acts[op["src"]], op["src_c0"], cin)
-                if wg_x6[lids[0]]:
+                if op.get("s2d"):
+                    # the stem in its space-to-depth form: 4x4-tap weight gradient on the split kernel, gathered back into
+                    # the 7x7 layout of the parameter (the bias gradient comes with it)
+                    xs2 = full(acts["data_s2d"])
+                    dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
+                    wcfg = tuned_tile("wgrad6s2d", n, cin, cout, k, s, hin)
+
+                    def run_wgrad():
+                        K.conv_wgrad_x6(g, xs2, dw2, db, 4, 2, ws, wcfg)
+                        K.s2d_weights_bwd(dw2, dw)
+                elif wg_x6[lids[0]]:
                     wcfg = tuned_tile("wgrad6", n, cin, cout, k, s, hin)
                     run_wgrad = lambda: K.conv_wgrad_x6(g, xin, dw, db, k, p, ws, wcfg,   # noqa: E731
                                                         g_row_split=op.get("row_split", 0), g_row_gap=op.get("row_gap", 0))
@@ -773,7 +802,7 @@ class BNInception(nn.Module):
                     def run_wgrad():
                         inner_wgrad()
                         K.channel_sum(g_pre, db_proj, ws)
-                wfam = "conv_wgrad_x6" if wg_x6[lids[0]] else "conv_wgrad_f32"
+                wfam = "conv_wgrad_x6" if (wg_x6[lids[0]] or op.get("s2d")) else "conv_wgrad_f32"
                 if use_side:
                     ready = torch.cuda.Event()
                     ready.record(main)            # the output gradient of this layer is final here

@@ -38,6 +38,7 @@ struct WgX6Args {
     const float* g_amax;   // amax slots of the tensors g and x belong to (required)
     const float* x_amax;
     int g_row_split, g_row_gap;   // rows m >= g_row_split of G sit g_row_gap channels further up its tensor (fused block-input launch)
+    uint32_t guard;               // readable bytes in front of x the shifted taps may reach into (multiple of 256)
     int N, Cin, H, W;
     long x_img_stride;
     int M;
@@ -56,7 +57,7 @@ struct WgX6Args {
 constexpr int CP = 16;          // pixels per chunk = one f16 MFMA k-step
 constexpr int ROW_DW = 8;       // LDS row of one plane: 16 f16 = 32 B
 constexpr uint32_t OOB = 0x80000000u;
-constexpr uint32_t GUARD = 256u;
+constexpr uint32_t GUARD = 256u;   // the default (3x3 taps on rows of <= 63 pixels); wider reaches use a larger multiple
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -118,10 +119,10 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
         const int tr = tap / KS, ts = tap - tr * KS;
         b_dh[i] = tr - p.pad;
         b_dw[i] = ts - p.pad;
-        b_const[i] = (r < BN && kk < p.K) ? (uint32_t)((c * HW + b_dh[i] * p.W + b_dw[i]) * 4 + (int)GUARD) : OOB;
+        b_const[i] = (r < BN && kk < p.K) ? (uint32_t)((c * HW + b_dh[i] * p.W + b_dw[i]) * 4 + (int)p.guard) : OOB;
     }
     const __amdgpu_buffer_rsrc_t grsrc = wg_rsrc(p.g, p.g_bytes);
-    const __amdgpu_buffer_rsrc_t xrsrc = wg_rsrc(reinterpret_cast<const char*>(p.x) - GUARD, p.x_bytes + GUARD);
+    const __amdgpu_buffer_rsrc_t xrsrc = wg_rsrc(reinterpret_cast<const char*>(p.x) - p.guard, p.x_bytes + p.guard);
 
     struct Staged {
         u32x4 a[NAR], b[NBR];
@@ -355,6 +356,16 @@ int launch_wgx6_tile(WgX6Args& a, int cfg, hipStream_t stream) {
     return SSN_ERR_ARG;
 }
 
+// 4x4 taps (the space-to-depth form of the 7x7 / stride-2 stem convolution, 64 x 192 weights): a few small tiles only
+int launch_wgx6_tile4(WgX6Args& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_wgx6<4, 2, 2, 1, 1>(a, stream);
+        case 3: return launch_wgx6<4, 2, 2, 1, 2>(a, stream);
+        case 6: return launch_wgx6<4, 2, 2, 2, 1>(a, stream);
+        default: return launch_wgx6<4, 1, 4, 2, 1>(a, stream);   // 5: 64 x 128, waves along kk
+    }
+}
+
 int pick_tile(int M, int K) {
     double best = 1e300;
     int bc = 0;
@@ -390,7 +401,8 @@ extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, 
 
 extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int H, int W, int ksize, int tile_cfg) {
     const int K = Cin * ksize * ksize;
-    const int cfg = (tile_cfg >= 0 && tile_cfg < NCFG) ? tile_cfg : pick_tile(Cout, K);
+    int cfg = (tile_cfg >= 0 && tile_cfg < NCFG) ? tile_cfg : pick_tile(Cout, K);
+    if (ksize == 4 && cfg != 0 && cfg != 3 && cfg != 6) cfg = 5;      // the tiles instantiated for 4x4 taps
     int splits, cps;
     plan(Cout, K, (long)N * ((H * W + 3) / 4 * 4), cfg, &splits, &cps);
     return (long)splits * Cout * (K + 1) * (long)sizeof(float);
@@ -404,10 +416,14 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
                                  int g_row_split, int g_row_gap, hipStream_t stream) {
     SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
     SSN_CHECK_ARG(g_amax && x_amax, "conv wgrad x6: the amax slots of both operand tensors are required");
-    SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv wgrad x6: ksize %d unsupported", ksize);
-    SSN_CHECK_ARG(2 * pad == ksize - 1, "conv wgrad x6: only same-size stride-1 convolutions (pad %d, ksize %d)", pad, ksize);
-    SSN_CHECK_ARG((pad * W + pad) * 4 <= (int)GUARD, "conv wgrad x6: image rows of %d pixels are too wide for the guard", W);
-    SSN_CHECK_ARG(x_guard_bytes >= (int)GUARD, "conv wgrad x6: needs %u readable bytes in front of x (got %d)", GUARD,
+    SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 4, "conv wgrad x6: ksize %d unsupported", ksize);
+    // same-size stride-1 convolutions; ksize 4 = the space-to-depth stem: taps -pad .. ksize-1-pad with pad = 2 (one tap less
+    // behind the pixel than in front of it)
+    SSN_CHECK_ARG(2 * pad == ksize - 1 || (ksize == 4 && pad == 2),
+                  "conv wgrad x6: only same-size stride-1 convolutions (pad %d, ksize %d)", pad, ksize);
+    const uint32_t guard = (uint32_t)(((pad * W + pad) * 4 + (int)GUARD - 1) / (int)GUARD * (int)GUARD);
+    SSN_CHECK_ARG(x_guard_bytes >= (int)(guard ? guard : GUARD),
+                  "conv wgrad x6: needs %u readable bytes in front of x (got %d): the taps in front of a pixel reach that far", guard,
                   x_guard_bytes);
     WgX6Args a;
     a.g = g;
@@ -415,6 +431,7 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.part = (float*)workspace;
     a.g_amax = g_amax;
     a.x_amax = x_amax;
+    a.guard = guard ? guard : GUARD;
     SSN_CHECK_ARG(g_row_gap >= 0 && (g_row_gap == 0 || (g_row_split > 0 && g_row_split < Cout)), "conv wgrad x6: bad row split");
     a.g_row_split = g_row_gap ? g_row_split : 0x7fffffff;
     a.g_row_gap = g_row_gap;
@@ -438,14 +455,16 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.g_bytes = (uint32_t)gb;
     a.x_bytes = (uint32_t)xb;
     SSN_CHECK_ARG(tile_cfg < NCFG, "conv wgrad x6: unknown tile config %d", tile_cfg);
-    const int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, a.K);
+    int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, a.K);
+    if (ksize == 4 && cfg != 0 && cfg != 3 && cfg != 6) cfg = 5;      // the tiles instantiated for 4x4 taps
     plan(Cout, a.K, a.P, cfg, &a.splits, &a.chunks_per_split);
     const long need = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
     if (ws_bytes < need) {
         ssn_set_error("conv wgrad x6: workspace %ld < %ld bytes", ws_bytes, need);
         return SSN_ERR_WORKSPACE;
     }
-    const int rc = ksize == 1 ? launch_wgx6_tile<1>(a, cfg, stream) : launch_wgx6_tile<3>(a, cfg, stream);
+    const int rc = ksize == 1 ? launch_wgx6_tile<1>(a, cfg, stream)
+                              : (ksize == 3 ? launch_wgx6_tile<3>(a, cfg, stream) : launch_wgx6_tile4(a, cfg, stream));
     if (rc != SSN_OK) return rc;
     return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
 }

@@ -147,7 +147,10 @@ extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const
                                     int tile_cfg, const float* x_amax, float* y_amax, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv x6 rect: null pointer");
     SSN_CHECK_ARG(x_amax, "conv x6 rect: the source tensor's amax slot is required");
-    SSN_CHECK_ARG(Ho == H + 2 * pad_h - kh + 1 && Wo == W + 2 * pad_w - kw + 1, "conv x6 rect: output %dx%d does not match", Ho, Wo);
+    // (an output grid SHORTER than H + 2 pad - k + 1 = less padding behind the image than in front of it: the space-to-depth
+    //  form of the 7x7 / stride-2 stem is a 4x4 convolution with 2 padding pixels in front and 1 behind)
+    SSN_CHECK_ARG(Ho <= H + 2 * pad_h - kh + 1 && Wo <= W + 2 * pad_w - kw + 1 && Ho >= H + pad_h - kh + 1 && Wo >= W + pad_w - kw + 1,
+                  "conv x6 rect: output %dx%d does not match", Ho, Wo);
     X6Args a;
     a.x = x;
     a.ap = (const uint32_t*)w_packed;
@@ -191,6 +194,7 @@ extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const
     a.a_bytes = (uint32_t)ab;
     a.y_bytes = (uint32_t)yb;
     a.mask_bytes = 0;
+    if (kh == 4 && kw == 4) return launch_rect<4, 4>(a, tile_cfg, stream);
     if (kh == 5 && kw == 5) return launch_rect<5, 5>(a, tile_cfg, stream);
     if (kh == 1 && kw == 7) return launch_rect<1, 7>(a, tile_cfg, stream);
     if (kh == 7 && kw == 1) return launch_rect<7, 1>(a, tile_cfg, stream);

@@ -246,6 +246,49 @@ __global__ __launch_bounds__(256) void scale_kernel(float* x, long n, const floa
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= c;
 }
 
+// ---- space-to-depth view of the stem (7x7 / stride 2 / pad 3 on c input channels = 4x4 / stride 1 on 4c channels) ----
+// xs[n][(c*2 + a)*2 + b][h'][w'] = x[n][c][2h' + a][2w' + b]; amax emitted (xs is an operand of the split kernels)
+__global__ __launch_bounds__(256) void s2d_kernel(const float* x, float* xs, long total, int C, int H2, int W2,
+                                                   FastDiv div_chw, FastDiv div_hw, FastDiv div_w, float* amax) {
+    float vmax = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {   // one output pixel pair row
+        uint32_t n, rem, c4, hw, h2, w2;
+        fd_divmod((uint32_t)idx, div_chw, n, rem);
+        fd_divmod(rem, div_hw, c4, hw);
+        fd_divmod(hw, div_w, h2, w2);
+        const int c = (int)c4 >> 2, a = ((int)c4 >> 1) & 1, b = (int)c4 & 1;
+        const float v = x[(((long)n * C + c) * (2 * H2) + (2 * h2 + a)) * (2 * W2) + 2 * w2 + b];
+        xs[idx] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+    }
+    amax_emit(amax, vmax);
+}
+// w2[co][(c*2+a)*2+b][r'][s'] = w[co][c][2r'+a-1][2s'+b-1] (0 outside the 7x7 window), and its transpose for the gradient:
+// dw[co][c][r][s] = dw2[co][(c*2 + a)*2 + b][r'][s'] with a = (r + 1) & 1, r' = (r + 1) >> 1 (likewise b, s')
+__global__ __launch_bounds__(256) void s2d_weight_kernel(const float* w, float* w2, int total, int C, int k) {
+    const int k2 = (k + 1) / 2;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        int t = idx;
+        const int s2 = t % k2; t /= k2;
+        const int r2 = t % k2; t /= k2;
+        const int c4 = t % (4 * C); t /= 4 * C;
+        const int co = t, c = c4 >> 2, a = (c4 >> 1) & 1, b = c4 & 1;
+        const int r = 2 * r2 + a - 1, s = 2 * s2 + b - 1;
+        w2[idx] = (r >= 0 && r < k && s >= 0 && s < k) ? w[((co * C + c) * k + r) * k + s] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void s2d_weight_bwd_kernel(const float* dw2, float* dw, int total, int C, int k) {
+    const int k2 = (k + 1) / 2;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        int t = idx;
+        const int s = t % k; t /= k;
+        const int r = t % k; t /= k;
+        const int c = t % C; t /= C;
+        const int co = t, a = (r + 1) & 1, r2 = (r + 1) >> 1, b = (s + 1) & 1, s2 = (s + 1) >> 1;
+        dw[idx] = dw2[((co * 4 * C + (c * 2 + a) * 2 + b) * k2 + r2) * k2 + s2];
+    }
+}
+
 // dst += src (the flat conv-gradient buffers of the sub-batches of one backward, see bninception.py: chunked execution)
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* dst, const float* src, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] += src[i];
@@ -404,6 +447,36 @@ extern "C" int ssn_sumsq(const float* x, long n, float* out, int accumulate, flo
 }
 
 // x *= coef  (coef read from device memory when coef_dev != nullptr, e.g. a clip coefficient)
+// Space-to-depth of the stem input: x [N][C][H][W] (H, W even) -> xs [N][4C][H/2][W/2]; with the weights re-indexed by
+// ssn_s2d_weights (k odd, stride 2, pad (k-1)/2 -> (k+1)/2 taps, stride 1, 2 padding pixels in front and 1 behind for k = 7)
+// the stem convolution of model_zoo.BNInception (conv1_7x7_s2, reached from /root/reference/ssn_models.py:266) runs on the
+// split kernels: y = ssn_conv_x6_fwd_rect(xs, pack(w2), 4x4 taps), dw2 = ssn_conv_wgrad_x6(ksize 4), dw = ssn_s2d_weights_bwd(dw2).
+extern "C" int ssn_space_to_depth2(const float* x, float* xs, int N, int C, int H, int W, float* xs_amax, hipStream_t stream) {
+    SSN_CHECK_ARG(x && xs && N >= 1 && C >= 1 && H % 2 == 0 && W % 2 == 0, "space_to_depth2: bad arguments");
+    const long total = (long)N * C * H * W;
+    SSN_CHECK_ARG(total < (1l << 31), "space_to_depth2: tensor too large");
+    const int H2 = H / 2, W2 = W / 2;
+    hipLaunchKernelGGL(s2d_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, stream, x, xs, total, C, H2, W2,
+                       make_fastdiv((uint32_t)(4 * C * H2 * W2)), make_fastdiv((uint32_t)(H2 * W2)), make_fastdiv((uint32_t)W2),
+                       xs_amax);
+    SSN_CHECK_LAUNCH("space_to_depth2");
+    return SSN_OK;
+}
+extern "C" int ssn_s2d_weights(const float* w, float* w2, int Cout, int C, int k, hipStream_t stream) {
+    SSN_CHECK_ARG(w && w2 && Cout >= 1 && C >= 1 && k % 2 == 1, "s2d_weights: bad arguments");
+    const int k2 = (k + 1) / 2, total = Cout * 4 * C * k2 * k2;
+    hipLaunchKernelGGL(s2d_weight_kernel, dim3(grid_for(total)), dim3(256), 0, stream, w, w2, total, C, k);
+    SSN_CHECK_LAUNCH("s2d_weights");
+    return SSN_OK;
+}
+extern "C" int ssn_s2d_weights_bwd(const float* dw2, float* dw, int Cout, int C, int k, hipStream_t stream) {
+    SSN_CHECK_ARG(dw2 && dw && Cout >= 1 && C >= 1 && k % 2 == 1, "s2d_weights_bwd: bad arguments");
+    const int total = Cout * C * k * k;
+    hipLaunchKernelGGL(s2d_weight_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dw2, dw, total, C, k);
+    SSN_CHECK_LAUNCH("s2d_weights_bwd");
+    return SSN_OK;
+}
+
 extern "C" int ssn_add_inplace(float* dst, const float* src, long n, hipStream_t stream) {
     SSN_CHECK_ARG(dst && src && n >= 0, "add_inplace: bad arguments");
     if (n == 0) return SSN_OK;

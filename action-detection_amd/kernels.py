@@ -350,6 +350,31 @@ def wgrad_x6_supported(ksize, stride, pad, h, w):
     return ksize in (1, 3) and stride == 1 and 2 * pad == ksize - 1 and (pad * w + pad) * 4 <= 256
 
 
+def space_to_depth2(x, guard_floats=256):
+    """x [N, C, H, W] -> xs [N, 4C, H/2, W/2] (tracked: amax slot attached; `guard_floats` readable floats in front)."""
+    lib = _check(x)
+    n, c, h, w = x.shape
+    xs = attach_amax(guarded_empty((n, 4 * c, h // 2, w // 2), x.device, guard_floats))
+    lib.call("ssn_space_to_depth2", _p(x), _p(xs), n, c, h, w, _amax_out(xs), _stream(lib, x))
+    return xs
+
+
+def s2d_weights(w):
+    """[Cout, C, k, k] (k odd, stride-2 layer) -> [Cout, 4C, (k+1)/2, (k+1)/2] for the space-to-depth input."""
+    lib = _check(w)
+    cout, c, k, _ = w.shape
+    w2 = torch.empty((cout, 4 * c, (k + 1) // 2, (k + 1) // 2), device=w.device, dtype=torch.float32)
+    lib.call("ssn_s2d_weights", _p(w.contiguous()), _p(w2), cout, c, k, _stream(lib, w))
+    return w2
+
+
+def s2d_weights_bwd(dw2, dw):
+    """Gradient of s2d_weights: gathers dw [Cout, C, k, k] out of dw2 [Cout, 4C, (k+1)/2, (k+1)/2]."""
+    lib = _check(dw2, dw)
+    cout, c, k, _ = dw.shape
+    lib.call("ssn_s2d_weights_bwd", _p(dw2), _p(dw), cout, c, k, _stream(lib, dw))
+
+
 def wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg=-1):
     return int(_lib.get_lib().cdll.ssn_conv_wgrad_x6_workspace_bytes(n, cin, cout, h, w, ksize, tile_cfg))
 

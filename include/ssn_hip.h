@@ -345,6 +345,14 @@ int ssn_sgd_step_multi(int count, float* const* w, const float* const* grad, flo
 /* clip_grad_norm support (ssn_train.py:245-249): out[0] (+)= sum(x^2); workspace >= 1024 floats. */
 int ssn_sumsq(const float* x, long n, float* out, int accumulate, float* workspace, hipStream_t stream);
 int ssn_scale(float* x, long n, const float* coef_dev, float coef, hipStream_t stream);
+/* The stem (conv1_7x7_s2 of model_zoo.BNInception, behind ssn_models.py:266) on the split kernels through its space-to-depth
+ * form: a k x k / stride-2 / pad (k-1)/2 convolution on C channels is a (k+1)/2-tap stride-1 convolution on the 4C channels
+ * xs[(c*2+a)*2+b][h'][w'] = x[c][2h'+a][2w'+b], with 2 padding pixels in front and 1 behind (k = 7): forward =
+ * ssn_conv_x6_fwd_rect(xs, pack_rect(ssn_s2d_weights(w)), 4, 4, pad 2, Ho = H/2), weight gradient = ssn_conv_wgrad_x6(ksize 4,
+ * pad 2) followed by ssn_s2d_weights_bwd.  (3 input channels fill 3/16 of a split slab directly; 12 fill 12/16.) */
+int ssn_space_to_depth2(const float* x, float* xs, int N, int C, int H, int W, float* xs_amax, hipStream_t stream);
+int ssn_s2d_weights(const float* w, float* w2, int Cout, int C, int k, hipStream_t stream);
+int ssn_s2d_weights_bwd(const float* dw2, float* dw, int Cout, int C, int k, hipStream_t stream);
 /* dst[i] += src[i]: sums the conv-gradient buffers of the sub-batches when one backward is executed in chunks (a batch
  * whose activations exceed the 2 GiB a kernel operand can address; DataParallel's reduce of replica gradients). */
 int ssn_add_inplace(float* dst, const float* src, long n, hipStream_t stream);

@@ -802,3 +802,34 @@ def test_conv_split_block_input_launch(backend):
     K.conv_wgrad_x6(K.ChanSlice(gt, 0, m), K.full(xd), dw, db, 1, 0, wsz, -1, g_row_split=c1, g_row_gap=gapc)
     assert rel_err(dw, torch.nn.grad.conv2d_weight(x.double(), wcat.shape, gy.double())) < 5e-5
     assert rel_err(db, gy.double().sum(dim=(0, 2, 3))) < 5e-5
+
+
+def test_stem_space_to_depth(backend):
+    """The 7x7 / stride-2 / pad-3 stem on the split kernels through its space-to-depth form: forward (4x4 taps on 4C channels,
+    2 padding pixels in front / 1 behind), weight + bias gradient (wgrad with 4x4 taps, mapped back to the 7x7 layout)."""
+    g = torch.Generator().manual_seed(96)
+    for (n, c, h, cout) in ([(4, 3, 224, 64), (2, 10, 64, 64)] if backend.is_gpu else [(1, 3, 16, 32), (2, 2, 12, 32)]):
+        x = torch.randn(n, c, h, h, generator=g) * 50
+        w = (torch.randn(cout, c, 7, 7, generator=g) * 0.05).double().requires_grad_()
+        b = torch.zeros(cout, dtype=torch.double, requires_grad=True)
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+        z = F.conv2d(x.double(), w, b, 2, 3)
+        ref = torch.relu(z * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+        gy = torch.randn(z.shape, generator=g)
+        z.backward(gy.double())
+        xs = K.space_to_depth2(backend.put(x))
+        assert xs._ssn_amax.item() == x.abs().max().item()
+        xs_ref = x.reshape(n, c, h // 2, 2, h // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(n, 4 * c, h // 2, h // 2)
+        assert torch.equal(xs.cpu(), xs_ref)
+        w2 = K.s2d_weights(backend.put(w.detach().float()))
+        assert rel_err(F.conv2d(F.pad(xs_ref.double(), (2, 1, 2, 1)), w2.cpu().double()), z.detach() - b.detach().view(1, -1, 1, 1)) < 1e-12
+        y = backend.put(torch.zeros(n, cout, h // 2, h // 2))
+        K.conv_x6_fwd_rect(K.full(xs), K.pack_weights_rect(w2), backend.put(scale), backend.put(shift), K.full(y), 4, 4, 2, 2, True)
+        assert rel_err(y, ref) < 2e-5, (n, c, h)
+        dw2 = backend.put(torch.empty(cout, 4 * c, 4, 4))
+        db = backend.put(torch.empty(cout))
+        ws = backend.put(torch.empty(K.wgrad_x6_workspace_bytes(n, 4 * c, cout, h // 2, h // 2, 4, -1) // 4))
+        K.conv_wgrad_x6(K.full(backend.put(gy)), K.full(xs), dw2, db, 4, 2, ws, -1)
+        dw = backend.put(torch.empty(cout, c, 7, 7))
+        K.s2d_weights_bwd(dw2, dw)
+        assert rel_err(dw, w.grad) < 5e-5 and rel_err(db, b.grad) < 5e-5, (n, c, h)

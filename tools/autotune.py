@@ -20,7 +20,7 @@ pkg.build()
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
 # optional second argument: comma list of kinds to (re)tune; the other kinds keep their entries
-only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None
+only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None     # e.g. fwd6,dgrad6,wgrad6,fwd6s2d,wgrad6s2d
 out_path = os.path.join(ROOT, "action-detection_amd", "tuned_tiles.json")
 shapes = {}
 for cin0 in (3, 10):
@@ -62,16 +62,23 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
     wt = K.pack_weights(w, lay)
     wp = K.pack_weights(w, False)
     wp6, wt6 = K.pack_weights_multi([([w], 0), ([w], 1)], x6=True) if k != 7 else (None, None)
+    if (k, s, p) == (7, 2, 3):
+        xs2d = K.space_to_depth2(x)
+        wps2d = K.pack_weights_rect(K.s2d_weights(w))
+        dw2d = torch.empty(cout, 4 * cin, 4, 4, device=dev)
     dx = torch.empty_like(x)
     dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
     flops = 2.0 * n * ho * ho * cout * cin * k * k
     res = {}
     for kind, cfgs in (("fwd", [0, 1, 2, 3, 4, 5, 6, 7]), ("dgrad", [0, 1, 2, 3, 4, 5, 6, 7]),
                        ("wgrad", [0, 1, 2, 3, 4, 5, 6]), ("fwd6", list(range(22))),
-                       ("dgrad6", list(range(22))), ("wgrad6", list(range(12)))):
+                       ("dgrad6", list(range(22))), ("wgrad6", list(range(12))),
+                       ("fwd6s2d", [1, 2, 3, 5, 6]), ("wgrad6s2d", [0, 3, 5, 6])):
         if only and kind not in only:
             continue
         if (kind in ("dgrad", "fwd6") and k == 7) or (kind == "dgrad6" and (k == 7 or s != 1)):
+            continue
+        if kind in ("fwd6s2d", "wgrad6s2d") and (k, s, p) != (7, 2, 3):
             continue
         if kind == "wgrad6" and not K.wgrad_x6_supported(k, s, p, hi, hi):
             continue
@@ -81,6 +88,11 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
                 fn = lambda: K.conv_fwd(K.full(x), wp, scale, shift, K.full(y), k, s, p, True, cfg)
             elif kind == "fwd6":
                 fn = lambda: K.conv_x6_fwd(K.full(x), wp6, scale, shift, K.full(y), k, s, p, True, cfg)
+            elif kind == "fwd6s2d":       # the stem through its space-to-depth form (bninception.py: stem_s2d)
+                fn = lambda: K.conv_x6_fwd_rect(K.full(xs2d), wps2d, scale, shift, K.full(y), 4, 4, 2, 2, True, cfg)
+            elif kind == "wgrad6s2d":
+                ws = torch.empty(K.wgrad_x6_workspace_bytes(n, 4 * cin, cout, ho, ho, 4, cfg) // 4, device=dev)
+                fn = lambda: K.conv_wgrad_x6(K.full(g), K.full(xs2d), dw2d, db, 4, 2, ws, cfg)
             elif kind == "dgrad6":
                 fn = lambda: K.conv_x6_dgrad(K.full(g), wt6, K.full(dx), k, p, False, cfg)
             elif kind == "wgrad6":
