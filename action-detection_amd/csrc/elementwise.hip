@@ -250,16 +250,22 @@ __global__ __launch_bounds__(256) void scale_kernel(float* x, long n, const floa
 // xs[n][(c*2 + a)*2 + b][h'][w'] = x[n][c][2h' + a][2w' + b]; amax emitted (xs is an operand of the split kernels)
 __global__ __launch_bounds__(256) void s2d_kernel(const float* x, float* xs, long total, int C, int H2, int W2,
                                                    FastDiv div_chw, FastDiv div_hw, FastDiv div_w, float* amax) {
+    // one thread = one horizontal pixel pair of the input (an 8-byte load: W is even, rows start 8-byte aligned when the
+    // tensor does) -> one element in each of the two b-planes; idx enumerates (n, c, h, w2)
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {   // one output pixel pair row
-        uint32_t n, rem, c4, hw, h2, w2;
-        fd_divmod((uint32_t)idx, div_chw, n, rem);
-        fd_divmod(rem, div_hw, c4, hw);
-        fd_divmod(hw, div_w, h2, w2);
-        const int c = (int)c4 >> 2, a = ((int)c4 >> 1) & 1, b = (int)c4 & 1;
-        const float v = x[(((long)n * C + c) * (2 * H2) + (2 * h2 + a)) * (2 * W2) + 2 * w2 + b];
-        xs[idx] = v;
-        vmax = fmaxf(vmax, fabsf(v));
+    const int W = 2 * W2, H = 2 * H2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        uint32_t n, rem, c, hw, h, w2;
+        fd_divmod((uint32_t)idx, div_chw, n, rem);      // div_chw = C * H * W2
+        fd_divmod(rem, div_hw, c, hw);                  // div_hw = H * W2
+        fd_divmod(hw, div_w, h, w2);                    // div_w = W2
+        const float* src = x + (((long)n * C + c) * H + h) * W + 2 * w2;
+        const float v0 = src[0], v1 = src[1];
+        const long plane = (long)H2 * W2;
+        float* dst = xs + ((long)n * 4 * C + (c * 2 + (h & 1)) * 2) * plane + (long)(h >> 1) * W2 + w2;
+        dst[0] = v0;
+        dst[plane] = v1;
+        vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
     }
     amax_emit(amax, vmax);
 }
@@ -453,11 +459,11 @@ extern "C" int ssn_sumsq(const float* x, long n, float* out, int accumulate, flo
 // split kernels: y = ssn_conv_x6_fwd_rect(xs, pack(w2), 4x4 taps), dw2 = ssn_conv_wgrad_x6(ksize 4), dw = ssn_s2d_weights_bwd(dw2).
 extern "C" int ssn_space_to_depth2(const float* x, float* xs, int N, int C, int H, int W, float* xs_amax, hipStream_t stream) {
     SSN_CHECK_ARG(x && xs && N >= 1 && C >= 1 && H % 2 == 0 && W % 2 == 0, "space_to_depth2: bad arguments");
-    const long total = (long)N * C * H * W;
-    SSN_CHECK_ARG(total < (1l << 31), "space_to_depth2: tensor too large");
     const int H2 = H / 2, W2 = W / 2;
+    const long total = (long)N * C * H * W2;       // horizontal pixel pairs
+    SSN_CHECK_ARG(2 * total < (1l << 31), "space_to_depth2: tensor too large");
     hipLaunchKernelGGL(s2d_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, stream, x, xs, total, C, H2, W2,
-                       make_fastdiv((uint32_t)(4 * C * H2 * W2)), make_fastdiv((uint32_t)(H2 * W2)), make_fastdiv((uint32_t)W2),
+                       make_fastdiv((uint32_t)(C * H * W2)), make_fastdiv((uint32_t)(H * W2)), make_fastdiv((uint32_t)W2),
                        xs_amax);
     SSN_CHECK_LAUNCH("space_to_depth2");
     return SSN_OK;

@@ -424,6 +424,73 @@ __global__ __launch_bounds__(256) void pool_max2_bwd_vec_kernel(PoolBwdArgs p, F
     amax_emit(p.amax, vmax);
 }
 
+// The same for a vertical PAIR of input rows (2k, 2k + 1; H even): they are covered by the output rows k - 1 (window row 2, the
+// even input row only) and k (window rows 0 and 1), so one thread fetches 2 x (1 + 2) gradient dwords and 2 x (1 + 2) argmax
+// bytes for EIGHT input pixels -- half the load instructions per pixel of the one-row kernel, which is what bounds it.
+__global__ __launch_bounds__(256) void pool_max2_bwd_vec2_kernel(PoolBwdArgs p, FastDiv div_chq, FastDiv div_hq,
+                                                                 FastDiv div_q, long total_q) {
+    const int howo = p.Ho * p.Wo;
+    const __amdgpu_buffer_rsrc_t dyr = pool_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t ixr = pool_rsrc(p.idx, p.idx_bytes);
+    float vmax = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_q; i += (long)gridDim.x * 256) {
+        uint32_t n, rem, c, hq, k, q;
+        fd_divmod((uint32_t)i, div_chq, n, rem);     // div_chq = C * (H / 2) * Wq
+        fd_divmod(rem, div_hq, c, hq);               // div_hq = (H / 2) * Wq
+        fd_divmod(hq, div_q, k, q);
+        const int wi0 = (int)q * 4, wq = (int)q * 2;
+        const uint32_t dybase = (uint32_t)(((long)n * p.dy_img_stride + (long)c * howo) * 4);
+        const uint32_t ixbase = (uint32_t)(((long)n * p.C + c) * howo);
+        float g[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // [input row 2k / 2k + 1][pixel]
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ho = (int)k - a;                        // a = 0: window rows 0 (even row) and 1 (odd row); a = 1: row 2 (even)
+            const bool rowin = (ho >= 0) && (ho < p.Ho);
+            const uint32_t e0 = (uint32_t)(ho * p.Wo + wq);
+            const bool left = rowin && wq > 0;
+            const float gl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                           dyr, left ? dybase + (e0 - 1u) * 4u : POOL_OOB, 0, 0));
+            const uint32_t il = __builtin_amdgcn_raw_buffer_load_b8(ixr, left ? ixbase + e0 - 1u : POOL_OOB, 0, 0);
+            const pu32x2 gm = __builtin_amdgcn_raw_buffer_load_b64(dyr, rowin ? dybase + e0 * 4u : POOL_OOB, 0, 0);
+            const uint32_t im = __builtin_amdgcn_raw_buffer_load_b16(ixr, rowin ? ixbase + e0 : POOL_OOB, 0, 0);
+            const uint32_t g0u = gm[0], g1u = gm[1];
+            const float g0 = __builtin_bit_cast(float, g0u), g1 = __builtin_bit_cast(float, g1u);
+            const uint32_t i0 = im & 0xFFu, i1 = (im >> 8) & 0xFFu;
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {               // input row 2k + row is window row r of output row ho
+                const int r = 2 * a + row;                    // a = 0: r = 0 / 1;  a = 1: r = 2 (even row only)
+                if (r > 2) continue;
+                const uint32_t rb = (uint32_t)(r * 3);
+                g[row][0] += (left && il == rb + 2u) ? gl : 0.f;        // wo = wq - 1, s = 2
+                g[row][0] += (rowin && i0 == rb + 0u) ? g0 : 0.f;       // wo = wq,     s = 0
+                g[row][1] += (rowin && i0 == rb + 1u) ? g0 : 0.f;       //              s = 1
+                g[row][2] += (rowin && i0 == rb + 2u) ? g0 : 0.f;       //              s = 2
+                g[row][2] += (rowin && i1 == rb + 0u) ? g1 : 0.f;       // wo = wq + 1, s = 0
+                g[row][3] += (rowin && i1 == rb + 1u) ? g1 : 0.f;       //              s = 1
+            }
+        }
+        const float sc = p.mask_y ? p.mask_scale[c] : 0.f;
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const long o = (long)n * p.dx_img_stride + (long)c * p.H * p.W + (long)(2 * k + row) * p.W + wi0;
+            if (p.accumulate) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p.dx + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[row][e] += t[e];
+            }
+            if (p.mask_y) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p.mask_y + (long)n * p.mask_img_stride + (long)c * p.H * p.W +
+                                                                (long)(2 * k + row) * p.W + wi0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[row][e] = (sc != sc) ? g[row][e] : (t[e] > 0.f ? g[row][e] * sc : 0.f);
+            }
+            *reinterpret_cast<f32x4*>(p.dx + o) = f32x4{g[row][0], g[row][1], g[row][2], g[row][3]};
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(g[row][0]), fabsf(g[row][1]))), fmaxf(fabsf(g[row][2]), fabsf(g[row][3])));
+        }
+    }
+    amax_emit(p.amax, vmax);
+}
+
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, float* y, int NC, int C, int HW,
                                                       long x_img_stride) {
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -436,20 +503,20 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, float* y, 
     s = wave_sum(s);
     if (lane == 0) y[wave] = s / (float)HW;
 }
-__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* dy, float* dx, long total, int C, int HW,
-                                                      long dx_img_stride, int accumulate, FastDiv div_chw,
-                                                      FastDiv div_hw, float* amax) {
-    const float inv = 1.f / (float)HW;
+// dx[n][c][:] (+)= dy[n][c] / HW: one wave per (n, c) plane, lanes along the contiguous pixels (no divisions per element)
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* dy, float* dx, int NC, int C, int HW,
+                                                      long dx_img_stride, int accumulate, float* amax) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     float vmax = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        uint32_t n, rem, c, hw;
-        fd_divmod((uint32_t)i, div_chw, n, rem);
-        fd_divmod(rem, div_hw, c, hw);
-        float* dst = dx + (long)n * dx_img_stride + rem;
-        const float g = dy[(long)n * C + c] * inv;
-        const float o = accumulate ? *dst + g : g;
-        *dst = o;
-        vmax = fmaxf(vmax, fabsf(o));
+    if (wave < NC) {
+        const int n = wave / C, c = wave - n * C;
+        const float g = dy[wave] / (float)HW;
+        float* dst = dx + (long)n * dx_img_stride + (long)c * HW;
+        for (int i = lane; i < HW; i += 64) {
+            const float o = accumulate ? dst[i] + g : g;
+            dst[i] = o;
+            vmax = fmaxf(vmax, fabsf(o));
+        }
     }
     amax_emit(amax, vmax);
 }
@@ -613,6 +680,14 @@ extern "C" int ssn_pool_bwd(int is_max, const float* dy, const unsigned char* ar
                       (!a.mask_y || (((uintptr_t)a.mask_y % 16 == 0) && mask_img_stride % 4 == 0));
     if (ksize == 3 && al16 && is_max && stride == 2 && pad == 0 && W == 2 * Wo && Wo % 2 == 0) {
         const int Wq = W / 4;
+        if (H % 2 == 0) {      // vertical pairs of input rows per thread
+            const long total_p = (long)N * C * (H / 2) * Wq;
+            hipLaunchKernelGGL(pool_max2_bwd_vec2_kernel, dim3(grid_for(total_p)), dim3(256), 0, stream, a,
+                               make_fastdiv((uint32_t)(C * (H / 2) * Wq)), make_fastdiv((uint32_t)((H / 2) * Wq)),
+                               make_fastdiv((uint32_t)Wq), total_p);
+            SSN_CHECK_LAUNCH("pool_bwd (vec max, row pairs)");
+            return SSN_OK;
+        }
         const long total_q = (long)N * C * H * Wq;
         hipLaunchKernelGGL(pool_max2_bwd_vec_kernel, dim3(grid_for(total_q)), dim3(256), 0, stream, a,
                            make_fastdiv((uint32_t)(C * H * Wq)), make_fastdiv((uint32_t)(H * Wq)),
@@ -684,9 +759,9 @@ extern "C" int ssn_global_avgpool_fwd(const float* x, float* y, int N, int C, in
 extern "C" int ssn_global_avgpool_bwd(const float* dy, float* dx, int N, int C, int HW, long dx_img_stride,
                                       int accumulate, float* dx_amax, hipStream_t stream) {
     SSN_CHECK_ARG(dy && dx, "gap_bwd: null pointer");
-    const long total = (long)N * C * HW;
-    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, dy, dx, total, C, HW,
-                       dx_img_stride, accumulate, make_fastdiv((uint32_t)(C * HW)), make_fastdiv((uint32_t)HW), dx_amax);
+    const int NC = N * C;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3((NC + 3) / 4), dim3(256), 0, stream, dy, dx, NC, C, HW, dx_img_stride, accumulate,
+                       dx_amax);
     SSN_CHECK_LAUNCH("gap_bwd");
     return SSN_OK;
 }
