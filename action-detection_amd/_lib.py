@@ -40,11 +40,11 @@ _SIGS = {
     "ssn_conv_pack_weights": "ppiiiip",
     "ssn_conv_pack_weights_multi": "ippppppppp",
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
-    "ssn_conv_wgrad_x6": "ppppiiiililiiiplippiip",
+    "ssn_conv_wgrad_x6": "ppppiiiililiiiplippiipp",
     "ssn_wgrad_reduce": "pppiiip",
     "ssn_conv_x6_pack_weights_multi": "ippppppppppppp",
-    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiippiiip",
-    "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiippiip",
+    "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiippiiipp",
+    "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiippiipp",
     "ssn_conv_x6_fwd_rect": "pppppiiiiliiiliiiiiiippp",
     "ssn_conv_x6_pack_dgrad_s2": "ppiip",
     "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiippp",

@@ -302,6 +302,7 @@ class BNInception(nn.Module):
                     if "raw_from" in pair:
                         merged["raw_from"] = c1 + pair["raw_from"]
                     shapes[blk] = (cblk + pair["cout"],) + tuple(shapes[blk][1:])
+                    shapes.setdefault("__ext__", {})[blk] = cblk      # first channel of the rows behind the block's own
                     out.append(merged)
                     continue
             out.append(op)
@@ -392,7 +393,8 @@ class BNInception(nn.Module):
 
         # one amax slot per activation tensor (kernels.py: "amax slots"): the kernels that write a tensor raise its
         # slot, the split convolutions that read it take their operand scale from it
-        slot_pool = torch.zeros(len(shapes) + 1, device=dev, dtype=torch.float32)
+        ext_base = shapes.get("__ext__", {})      # tensors with a second region (the reduce rows behind a block's output)
+        slot_pool = torch.zeros(2 * len(shapes) + 2, device=dev, dtype=torch.float32)
         slot_of = {}
 
         def get(name):
@@ -400,7 +402,9 @@ class BNInception(nn.Module):
                 c, h, w = shapes[name]
                 i = slot_of.setdefault(name, len(slot_of))
                 # readable floats in front of every activation: lets the x6 kernels use 16-byte loads
-                acts[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), slot_pool[i:i + 1])
+                acts[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), slot_pool[2 * i:2 * i + 1])
+                if name in ext_base:
+                    K.attach_amax_ext(acts[name], slot_pool[2 * i + 1:2 * i + 2], ext_base[name])
             return acts[name]
 
         def scale_slice(name, c0, c):
@@ -610,14 +614,17 @@ class BNInception(nn.Module):
         grads = {}
         inited = set()      # (tensor, c0) gradient slices that already hold a contribution
 
-        gslot_pool = torch.zeros(len(shapes) + 1, device=dev, dtype=torch.float32)   # amax slots of the gradient tensors
+        ext_base = shapes.get("__ext__", {})
+        gslot_pool = torch.zeros(2 * len(shapes) + 2, device=dev, dtype=torch.float32)   # amax slots of the gradient tensors
         gslot_of = {}
 
         def gbuf(name):
             if name not in grads:
                 c, h, w = shapes[name]
                 i = gslot_of.setdefault(name, len(gslot_of))
-                grads[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), gslot_pool[i:i + 1])
+                grads[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), gslot_pool[2 * i:2 * i + 1])
+                if name in ext_base:
+                    K.attach_amax_ext(grads[name], gslot_pool[2 * i + 1:2 * i + 2], ext_base[name])
             return grads[name]
 
         ws_bytes = 0

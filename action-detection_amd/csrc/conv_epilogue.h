@@ -28,6 +28,7 @@ struct EpiArgs {
     int M;
     int relu, accumulate;
     float* amax;           // nullptr: the output tensor is not tracked
+    float* amax2;          // second slot raised by the same value (a launch whose rows land in two regions of a tensor), or nullptr
     // Output rows m >= row_split are stored row_gap channels further up the tensor (both multiples of 32, so a 32-row MFMA
     // tile never straddles the split): the fused launch on an Inception block input writes the block's 1x1 branch to the head
     // of the block-output tensor and the reduce / projection rows behind the block's own channels.  No split: INT_MAX, 0.
@@ -130,6 +131,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[TM][TN], const
         }
     }
     amax_emit(e.amax, vmax);
+    amax_emit(e.amax2, vmax);
 }
 
 }  // namespace

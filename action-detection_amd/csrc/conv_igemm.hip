@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     e.relu = p.relu;
     e.accumulate = p.accumulate;
     e.amax = p.y_amax;
+    e.amax2 = nullptr;
     e.row_split = 0x7fffffff;
     e.row_gap = 0;
     uint32_t yoff[TN], moff[TN];

@@ -37,6 +37,7 @@ struct WgX6Args {
     float* part;     // [splits][M][ldp]
     const float* g_amax;   // amax slots of the tensors g and x belong to (required)
     const float* x_amax;
+    const float* g_amax2;         // second region of g's tensor (rows behind the gap), or nullptr: the larger of both counts
     int g_row_split, g_row_gap;   // rows m >= g_row_split of G sit g_row_gap channels further up its tensor (fused block-input launch)
     uint32_t guard;               // readable bytes in front of x the shifted taps may reach into (multiple of 256)
     int N, Cin, H, W;
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     const int m0 = (int)mt * BM;
     const int kk0 = (int)kt * BN;
 
-    const float sg = f16_scale_of(*p.g_amax), sx = f16_scale_of(*p.x_amax);   // power-of-two operand scales
+    const float sg = f16_scale_of(p.g_amax2 ? fmaxf(*p.g_amax, *p.g_amax2) : *p.g_amax);   // power-of-two operand scales
+    const float sx = f16_scale_of(*p.x_amax);
     const float inv = 1.f / (sg * sx);
 
     const int pxg = tid & 3;       // which 4-pixel group of the chunk
@@ -413,7 +415,7 @@ extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int 
 extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                                  long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
                                  void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
-                                 int g_row_split, int g_row_gap, hipStream_t stream) {
+                                 int g_row_split, int g_row_gap, const float* g_amax2, hipStream_t stream) {
     SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
     SSN_CHECK_ARG(g_amax && x_amax, "conv wgrad x6: the amax slots of both operand tensors are required");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 4, "conv wgrad x6: ksize %d unsupported", ksize);
@@ -431,6 +433,7 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.part = (float*)workspace;
     a.g_amax = g_amax;
     a.x_amax = x_amax;
+    a.g_amax2 = g_amax2;
     a.guard = guard ? guard : GUARD;
     SSN_CHECK_ARG(g_row_gap >= 0 && (g_row_gap == 0 || (g_row_split > 0 && g_row_split < Cout)), "conv wgrad x6: bad row split");
     a.g_row_split = g_row_gap ? g_row_split : 0x7fffffff;

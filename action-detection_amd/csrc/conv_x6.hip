@@ -237,6 +237,8 @@ int fill_args(X6Args& a, const float* x, const uint32_t* ap, float* y, int N, in
     a.y = y;
     a.x_amax = x_amax;
     a.y_amax = y_amax;
+    a.x_amax2 = nullptr;
+    a.y_amax2 = nullptr;
     a.N = N;
     a.C = C;
     a.H = H;
@@ -403,7 +405,7 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
                                float* y, int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                                long y_img_stride, int ksize, int stride, int pad, int relu, int x_guard_bytes,
                                int tile_cfg, const float* x_amax, float* y_amax, int raw_from, int row_split,
-                               int row_gap, hipStream_t stream) {
+                               int row_gap, float* y_amax2, hipStream_t stream) {
     SSN_CHECK_ARG(x && w_packed && y, "conv x6 fwd: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 fwd: ksize %d unsupported", ksize);
     SSN_CHECK_ARG(stride == 1 || stride == 2, "conv x6 fwd: stride %d unsupported", stride);
@@ -416,6 +418,7 @@ extern "C" int ssn_conv_x6_fwd(const float* x, const float* w_packed, const floa
     a.shift = shift;
     a.relu = relu;
     a.raw_from = raw_from > 0 ? raw_from : 0x7fffffff;    // <= 0: every output row takes the affine / ReLU
+    a.y_amax2 = y_amax2;
     a.accumulate = 0;
     a.mask_y = nullptr;
     a.mask_scale = nullptr;
@@ -433,7 +436,7 @@ extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float*
                                  long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                                  int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
                                  int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, int k_split,
-                                 int k_gap, hipStream_t stream) {
+                                 int k_gap, const float* dy_amax2, hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad: null pointer");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3, "conv x6 dgrad: ksize %d unsupported", ksize);
     X6Args a;
@@ -441,6 +444,7 @@ extern "C" int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float*
                        dx_img_stride, ksize, pad, dy_amax, dx_amax, 0, 0, k_split, k_gap, "conv x6 dgrad");
     if (rc != SSN_OK) return rc;
     a.x_guard = dy_guard_bytes;
+    a.x_amax2 = dy_amax2;
     a.scale = nullptr;
     a.shift = nullptr;
     a.relu = 0;

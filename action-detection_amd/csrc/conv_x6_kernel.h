@@ -23,6 +23,11 @@ struct X6Args {
     const uint32_t* ap;   // packed split weights [nslab][M][APITCH], then ATAIL dwords (the weight's amax)
     const float* x_amax;  // amax slot of the gather source's tensor (required)
     float* y_amax;        // amax slot of the output tensor (nullptr: not tracked)
+    // A tensor that holds a block's output AND (behind it) the block's reduce rows has one slot per region, so that every slot
+    // is final before anybody reads it (the two regions are written and read by concurrent launches): a launch whose rows /
+    // channels span both regions raises both (y_amax2) resp. takes the larger of both (x_amax2).  nullptr: one region.
+    const float* x_amax2;
+    float* y_amax2;
     float* y;
     const float* scale;
     const float* shift;
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
     // operand scales (powers of two, exact): the weight's amax sits behind its packed rows, the activations' in the
     // slot their producers maintained
     const float sa = f16_scale_of(__builtin_bit_cast(float, p.ap[p.a_bytes >> 2]));
-    const float sb = f16_scale_of(*p.x_amax);
+    const float sb = f16_scale_of(p.x_amax2 ? fmaxf(*p.x_amax, *p.x_amax2) : *p.x_amax);
     const float inv = 1.f / (sa * sb);
 
     // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 2) & 3): the 16 lanes of a
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
     e.relu = p.relu;
     e.accumulate = p.accumulate;
     e.amax = p.y_amax;
+    e.amax2 = p.y_amax2;
     e.row_split = p.row_split;
     e.row_gap = p.row_gap;
     uint32_t yoff[TN], moff[TN];

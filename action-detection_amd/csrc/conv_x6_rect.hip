@@ -83,6 +83,8 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         a.y = dx;
         a.x_amax = dy_amax;
         a.y_amax = dx_amax;
+        a.x_amax2 = nullptr;
+        a.y_amax2 = nullptr;
         a.scale = nullptr;
         a.shift = nullptr;
         a.N = N;
@@ -157,6 +159,8 @@ extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const
     a.y = y;
     a.x_amax = x_amax;
     a.y_amax = y_amax;
+    a.x_amax2 = nullptr;
+    a.y_amax2 = nullptr;
     a.scale = scale;
     a.shift = shift;
     a.N = N;

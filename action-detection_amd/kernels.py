@@ -81,9 +81,31 @@ def _tensor_of(x):
     return x.t if isinstance(x, ChanSlice) else x
 
 
+def attach_amax_ext(t, slot, first_channel):
+    """Second amax slot for the channels >= first_channel of `t` (a block-output tensor that also holds the block's reduce
+    rows): the two regions are written and read by concurrent launches, so each has its own slot -- a slot is then always
+    complete before anything reads it (results stay bit-deterministic)."""
+    t._ssn_amax_ext = (slot, int(first_channel))
+    return t
+
+
+def _slot_of(x):
+    """The amax slot that covers ChanSlice / tensor x (None: not tracked)."""
+    t = _tensor_of(x)
+    ext = getattr(t, "_ssn_amax_ext", None)
+    if ext is not None and isinstance(x, ChanSlice) and x.c0 >= ext[1]:
+        return ext[0]
+    return getattr(t, "_ssn_amax", None)
+
+
+def _slot_ext(x):
+    ext = getattr(_tensor_of(x), "_ssn_amax_ext", None)
+    return None if ext is None else ext[0]
+
+
 def _amax_out(x):
-    """Slot pointer of the tensor a kernel writes (None: not tracked)."""
-    return _p(getattr(_tensor_of(x), "_ssn_amax", None))
+    """Slot pointer of the tensor (region) a kernel writes (None: not tracked)."""
+    return _p(_slot_of(x))
 
 
 def tensor_amax(t, slot=None):
@@ -97,9 +119,8 @@ def tensor_amax(t, slot=None):
 
 def _amax_in(x):
     """Slot (tensor, kept alive by the caller) of the tensor a split kernel reads; untracked tensors are measured now."""
-    t = _tensor_of(x)
-    slot = getattr(t, "_ssn_amax", None)
-    return slot if slot is not None else tensor_amax(t)
+    slot = _slot_of(x)
+    return slot if slot is not None else tensor_amax(_tensor_of(x))
 
 
 # Measurement hook (bench.py): when a list is installed here, the wrappers of the HBM-bound kernels of the path (STPP,
@@ -249,7 +270,8 @@ def conv_x6_fwd(x, w_packed, scale, shift, y, ksize, stride, pad, relu=True, til
     xa = _amax_in(x)
     lib.call("ssn_conv_x6_fwd", _p(x), _p(w_packed), _p(scale), _p(shift), _p(y), x.n, x.c, h, wd,
              x.img_stride, y.c, ho, wo, y.img_stride, ksize, stride, pad, int(relu), guard_bytes(x), tile_cfg,
-             _p(xa), _amax_out(y), int(raw_from), int(row_split), int(row_gap), _stream(lib, w_packed))
+             _p(xa), _amax_out(y), int(raw_from), int(row_split), int(row_gap),
+             _p(_slot_ext(y)) if row_gap else None, _stream(lib, w_packed))
 
 
 def pack_weights_rect(w):
@@ -284,7 +306,7 @@ def conv_x6_dgrad(dy, wt, dx, ksize, pad, accumulate, tile_cfg=-1, mask_y=None, 
     lib.call("ssn_conv_x6_dgrad", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, ksize, pad, int(accumulate), _p(mask_y),
              mask_y.img_stride if mask_y is not None else 0, _p(mask_scale), guard_bytes(dy), tile_cfg,
-             _p(ga), _amax_out(dx), int(k_split), int(k_gap), _stream(lib, wt))
+             _p(ga), _amax_out(dx), int(k_split), int(k_gap), _p(_slot_ext(dy)) if k_gap else None, _stream(lib, wt))
 
 
 def pack_dgrad_s2(w):
@@ -388,7 +410,7 @@ def conv_wgrad_x6(g, x, dw, db, ksize, pad, workspace, tile_cfg=-1, g_row_split=
     ga, xa = _amax_in(g), _amax_in(x)
     lib.call("ssn_conv_wgrad_x6", _p(g), _p(x), _p(dw), _p(db), x.n, x.c, h, w, x.img_stride, g.c, g.img_stride,
              ksize, pad, guard_bytes(x), _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg,
-             _p(ga), _p(xa), int(g_row_split), int(g_row_gap), _stream(lib, dw))
+             _p(ga), _p(xa), int(g_row_split), int(g_row_gap), _p(_slot_ext(g)) if g_row_gap else None, _stream(lib, dw))
 
 
 def pool_fwd(kind, x, y, argmax, ksize, stride, pad):

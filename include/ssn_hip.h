@@ -127,7 +127,10 @@ void ssn_conv_x6_debug_flags(int flags);   /* tooling only (tools/ablate_x6.py);
  *  - row_split / row_gap (fwd; multiples of 32, 0 = none): output channels >= row_split are stored row_gap channels further
  *    up y's tensor (the 1x1 branch goes to the head of the block output, the rest behind the block's own channels);
  *  - k_split / k_gap (dgrad; multiples of 16): the same displacement on the channel axis of dy;
- *  - g_row_split / g_row_gap (wgrad): ... and on the rows of g. */
+ *  - g_row_split / g_row_gap (wgrad): ... and on the rows of g;
+ *  - y_amax2 / dy_amax2 / g_amax2 (NULL = none): such a tensor has ONE AMAX SLOT PER REGION (the block's own channels; the rows
+ *    behind them), so that every slot is complete before anything reads it although the regions are written and read by
+ *    concurrent launches; the launch that spans both raises both (fwd) resp. uses the larger of both (dgrad, wgrad). */
 int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const float* const* w1, const float* const* w2,
                                    const float* const* w3, float* const* out, const int* cout, const int* cin,
                                    const int* ksize, const int* mode, const int* split, const int* split2,
@@ -135,12 +138,12 @@ int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const floa
 int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
                     int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo, long y_img_stride,
                     int ksize, int stride, int pad, int relu, int x_guard_bytes, int tile_cfg, const float* x_amax,
-                    float* y_amax, int raw_from, int row_split, int row_gap, hipStream_t stream);
+                    float* y_amax, int raw_from, int row_split, int row_gap, float* y_amax2, hipStream_t stream);
 int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                       long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int ksize, int pad,
                       int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
                       int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, int k_split, int k_gap,
-                      hipStream_t stream);
+                      const float* dy_amax2, hipStream_t stream);
 
 /* Rectangular taps (csrc/conv_x6_rect.hip): the forward convolutions of the Inception-v3 backbone the reference's
  * tester runs on ActivityNet (ssn_models.py:133-139): kh x kw in {5x5, 1x7, 7x1, 1x3, 3x1}, stride 1, per-axis
@@ -171,7 +174,7 @@ long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int H, int W, i
 int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                       long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
                       void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
-                      int g_row_split, int g_row_gap, hipStream_t stream);
+                      int g_row_split, int g_row_gap, const float* g_amax2, hipStream_t stream);
 /* second pass of both wgrad kernels: dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] */
 int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
 
