@@ -47,7 +47,10 @@ _SIGS = {
     "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiippiipp",
     "ssn_conv_x6_fwd_rect": "pppppiiiiliiiliiiiiiippp",
     "ssn_conv_x6_pack_dgrad_s2": "ppiip",
-    "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiippp",
+    "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiippip",
+    "ssn_conv_x6_pack_dgrad_rect": "ppiiiip",
+    "ssn_conv_x6_dgrad_rect": "pppiiiililiiiiiplpiippp",
+    "ssn_conv_wgrad_x6_rect": "ppppiiiililiiiiiplippp",
     "ssn_conv_x6_pack_weights_rect": "ppiiiip",
     "ssn_pool_fwd": "ipppiiiiliiliiipp",
     "ssn_pool_bwd": "ipppiiiiliiliiiiplppp",
@@ -93,7 +96,7 @@ _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.
        "u": ctypes.c_ulonglong}
 
 EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_wgrad_workspace_bytes",
-                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
+                                "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_packed_floats_dgrad_rect", "ssn_conv_wgrad_x6_rect_workspace_bytes", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
                                 "ssn_conv_dgrad_layout"])
@@ -119,6 +122,10 @@ class SsnLibrary:
         self.cdll.ssn_conv_x6_dgrad_s2_packed_floats.argtypes = [ctypes.c_int] * 2
         self.cdll.ssn_conv_x6_packed_floats_rect.restype = ctypes.c_long
         self.cdll.ssn_conv_x6_packed_floats_rect.argtypes = [ctypes.c_int] * 4
+        self.cdll.ssn_conv_x6_packed_floats_dgrad_rect.restype = ctypes.c_long
+        self.cdll.ssn_conv_x6_packed_floats_dgrad_rect.argtypes = [ctypes.c_int] * 4
+        self.cdll.ssn_conv_wgrad_x6_rect_workspace_bytes.restype = ctypes.c_long
+        self.cdll.ssn_conv_wgrad_x6_rect_workspace_bytes.argtypes = [ctypes.c_int] * 8
         self.cdll.ssn_conv_wgrad_x6_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_conv_wgrad_x6_workspace_bytes.argtypes = [ctypes.c_int] * 7
         self.cdll.ssn_detections_workspace_bytes.restype = ctypes.c_size_t

@@ -715,6 +715,13 @@ class BNInception(nn.Module):
                 key = (op["src"], 0)
                 K.gap_bwd(dfeat, ChanSlice(gbuf(op["src"]), 0, op["c"]), accumulate=key in inited)
                 inited.add(key)
+                # The global pool cannot fuse the ReLU / frozen-BN backward of the block it reads, so it is applied here, once,
+                # for all of the block's channels -- not slice by slice when each branch gets its turn: the tensor (and its amax
+                # slot) is then final before the first weight gradient on the side stream reads it.
+                if op["src"] in tscale and not self._train_bn_ids():
+                    c = op["c"]
+                    K.relu_bn_bwd(ChanSlice(grads[op["src"]], 0, c), ChanSlice(acts[op["src"]], 0, c), tscale[op["src"]][0:c])
+                    masked.setdefault(op["src"], []).append((0, c))
             elif op["kind"] == "pool":
                 c = op["c"]
                 key = (op["src"], 0)

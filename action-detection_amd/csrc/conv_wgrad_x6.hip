@@ -48,7 +48,8 @@ struct WgX6Args {
     int ldp;  // K + 1 (last column = bias gradient)
     int P;    // N * HWp pixel slots
     int HWp;  // pixel slots per image: H*W rounded up to a multiple of 4 (PAD: the slots past H*W hold zeros)
-    int pad;
+    int pad;                       // square taps (KS > 0)
+    int kh, kw, pad_h, pad_w;      // runtime taps (KS == 0): rectangular layers
     int splits, chunks_per_split;  // chunk = 16 pixels
     int n_mtiles, n_ktiles;
     uint32_t g_bytes, x_bytes;
@@ -65,6 +66,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base, uint
 }
 // (operand scaling and split: f16_scale_of / f16_split2_pair of ssn_common.h)
 
+// KS = 0: kh x kw taps with per-axis padding taken from the arguments (the 5x5 / 1x7 / 7x1 / 1x3 / 3x1 layers of
+// Inception-v3): the tap geometry only enters the per-row constants in front of the loop.
 // tiles of 8+ MFMA tiles per wave run one wave per SIMD (up to 512 VGPRs): the elements to split per MFMA drop with
 // the tile size, which moves the kernel from VALU-bound towards matrix-bound
 template <int KS, bool PAD, int WM, int WN, int TM, int TN>
@@ -73,7 +76,9 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
     constexpr int BN = WN * TN * 32;
     constexpr int NAR = (BM + 63) / 64;   // G rows per thread (thread = one row x 4 pixels of a chunk)
     constexpr int NBR = (BN + 63) / 64;   // X rows per thread
-    constexpr int KK = KS * KS;
+    const int KW_ = KS ? KS : p.kw;
+    const int KK = KS ? KS * KS : p.kh * p.kw;
+    const int PH = KS ? p.pad : p.pad_h, PW = KS ? p.pad : p.pad_w;
     constexpr int STAGE = 2 * (BM + BN) * ROW_DW;   // [A plane 0..1][B plane 0..1], rows x 8 dwords each
     static_assert(WM * WN == 4, "4 waves per workgroup");
 
@@ -118,9 +123,9 @@ __global__ __launch_bounds__(256, TM * TN >= 8 ? 1 : 2) void wgrad_x6_kernel(WgX
             c = kk / KK;
             tap = kk - c * KK;
         }
-        const int tr = tap / KS, ts = tap - tr * KS;
-        b_dh[i] = tr - p.pad;
-        b_dw[i] = ts - p.pad;
+        const int tr = tap / KW_, ts = tap - tr * KW_;
+        b_dh[i] = tr - PH;
+        b_dw[i] = ts - PW;
         b_const[i] = (r < BN && kk < p.K) ? (uint32_t)((c * HW + b_dh[i] * p.W + b_dw[i]) * 4 + (int)p.guard) : OOB;
     }
     const __amdgpu_buffer_rsrc_t grsrc = wg_rsrc(p.g, p.g_bytes);
@@ -368,6 +373,18 @@ int launch_wgx6_tile4(WgX6Args& a, int cfg, hipStream_t stream) {
     }
 }
 
+// runtime taps (rectangular layers): the mid-size tiles
+int launch_wgx6_tile_rt(WgX6Args& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_wgx6<0, 2, 2, 1, 1>(a, stream);
+        case 2: return launch_wgx6<0, 2, 2, 2, 2>(a, stream);
+        case 3: return launch_wgx6<0, 2, 2, 1, 2>(a, stream);
+        case 6: return launch_wgx6<0, 2, 2, 2, 1>(a, stream);
+        default: return launch_wgx6<0, 1, 4, 2, 1>(a, stream);   // 5: 64 x 128, waves along kk
+    }
+}
+int rt_tile(int cfg, int M, int K);
+
 int pick_tile(int M, int K) {
     double best = 1e300;
     int bc = 0;
@@ -396,6 +413,11 @@ void plan(int M, int K, long P, int cfg, int* splits, int* chunks_per_split) {
     }
 }
 
+int rt_tile(int cfg, int M, int K) {
+    if (cfg < 0) cfg = pick_tile(M, K);
+    return (cfg == 0 || cfg == 2 || cfg == 3 || cfg == 6) ? cfg : 5;
+}
+
 }  // namespace
 
 // reduce kernel shared with conv_wgrad.hip
@@ -412,18 +434,52 @@ extern "C" long ssn_conv_wgrad_x6_workspace_bytes(int N, int Cin, int Cout, int 
 
 // Stride-1, same-size (2*pad == ksize-1) convolutions; x_guard_bytes >= 256 (see header).  Planes whose H*W is not a
 // multiple of 4 (the 7x7 stage) are enumerated in groups of 4 pixel slots per image, the slots past the plane zeroed.
+extern "C" long ssn_conv_wgrad_x6_rect_workspace_bytes(int N, int Cin, int Cout, int H, int W, int kh, int kw, int tile_cfg) {
+    const int K = Cin * kh * kw;
+    const int cfg = rt_tile(tile_cfg < NCFG ? tile_cfg : -1, Cout, K);
+    int splits, cps;
+    plan(Cout, K, (long)N * ((H * W + 3) / 4 * 4), cfg, &splits, &cps);
+    return (long)splits * Cout * (K + 1) * (long)sizeof(float);
+}
+
+static int wgrad_x6_impl(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                         long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int kh, int kw, int pad_h,
+                         int pad_w, int x_guard_bytes, void* workspace, long ws_bytes, int tile_cfg, const float* g_amax,
+                         const float* x_amax, int g_row_split, int g_row_gap, const float* g_amax2, hipStream_t stream);
+
+// Weight gradient of a stride-1, same-size layer with kh x kw taps (5x5, 1x7, 7x1, 1x3, 3x1: the layers
+// ssn_conv_x6_fwd_rect runs forward); dw [Cout][Cin][kh][kw].  x needs (pad_h * W + pad_w) * 4 readable bytes in front of
+// it, rounded up to a multiple of 256.  Other arguments as ssn_conv_wgrad_x6.
+extern "C" int ssn_conv_wgrad_x6_rect(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                                      long x_img_stride, int Cout, long g_img_stride, int kh, int kw, int pad_h, int pad_w,
+                                      int x_guard_bytes, void* workspace, long ws_bytes, int tile_cfg, const float* g_amax,
+                                      const float* x_amax, hipStream_t stream) {
+    SSN_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= 49 && 2 * pad_h == kh - 1 && 2 * pad_w == kw - 1,
+                  "conv wgrad x6 rect: only same-size stride-1 convolutions (%dx%d taps, pad %d,%d)", kh, kw, pad_h, pad_w);
+    return wgrad_x6_impl(g, x, dw, db, N, Cin, H, W, x_img_stride, Cout, g_img_stride, 0, 0, kh, kw, pad_h, pad_w,
+                         x_guard_bytes, workspace, ws_bytes, tile_cfg, g_amax, x_amax, 0, 0, nullptr, stream);
+}
+
 extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                                  long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
                                  void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
                                  int g_row_split, int g_row_gap, const float* g_amax2, hipStream_t stream) {
-    SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
-    SSN_CHECK_ARG(g_amax && x_amax, "conv wgrad x6: the amax slots of both operand tensors are required");
     SSN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 4, "conv wgrad x6: ksize %d unsupported", ksize);
     // same-size stride-1 convolutions; ksize 4 = the space-to-depth stem: taps -pad .. ksize-1-pad with pad = 2 (one tap less
     // behind the pixel than in front of it)
     SSN_CHECK_ARG(2 * pad == ksize - 1 || (ksize == 4 && pad == 2),
                   "conv wgrad x6: only same-size stride-1 convolutions (pad %d, ksize %d)", pad, ksize);
-    const uint32_t guard = (uint32_t)(((pad * W + pad) * 4 + (int)GUARD - 1) / (int)GUARD * (int)GUARD);
+    return wgrad_x6_impl(g, x, dw, db, N, Cin, H, W, x_img_stride, Cout, g_img_stride, ksize, pad, ksize, ksize, pad, pad,
+                         x_guard_bytes, workspace, ws_bytes, tile_cfg, g_amax, x_amax, g_row_split, g_row_gap, g_amax2, stream);
+}
+
+static int wgrad_x6_impl(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                         long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int kh, int kw, int pad_h,
+                         int pad_w, int x_guard_bytes, void* workspace, long ws_bytes, int tile_cfg, const float* g_amax,
+                         const float* x_amax, int g_row_split, int g_row_gap, const float* g_amax2, hipStream_t stream) {
+    SSN_CHECK_ARG(g && x && dw && workspace, "conv wgrad x6: null pointer");
+    SSN_CHECK_ARG(g_amax && x_amax, "conv wgrad x6: the amax slots of both operand tensors are required");
+    const uint32_t guard = (uint32_t)(((pad_h * W + pad_w) * 4 + (int)GUARD - 1) / (int)GUARD * (int)GUARD);
     SSN_CHECK_ARG(x_guard_bytes >= (int)(guard ? guard : GUARD),
                   "conv wgrad x6: needs %u readable bytes in front of x (got %d): the taps in front of a pixel reach that far", guard,
                   x_guard_bytes);
@@ -445,11 +501,15 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     a.x_img_stride = x_img_stride;
     a.M = Cout;
     a.g_img_stride = g_img_stride;
-    a.K = Cin * ksize * ksize;
+    a.K = Cin * kh * kw;
     a.ldp = a.K + 1;
     a.HWp = (H * W + 3) / 4 * 4;
     a.P = N * a.HWp;
     a.pad = pad;
+    a.kh = kh;
+    a.kw = kw;
+    a.pad_h = pad_h;
+    a.pad_w = pad_w;
     a.div_hw = make_fastdiv((uint32_t)a.HWp);
     a.div_w = make_fastdiv((uint32_t)W);
     const long gb = ((long)(N - 1) * g_img_stride + (long)(Cout + g_row_gap) * H * W) * 4;
@@ -460,14 +520,16 @@ extern "C" int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, floa
     SSN_CHECK_ARG(tile_cfg < NCFG, "conv wgrad x6: unknown tile config %d", tile_cfg);
     int cfg = tile_cfg >= 0 ? tile_cfg : pick_tile(Cout, a.K);
     if (ksize == 4 && cfg != 0 && cfg != 3 && cfg != 6) cfg = 5;      // the tiles instantiated for 4x4 taps
+    if (ksize == 0) cfg = rt_tile(cfg, Cout, a.K);
     plan(Cout, a.K, a.P, cfg, &a.splits, &a.chunks_per_split);
     const long need = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
     if (ws_bytes < need) {
         ssn_set_error("conv wgrad x6: workspace %ld < %ld bytes", ws_bytes, need);
         return SSN_ERR_WORKSPACE;
     }
-    const int rc = ksize == 1 ? launch_wgx6_tile<1>(a, cfg, stream)
-                              : (ksize == 3 ? launch_wgx6_tile<3>(a, cfg, stream) : launch_wgx6_tile4(a, cfg, stream));
+    const int rc = ksize == 0 ? launch_wgx6_tile_rt(a, cfg, stream)
+                 : ksize == 1 ? launch_wgx6_tile<1>(a, cfg, stream)
+                 : (ksize == 3 ? launch_wgx6_tile<3>(a, cfg, stream) : launch_wgx6_tile4(a, cfg, stream));
     if (rc != SSN_OK) return rc;
     return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
 }

@@ -41,7 +41,8 @@ using namespace x6;
 // slab = g (1x1) or g * 9 + tap (3x3); row k of a slab = channel 16 g + k.  Logical 16-byte chunk c = 2 * plane +
 // khalf holds f16 k = 8 * khalf + 0..7 of that plane; it is stored at chunk position c ^ ((m >> 2) & 3), which makes
 // the straight LDS copy conflict-free for the ds_read_b128 fragment reads.
-//   mode 0 (forward operand): A[m][c][tap] = w[m][c][tap];  mode 1 (dgrad operand): A[m][c][tap] = w[c][m][tap]
+//   mode 0 (forward operand): A[m][c][tap] = w[m][c][tap];  mode 1 (dgrad operand): A[m][c][tap] = w[c][m][tap];
+//   mode 2 (dgrad operand of a rectangular-tap layer, run as a forward correlation): A[m][c][tap] = w[c][m][KK - 1 - tap]
 // Up to four sources (fused launches on an Inception block input: 1x1 branch, reduce pair, pool projection): output
 // channel co < split comes from w0, split <= co < split2 from w1, split2 <= co < split3 from w2, the rest from w3.
 // Three launches: clear the amax tails, max |w| of every entry into its tail (one workgroup per XP_ACHUNK source
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
                 const float* src = co < t.split[ti] ? t.w0[ti] : (co < t.split2[ti] ? t.w1[ti] : (co < t.split3[ti] ? t.w2[ti] : t.w3[ti]));
                 const int cor = co < t.split[ti] ? co : (co < t.split2[ti] ? co - t.split[ti]
                                                          : (co < t.split3[ti] ? co - t.split2[ti] : co - t.split3[ti]));
-                const int stap = t.srckk[ti] == KK ? tap : (int)((t.tapmap[ti] >> (4 * tap)) & 15u);
+                const int stap = t.srckk[ti] == KK ? (mode == 2 ? KK - 1 - tap : tap) : (int)((t.tapmap[ti] >> (4 * tap)) & 15u);
                 x = src[((long)cor * Cin + ci) * t.srckk[ti] + stap];
             }
             v[e] = x;
@@ -357,6 +358,37 @@ extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cou
     t.blk0[1] = (int)((triples + XP_CHUNK - 1) / XP_CHUNK);
     launch_pack(t, stream);
     SSN_CHECK_LAUNCH("conv_x6_pack_weights_rect");
+    return SSN_OK;
+}
+
+// dgrad operand of a stride-1 layer with kh x kw taps [cout][cin][kh][kw] for ssn_conv_x6_dgrad_rect: transposed and
+// tap-reversed, so that the data gradient is the FORWARD correlation of dy with it (padding kh-1-pad_h, kw-1-pad_w).
+// out holds ssn_conv_x6_packed_floats_dgrad_rect() floats.
+extern "C" long ssn_conv_x6_packed_floats_dgrad_rect(int Cout, int Cin, int kh, int kw) {
+    return x6_packed_dwords_kk(Cout, Cin, kh * kw, 1);
+}
+extern "C" int ssn_conv_x6_pack_dgrad_rect(const float* w, float* out, int cout, int cin, int kh, int kw,
+                                           hipStream_t stream) {
+    SSN_CHECK_ARG(w && out && cout > 0 && cin > 0 && kh > 0 && kw > 0 && kh * kw <= 32, "conv x6 pack dgrad rect: bad arguments");
+    X6PackTable t;
+    t.count = 1;
+    t.w0[0] = w;
+    t.w1[0] = nullptr;
+    t.w2[0] = t.w3[0] = nullptr;
+    t.split[0] = t.split2[0] = t.split3[0] = cout;
+    t.out[0] = (uint32_t*)out;
+    t.cout[0] = cout;
+    t.cin[0] = cin;
+    t.kk[0] = kh * kw;
+    t.srckk[0] = kh * kw;
+    t.tapmap[0] = 0;
+    t.mode[0] = 2;
+    t.blk0[0] = 0;
+    t.rows_dw[0] = x6_row_dwords_kk(cout, cin, kh * kw, 1);
+    const long triples = t.rows_dw[0] / APITCH * 8;
+    t.blk0[1] = (int)((triples + XP_CHUNK - 1) / XP_CHUNK);
+    launch_pack(t, stream);
+    SSN_CHECK_LAUNCH("conv_x6_pack_dgrad_rect");
     return SSN_OK;
 }
 

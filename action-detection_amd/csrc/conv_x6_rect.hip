@@ -68,15 +68,23 @@ extern "C" long ssn_conv_x6_dgrad_s2_packed_floats(int Cout, int Cin) {
 extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                                     long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int accumulate,
                                     const float* mask_y, long mask_img_stride, const float* mask_scale,
-                                    int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax,
+                                    int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, int pad,
                                     hipStream_t stream) {
     SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad s2: null pointer");
     SSN_CHECK_ARG(dy_amax, "conv x6 dgrad s2: the source tensor's amax slot is required");
-    SSN_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2,
-                  "conv x6 dgrad s2: needs a 3x3 / stride-2 / pad-1 convolution with even input size (%dx%d -> %dx%d)", H, W, Ho, Wo);
+    SSN_CHECK_ARG((pad == 1 && H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2) ||
+                      (pad == 0 && H >= 3 && W >= 3 && Ho == (H - 3) / 2 + 1 && Wo == (W - 3) / 2 + 1),
+                  "conv x6 dgrad s2: needs a 3x3 / stride-2 convolution with pad 1 and even input size, or pad 0 (%dx%d -> %dx%d, pad %d)",
+                  H, W, Ho, Wo, pad);
+    // pad 1: the two-tap classes are the ODD input rows / columns (2u + 1 <- dy[u], dy[u + 1]), every class grid is dy's.
+    // pad 0: the two-tap classes are the EVEN ones (2u <- dy[u - 1], dy[u]: one padding row in front of the gather), and
+    //        the class grids cover the input rows / columns of their parity (input rows a 3x3 window never reaches --
+    //        the last one of an even-sized input -- get the zero they are owed from taps that fall off dy).
     long off = 0;
     for (int cls = 0; cls < 4; ++cls) {
         const int ca = cls >> 1, cb = cls & 1, kh = 1 + ca, kw = 1 + cb;
+        const int sub_a = pad ? ca : 1 - ca, sub_b = pad ? cb : 1 - cb;     // parity of the class's input rows / columns
+        const int gh = pad ? Ho : (H - sub_a + 1) / 2, gw = pad ? Wo : (W - sub_b + 1) / 2;
         X6Args a;
         a.x = dy;
         a.ap = (const uint32_t*)wt_packed + off;
@@ -93,12 +101,12 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         a.W = Wo;
         a.x_img_stride = dy_img_stride;
         a.M = Cin;
-        a.Ho = Ho;          // enumerated grid = the class's pixels (u, v), same size as dy
-        a.Wo = Wo;
+        a.Ho = gh;          // enumerated grid = the class's pixels (u, v)
+        a.Wo = gw;
         a.y_img_stride = dx_img_stride;
-        a.P = N * Ho * Wo;
-        a.pad_h = 0;
-        a.pad_w = 0;
+        a.P = N * gh * gw;
+        a.pad_h = pad ? 0 : ca;
+        a.pad_w = pad ? 0 : cb;
         a.relu = 0;
         a.raw_from = a.row_split = 0x7fffffff;
         a.row_gap = a.k_split = a.k_gap = 0;
@@ -110,12 +118,12 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         a.x_guard = dy_guard_bytes;
         a.trace = nullptr;
         a.dbg = 0;
-        a.sub_a = ca;
-        a.sub_b = cb;
+        a.sub_a = sub_a;
+        a.sub_b = sub_b;
         a.sub_W = W;
         a.sub_HW = H * W;
-        a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
-        a.div_w = make_fastdiv((uint32_t)Wo);
+        a.div_hw = make_fastdiv((uint32_t)(gh * gw));
+        a.div_w = make_fastdiv((uint32_t)gw);
         const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * Ho * Wo) * 4;
         const long ab = x6_row_dwords_kk(Cout, Cin, kh * kw, 1) * 4;   // packed rows; the amax tail follows
         const long yb = ((long)(N - 1) * dx_img_stride + (long)Cin * H * W) * 4;
@@ -135,6 +143,78 @@ extern "C" int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, flo
         off += ab / 4 + ATAIL;
     }
     return SSN_OK;
+}
+
+static int dispatch_rect(X6Args& a, int kh, int kw, int tile_cfg, hipStream_t stream) {
+    if (kh == 4 && kw == 4) return launch_rect<4, 4>(a, tile_cfg, stream);
+    if (kh == 5 && kw == 5) return launch_rect<5, 5>(a, tile_cfg, stream);
+    if (kh == 1 && kw == 7) return launch_rect<1, 7>(a, tile_cfg, stream);
+    if (kh == 7 && kw == 1) return launch_rect<7, 1>(a, tile_cfg, stream);
+    if (kh == 1 && kw == 3) return launch_rect<1, 3>(a, tile_cfg, stream);
+    if (kh == 3 && kw == 1) return launch_rect<3, 1>(a, tile_cfg, stream);
+    ssn_set_error("conv x6 rect: %dx%d taps have no kernel", kh, kw);
+    return SSN_ERR_ARG;
+}
+
+// Data gradient of a stride-1, same-size layer with kh x kw taps (the layers ssn_conv_x6_fwd_rect runs forward): the
+// forward correlation of dy with the transposed, tap-reversed weight (ssn_conv_x6_pack_dgrad_rect), i.e. the SAME kernel
+// instantiations as the forward pass.  accumulate / mask_y / mask_scale as ssn_conv_x6_dgrad.
+extern "C" int ssn_conv_x6_dgrad_rect(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int H, int W,
+                                      long dy_img_stride, int Cin, long dx_img_stride, int kh, int kw, int pad_h, int pad_w,
+                                      int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
+                                      int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax,
+                                      hipStream_t stream) {
+    SSN_CHECK_ARG(dy && wt_packed && dx, "conv x6 dgrad rect: null pointer");
+    SSN_CHECK_ARG(dy_amax, "conv x6 dgrad rect: the source tensor's amax slot is required");
+    SSN_CHECK_ARG(2 * pad_h == kh - 1 && 2 * pad_w == kw - 1, "conv x6 dgrad rect: same-size layers only (%dx%d taps, pad %d,%d)",
+                  kh, kw, pad_h, pad_w);
+    X6Args a;
+    a.x = dy;
+    a.ap = (const uint32_t*)wt_packed;
+    a.y = dx;
+    a.x_amax = dy_amax;
+    a.y_amax = dx_amax;
+    a.x_amax2 = nullptr;
+    a.y_amax2 = nullptr;
+    a.scale = nullptr;
+    a.shift = nullptr;
+    a.N = N;
+    a.C = Cout;
+    a.H = H;
+    a.W = W;
+    a.x_img_stride = dy_img_stride;
+    a.M = Cin;
+    a.Ho = H;
+    a.Wo = W;
+    a.y_img_stride = dx_img_stride;
+    a.P = N * H * W;
+    a.pad_h = kh - 1 - pad_h;
+    a.pad_w = kw - 1 - pad_w;
+    a.relu = 0;
+    a.raw_from = a.row_split = 0x7fffffff;
+    a.row_gap = a.k_split = a.k_gap = 0;
+    a.accumulate = accumulate;
+    a.mask_y = mask_scale ? mask_y : nullptr;
+    a.mask_scale = mask_y ? mask_scale : nullptr;
+    a.mask_img_stride = mask_img_stride;
+    a.ngroups = (Cout + 15) / 16;
+    a.x_guard = dy_guard_bytes;
+    a.trace = nullptr;
+    a.dbg = 0;
+    a.sub_a = a.sub_b = a.sub_W = a.sub_HW = 0;
+    a.div_hw = make_fastdiv((uint32_t)(H * W));
+    a.div_w = make_fastdiv((uint32_t)W);
+    const long xb = ((long)(N - 1) * dy_img_stride + (long)Cout * H * W) * 4;
+    const long ab = x6_row_dwords_kk(Cout, Cin, kh * kw, 1) * 4;
+    const long yb = ((long)(N - 1) * dx_img_stride + (long)Cin * H * W) * 4;
+    const long mb = a.mask_y ? ((long)(N - 1) * mask_img_stride + (long)Cin * H * W) * 4 : 0;
+    SSN_CHECK_ARG(xb < (1l << 31) && ab < (1l << 31) && yb < (1l << 31) && mb < (1l << 31) && (long)N * H * W < (1l << 31),
+                  "conv x6 dgrad rect: operand larger than 2 GiB (buffer addressing)");
+    a.x_bytes = (uint32_t)xb;
+    a.a_bytes = (uint32_t)ab;
+    a.y_bytes = (uint32_t)yb;
+    a.mask_bytes = (uint32_t)mb;
+    return dispatch_rect(a, kh, kw, tile_cfg, stream);
 }
 
 extern "C" long ssn_conv_x6_packed_floats_rect(int Cout, int Cin, int kh, int kw) {
@@ -198,12 +278,5 @@ extern "C" int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const
     a.a_bytes = (uint32_t)ab;
     a.y_bytes = (uint32_t)yb;
     a.mask_bytes = 0;
-    if (kh == 4 && kw == 4) return launch_rect<4, 4>(a, tile_cfg, stream);
-    if (kh == 5 && kw == 5) return launch_rect<5, 5>(a, tile_cfg, stream);
-    if (kh == 1 && kw == 7) return launch_rect<1, 7>(a, tile_cfg, stream);
-    if (kh == 7 && kw == 1) return launch_rect<7, 1>(a, tile_cfg, stream);
-    if (kh == 1 && kw == 3) return launch_rect<1, 3>(a, tile_cfg, stream);
-    if (kh == 3 && kw == 1) return launch_rect<3, 1>(a, tile_cfg, stream);
-    ssn_set_error("conv x6 rect: %dx%d taps have no kernel", kh, kw);
-    return SSN_ERR_ARG;
+    return dispatch_rect(a, kh, kw, tile_cfg, stream);
 }

@@ -15,7 +15,7 @@ void ssn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* ssn_last_error(void) { return g_err; }
-extern "C" int ssn_abi_version(void) { return 3; }
+extern "C" int ssn_abi_version(void) { return 4; }
 
 namespace {
 
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_kernel(float* dy, const float
         const long di = (long)n * dy_img_stride + rem;
         const long yi = (long)n * y_img_stride + rem;
         const float yv = y[yi];
-        const float o = (yv > 0.f) ? dy[di] * scale[c] : 0.f;
+        const float sc = scale[c];     // NaN: not a ReLU / frozen-BN output (pass-through channel), as in the fused epilogues
+        const float o = (sc != sc) ? dy[di] : ((yv > 0.f) ? dy[di] * sc : 0.f);
         dy[di] = o;
         vmax = fmaxf(vmax, fabsf(o));
     }

@@ -319,15 +319,36 @@ def pack_dgrad_s2(w):
     return out
 
 
-def conv_x6_dgrad_s2(dy, wt, dx, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
-    """dgrad of a 3x3 / stride-2 / pad-1 conv (even input size) on the f16 matrix cores.  wt: pack_dgrad_s2(w)."""
+def pack_dgrad_rect(w):
+    """dgrad operand of a stride-1 layer with rectangular taps for conv_x6_dgrad_rect (transposed, taps reversed)."""
+    lib = _check(w)
+    cout, cin, kh, kw = w.shape
+    out = torch.empty(int(lib.cdll.ssn_conv_x6_packed_floats_dgrad_rect(cout, cin, kh, kw)), device=w.device,
+                      dtype=torch.float32)
+    lib.call("ssn_conv_x6_pack_dgrad_rect", _p(w.contiguous()), _p(out), cout, cin, kh, kw, _stream(lib, w))
+    return out
+
+
+def conv_x6_dgrad_rect(dy, wt, dx, kh, kw, pad_h, pad_w, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
+    """dgrad of a stride-1 same-size layer with kh x kw taps on the f16 matrix cores.  wt: pack_dgrad_rect(w)."""
+    lib = _check(dy, wt, dx, mask_y, mask_scale)
+    h, w = dx.hw
+    assert dy.hw == dx.hw
+    ga = _amax_in(dy)
+    lib.call("ssn_conv_x6_dgrad_rect", _p(dy), _p(wt), _p(dx), dy.n, dy.c, h, w, dy.img_stride, dx.c, dx.img_stride,
+             kh, kw, pad_h, pad_w, int(accumulate), _p(mask_y), mask_y.img_stride if mask_y is not None else 0,
+             _p(mask_scale), guard_bytes(dy), tile_cfg, _p(ga), _amax_out(dx), _stream(lib, wt))
+
+
+def conv_x6_dgrad_s2(dy, wt, dx, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None, pad=1):
+    """dgrad of a 3x3 / stride-2 conv on the f16 matrix cores: pad 1 (even input size) or pad 0.  wt: pack_dgrad_s2(w)."""
     lib = _check(dy, wt, dx, mask_y, mask_scale)
     ho, wo = dy.hw
     h, w = dx.hw
     ga = _amax_in(dy)
     lib.call("ssn_conv_x6_dgrad_s2", _p(dy), _p(wt), _p(dx), dy.n, dy.c, ho, wo, dy.img_stride, dx.c, h, w,
              dx.img_stride, int(accumulate), _p(mask_y), mask_y.img_stride if mask_y is not None else 0,
-             _p(mask_scale), guard_bytes(dy), tile_cfg, _p(ga), _amax_out(dx), _stream(lib, wt))
+             _p(mask_scale), guard_bytes(dy), tile_cfg, _p(ga), _amax_out(dx), int(pad), _stream(lib, wt))
 
 
 def relu_bn_bwd(dy, y, scale):
@@ -411,6 +432,26 @@ def conv_wgrad_x6(g, x, dw, db, ksize, pad, workspace, tile_cfg=-1, g_row_split=
     lib.call("ssn_conv_wgrad_x6", _p(g), _p(x), _p(dw), _p(db), x.n, x.c, h, w, x.img_stride, g.c, g.img_stride,
              ksize, pad, guard_bytes(x), _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg,
              _p(ga), _p(xa), int(g_row_split), int(g_row_gap), _p(_slot_ext(g)) if g_row_gap else None, _stream(lib, dw))
+
+
+def wgrad_x6_rect_workspace_bytes(n, cin, cout, h, w, kh, kw, tile_cfg=-1):
+    return int(_lib.get_lib().cdll.ssn_conv_wgrad_x6_rect_workspace_bytes(n, cin, cout, h, w, kh, kw, tile_cfg))
+
+
+def wgrad_x6_rect_guard_floats(pad_h, pad_w, w):
+    """Readable floats conv_wgrad_x6_rect needs in front of x (the taps in front of a pixel reach that far)."""
+    return max(64, ((pad_h * w + pad_w) * 4 + 255) // 256 * 64)
+
+
+def conv_wgrad_x6_rect(g, x, dw, db, kh, kw, pad_h, pad_w, workspace, tile_cfg=-1):
+    """conv_wgrad of a stride-1 same-size layer with kh x kw taps on the f16 matrix cores; dw [Cout, Cin, kh, kw]."""
+    lib = _check(g, x, dw, db, workspace)
+    h, w = x.hw
+    assert g.hw == x.hw
+    ga, xa = _amax_in(g), _amax_in(x)
+    lib.call("ssn_conv_wgrad_x6_rect", _p(g), _p(x), _p(dw), _p(db), x.n, x.c, h, w, x.img_stride, g.c, g.img_stride,
+             kh, kw, pad_h, pad_w, guard_bytes(x), _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg,
+             _p(ga), _p(xa), _stream(lib, dw))
 
 
 def pool_fwd(kind, x, y, argmax, ksize, stride, pad):

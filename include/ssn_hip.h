@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define SSN_ERR_WORKSPACE (-3)
 
 const char* ssn_last_error(void);
-int ssn_abi_version(void);   /* 3 */
+int ssn_abi_version(void);   /* 4 */
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
@@ -147,24 +147,34 @@ int ssn_conv_x6_dgrad(const float* dy, const float* wt_packed, float* dx, int N,
 
 /* Rectangular taps (csrc/conv_x6_rect.hip): the forward convolutions of the Inception-v3 backbone the reference's
  * tester runs on ActivityNet (ssn_models.py:133-139): kh x kw in {5x5, 1x7, 7x1, 1x3, 3x1}, stride 1, per-axis
- * padding; same kernel, arguments and accuracy class as ssn_conv_x6_fwd.  Forward only (dense testing). */
+ * padding; same kernel, arguments and accuracy class as ssn_conv_x6_fwd.  Their data gradient (training SSN on
+ * Inception-v3, ssn_models.py:133-139 + ssn_train.py:236) is the forward correlation of dy with the transposed,
+ * tap-reversed weight (ssn_conv_x6_pack_dgrad_rect): ssn_conv_x6_dgrad_rect, same-size layers (2 pad = taps - 1),
+ * accumulate / mask_y / mask_scale as ssn_conv_x6_dgrad. */
 long ssn_conv_x6_packed_floats_rect(int Cout, int Cin, int kh, int kw);
 int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cout, int cin, int kh, int kw, hipStream_t stream);
 int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const float* scale, const float* shift, float* y,
                          int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                          long y_img_stride, int kh, int kw, int pad_h, int pad_w, int relu, int x_guard_bytes,
                          int tile_cfg, const float* x_amax, float* y_amax, hipStream_t stream);
+long ssn_conv_x6_packed_floats_dgrad_rect(int Cout, int Cin, int kh, int kw);
+int ssn_conv_x6_pack_dgrad_rect(const float* w, float* out, int cout, int cin, int kh, int kw, hipStream_t stream);
+int ssn_conv_x6_dgrad_rect(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int H, int W,
+                           long dy_img_stride, int Cin, long dx_img_stride, int kh, int kw, int pad_h, int pad_w,
+                           int accumulate, const float* mask_y, long mask_img_stride, const float* mask_scale,
+                           int dy_guard_bytes, int tile_cfg, const float* dy_amax, float* dx_amax, hipStream_t stream);
 
 /* Data gradient of the 3x3 / stride-2 / pad-1 layers (even input size) on the x6 kernel: four stride-1 launches, one
  * per parity class of the input pixel, each multiplying only the taps that reach that class (cuDNN dgrad behind
  * loss.backward(), ssn_train.py:236).  wt_packed: ssn_conv_x6_pack_dgrad_s2 (ssn_conv_x6_dgrad_s2_packed_floats
- * floats) of the torch-layout weight [Cout][Cin][3][3].  Other arguments as ssn_conv_x6_dgrad. */
+ * floats) of the torch-layout weight [Cout][Cin][3][3].  pad = 1 (BN-Inception; even input size) or 0 (the "valid"
+ * stride-2 layers of Inception-v3, any input size >= 3).  Other arguments as ssn_conv_x6_dgrad. */
 long ssn_conv_x6_dgrad_s2_packed_floats(int Cout, int Cin);
 int ssn_conv_x6_pack_dgrad_s2(const float* w, float* out, int cout, int cin, hipStream_t stream);
 int ssn_conv_x6_dgrad_s2(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int Ho, int Wo,
                          long dy_img_stride, int Cin, int H, int W, long dx_img_stride, int accumulate,
                          const float* mask_y, long mask_img_stride, const float* mask_scale, int dy_guard_bytes,
-                         int tile_cfg, const float* dy_amax, float* dx_amax, hipStream_t stream);
+                         int tile_cfg, const float* dy_amax, float* dx_amax, int pad, hipStream_t stream);
 
 /* x6 weight gradient (csrc/conv_wgrad_x6.hip): stride-1 same-size 1x1 / 3x3 convolutions with H*W % 4 == 0, both
  * operands scaled and split to f16 on the fly (g_amax / x_amax: their tensors' amax slots, required), 16-byte loads
@@ -175,6 +185,13 @@ int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int 
                       long x_img_stride, int Cout, long g_img_stride, int ksize, int pad, int x_guard_bytes,
                       void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
                       int g_row_split, int g_row_gap, const float* g_amax2, hipStream_t stream);
+/* ... of the stride-1 same-size layers with rectangular taps (kh x kw, 2 pad = taps - 1; dw [Cout][Cin][kh][kw]); x needs
+ * (pad_h * W + pad_w) * 4 readable bytes in front of it, rounded up to a multiple of 256 */
+long ssn_conv_wgrad_x6_rect_workspace_bytes(int N, int Cin, int Cout, int H, int W, int kh, int kw, int tile_cfg);
+int ssn_conv_wgrad_x6_rect(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
+                           long x_img_stride, int Cout, long g_img_stride, int kh, int kw, int pad_h, int pad_w,
+                           int x_guard_bytes, void* workspace, long ws_bytes, int tile_cfg, const float* g_amax,
+                           const float* x_amax, hipStream_t stream);
 /* second pass of both wgrad kernels: dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] */
 int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
 

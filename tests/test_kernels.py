@@ -692,6 +692,93 @@ def test_conv_x6_dgrad_s2(backend):
         assert torch.equal(wide[:, :5].cpu(), prev[:, :5])
 
 
+def test_conv_split_rect_backward(backend):
+    """Backward of the rectangular-tap layers (Inception-v3 training): data gradient as a forward correlation with the
+    transposed, tap-reversed operand (plain / accumulating + fused ReLU-BN mask into a channel slice) and the weight + bias
+    gradient with runtime taps, vs torch autograd in fp64; planes that are / are not a multiple of 4 pixels."""
+    g = torch.Generator().manual_seed(47)
+    cases = ([(3, 48, 16, 64, 5, 5, -1, -1), (2, 128, 17, 160, 1, 7, 2, 2), (2, 160, 17, 192, 7, 1, 5, 3), (2, 96, 8, 100, 1, 3, 6, 0),
+              (2, 40, 8, 96, 3, 1, 1, 6), (1, 48, 35, 64, 5, 5, 2, 5), (4, 384, 8, 384, 3, 1, -1, -1)] if backend.is_gpu else
+             [(1, 8, 6, 40, 5, 5, -1, -1), (1, 20, 5, 33, 1, 7, 2, 2), (1, 16, 6, 64, 7, 1, 6, 3), (2, 8, 4, 32, 1, 3, 1, 0),
+              (1, 8, 3, 70, 3, 1, 5, 6)])
+    for (n, cin, h, cout, kh, kw, tile, wcfg) in cases:
+        ph, pw = (kh - 1) // 2, (kw - 1) // 2
+        x = torch.randn(n, cin, h, h, generator=g).double().requires_grad_()
+        w = (torch.randn(cout, cin, kh, kw, generator=g) * 0.1).double().requires_grad_()
+        b = torch.zeros(cout, dtype=torch.double, requires_grad=True)
+        y = F.conv2d(x, w, b, 1, (ph, pw))
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy.double())
+        dev = backend.put(torch.zeros(1)).device
+        guard = K.wgrad_x6_rect_guard_floats(ph, pw, h)
+        gd = K.guarded_empty(gy.shape, dev)
+        gd.copy_(gy)
+        wt = K.pack_dgrad_rect(backend.put(w.detach().float()))
+        dx = backend.put(torch.full((n, cin, h, h), 7.0))
+        K.conv_x6_dgrad_rect(K.full(gd), wt, K.full(dx), kh, kw, ph, pw, False, tile)
+        assert rel_err(dx, x.grad) < 2e-6, ("dgrad rect", n, cin, h, cout, kh, kw, tile)
+        prev = torch.randn(n, cin + 5, h, h, generator=g)
+        act = torch.randn(n, cin + 5, h, h, generator=g)
+        msc = torch.rand(cin, generator=g) + 0.5
+        msc[1::3] = -msc[1::3]
+        msc[::3] = float("nan")
+        wide = backend.put(prev.clone())
+        K.conv_x6_dgrad_rect(K.full(gd), wt, K.ChanSlice(wide, 5, cin), kh, kw, ph, pw, True, tile,
+                             mask_y=K.ChanSlice(backend.put(act), 5, cin), mask_scale=backend.put(msc))
+        tot = prev[:, 5:].double() + x.grad
+        m = msc.view(1, -1, 1, 1).double()
+        ref = torch.where(torch.isnan(m), tot, torch.where(act[:, 5:].double() > 0, tot * m, torch.zeros_like(tot)))
+        assert rel_err(wide[:, 5:], ref) < 2e-6, ("dgrad rect acc+mask", n, cin, h, cout, kh, kw, tile)
+        assert torch.equal(wide[:, :5].cpu(), prev[:, :5])
+        # weight + bias gradient
+        xd = K.guarded_empty(x.shape, dev, guard)
+        xd.copy_(x.detach().float())
+        ws = backend.put(torch.empty(K.wgrad_x6_rect_workspace_bytes(n, cin, cout, h, h, kh, kw, wcfg) // 4))
+        dw, db = backend.put(torch.empty(cout, cin, kh, kw)), backend.put(torch.empty(cout))
+        K.conv_wgrad_x6_rect(K.full(gd), K.full(xd), dw, db, kh, kw, ph, pw, ws, wcfg)
+        assert rel_err(dw, w.grad) < 5e-5, ("wgrad rect", n, cin, h, cout, kh, kw, wcfg)
+        assert rel_err(db, b.grad) < 5e-5
+
+
+def test_conv_split_valid_and_stride2_pad0_dgrad(backend):
+    """The unpadded 3x3 layers of Inception-v3: stride 1 (dx is larger than dy) on the square dgrad kernel, stride 2 as four
+    parity-class launches with the two-tap classes on the EVEN rows / columns; odd and even input sizes; accumulate + mask."""
+    g = torch.Generator().manual_seed(48)
+    cases = ([(2, 32, 21, 32, 1, -1), (2, 80, 17, 192, 1, 2), (2, 288, 35, 384, 2, -1), (3, 96, 17, 96, 2, 3), (2, 192, 17, 320, 2, 5),
+              (2, 40, 8, 48, 2, 1), (1, 24, 12, 70, 2, 6)] if backend.is_gpu else
+             [(1, 8, 7, 40, 1, -1), (1, 8, 9, 40, 2, -1), (2, 20, 5, 33, 2, 3), (1, 16, 8, 20, 2, 2), (1, 8, 6, 16, 2, 6)])
+    for (n, cin, h, cout, s, tile) in cases:
+        x = torch.randn(n, cin, h, h + 2, generator=g).double().requires_grad_()
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1)
+        y = F.conv2d(x, w.double(), None, s, 0)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy.double())
+        dev = backend.put(torch.zeros(1)).device
+        gd = K.guarded_empty(gy.shape, dev)
+        gd.copy_(gy)
+        if s == 1:
+            (wt,) = K.pack_weights_multi([([backend.put(w)], 1)], x6=True)
+            run = lambda dst, acc, **kw: K.conv_x6_dgrad(K.full(gd), wt, dst, 3, 0, acc, tile, **kw)   # noqa: E731
+        else:
+            wt = K.pack_dgrad_s2(backend.put(w))
+            run = lambda dst, acc, **kw: K.conv_x6_dgrad_s2(K.full(gd), wt, dst, acc, tile, pad=0, **kw)   # noqa: E731
+        dx = backend.put(torch.full(tuple(x.shape), 7.0))
+        run(K.full(dx), False)
+        assert rel_err(dx, x.grad) < 2e-6, ("dgrad pad 0", n, cin, h, cout, s, tile)
+        prev = torch.randn(n, cin + 5, h, h + 2, generator=g)
+        act = torch.randn(n, cin + 5, h, h + 2, generator=g)
+        msc = torch.rand(cin, generator=g) + 0.5
+        msc[1::3] = -msc[1::3]
+        msc[::3] = float("nan")
+        wide = backend.put(prev.clone())
+        run(K.ChanSlice(wide, 5, cin), True, mask_y=K.ChanSlice(backend.put(act), 5, cin), mask_scale=backend.put(msc))
+        tot = prev[:, 5:].double() + x.grad
+        m = msc.view(1, -1, 1, 1).double()
+        ref = torch.where(torch.isnan(m), tot, torch.where(act[:, 5:].double() > 0, tot * m, torch.zeros_like(tot)))
+        assert rel_err(wide[:, 5:], ref) < 2e-6, ("dgrad pad 0 acc+mask", n, cin, h, cout, s, tile)
+        assert torch.equal(wide[:, :5].cpu(), prev[:, :5])
+
+
 def test_bn_train(backend):
     """Training-mode BatchNorm2d + ReLU (bn_mode 'partial' / 'full'): statistics, running-stat update, output and the full
     backward against torch autograd in float64, on channel slices, with a large per-channel offset (|mean| >> sigma)."""
