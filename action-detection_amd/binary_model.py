@@ -4,8 +4,7 @@ actionness classifier the TAG proposal pipeline trains on the same backbone (``b
 -> ``classifier_fc``; test mode scores single frames with ``test_fc``.
 
 Same constructor, ``forward(inputdata, target)`` -> ``(logits, target)``, ``prepare_test_fc``, ``train()`` BN
-freezing and ``get_optim_policies`` as the reference.  Backbones: BNInception (training and testing) and
-InceptionV3 (testing), as for ``SSN``.  The segment mean runs on the STPP kernels (one part = all segments).
+freezing and ``get_optim_policies`` as the reference.  Backbones: BNInception and InceptionV3, as for ``SSN``.  The segment mean runs on the STPP kernels (one part = all segments).
 """
 import torch
 from torch import nn

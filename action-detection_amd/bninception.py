@@ -56,6 +56,17 @@ def x6_wins(kind, cin, cout, k, s, hin):
     return t6 is None or t32 is None or t6 <= t32
 
 
+def conv_taps(op):
+    """(kh, kw, pad_h, pad_w) of a plan convolution: square layers carry k / p only, the rectangular ones of Inception-v3
+    (5x5, 1x7, 7x1, 1x3, 3x1; csrc/conv_x6_rect.hip) carry the per-axis values."""
+    return op.get("kh", op["k"]), op.get("kw", op["k"]), op.get("ph", op["p"]), op.get("pw", op["p"])
+
+
+def is_rect(op):
+    kh, kw, _, _ = conv_taps(op)
+    return kh != kw or kh not in (1, 3, 7)
+
+
 class _BackboneFn(torch.autograd.Function):
     """The whole backbone as one autograd node.  A batch whose largest activation tensor would exceed what one kernel operand
     can address (32-bit buffer offsets: 2 GiB, 668 frames of 224 x 224) runs as consecutive sub-batches -- forward and backward
@@ -121,6 +132,9 @@ class BNInception(nn.Module):
                 setattr(self, lid + "_bn", nn.BatchNorm2d(cout, eps=1e-5))
                 self._conv_ids.append(lid)
         self.fc = nn.Linear(FEATURE_DIM, num_classes)
+        self._init_executor()
+
+    def _init_executor(self):
         self.grad_ready_hook = None   # object with range_ready(flat, start, end) / finish() (parallel.GradReducer)
         self._ws = None
         self._side = {}               # device -> side HIP stream for the weight-gradient chain
@@ -396,13 +410,22 @@ class BNInception(nn.Module):
         ext_base = shapes.get("__ext__", {})      # tensors with a second region (the reduce rows behind a block's output)
         slot_pool = torch.zeros(2 * len(shapes) + 2, device=dev, dtype=torch.float32)
         slot_of = {}
+        # readable floats in front of every activation: lets the x6 kernels use 16-byte loads; the weight gradient of a
+        # rectangular-tap layer reaches (pad_h * W + pad_w) floats in front of its input
+        guard = 64
+        for op in plan:
+            if op["kind"] == "conv":
+                op["rect"] = is_rect(op)
+                if op["rect"]:
+                    if self.conv_precision != "split":
+                        raise NotImplementedError("%dx%d taps only exist on the split-precision kernels" % conv_taps(op)[:2])
+                    guard = max(guard, K.wgrad_x6_rect_guard_floats(conv_taps(op)[2], conv_taps(op)[3], shapes[op["src"]][2]))
 
         def get(name):
             if name not in acts:
                 c, h, w = shapes[name]
                 i = slot_of.setdefault(name, len(slot_of))
-                # readable floats in front of every activation: lets the x6 kernels use 16-byte loads
-                acts[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev), slot_pool[2 * i:2 * i + 1])
+                acts[name] = K.attach_amax(K.guarded_empty((n, c, h, w), dev, guard), slot_pool[2 * i:2 * i + 1])
                 if name in ext_base:
                     K.attach_amax_ext(acts[name], slot_pool[2 * i + 1:2 * i + 2], ext_base[name])
             return acts[name]
@@ -456,7 +479,7 @@ class BNInception(nn.Module):
                          and (op["k"], op["s"], op["p"]) == (7, 2, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                          and not op.get("raw"))
         for op in conv_ops:      # which matrix path each layer takes (f16 2-way split, or exact f32 MFMA)
-            op["x6"] = (self.conv_precision == "split" and op["k"] in (1, 3)
+            op["x6"] = (self.conv_precision == "split" and op["k"] in (1, 3) and not op["rect"] and op["cin"] >= 16
                         and ("raw_from" in op or "row_gap" in op      # (raw rows / displaced rows: split kernel only)
                              or x6_wins("fwd", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
         packed_fwd = {}
@@ -464,8 +487,10 @@ class BNInception(nn.Module):
             if op["s2d"]:
                 acts["data_s2d"] = K.space_to_depth2(x)
                 packed_fwd[op["lids"][0]] = K.pack_weights_rect(K.s2d_weights(getattr(self, op["lids"][0]).weight.detach()))
+            elif op["rect"]:
+                packed_fwd[op["lids"][0]] = K.pack_weights_rect(getattr(self, op["lids"][0]).weight.detach())
         for x6 in (False, True):
-            ops = [op for op in conv_ops if op["x6"] == x6 and not op["s2d"]]
+            ops = [op for op in conv_ops if op["x6"] == x6 and not op["s2d"] and not op["rect"]]
             packed_fwd.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
                 [([getattr(self, lid).weight.detach() for lid in op["lids"]], 0) for op in ops], x6=x6)))
 
@@ -525,12 +550,16 @@ class BNInception(nn.Module):
                 # (per-channel vector of the destination tensor from the slice's first channel; a block-head launch reaches
                 #  row_gap channels further up for its rows behind the split, like its stores)
                 scale = None if raw else scale_slice(op["dst"], op["dst_c0"], cout + op.get("row_gap", 0))
-                ho = shapes[op["dst"]][1]
+                ho, wo = shapes[op["dst"]][1], shapes[op["dst"]][2]
                 hin = shapes[op["src"]][1]
-                flops = 2.0 * n * ho * ho * cout * cin * k * k
+                kh, kw, ph, pw = conv_taps(op)
+                flops = 2.0 * n * ho * wo * cout * cin * kh * kw
                 src_slice = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 dst_slice = ChanSlice(get(op["dst"]), op["dst_c0"], cout)
-                if op["s2d"]:
+                if op["rect"]:
+                    self._timed("conv_fwd_x6", op["lids"][0], flops,
+                                lambda: K.conv_x6_fwd_rect(src_slice, wp, scale, shift, dst_slice, kh, kw, ph, pw, not raw))
+                elif op["s2d"]:
                     xs = acts["data_s2d"]
                     self._timed("conv_fwd_x6", op["lids"][0], flops,
                                 lambda: K.conv_x6_fwd_rect(full(xs), wp, scale, shift, dst_slice, 4, 4, 2, 2, True,
@@ -636,6 +665,11 @@ class BNInception(nn.Module):
                     ws_bytes = max(ws_bytes, K.wgrad_x6_workspace_bytes(
                         n, 4 * op["cin"], op["cout"], hin // 2, win // 2, 4,
                         tuned_tile("wgrad6s2d", n, op["cin"], op["cout"], op["k"], op["s"], hin)))
+                kh, kw, ph, pw = conv_taps(op)
+                if op["rect"]:      # stride-1 same-size layers with rectangular taps: runtime-tap instantiation of the split kernel
+                    wg_x6[op["lids"][0]] = True
+                    ws_bytes = max(ws_bytes, K.wgrad_x6_rect_workspace_bytes(n, op["cin"], op["cout"], hin, win, kh, kw))
+                    continue
                 x6 = (self.conv_precision == "split" and op["src"] != "data"
                       and K.wgrad_x6_supported(op["k"], op["s"], op["p"], hin, win)
                       and ("row_gap" in op or (self.wgrad_x6 and x6_wins("wgrad", op["cin"], op["cout"], op["k"], op["s"], hin))))
@@ -653,21 +687,25 @@ class BNInception(nn.Module):
         ws = self._workspace(ws_bytes, dev)
         # all dgrad weight operands in two launches
         dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
-        dg_layout = {op["lids"][0]: K.dgrad_layout(op["k"], op["s"], op["p"], shapes[op["src"]][1],
-                                                   shapes[op["src"]][2]) for op in dg_ops}
-        dg_x6 = {op["lids"][0]: (self.conv_precision == "split" and op["k"] in (1, 3) and op["s"] == 1
+        dg_layout = {op["lids"][0]: 1 if op["rect"] else K.dgrad_layout(op["k"], op["s"], op["p"], shapes[op["src"]][1],
+                                                                        shapes[op["src"]][2]) for op in dg_ops}
+        dg_x6 = {op["lids"][0]: (self.conv_precision == "split" and op["k"] in (1, 3) and op["s"] == 1 and not op["rect"]
                                  and ("raw_from" in op or "row_gap" in op
                                       or x6_wins("dgrad", op["cin"], op["cout"], op["k"], op["s"], shapes[op["src"]][1])))
                  for op in dg_ops}
         # 3x3 / stride-2 layers: four parity-class stride-1 launches on the x6 kernel (no tap that does not contribute)
-        dg_s2 = {op["lids"][0]: (self.conv_precision == "split" and dg_layout[op["lids"][0]] == 2 and len(op["lids"]) == 1)
+        # (pad 1 on an even input: BN-Inception; pad 0: the "valid" stride-2 layers of Inception-v3)
+        dg_s2 = {op["lids"][0]: (self.conv_precision == "split" and len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3
+                                 and op["s"] == 2 and (dg_layout[op["lids"][0]] == 2 or op["p"] == 0))
                  for op in dg_ops}
         packed_dg = {}
         for op in dg_ops:
             if dg_s2[op["lids"][0]]:
                 packed_dg[op["lids"][0]] = K.pack_dgrad_s2(getattr(self, op["lids"][0]).weight.detach())
+            elif op["rect"]:
+                packed_dg[op["lids"][0]] = K.pack_dgrad_rect(getattr(self, op["lids"][0]).weight.detach())
         for x6 in (False, True):
-            ops = [op for op in dg_ops if dg_x6[op["lids"][0]] == x6 and not dg_s2[op["lids"][0]]]
+            ops = [op for op in dg_ops if dg_x6[op["lids"][0]] == x6 and not dg_s2[op["lids"][0]] and not op["rect"]]
             packed_dg.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
                 [([getattr(self, lid).weight.detach() for lid in op["lids"]], 1 if x6 else dg_layout[op["lids"][0]])
                  for op in ops], x6=x6)))
@@ -781,13 +819,16 @@ class BNInception(nn.Module):
                     wo2, wn2, bo2, bn2 = lay[extra]
                     assert wo2 == wo + wn and bo2 == bo + bn
                     wn, bn = wn + wn2, bn + bn2
-                dw = flat[wo:wo + wn].view(cout, cin, k, k)
+                kh, kw, ph, pw = conv_taps(op)
+                dw = flat[wo:wo + wn].view(cout, cin, kh, kw)
                 db = flat[bo:bo + bn]
                 ho = shapes[op["dst"]][1]
                 hin = shapes[op["src"]][1]
-                flops = 2.0 * n * ho * ho * cout * cin * k * k
+                flops = 2.0 * n * ho * shapes[op["dst"]][2] * cout * cin * kh * kw
                 xin = ChanSlice(acts[op["src"]], op["src_c0"], cin)
-                if op.get("s2d"):
+                if op["rect"]:
+                    run_wgrad = lambda: K.conv_wgrad_x6_rect(g, xin, dw, db, kh, kw, ph, pw, ws)   # noqa: E731
+                elif op.get("s2d"):
                     # the stem in its space-to-depth form: 4x4-tap weight gradient on the split kernel, gathered back into
                     # the 7x7 layout of the parameter (the bias gradient comes with it)
                     xs2 = full(acts["data_s2d"])
@@ -832,11 +873,14 @@ class BNInception(nn.Module):
                     acc_flag = key in inited
                     my, ms = mask_args(idx, op, cin)
                     dx = ChanSlice(gbuf(op["src"]), op["src_c0"], cin)
-                    if dg_s2[lids[0]]:
+                    if op["rect"]:
+                        self._timed("conv_dgrad_x6", lids[0], flops,
+                                    lambda: K.conv_x6_dgrad_rect(g, wt, dx, kh, kw, ph, pw, acc_flag, mask_y=my, mask_scale=ms))
+                    elif dg_s2[lids[0]]:
                         self._timed("conv_dgrad_x6", lids[0], flops,
                                     lambda: K.conv_x6_dgrad_s2(g, wt, dx, acc_flag,
                                                                tuned_tile("dgrad6s2", n, cin, cout, k, s, hin),
-                                                               mask_y=my, mask_scale=ms))
+                                                               mask_y=my, mask_scale=ms, pad=p))
                     elif dg_x6[lids[0]]:
                         self._timed("conv_dgrad_x6", lids[0], flops,
                                     lambda: K.conv_x6_dgrad(g, wt, dx, k, p, acc_flag,

@@ -5,7 +5,7 @@ Same constructor, ``forward`` 7-tuple / test 2-tuple, ``prepare_test_fc``,
 ``get_optim_policies``, BN-freezing ``train()`` and ``state_dict`` keys as the reference, so it
 drops into the loops of ssn_train.py:205-253 and ssn_test.py:78-92.  Differences that are
 deliberate and documented in DESIGN.md:
-  * BNInception is built for training and testing, InceptionV3 for testing (forward only); resnet/vgg raise;
+  * BNInception and InceptionV3 are built (training and testing, one executor); resnet/vgg raise;
   * the backbone is this repo's ``bninception.BNInception`` executor instead of ``model_zoo``;
   * ``bn_mode`` 'partial' / 'full' run the training-mode BatchNorm kernels of csrc/bn_train.hip (batch statistics per
     rank, like the per-replica statistics of the reference's DataParallel);
@@ -133,7 +133,7 @@ class SSN(torch.nn.Module):
     # ---- /root/reference/ssn_models.py:107-154
     _BACKBONES = {   # name -> (constructor, last layer, input size): the ones built on the MI355X kernels
         'BNInception': (BNInception, 'fc', 224),            # training and testing
-        'InceptionV3': (InceptionV3, 'top_cls_fc', 299),    # forward only (dense testing, BASELINE.json configs[4])
+        'InceptionV3': (InceptionV3, 'top_cls_fc', 299),    # training and testing (BASELINE.json configs[4] tests on it)
     }
 
     def _prepare_base_model(self, base_model):
@@ -152,8 +152,8 @@ class SSN(torch.nn.Module):
                 self.input_mean = [104, 117, 128]
         elif 'resnet' in base_model or 'vgg' in base_model or 'inception' in base_model:
             raise NotImplementedError(
-                "base model {} is not built: the MI355X hot path covers BNInception (training and testing) and "
-                "InceptionV3 (testing)".format(base_model))
+                "base model {} is not built: the MI355X hot path covers BNInception and InceptionV3 "
+                "(training and testing)".format(base_model))
         else:
             raise ValueError('Unknown base model: {}'.format(base_model))
 

@@ -70,7 +70,7 @@ def test_ssn_api_surface():
         SSN(20, 2, 5, 2, "RGB", base_model="alexnet")
     with pytest.raises(NotImplementedError):
         SSN(20, 2, 5, 2, "RGB", base_model="resnet50")
-    v3 = SSN(20, 2, 5, 2, "RGB", base_model="InceptionV3", test_mode=True)      # forward-only backbone
+    v3 = SSN(20, 2, 5, 2, "RGB", base_model="InceptionV3", test_mode=True)
     assert (v3.input_size, v3.crop_size, v3.scale_size) == (299, 299, 299 * 256 // 224)
     assert v3.activity_fc.in_features == 2048 and v3.base_model.last_layer_name == "top_cls_fc"
 

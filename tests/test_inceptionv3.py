@@ -1,6 +1,9 @@
-"""Inception-v3 backbone (BASELINE.json configs[4], forward only): product executor vs the oracle's block-by-block
-restatement -- through the host emulator at a reduced input size (CPU tier) and at 299x299 on the MI355X (-m gpu,
-SSN test_forward + the dense-testing loop)."""
+"""Inception-v3 backbone (BASELINE.json configs[4] tests on it, ssn_train.py trains on it): product executor vs the
+oracle's block-by-block restatement -- through the host emulator at a reduced input size (CPU tier; the backward is
+opt-in, ~5 min) and at 299x299 on the MI355X (-m gpu: SSN test_forward + the dense-testing loop, backbone forward +
+backward, an SSN training step)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -32,8 +35,137 @@ def test_inceptionv3_features_emulated(emu):
         ref = orc.features(x)
     assert feat.shape == (1, 2048)
     assert rel_err(feat, ref) < 1e-4
-    with pytest.raises(NotImplementedError):
-        prod.features(x.requires_grad_())
+
+
+def _backbone_grads(prod, orc, x, w, dev="cpu", with_cpu=False):
+    """Features and parameter gradients of  sum(features * w)  from the product and from a float64 copy of the oracle."""
+    prod.zero_grad(set_to_none=True)
+    f = prod.features(x.to(dev))
+    (f * w.to(dev)).sum().backward()
+    o64 = O.OracleInceptionV3(num_classes=10).double()
+    o64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in orc.state_dict().items()})
+    o64.eval()
+    for a, b in zip(prod.modules(), o64.modules()):       # same BatchNorm modes
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.train(a.training)
+    fo = o64.features(x.double())
+    (fo * w.double()).sum().backward()
+    ref = dict(o64.named_parameters())
+    errs = {}
+    for n, p in prod.named_parameters():
+        if p.grad is not None:
+            errs[n] = rel_err(p.grad, ref[n].grad)
+    if not with_cpu:
+        return rel_err(f, fo), errs
+    # the oracle in fp32 against the same float64 referee: how far torch's own fp32 path is off (ReLU / max-pool units
+    # within rounding of their threshold take the other branch, see test_model_gpu.py)
+    o32 = O.OracleInceptionV3(num_classes=10)
+    o32.load_state_dict(orc.state_dict())
+    o32.eval()
+    for a, b in zip(prod.modules(), o32.modules()):
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.train(a.training)
+    (o32.features(x) * w).sum().backward()
+    cpu = {n: rel_err(p.grad, ref[n].grad) for n, p in o32.named_parameters() if n in errs}
+    return rel_err(f, fo), errs, cpu
+
+
+@pytest.mark.slow_emu
+@pytest.mark.skipif(os.environ.get("SSN_SLOW") != "1", reason="~5 min through the host emulator; set SSN_SLOW=1")
+def test_inceptionv3_backward_emulated(emu):
+    """Forward + backward of the whole backbone on two 75x75 images, a quarter of the BN gammas negative, against the
+    oracle in float64: every conv weight / bias gradient (rectangular-tap dgrad + wgrad, unpadded stride-1 / stride-2
+    dgrads, pools behind their projections, shared inputs accumulated, fused ReLU/BN masks)."""
+    from action_detection_amd.inceptionv3 import InceptionV3
+    torch.manual_seed(0)
+    prod = InceptionV3(num_classes=10, input_size=75)
+    init_backbone_synthetic(prod, negative_gamma_frac=0.25)
+    orc = O.OracleInceptionV3(num_classes=10)
+    orc.load_state_dict(prod.state_dict())
+    prod.eval()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (2, 3, 75, 75), generator=g).float() - 110.0
+    w = torch.randn(2, 2048, generator=g)
+    ferr, errs = _backbone_grads(prod, orc, x, w)
+    assert ferr < 1e-5
+    assert len(errs) == 2 * 94
+    assert max(errs.values()) < 2e-5, max(errs.items(), key=lambda kv: kv[1])
+
+
+@pytest.mark.gpu
+def test_inceptionv3_backbone_backward_gpu(hip_library):
+    """299x299, 4 images: features and every conv gradient against the oracle in float64 (distribution criterion of
+    test_model_gpu.py: the bulk at fp32 level, a few tensors may sit behind a flipped ReLU)."""
+    prod, orc = pair(299)
+    prod.to("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (4, 3, 299, 299), generator=g).float() - 110.0
+    w = torch.randn(4, 2048, generator=g)
+    ferr, errs, cpu = _backbone_grads(prod, orc, x, w, "cuda:0", with_cpu=True)
+    e, ec = torch.tensor(list(errs.values())), torch.tensor([cpu[k] for k in errs])
+    print("Inception-v3 gradients vs float64 (%d tensors): HIP median %.2e max %.2e | torch fp32 CPU median %.2e max %.2e"
+          % (len(e), e.median(), e.max(), ec.median(), ec.max()))
+    assert ferr < 1e-4
+    assert len(errs) == 2 * 94
+    # 4 images and a random linear loss: this configuration is dominated by units that take the other ReLU / max-pool branch
+    # (torch's own fp32 path is 5e-4 / 1.2e-2 off float64); the split kernels' forward error is ~3x an fp32 FMA chain's, so
+    # proportionally more units sit within rounding of their threshold.  The tight bounds are the kernel tests (2e-6 / 5e-5)
+    # and the emulated whole-backbone run above (2e-5 on every tensor).
+    assert e.median() <= 3.0 * ec.median() + 1e-5 and e.max() <= max(2.0 * ec.max(), 5e-3)
+    # training-mode BatchNorm on a few layers (bn_mode 'partial' touches the first; 'full' all): rectangular, strided, pooled
+    train = ("conv_1a_3x3", "mixed_5b_5x5", "mixed_6b_1x7", "mixed_6a_3x3", "mixed_7b_3x3_3x1", "mixed_5c_pool_proj")
+    for lid in train:
+        getattr(prod, lid + "_bn").train()
+    ferr, errs, cpu = _backbone_grads(prod, orc, x, w, "cuda:0", with_cpu=True)
+    # (the bias of a convolution in front of a batch-statistics BatchNorm has a true gradient of zero: rounding noise only)
+    keys = [k for k in errs if k not in [lid + ".bias" for lid in train]]
+    e, ec = torch.tensor([errs[k] for k in keys]), torch.tensor([cpu[k] for k in keys])
+    print("  with 6 training-mode BatchNorms: feature error %.2e, gradients HIP median %.2e max %.2e | torch fp32 CPU median "
+          "%.2e max %.2e" % (ferr, e.median(), e.max(), ec.median(), ec.max()))
+    assert ferr < 1e-4
+    assert len(errs) == 2 * 94 + 2 * 6
+    assert e.median() <= 3.0 * ec.median() + 1e-5 and e.max() <= max(2.0 * ec.max(), 2e-2)
+
+
+@pytest.mark.gpu
+def test_inceptionv3_ssn_training_step(hip_library):
+    """SSN on Inception-v3 in training mode (ssn_train.py with arch InceptionV3): 2 videos x 8 proposals x 9 segments
+    at 139x139 (the topology accepts it; keeps the CPU oracle to seconds), logits / losses 1e-4, gradients vs the oracle."""
+    from action_detection_amd.ops.ssn_ops import ActivityLoss, ClassWiseRegressionLoss, CompletenessLoss
+    from action_detection_amd.ssn_models import SSN
+    from action_detection_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    m = SSN(20, 2, 5, 2, "RGB", base_model="InceptionV3", dropout=0.0, stpp_cfg=(1, 1, 1))
+    init_backbone_synthetic(m.base_model)
+    init_heads_synthetic(m)
+    o = O.OracleSSN(20, 2, 5, 2, "RGB", dropout=0.0, stpp_cfg=(1, 1, 1), base_model="InceptionV3")
+    o.load_state_dict(m.state_dict())
+    m.to("cuda:0").train()
+    o.train()
+    batch = make_batch(2, "RGB", 20, seed=11, input_size=139)
+    out = m(*[t.cuda() for t in batch])
+    ref = o(*batch)
+    for i, (a, b) in enumerate(zip(out, ref)):
+        if i % 2 == 1 or i == 6:
+            assert torch.equal(a.cpu(), b), i
+        else:
+            assert rel_err(a, b) < 1e-4, (i, rel_err(a, b))
+    total = ActivityLoss()(out[0], out[1]) + 0.1 * CompletenessLoss()(out[2], out[3], 1, 7) + \
+        0.1 * ClassWiseRegressionLoss()(out[4], out[5], out[6])
+    rt = O.ssn_total_loss(ref, 2)[0]
+    assert abs(total.item() - rt.item()) <= 1e-4 * abs(rt.item())
+    total.backward()
+    rt.backward()
+    errs = []
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), o.named_parameters()):
+        assert n1 == n2
+        if p2.grad is None:
+            assert p1.grad is None, n1
+            continue
+        errs.append(rel_err(p1.grad, p2.grad))
+    e = torch.tensor(errs)
+    print("SSN / Inception-v3 training step: %d gradient tensors, median %.2e max %.2e" % (len(e), e.median(), e.max()))
+    assert e.median() < 1e-3 and e.max() < 2e-2 and int((e > 5e-3).sum()) <= len(e) // 20
 
 
 @pytest.mark.gpu
