@@ -88,6 +88,7 @@ _SIGS = {
     "ssn_sumsq": "plpipp",
     "ssn_scale": "plpfp",
     "ssn_add_inplace": "pplp",
+    "ssn_embed_planes": "ppiiiiliilp",
     "ssn_space_to_depth2": "ppiiiipp",
     "ssn_s2d_weights": "ppiiip",
     "ssn_s2d_weights_bwd": "ppiiip",

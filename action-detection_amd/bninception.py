@@ -420,6 +420,9 @@ class BNInception(nn.Module):
                     if self.conv_precision != "split":
                         raise NotImplementedError("%dx%d taps only exist on the split-precision kernels" % conv_taps(op)[:2])
                     guard = max(guard, K.wgrad_x6_rect_guard_floats(conv_taps(op)[2], conv_taps(op)[3], shapes[op["src"]][2]))
+                elif op["k"] == 3 and op["s"] == 1 and op["p"] == 1 and shapes[op["src"]][2] < 256:
+                    # (rows wider than 63 pixels: the tap in front of a pixel reaches further than the default 256 bytes)
+                    guard = max(guard, K.wgrad_x6_rect_guard_floats(1, 1, shapes[op["src"]][2]))
 
         def get(name):
             if name not in acts:
@@ -670,8 +673,15 @@ class BNInception(nn.Module):
                     wg_x6[op["lids"][0]] = True
                     ws_bytes = max(ws_bytes, K.wgrad_x6_rect_workspace_bytes(n, op["cin"], op["cout"], hin, win, kh, kw))
                     continue
+                # an unpadded stride-1 3x3 layer: same-grid problem once its output gradient is laid into planes of the input's size
+                op["wg_embed"] = (self.conv_precision == "split" and self.wgrad_x6 and op["src"] != "data" and len(op["lids"]) == 1
+                                  and (op["k"], op["s"], op["p"]) == (3, 1, 0) and op["cin"] >= 16)
+                if op["wg_embed"]:
+                    wg_x6[op["lids"][0]] = True
+                    ws_bytes = max(ws_bytes, K.wgrad_x6_rect_workspace_bytes(n, op["cin"], op["cout"], hin, win, 3, 3))
+                    continue
                 x6 = (self.conv_precision == "split" and op["src"] != "data"
-                      and K.wgrad_x6_supported(op["k"], op["s"], op["p"], hin, win)
+                      and K.wgrad_x6_supported(op["k"], op["s"], op["p"], hin, win, K.guard_bytes(ChanSlice(acts[op["src"]], op["src_c0"], op["cin"])))
                       and ("row_gap" in op or (self.wgrad_x6 and x6_wins("wgrad", op["cin"], op["cout"], op["k"], op["s"], hin))))
                 wg_x6[op["lids"][0]] = x6
                 if x6:
@@ -828,6 +838,11 @@ class BNInception(nn.Module):
                 xin = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 if op["rect"]:
                     run_wgrad = lambda: K.conv_wgrad_x6_rect(g, xin, dw, db, kh, kw, ph, pw, ws)   # noqa: E731
+                elif op.get("wg_embed"):
+                    def run_wgrad():
+                        gp = torch.empty((n, cout, hin, shapes[op["src"]][2]), device=dev, dtype=torch.float32)
+                        K.embed_planes(g, gp)
+                        K.conv_wgrad_x6_rect(full(gp), xin, dw, db, 3, 3, 0, 0, ws)
                 elif op.get("s2d"):
                     # the stem in its space-to-depth form: 4x4-tap weight gradient on the split kernel, gathered back into
                     # the 7x7 layout of the parameter (the bias gradient comes with it)

@@ -454,8 +454,9 @@ extern "C" int ssn_conv_wgrad_x6_rect(const float* g, const float* x, float* dw,
                                       long x_img_stride, int Cout, long g_img_stride, int kh, int kw, int pad_h, int pad_w,
                                       int x_guard_bytes, void* workspace, long ws_bytes, int tile_cfg, const float* g_amax,
                                       const float* x_amax, hipStream_t stream) {
-    SSN_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= 49 && 2 * pad_h == kh - 1 && 2 * pad_w == kw - 1,
-                  "conv wgrad x6 rect: only same-size stride-1 convolutions (%dx%d taps, pad %d,%d)", kh, kw, pad_h, pad_w);
+    // (pad 0, 0: an unpadded convolution whose output gradient the caller embedded into planes of the input's size)
+    SSN_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= 49 && ((2 * pad_h == kh - 1 && 2 * pad_w == kw - 1) || (pad_h == 0 && pad_w == 0)),
+                  "conv wgrad x6 rect: only same-grid stride-1 convolutions (%dx%d taps, pad %d,%d)", kh, kw, pad_h, pad_w);
     return wgrad_x6_impl(g, x, dw, db, N, Cin, H, W, x_img_stride, Cout, g_img_stride, 0, 0, kh, kw, pad_h, pad_w,
                          x_guard_bytes, workspace, ws_bytes, tile_cfg, g_amax, x_amax, 0, 0, nullptr, stream);
 }

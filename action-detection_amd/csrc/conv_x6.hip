@@ -210,6 +210,10 @@ int launch_tile(X6Args& a, int cfg, hipStream_t stream) {
 int default_tile(int M, long P) {
     if (M % 128 == 0 || M > 256) return 0;
     if (M % 96 == 0) return 2;
+    // no exact fit: the tile height with the fewest padded rows (80 rows: 96, not 2 x 64), the taller one on a tie
+    const int p128 = (M + 127) / 128 * 128, p96 = (M + 95) / 96 * 96, p64 = (M + 63) / 64 * 64;
+    if (p96 < p128 && p96 < p64) return 2;
+    if (p128 <= p64) return 0;
     return (P >= 100000) ? 1 : 3;
 }
 

@@ -38,7 +38,7 @@ int launch_rect_cfg(X6Args& a, hipStream_t stream) {
 template <int KH, int KW>
 int launch_rect(X6Args& a, int cfg, hipStream_t stream) {
     if (cfg < 0) {
-        cfg = (a.M % 128 == 0 || a.M > 256) ? 5 : (a.M % 96 == 0 ? 2 : (a.M <= 64 ? 6 : 5));
+        cfg = (a.M % 128 == 0 || a.M > 256) ? 5 : ((a.M % 96 == 0 || (a.M > 128 && a.M <= 192)) ? 2 : (a.M <= 64 ? 6 : 5));
         // a small problem does not fill the 512 workgroup slots with 128-pixel tiles: take 64 x 64 ones
         const long wg = ((a.P + 127) / 128) * ((a.M + 127) / 128);
         if (wg < 384) cfg = 3;

@@ -301,6 +301,22 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* dst, const floa
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] += src[i];
 }
 
+// out[n][c][h][w] = (h < Ho && w < Wo) ? g[n][c][h][w] : 0: the output gradient of an UNPADDED stride-1 convolution laid
+// into planes of its input's size, so that its weight gradient is a same-grid problem (see ssn_embed_planes)
+__global__ __launch_bounds__(256) void embed_planes_kernel(const float* g, float* out, int C, int Ho, int Wo, long g_img_stride,
+                                                           int H, int W, long out_img_stride, long total, FastDiv div_chw,
+                                                           FastDiv div_hw, FastDiv div_w) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        uint32_t n, rem, c, hw, h, w;
+        fd_divmod((uint32_t)idx, div_chw, n, rem);
+        fd_divmod(rem, div_hw, c, hw);
+        fd_divmod(hw, div_w, h, w);
+        float v = 0.f;
+        if ((int)h < Ho && (int)w < Wo) v = g[(long)n * g_img_stride + ((long)c * Ho + h) * Wo + w];
+        out[(long)n * out_img_stride + rem] = v;
+    }
+}
+
 inline unsigned grid_for(long total, int cap = 4096) {
     long b = (total + 255) / 256;
     if (b > cap) b = cap;
@@ -489,6 +505,18 @@ extern "C" int ssn_add_inplace(float* dst, const float* src, long n, hipStream_t
     if (n == 0) return SSN_OK;
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, src, n);
     SSN_CHECK_LAUNCH("add_inplace");
+    return SSN_OK;
+}
+
+extern "C" int ssn_embed_planes(const float* g, float* out, int N, int C, int Ho, int Wo, long g_img_stride, int H, int W,
+                                long out_img_stride, hipStream_t stream) {
+    SSN_CHECK_ARG(g && out && N >= 1 && C >= 1 && Ho >= 1 && Wo >= 1 && H >= Ho && W >= Wo, "embed_planes: bad arguments");
+    const long total = (long)N * C * H * W;
+    SSN_CHECK_ARG(total < (1l << 32), "embed_planes: tensor too large");
+    hipLaunchKernelGGL(embed_planes_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, stream, g, out, C, Ho, Wo, g_img_stride, H, W,
+                       out_img_stride, total, make_fastdiv((uint32_t)(C * H * W)), make_fastdiv((uint32_t)(H * W)),
+                       make_fastdiv((uint32_t)W));
+    SSN_CHECK_LAUNCH("embed_planes");
     return SSN_OK;
 }
 

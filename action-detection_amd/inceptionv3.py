@@ -40,6 +40,7 @@ class InceptionV3(BNInception):
                 self._conv_ids.append(lid)
         self.top_cls_fc = nn.Linear(FEATURE_DIM, num_classes)
         self._init_executor()
+        self.fuse_block_inputs = True     # reduce pairs / block-input merges of BNInception's plan (False: one launch per layer)
 
     def forward(self, x):
         return self.top_cls_fc(self.features(x))
@@ -56,11 +57,36 @@ class InceptionV3(BNInception):
         ops, shapes = self._manifest(x)
         shapes = dict(shapes)
         plan = []
+        train_bn = set(self._train_bn_ids())
+        fuse = self.fuse_block_inputs and self.conv_precision == "split" and not train_bn
+        # The two 1x1 "reduce" convolutions of a block (5x5 + double 3x3, 7x7 + double 7x7, 3x3 + 7x7x3 / double 3x3) read the
+        # same input and write private tensors: planned as ONE convolution with concatenated output channels into a shared
+        # "<block>_reduce" tensor, as in BNInception._plan -- the precondition for its block-input merges below.
+        reduces = {}
+        for op in ops:
+            if op[0] == "conv" and (op[7], op[8], op[9]) == (1, 1, 1) and op[4] == 0 and shapes[op[3]][0] == op[6] \
+                    and op[2] != "data" and op[1].endswith("_reduce"):
+                reduces.setdefault(op[2], []).append(op)
+        mates = {v[0][1]: v[1] for v in reduces.values() if len(v) == 2} if fuse else {}
+        skip = {m[1] for m in mates.values()}
+        alias = {}       # manifest tensor -> (plan tensor, channel offset)
         for op in ops:
             if op[0] == "conv":
                 _, lid, src, dst, c0, cin, cout, kh, kw, s, ph, pw = op
+                if lid in skip:
+                    continue
+                psrc, sc0 = alias.get(src, (src, 0))
+                if lid in mates:
+                    mop = mates[lid]
+                    red = lid[:lid.index("_", 6) + 1] + "reduce"       # "mixed_5b_reduce"
+                    shapes[red] = (cout + mop[6],) + tuple(shapes[dst][1:])
+                    alias[dst], alias[mop[3]] = (red, 0), (red, cout)
+                    del shapes[dst], shapes[mop[3]]
+                    plan.append(dict(kind="conv", lids=[lid, mop[1]], src=psrc, src_c0=sc0, cin=cin, dst=red, dst_c0=0,
+                                     cout=cout + mop[6], couts=[cout, mop[6]], k=1, s=1, p=0))
+                    continue
                 square = kh == kw and ph == pw
-                plan.append(dict(kind="conv", lids=[lid], src=src, src_c0=0, cin=cin, dst=dst, dst_c0=c0, cout=cout,
+                plan.append(dict(kind="conv", lids=[lid], src=psrc, src_c0=sc0, cin=cin, dst=dst, dst_c0=c0, cout=cout,
                                  couts=[cout], k=kh if square else 0, s=s, p=ph if square else 0, kh=kh, kw=kw, ph=ph, pw=pw))
             elif op[0] == "pool":
                 _, lid, kind, src, dst, c0, k, s, p = op
@@ -68,9 +94,11 @@ class InceptionV3(BNInception):
             else:
                 _, lid, src, dst = op
                 plan.append(dict(kind="gap", lid=lid, src=src, dst=dst, c=shapes[src][0]))
-        train_bn = set(self._train_bn_ids())
         if self.pool_after_projection and not train_bn:
-            plan = self._move_avg_pools(plan, shapes, merge=False)
+            merge = fuse and self.merge_projection
+            plan = self._move_avg_pools(plan, shapes, merge=merge)
+            if merge:        # 1x1 branch + reduce pair + projection: one launch on the block input
+                plan = self._merge_block_heads(plan, shapes)
         if train_bn:
             plan = self._split_train_bn(plan, shapes, train_bn)
         return plan, shapes

@@ -388,9 +388,10 @@ def conv_wgrad(g, x, dw, db, ksize, stride, pad, workspace, tile_cfg=-1):
              tile_cfg, _stream(lib, dw))
 
 
-def wgrad_x6_supported(ksize, stride, pad, h, w):
-    """Layers the x6 weight-gradient kernel takes (the others stay on the exact-f32 kernel)."""
-    return ksize in (1, 3) and stride == 1 and 2 * pad == ksize - 1 and (pad * w + pad) * 4 <= 256
+def wgrad_x6_supported(ksize, stride, pad, h, w, guard_bytes=256):
+    """Layers the x6 weight-gradient kernel takes (the others stay on the exact-f32 kernel); guard_bytes: the readable bytes
+    in front of the layer's input."""
+    return ksize in (1, 3) and stride == 1 and 2 * pad == ksize - 1 and (pad * w + pad) * 4 <= guard_bytes
 
 
 def space_to_depth2(x, guard_floats=256):
@@ -765,6 +766,18 @@ def bn_fold_multi(biases, gammas, betas, means, variances, eps, scales, shifts):
 def sumsq(x, out, accumulate, workspace):
     lib = _check(x, out, workspace)
     lib.call("ssn_sumsq", _p(x), x.numel(), _p(out), int(accumulate), _p(workspace), _stream(lib, x))
+
+
+def embed_planes(g, out):
+    """out (ChanSlice / tensor [N, C, H, W]) <- g (ChanSlice [N, C, Ho, Wo]) in the top-left corner of every plane, zero elsewhere;
+    out shares g's amax slot (same values)."""
+    lib = _check(g, out)
+    out_s = out if isinstance(out, ChanSlice) else full(out)
+    ho, wo = g.hw
+    h, w = out_s.hw
+    lib.call("ssn_embed_planes", _p(g), _p(out_s), g.n, g.c, ho, wo, g.img_stride, h, w, out_s.img_stride, _stream(lib, _tensor_of(out_s)))
+    attach_amax(_tensor_of(out_s), _amax_in(g))
+    return out
 
 
 def add_(dst, src):

@@ -186,7 +186,9 @@ int ssn_conv_wgrad_x6(const float* g, const float* x, float* dw, float* db, int 
                       void* workspace, long ws_bytes, int tile_cfg, const float* g_amax, const float* x_amax,
                       int g_row_split, int g_row_gap, const float* g_amax2, hipStream_t stream);
 /* ... of the stride-1 same-size layers with rectangular taps (kh x kw, 2 pad = taps - 1; dw [Cout][Cin][kh][kw]); x needs
- * (pad_h * W + pad_w) * 4 readable bytes in front of it, rounded up to a multiple of 256 */
+ * (pad_h * W + pad_w) * 4 readable bytes in front of it, rounded up to a multiple of 256.  pad_h = pad_w = 0: the taps reach
+ * 0 .. k-1 pixels BEHIND the pixel -- the weight gradient of an unpadded convolution whose output gradient was laid into
+ * planes of the input's size (ssn_embed_planes). */
 long ssn_conv_wgrad_x6_rect_workspace_bytes(int N, int Cin, int Cout, int H, int W, int kh, int kw, int tile_cfg);
 int ssn_conv_wgrad_x6_rect(const float* g, const float* x, float* dw, float* db, int N, int Cin, int H, int W,
                            long x_img_stride, int Cout, long g_img_stride, int kh, int kw, int pad_h, int pad_w,
@@ -376,6 +378,11 @@ int ssn_s2d_weights_bwd(const float* dw2, float* dw, int Cout, int C, int k, hip
 /* dst[i] += src[i]: sums the conv-gradient buffers of the sub-batches when one backward is executed in chunks (a batch
  * whose activations exceed the 2 GiB a kernel operand can address; DataParallel's reduce of replica gradients). */
 int ssn_add_inplace(float* dst, const float* src, long n, hipStream_t stream);
+/* out[n][c][h][w] = h < Ho && w < Wo ? g[n][c][h][w] : 0 (planes H x W >= Ho x Wo): the output gradient of an UNPADDED
+ * stride-1 convolution on its input's grid, which makes its weight gradient a same-grid problem with taps 0 .. k-1 behind
+ * the pixel: ssn_conv_wgrad_x6_rect(kh, kw, pad 0, 0) on (out, x).  The values are g's: out shares g's amax slot. */
+int ssn_embed_planes(const float* g, float* out, int N, int C, int Ho, int Wo, long g_img_stride, int H, int W,
+                     long out_img_stride, hipStream_t stream);
 
 #ifdef __cplusplus
 }

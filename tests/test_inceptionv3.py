@@ -112,6 +112,15 @@ def test_inceptionv3_backbone_backward_gpu(hip_library):
     # proportionally more units sit within rounding of their threshold.  The tight bounds are the kernel tests (2e-6 / 5e-5)
     # and the emulated whole-backbone run above (2e-5 on every tensor).
     assert e.median() <= 3.0 * ec.median() + 1e-5 and e.max() <= max(2.0 * ec.max(), 5e-3)
+    # one launch per layer (no reduce pairs, no block-input merges) against the fused plan: same arithmetic, other launches
+    fused = {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None}
+    prod.fuse_block_inputs = False
+    prod.zero_grad(set_to_none=True)
+    (prod.features(x.cuda()) * w.cuda()).sum().backward()
+    d = torch.tensor([rel_err(p.grad, fused[n]) for n, p in prod.named_parameters() if p.grad is not None])
+    print("  fused plan vs one launch per layer: gradient difference median %.2e max %.2e" % (d.median(), d.max()))
+    assert len(d) == 2 * 94 and d.median() < 1e-4 and d.max() < 5e-3
+    prod.fuse_block_inputs = True
     # training-mode BatchNorm on a few layers (bn_mode 'partial' touches the first; 'full' all): rectangular, strided, pooled
     train = ("conv_1a_3x3", "mixed_5b_5x5", "mixed_6b_1x7", "mixed_6a_3x3", "mixed_7b_3x3_3x1", "mixed_5c_pool_proj")
     for lid in train:

@@ -777,6 +777,20 @@ def test_conv_split_valid_and_stride2_pad0_dgrad(backend):
         ref = torch.where(torch.isnan(m), tot, torch.where(act[:, 5:].double() > 0, tot * m, torch.zeros_like(tot)))
         assert rel_err(wide[:, 5:], ref) < 2e-6, ("dgrad pad 0 acc+mask", n, cin, h, cout, s, tile)
         assert torch.equal(wide[:, :5].cpu(), prev[:, :5])
+        if s == 1:
+            # weight gradient of the unpadded layer: dy laid into planes of x's size, then the same-grid kernel with taps 0..2
+            wd = w.double().requires_grad_()
+            bd = torch.zeros(cout, dtype=torch.double, requires_grad=True)
+            F.conv2d(x.detach(), wd, bd, 1, 0).backward(gy.double())
+            xd = K.guarded_empty(tuple(x.shape), dev)
+            xd.copy_(x.detach().float())
+            gp = backend.put(torch.full((n, cout, h, h + 2), 3.0))
+            K.embed_planes(K.full(gd), gp)
+            assert torch.equal(gp[:, :, :h - 2, :h].cpu(), gy) and float(gp[:, :, h - 2:].abs().max()) == 0 and float(gp[:, :, :, h:].abs().max()) == 0
+            ws = backend.put(torch.empty(K.wgrad_x6_rect_workspace_bytes(n, cin, cout, h, h + 2, 3, 3) // 4))
+            dw, db = backend.put(torch.empty(cout, cin, 3, 3)), backend.put(torch.empty(cout))
+            K.conv_wgrad_x6_rect(K.full(gp), K.full(xd), dw, db, 3, 3, 0, 0, ws)
+            assert rel_err(dw, wd.grad) < 5e-5 and rel_err(db, bd.grad) < 5e-5, ("wgrad valid", n, cin, h, cout)
 
 
 def test_bn_train(backend):

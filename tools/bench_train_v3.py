@@ -37,7 +37,7 @@ model = SSN(args.num_class, 2, 5, 2, "RGB", base_model="InceptionV3", dropout=0.
 init_backbone_synthetic(model.base_model)
 init_heads_synthetic(model)
 model.to(dev).train()
-opt = SSNSGD(model.get_optim_policies(), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+opt = SSNSGD(model.get_optim_policies(), lr=1e-5, momentum=0.9, weight_decay=5e-4)     # (synthetic weights: keep the steps small)
 batch = [t.to(dev) for t in make_batch(args.videos, "RGB", args.num_class, seed=0, input_size=299)]
 crit = (ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss())
 
@@ -51,8 +51,10 @@ def step():
     return loss
 
 
+first_loss = None
 for _ in range(args.warmup):
-    step()
+    l_ = step()
+    first_loss = l_.item() if first_loss is None else first_loss
 torch.cuda.synchronize()
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0.record()
@@ -68,7 +70,7 @@ first = next(op for op in ops if op[0] == "conv")
 first_macs = shapes[first[3]][1] * shapes[first[3]][2] * first[5] * first[6] * first[7] * first[8]
 gflop = 2.0 * (3 * macs - first_macs) * frames / 1e9          # fwd + dgrad + wgrad, no data gradient for the first layer
 line = {"metric": "ssn_inceptionv3_train_proposals_per_s", "value": round(args.videos * 8 / (ms * 1e-3), 1), "unit": "proposals/s",
-        "ms_per_step": round(ms, 3), "frames_per_step": frames, "conv_tflops": round(gflop / ms, 2), "loss": round(loss.item(), 5),
+        "ms_per_step": round(ms, 3), "frames_per_step": frames, "conv_tflops": round(gflop / ms, 2), "first_step_loss": None if first_loss is None else round(first_loss, 5), "loss": round(loss.item(), 5),
         "dtype": "f32 (f16 x 3 split MFMA)", "data": "synthetic", "steps": args.steps, "warmup": args.warmup,
         "config": {"workload": "InceptionV3 RGB SSN, %d videos x 8 proposals x 9 segments (299x299), fwd + losses + bwd + SGD, eager"
                    % args.videos}}
