@@ -49,6 +49,7 @@ _SIGS = {
     "ssn_conv_x6_pack_dgrad_s2": "ppiip",
     "ssn_conv_x6_dgrad_s2": "pppiiiiliiiliplpiippip",
     "ssn_conv_x6_pack_dgrad_rect": "ppiiiip",
+    "ssn_conv_x6_pack_rect_multi": "ipppppppp",
     "ssn_conv_x6_dgrad_rect": "pppiiiililiiiiiplpiippp",
     "ssn_conv_wgrad_x6_rect": "ppppiiiililiiiiiplippp",
     "ssn_conv_x6_pack_weights_rect": "ppiiiip",

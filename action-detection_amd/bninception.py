@@ -490,8 +490,9 @@ class BNInception(nn.Module):
             if op["s2d"]:
                 acts["data_s2d"] = K.space_to_depth2(x)
                 packed_fwd[op["lids"][0]] = K.pack_weights_rect(K.s2d_weights(getattr(self, op["lids"][0]).weight.detach()))
-            elif op["rect"]:
-                packed_fwd[op["lids"][0]] = K.pack_weights_rect(getattr(self, op["lids"][0]).weight.detach())
+        rect_ops = [op for op in conv_ops if op["rect"]]
+        packed_fwd.update(zip((op["lids"][0] for op in rect_ops),
+                              K.pack_rect_multi([getattr(self, op["lids"][0]).weight.detach() for op in rect_ops])))
         for x6 in (False, True):
             ops = [op for op in conv_ops if op["x6"] == x6 and not op["s2d"] and not op["rect"]]
             packed_fwd.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(
@@ -712,8 +713,9 @@ class BNInception(nn.Module):
         for op in dg_ops:
             if dg_s2[op["lids"][0]]:
                 packed_dg[op["lids"][0]] = K.pack_dgrad_s2(getattr(self, op["lids"][0]).weight.detach())
-            elif op["rect"]:
-                packed_dg[op["lids"][0]] = K.pack_dgrad_rect(getattr(self, op["lids"][0]).weight.detach())
+        rect_ops = [op for op in dg_ops if op["rect"]]
+        packed_dg.update(zip((op["lids"][0] for op in rect_ops),
+                             K.pack_rect_multi([getattr(self, op["lids"][0]).weight.detach() for op in rect_ops], dgrad=True)))
         for x6 in (False, True):
             ops = [op for op in dg_ops if dg_x6[op["lids"][0]] == x6 and not dg_s2[op["lids"][0]] and not op["rect"]]
             packed_dg.update(zip((op["lids"][0] for op in ops), K.pack_weights_multi(

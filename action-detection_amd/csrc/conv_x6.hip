@@ -337,6 +337,42 @@ extern "C" int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0,
     return SSN_OK;
 }
 
+// `count` rectangular-tap weights [cout][cin][kh][kw] in ceil(count / 40) x 3 launches (HOST arrays, one entry per layer):
+// mode 0 = forward operand (ssn_conv_x6_packed_floats_rect floats), mode 2 = dgrad operand (transposed, taps reversed;
+// ssn_conv_x6_packed_floats_dgrad_rect floats).  The Inception-v3 plan has ~40 such layers per pass.
+extern "C" int ssn_conv_x6_pack_rect_multi(int count, const float* const* w, float* const* out, const int* cout,
+                                           const int* cin, const int* kh, const int* kw, const int* mode, hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (w && out && cout && cin && kh && kw && mode)), "conv x6 pack rect multi: bad arguments");
+    for (int base = 0; base < count; base += XP_MAX) {
+        X6PackTable t;
+        t.count = count - base < XP_MAX ? count - base : XP_MAX;
+        int blocks = 0;
+        for (int i = 0; i < t.count; ++i) {
+            const int j = base + i;
+            SSN_CHECK_ARG(w[j] && out[j] && cout[j] > 0 && cin[j] > 0 && kh[j] > 0 && kw[j] > 0 && kh[j] * kw[j] <= 32 &&
+                              (mode[j] == 0 || mode[j] == 2),
+                          "conv x6 pack rect multi: bad entry %d", j);
+            t.w0[i] = w[j];
+            t.w1[i] = t.w2[i] = t.w3[i] = nullptr;
+            t.split[i] = t.split2[i] = t.split3[i] = cout[j];
+            t.out[i] = (uint32_t*)out[j];
+            t.cout[i] = cout[j];
+            t.cin[i] = cin[j];
+            t.kk[i] = kh[j] * kw[j];
+            t.srckk[i] = t.kk[i];
+            t.tapmap[i] = 0;
+            t.mode[i] = mode[j];
+            t.blk0[i] = blocks;
+            t.rows_dw[i] = x6_row_dwords_kk(cout[j], cin[j], t.kk[i], mode[j] ? 1 : 0);
+            blocks += (int)((t.rows_dw[i] / APITCH * 8 + XP_CHUNK - 1) / XP_CHUNK);
+        }
+        t.blk0[t.count] = blocks;
+        launch_pack(t, stream);
+    }
+    SSN_CHECK_LAUNCH("conv_x6_pack_rect_multi");
+    return SSN_OK;
+}
+
 // Split + pack ONE forward weight [cout][cin][kh][kw] (rectangular taps: conv_x6_rect.hip); out holds
 // ssn_conv_x6_packed_floats_rect() floats.
 extern "C" int ssn_conv_x6_pack_weights_rect(const float* w, float* out, int cout, int cin, int kh, int kw,

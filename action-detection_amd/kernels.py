@@ -329,6 +329,30 @@ def pack_dgrad_rect(w):
     return out
 
 
+def pack_rect_multi(ws, dgrad=False):
+    """Rectangular-tap weights [cout, cin, kh, kw] -> their packed operands (views of one flat buffer) in ceil(len / 40) x 3
+    launches: forward operands (pack_weights_rect) or, with dgrad, the transposed tap-reversed ones (pack_dgrad_rect)."""
+    if not ws:
+        return []
+    lib = _check(*ws)
+    n = len(ws)
+    size_fn = lib.cdll.ssn_conv_x6_packed_floats_dgrad_rect if dgrad else lib.cdll.ssn_conv_x6_packed_floats_rect
+    sizes = [int(size_fn(*w.shape)) for w in ws]
+    flat = torch.empty(sum(sizes), device=ws[0].device, dtype=torch.float32)
+    outs, off = [], 0
+    for sz in sizes:
+        outs.append(flat[off:off + sz])
+        off += sz
+    ws = [w.contiguous() for w in ws]
+    ia = lambda vals: (ctypes.c_int * n)(*[int(v) for v in vals])   # noqa: E731
+    pw, po = _ptr_array(ws), _ptr_array(outs)
+    a_cout, a_cin, a_kh, a_kw = (ia([w.shape[d] for w in ws]) for d in range(4))
+    a_mode = ia([2 if dgrad else 0] * n)
+    lib.call("ssn_conv_x6_pack_rect_multi", n, ctypes.addressof(pw), ctypes.addressof(po), ctypes.addressof(a_cout),
+             ctypes.addressof(a_cin), ctypes.addressof(a_kh), ctypes.addressof(a_kw), ctypes.addressof(a_mode), _stream(lib, ws[0]))
+    return outs
+
+
 def conv_x6_dgrad_rect(dy, wt, dx, kh, kw, pad_h, pad_w, accumulate, tile_cfg=-1, mask_y=None, mask_scale=None):
     """dgrad of a stride-1 same-size layer with kh x kw taps on the f16 matrix cores.  wt: pack_dgrad_rect(w)."""
     lib = _check(dy, wt, dx, mask_y, mask_scale)

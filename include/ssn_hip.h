@@ -157,6 +157,9 @@ int ssn_conv_x6_fwd_rect(const float* x, const float* w_packed, const float* sca
                          int N, int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo,
                          long y_img_stride, int kh, int kw, int pad_h, int pad_w, int relu, int x_guard_bytes,
                          int tile_cfg, const float* x_amax, float* y_amax, hipStream_t stream);
+/* `count` rectangular-tap weights in one call (host arrays, one entry per layer); mode 0: forward operand, 2: dgrad operand */
+int ssn_conv_x6_pack_rect_multi(int count, const float* const* w, float* const* out, const int* cout, const int* cin,
+                                const int* kh, const int* kw, const int* mode, hipStream_t stream);
 long ssn_conv_x6_packed_floats_dgrad_rect(int Cout, int Cin, int kh, int kw);
 int ssn_conv_x6_pack_dgrad_rect(const float* w, float* out, int cout, int cin, int kh, int kw, hipStream_t stream);
 int ssn_conv_x6_dgrad_rect(const float* dy, const float* wt_packed, float* dx, int N, int Cout, int H, int W,

@@ -740,6 +740,20 @@ def test_conv_split_rect_backward(backend):
         assert rel_err(db, b.grad) < 5e-5
 
 
+def test_pack_rect_multi(backend):
+    """All rectangular-tap operands of a pass in one call == the single-layer packers, bit for bit (forward and dgrad form);
+    more entries than one launch table holds."""
+    g = torch.Generator().manual_seed(49)
+    shapes = [(40, 8, 5, 5), (33, 20, 1, 7), (64, 16, 7, 1), (32, 8, 1, 3), (70, 8, 3, 1)] * (9 if backend.is_gpu else 1)
+    ws = [backend.put(torch.randn(sh, generator=g) * (0.01 + 0.1 * (i % 4))) for i, sh in enumerate(shapes)]
+    for dgrad in (False, True):
+        multi = K.pack_rect_multi(ws, dgrad=dgrad)
+        assert len(multi) == len(ws)
+        for w, m in zip(ws, multi):
+            one = K.pack_dgrad_rect(w) if dgrad else K.pack_weights_rect(w)
+            assert torch.equal(one.cpu().view(torch.int32), m.cpu().view(torch.int32))
+
+
 def test_conv_split_valid_and_stride2_pad0_dgrad(backend):
     """The unpadded 3x3 layers of Inception-v3: stride 1 (dx is larger than dy) on the square dgrad kernel, stride 2 as four
     parity-class launches with the two-tap classes on the EVEN rows / columns; odd and even input sizes; accumulate + mask."""
