@@ -147,22 +147,27 @@ template <int KH, int KW, int S, int MODE, int NG, int WM, int WN, int TM, int T
 int launch_cfg(X6Args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = NG * WN * TN * 32;
-    a.n_ptiles = (a.P + BN - 1) / BN;
+    a.hw_real = a.Ho * a.Wo;
     a.n_mtiles = (a.M + BM - 1) / BM;
     a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
-    const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
-    // 16-byte activation loads: stride 1, images a multiple of 4 pixels (a lane's 4 pixels never straddle two images),
-    // a tile width the 1 KiB pieces divide, and the caller's guarantee that the bytes in front of x are readable
+    // 16-byte activation loads: stride 1, same-size, a tile width the 1 KiB pieces divide, and the caller's guarantee that the
+    // bytes in front of x are readable; images that are not a multiple of 4 pixels are enumerated padded (a lane's 4 pixels
+    // must not straddle two images)
     constexpr bool wide_ok = (S == 1) && BN <= 256 && BN / 16 >= 4 * NG;
     if constexpr (wide_ok) {
-        if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W && x6_reach_bytes(a.pad_h, a.pad_w, KH, KW, a.W) <= 256 &&
+        if (a.x_guard >= 256 && a.Ho == a.H && a.Wo == a.W && x6_reach_bytes(a.pad_h, a.pad_w, KH, KW, a.W) <= 256 &&
             !(g_x6_dbg & 16)) {
+            x6_pad_enumeration(a);
+            a.n_ptiles = (a.P + BN - 1) / BN;
+            const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
             hipLaunchKernelGGL((conv_x6_kernel<KH, KW, S, MODE, true, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0,
                                stream, a);
             SSN_CHECK_LAUNCH("conv_x6 (wide)");
             return SSN_OK;
         }
     }
+    a.n_ptiles = (a.P + BN - 1) / BN;
+    const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
     hipLaunchKernelGGL((conv_x6_kernel<KH, KW, S, MODE, false, NG, WM, WN, TM, TN>), dim3(nblk), dim3(256 * NG), 0, stream,
                        a);
     SSN_CHECK_LAUNCH("conv_x6");

@@ -36,7 +36,11 @@ struct X6Args {
     int M;
     int Ho, Wo;           // enumerated pixel grid
     long y_img_stride;
-    int P;
+    int P;                // enumerated pixel slots (N * Ho * Wo, or N * the padded plane size: see hw_real)
+    // 16-byte activation loads need 4 consecutive pixel slots to lie in ONE image: planes whose size is not a multiple of 4 are
+    // enumerated with their size rounded up (div_hw divides by the padded size); slots >= hw_real of an image do not exist --
+    // they gather whatever follows the plane, contribute to nothing that is stored and are kept out of the amax.
+    int hw_real;
     int pad_h, pad_w;
     int relu, accumulate;
     int raw_from;         // output rows >= raw_from take no affine and no ReLU (conv_epilogue.h); M or more: none
@@ -148,9 +152,10 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
     uint32_t gmask = 0;                    // bit t: tap t reads inside the image (WIDE: bit 0 = pixel exists)
     const uint32_t hw_bytes = (uint32_t)(p.H * p.W) * 4u;
     auto tap_mask = [&](int gp, uint32_t& n, int& h0, int& w0) {
-        const bool gvalid = gp < p.P;
+        bool gvalid = gp < p.P;
         uint32_t hw, ho, wo, m = 0;
         fd_divmod((uint32_t)(gvalid ? gp : 0), p.div_hw, n, hw);
+        gvalid = gvalid && hw < (uint32_t)p.hw_real;
         fd_divmod(hw, p.div_w, ho, wo);
         h0 = (MODE == MODE_FWD) ? (int)ho * S - p.pad_h : (int)ho + p.pad_h;
         w0 = (MODE == MODE_FWD) ? (int)wo * S - p.pad_w : (int)wo + p.pad_w;
@@ -512,14 +517,15 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
         const int pp = p0 + grp * BNG + (wn * TN + j) * 32 + li;
         uint32_t n, hw;
         fd_divmod((uint32_t)(pp < p.P ? pp : 0), p.div_hw, n, hw);
+        const bool exists = pp < p.P && hw < (uint32_t)p.hw_real;
         if (p.sub_HW) {
             uint32_t u, v;
             fd_divmod(hw, p.div_w, u, v);
             hw = (2u * u + (uint32_t)p.sub_a) * (uint32_t)p.sub_W + 2u * v + (uint32_t)p.sub_b;
         }
         const uint32_t row0 = (uint32_t)(m0 + 4 * lh) * e.howo4 + hw * 4u;
-        yoff[j] = pp < p.P ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : EPI_OOB;
-        moff[j] = pp < p.P ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : EPI_OOB;
+        yoff[j] = exists ? (uint32_t)((long)n * p.y_img_stride * 4) + row0 : EPI_OOB;
+        moff[j] = exists ? (uint32_t)((long)n * p.mask_img_stride * 4) + row0 : EPI_OOB;
     }
     conv_epilogue<TM, TN, BM>(acc, ch, e, yoff, moff, wm * TM * 32, lh, m0);
 #ifdef X6_PHASE_TRACE
@@ -542,6 +548,15 @@ __global__ __launch_bounds__(256 * NG, (NG == 1 && TM * TN >= 6 && TN >= 2) ? 1 
 
 // bytes a 16-byte (WIDE) activation load may reach in front of / behind the tile's own pixels: the largest tap
 // displacement of a same-size stride-1 convolution
+// host side, before a launch with 16-byte activation loads: planes that are not a multiple of 4 pixels are enumerated padded
+static inline void x6_pad_enumeration(X6Args& a) {
+    const int hw = a.Ho * a.Wo, hwp = (hw + 3) / 4 * 4;
+    a.hw_real = hw;
+    if (hwp != hw) {
+        a.P = a.N * hwp;
+        a.div_hw = make_fastdiv((uint32_t)hwp);
+    }
+}
 static inline int x6_reach_bytes(int pad_h, int pad_w, int kh, int kw, int W) {
     const int rh = pad_h > kh - 1 - pad_h ? pad_h : kh - 1 - pad_h;
     const int rw = pad_w > kw - 1 - pad_w ? pad_w : kw - 1 - pad_w;

@@ -17,18 +17,22 @@ template <int KH, int KW, int WM, int WN, int TM, int TN>
 int launch_rect_cfg(X6Args& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
-    a.n_ptiles = (a.P + BN - 1) / BN;
+    a.hw_real = a.Ho * a.Wo;
     a.n_mtiles = (a.M + BM - 1) / BM;
     a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
-    const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
-    // 16-byte activation loads under the same conditions as the square kernels (same-size stride-1 convolution,
-    // planes a multiple of 4 pixels, the largest tap displacement inside the readable guard in front of x)
-    if (a.x_guard >= 256 && (a.H * a.W) % 4 == 0 && a.Ho == a.H && a.Wo == a.W &&
-        x6_reach_bytes(a.pad_h, a.pad_w, KH, KW, a.W) <= 256) {
+    // 16-byte activation loads under the same conditions as the square kernels (same-size stride-1 convolution, the largest
+    // tap displacement inside the readable guard in front of x; planes that are not a multiple of 4 pixels -- 35 x 35, 17 x 17
+    // -- enumerated padded)
+    if (a.x_guard >= 256 && a.Ho == a.H && a.Wo == a.W && x6_reach_bytes(a.pad_h, a.pad_w, KH, KW, a.W) <= 256) {
+        x6_pad_enumeration(a);
+        a.n_ptiles = (a.P + BN - 1) / BN;
+        const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
         hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1, MODE_FWD, true, 1, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
         SSN_CHECK_LAUNCH("conv_x6_rect (wide)");
         return SSN_OK;
     }
+    a.n_ptiles = (a.P + BN - 1) / BN;
+    const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
     hipLaunchKernelGGL((conv_x6_kernel<KH, KW, 1, MODE_FWD, false, 1, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("conv_x6_rect");
     return SSN_OK;
