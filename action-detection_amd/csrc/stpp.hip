@@ -9,7 +9,8 @@
 // ssn_stpp_reorg replaces STPPReorgainzed.forward (/root/reference/ops/ssn_ops.py:109-170): the
 // Python loop over proposals x stages x parts becomes one workgroup per proposal.
 //
-// All are HBM-bound scans: one float4 per lane, D-contiguous.
+// All are scans with D-contiguous lanes (one float per lane and step: a wave instruction moves 256 consecutive bytes).  At the
+// sizes of the path (<= 5 MB per launch) they are latency-bound, 5-25 us each (bench.py: hbm_kernels).
 #include "ssn_common.h"
 
 #define SSN_STPP_MAX_PARTS 24
