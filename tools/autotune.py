@@ -3,7 +3,9 @@
 
 Writes action-detection_amd/tuned_tiles.json; the executor (bninception.py) looks shapes up there
 and falls back to the C-side heuristic for unknown shapes.  Run on the GPU box:
-    python tools/autotune.py [N_IMAGES]
+    python tools/autotune.py [N_IMAGES] [KINDS] [ARCH]
+ARCH = InceptionV3: add the square-tap (1x1 / 3x3) launches of the Inception-v3 plan at 299x299 to the existing table (split
+kernels only; its rectangular-tap layers use the C-side heuristic).
 """
 import json
 import os
@@ -21,9 +23,18 @@ dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
 # optional second argument: comma list of kinds to (re)tune; the other kinds keep their entries
 only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None     # e.g. fwd6,dgrad6,wgrad6,fwd6s2d,wgrad6s2d
+arch = sys.argv[3] if len(sys.argv) > 3 else "BNInception"
 out_path = os.path.join(ROOT, "action-detection_amd", "tuned_tiles.json")
 shapes = {}
-for cin0 in (3, 10):
+if arch == "InceptionV3":
+    from action_detection_amd.bninception import is_rect  # noqa: E402
+    from action_detection_amd.inceptionv3 import InceptionV3  # noqa: E402
+    only = (only or {"fwd6", "dgrad6", "wgrad6"}) & {"fwd6", "dgrad6", "wgrad6"}
+    plan, t = InceptionV3().eval()._plan(torch.zeros(1, 3, 299, 299))
+    for op in plan:
+        if op["kind"] == "conv" and not is_rect(op) and op["k"] in (1, 3) and op["cin"] >= 16:
+            shapes[(op["cin"], op["cout"], op["k"], op["s"], op["p"], t[op["src"]][1], t[op["dst"]][1])] = "+".join(op["lids"])
+for cin0 in ((3, 10) if arch == "BNInception" else ()):
     # the executor's launch plan (fused reduce convolutions included), not the raw manifest
     # (.eval(): the frozen-BatchNorm plan of SSN's default bn_mode -- with the fused block-input launches)
     plan, t = BNInception(in_channels=cin0).eval()._plan(torch.zeros(1, cin0, 224, 224))
@@ -112,8 +123,9 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
         res[kind] = (best[1], best[0], flops / best[0] / 1e9)
     report.append((lid, cin, cout, k, s, ho, res))
     print(lid, cin, cout, k, s, ho, {kk: "cfg%d %.3fms %.1fTF" % v for kk, v in res.items()}, flush=True)
-json.dump({"n_images": n, "tiles": table, "ms": times}, open(out_path, "w"), indent=0, sort_keys=True)
+n_rec = prev.get("n_images", n) if arch != "BNInception" else n      # (the table's batch-size gate stays BN-Inception's)
+json.dump({"n_images": n_rec, "tiles": table, "ms": times}, open(out_path, "w"), indent=0, sort_keys=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump({"n_images": n, "tiles": table, "ms": times}, open(os.path.join(ROOT, "gpurun_out", "tuned_tiles.json"), "w"),
+json.dump({"n_images": n_rec, "tiles": table, "ms": times}, open(os.path.join(ROOT, "gpurun_out", "tuned_tiles.json"), "w"),
           indent=0, sort_keys=True)
 print("wrote", out_path)
