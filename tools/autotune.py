@@ -44,6 +44,11 @@ for cin0 in ((3, 10) if arch == "BNInception" else ()):
                 "+".join(op["lids"])
 
 
+if os.environ.get("AUTOTUNE_HIN"):       # only the layers at these input sizes, e.g. AUTOTUNE_HIN=7
+    keep = {int(v) for v in os.environ["AUTOTUNE_HIN"].split(",")}
+    shapes = {k: v for k, v in shapes.items() if k[5] in keep}
+
+
 def timeit(fn, reps=3):
     fn()
     torch.cuda.synchronize()
