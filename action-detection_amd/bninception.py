@@ -139,8 +139,10 @@ class BNInception(nn.Module):
         self._ws = None
         self._side = {}               # device -> side HIP stream for the weight-gradient chain
         self._lanes = {}              # device -> two more streams for the forward branches of a block
-        self.overlap_wgrad = True     # run wgrad launches on a second stream, concurrently with the dgrad chain
-        self.branch_streams = True    # forward: the branches of an Inception block run on three HIP streams
+        # run wgrad launches on a second stream, concurrently with the dgrad chain
+        self.overlap_wgrad = os.environ.get("SSN_OVERLAP_WGRAD", "1") != "0"
+        # forward: the branches of an Inception block run on three HIP streams
+        self.branch_streams = os.environ.get("SSN_BRANCH_STREAMS", "1") != "0"
         self.profiler = None          # list; when set, every conv launch is bracketed by HIP events
         # "split": 1x1/3x3 convolutions (forward, dgrad, wgrad) multiply on the f16 matrix cores with every fp32 operand
         # scaled per tensor and split into two f16 terms, three products per multiply (fp32-class accuracy,
