@@ -564,7 +564,8 @@ class BNInception(nn.Module):
                 dst_slice = ChanSlice(get(op["dst"]), op["dst_c0"], cout)
                 if op["rect"]:
                     self._timed("conv_fwd_x6", op["lids"][0], flops,
-                                lambda: K.conv_x6_fwd_rect(src_slice, wp, scale, shift, dst_slice, kh, kw, ph, pw, not raw))
+                                lambda: K.conv_x6_fwd_rect(src_slice, wp, scale, shift, dst_slice, kh, kw, ph, pw, not raw,
+                                                           tuned_tile("fwd6r%dx%d" % (kh, kw), n, cin, cout, 0, 1, hin)))
                 elif op["s2d"]:
                     xs = acts["data_s2d"]
                     self._timed("conv_fwd_x6", op["lids"][0], flops,
@@ -674,7 +675,9 @@ class BNInception(nn.Module):
                 kh, kw, ph, pw = conv_taps(op)
                 if op["rect"]:      # stride-1 same-size layers with rectangular taps: runtime-tap instantiation of the split kernel
                     wg_x6[op["lids"][0]] = True
-                    ws_bytes = max(ws_bytes, K.wgrad_x6_rect_workspace_bytes(n, op["cin"], op["cout"], hin, win, kh, kw))
+                    ws_bytes = max(ws_bytes, K.wgrad_x6_rect_workspace_bytes(
+                        n, op["cin"], op["cout"], hin, win, kh, kw,
+                        tuned_tile("wgrad6r%dx%d" % (kh, kw), n, op["cin"], op["cout"], 0, 1, hin)))
                     continue
                 # an unpadded stride-1 3x3 layer: same-grid problem once its output gradient is laid into planes of the input's size
                 op["wg_embed"] = (self.conv_precision == "split" and self.wgrad_x6 and op["src"] != "data" and len(op["lids"]) == 1
@@ -841,7 +844,8 @@ class BNInception(nn.Module):
                 flops = 2.0 * n * ho * shapes[op["dst"]][2] * cout * cin * kh * kw
                 xin = ChanSlice(acts[op["src"]], op["src_c0"], cin)
                 if op["rect"]:
-                    run_wgrad = lambda: K.conv_wgrad_x6_rect(g, xin, dw, db, kh, kw, ph, pw, ws)   # noqa: E731
+                    wcfg = tuned_tile("wgrad6r%dx%d" % (kh, kw), n, cin, cout, 0, 1, hin)
+                    run_wgrad = lambda: K.conv_wgrad_x6_rect(g, xin, dw, db, kh, kw, ph, pw, ws, wcfg)   # noqa: E731
                 elif op.get("wg_embed"):
                     def run_wgrad():
                         gp = torch.empty((n, cout, hin, shapes[op["src"]][2]), device=dev, dtype=torch.float32)
@@ -894,7 +898,9 @@ class BNInception(nn.Module):
                     dx = ChanSlice(gbuf(op["src"]), op["src_c0"], cin)
                     if op["rect"]:
                         self._timed("conv_dgrad_x6", lids[0], flops,
-                                    lambda: K.conv_x6_dgrad_rect(g, wt, dx, kh, kw, ph, pw, acc_flag, mask_y=my, mask_scale=ms))
+                                    lambda: K.conv_x6_dgrad_rect(g, wt, dx, kh, kw, ph, pw, acc_flag,
+                                                                 tuned_tile("dgrad6r%dx%d" % (kh, kw), n, cin, cout, 0, 1, hin),
+                                                                 mask_y=my, mask_scale=ms))
                     elif dg_s2[lids[0]]:
                         self._timed("conv_dgrad_x6", lids[0], flops,
                                     lambda: K.conv_x6_dgrad_s2(g, wt, dx, acc_flag,

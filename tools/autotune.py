@@ -31,9 +31,12 @@ if arch == "InceptionV3":
     from action_detection_amd.inceptionv3 import InceptionV3  # noqa: E402
     only = (only or {"fwd6", "dgrad6", "wgrad6"}) & {"fwd6", "dgrad6", "wgrad6"}
     plan, t = InceptionV3().eval()._plan(torch.zeros(1, 3, 299, 299))
+    rect_shapes = {}
     for op in plan:
         if op["kind"] == "conv" and not is_rect(op) and op["k"] in (1, 3) and op["cin"] >= 16:
             shapes[(op["cin"], op["cout"], op["k"], op["s"], op["p"], t[op["src"]][1], t[op["dst"]][1])] = "+".join(op["lids"])
+        elif op["kind"] == "conv" and is_rect(op):
+            rect_shapes[(op["cin"], op["cout"], op["kh"], op["kw"], op["ph"], op["pw"], t[op["src"]][1])] = op["lids"][0]
 for cin0 in ((3, 10) if arch == "BNInception" else ()):
     # the executor's launch plan (fused reduce convolutions included), not the raw manifest
     # (.eval(): the frozen-BatchNorm plan of SSN's default bn_mode -- with the fused block-input launches)
@@ -44,6 +47,8 @@ for cin0 in ((3, 10) if arch == "BNInception" else ()):
                 "+".join(op["lids"])
 
 
+if os.environ.get("AUTOTUNE_RECT_ONLY"):      # Inception-v3: only the rectangular-tap launches
+    shapes = {}
 if os.environ.get("AUTOTUNE_HIN"):       # only the layers at these input sizes, e.g. AUTOTUNE_HIN=7
     keep = {int(v) for v in os.environ["AUTOTUNE_HIN"].split(",")}
     shapes = {k: v for k, v in shapes.items() if k[5] in keep}
@@ -128,6 +133,37 @@ for (cin, cout, k, s, p, hi, ho), lid in sorted(shapes.items()):
         res[kind] = (best[1], best[0], flops / best[0] / 1e9)
     report.append((lid, cin, cout, k, s, ho, res))
     print(lid, cin, cout, k, s, ho, {kk: "cfg%d %.3fms %.1fTF" % v for kk, v in res.items()}, flush=True)
+# rectangular-tap launches (forward, dgrad as a forward correlation, runtime-tap wgrad): kinds "<dir>6r<kh>x<kw>"
+for (cin, cout, kh, kw, ph, pw, hi), lid in sorted(rect_shapes.items()) if (arch == "InceptionV3" and not os.environ.get("AUTOTUNE_HIN")) else []:
+    guard = K.wgrad_x6_rect_guard_floats(ph, pw, hi)
+    x = K.guarded_empty((n, cin, hi, hi), dev, guard).normal_()
+    g = K.guarded_empty((n, cout, hi, hi), dev, guard).normal_()
+    K.attach_amax(x, K.tensor_amax(x))
+    K.attach_amax(g, K.tensor_amax(g))
+    w = torch.randn(cout, cin, kh, kw, device=dev) * 0.05
+    y, dx = torch.empty_like(g), torch.empty_like(x)
+    dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
+    scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    wp, wt = K.pack_weights_rect(w), K.pack_dgrad_rect(w)
+    res = {}
+    for kind, cfgs in (("fwd6r", [1, 2, 3, 5, 6]), ("dgrad6r", [1, 2, 3, 5, 6]), ("wgrad6r", [0, 2, 3, 5, 6])):
+        best = (1e9, -1)
+        for cfg in cfgs:
+            if kind == "fwd6r":
+                fn = lambda: K.conv_x6_fwd_rect(K.full(x), wp, scale, shift, K.full(y), kh, kw, ph, pw, True, cfg)
+            elif kind == "dgrad6r":
+                fn = lambda: K.conv_x6_dgrad_rect(K.full(g), wt, K.full(dx), kh, kw, ph, pw, False, cfg)
+            else:
+                ws = torch.empty(K.wgrad_x6_rect_workspace_bytes(n, cin, cout, hi, hi, kh, kw, cfg) // 4, device=dev)
+                fn = lambda: K.conv_wgrad_x6_rect(K.full(g), K.full(x), dw, db, kh, kw, ph, pw, ws, cfg)
+            ms = timeit(fn)
+            if ms < best[0]:
+                best = (ms, cfg)
+        key = "%s%dx%d|%d|%d|%d|%d|%d" % (kind, kh, kw, cin, cout, 0, 1, hi)
+        table[key] = best[1]
+        times[key] = round(best[0], 4)
+        res[kind] = "cfg%d %.3fms %.1fTF" % (best[1], best[0], 2.0 * n * hi * hi * cout * cin * kh * kw / best[0] / 1e9)
+    print(lid, cin, cout, "%dx%d" % (kh, kw), hi, res, flush=True)
 n_rec = prev.get("n_images", n) if arch != "BNInception" else n      # (the table's batch-size gate stays BN-Inception's)
 json.dump({"n_images": n_rec, "tiles": table, "ms": times}, open(out_path, "w"), indent=0, sort_keys=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
