@@ -83,6 +83,18 @@ def test_inceptionv3_backward_emulated(emu):
     orc = O.OracleInceptionV3(num_classes=10)
     orc.load_state_dict(prod.state_dict())
     prod.eval()
+
+    class Recorder:      # what parallel.GradReducer sees: finished tail ranges of the flat conv-gradient buffer
+        def __init__(self):
+            self.ranges, self.finished = [], 0
+
+        def range_ready(self, flat, start, end):
+            self.ranges.append((start, end, flat.numel()))
+
+        def finish(self):
+            self.finished += 1
+
+    rec = prod.grad_ready_hook = Recorder()
     g = torch.Generator().manual_seed(2)
     x = torch.randint(0, 256, (2, 3, 75, 75), generator=g).float() - 110.0
     w = torch.randn(2, 2048, generator=g)
@@ -90,6 +102,14 @@ def test_inceptionv3_backward_emulated(emu):
     assert ferr < 1e-5
     assert len(errs) == 2 * 94
     assert max(errs.values()) < 2e-5, max(errs.items(), key=lambda kv: kv[1])
+    # the gradient-ready ranges (one per block that closes, the overlapped all-reduce of parallel.py rides on them) tile the
+    # whole buffer from its end to its start, each exactly once
+    total = rec.ranges[0][2]
+    assert rec.finished == 1 and len(rec.ranges) >= 10
+    assert rec.ranges[0][1] == total and rec.ranges[-1][0] == 0
+    for (s0, e0, _), (s1, e1, _) in zip(rec.ranges, rec.ranges[1:]):
+        assert s0 < e0 and e1 == s0
+    assert total == sum(p.numel() for n, p in prod.named_parameters() if "_bn" not in n and "top_cls" not in n)
 
 
 @pytest.mark.gpu
