@@ -194,6 +194,39 @@ def test_inceptionv3_spec_matches_oracle_and_known_answers():
     assert set(dict(prod.named_buffers())) == set(dict(orc.named_buffers()))
 
 
+def test_inceptionv3_launch_plan():
+    """The Inception-v3 plan on the shared executor: reduce pairs fused, pools behind their projections, one launch per block
+    input (94 convolutions = 66 launches); every layer's parameters exactly once in the flat gradient layout; without the
+    fusions (or with a training-mode BatchNorm) one launch per layer."""
+    from action_detection_amd.bninception import is_rect
+    from action_detection_amd.inceptionv3 import InceptionV3
+    m = InceptionV3().eval()
+    x = torch.zeros(1, 3, 299, 299)
+    plan, shapes = m._plan(x)
+    convs = [op for op in plan if op["kind"] == "conv"]
+    assert len(convs) == 66 and sum(len(op["lids"]) for op in convs) == 94
+    heads = [op for op in convs if "row_gap" in op]
+    assert len(heads) == 9 and all(len(op["lids"]) == 4 and op["lids"][0].endswith("_1x1") for op in heads)
+    assert [op["lids"] for op in convs if len(op["lids"]) == 2] == [["mixed_7a_3x3_reduce", "mixed_7a_7x7x3_reduce"]]
+    assert sum(1 for op in plan if op["kind"] == "pool_aff") == 9 and sum(1 for op in plan if op["kind"] == "pool") == 4
+    assert sum(1 for op in convs if is_rect(op)) == 37      # 3 x 5x5, 26 x 1x7 / 7x1, 8 x 1x3 / 3x1
+    for op in heads:        # the reduce rows live behind the block's own channels, 32-row aligned (conv_epilogue.h)
+        assert op["row_split"] % 32 == 0 and op["row_gap"] % 32 == 0 and op["cout"] % 16 == 0
+        assert shapes[op["dst"]][0] == op["block_channels"] + op["cout"] - op["row_split"]
+    lay, total = m.flat_grad_layout(plan)
+    assert sorted(e[0] for e in lay) == sorted(m._conv_ids)
+    assert total == sum(p.numel() for n, p in m.named_parameters() if "_bn" not in n and "top_cls" not in n)
+    spans = sorted([(e[1], e[1] + e[2]) for e in lay] + [(e[3], e[3] + e[4]) for e in lay])
+    assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    m.fuse_block_inputs = False
+    plan1, _ = m._plan(x)
+    assert sum(1 for op in plan1 if op["kind"] == "conv") == 94 and not any("row_gap" in op for op in plan1)
+    m.fuse_block_inputs = True
+    m.mixed_5b_5x5_bn.train()
+    plan2, _ = m._plan(x)
+    assert sum(1 for op in plan2 if op["kind"] == "conv") == 94 and sum(1 for op in plan2 if op["kind"] == "bn_train") == 1
+
+
 def test_proposal_list_io_matches_reference(tmp_path):
     """ops/io.py:7-59: parser and normalised -> processed conversion against files written by the reference."""
     import json
