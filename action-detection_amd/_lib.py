@@ -19,7 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "bn_train.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "bn_train.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip", "conv_pl.hip", "planes_ops.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -93,6 +93,12 @@ _SIGS = {
     "ssn_space_to_depth2": "ppiiiipp",
     "ssn_s2d_weights": "ppiiip",
     "ssn_s2d_weights_bwd": "ppiiip",
+    # planes tensors (csrc/planes.h): hi/lo f16 planes, NC8HW8
+    "ssn_pl_scales_update": "pppiip",
+    "ssn_pl_from_f32": "plppiiiilippp",
+    "ssn_pl_to_f32": "pplpliiipp",
+    "ssn_conv_pl_fwd": "pppppppiiiiliiiliiiiiiipppiiip",
+    "ssn_conv_pl_dgrad": "pppppiiiiliiiliiiiiplpipppiiip",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double,
        "u": ctypes.c_ulonglong}
@@ -101,7 +107,7 @@ EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_w
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_packed_floats_dgrad_rect", "ssn_conv_wgrad_x6_rect_workspace_bytes", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
-                                "ssn_conv_dgrad_layout"])
+                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles"])
 
 
 class SsnLibrary:
@@ -174,7 +180,7 @@ def build(force=False, verbose=False):
     a multi-GPU launch all call this)."""
     import fcntl
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("ssn_common.h", "conv_epilogue.h", "conv_x6_kernel.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("ssn_common.h", "conv_epilogue.h", "conv_x6_kernel.h", "planes.h")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     stamp_path = LIB_PATH + ".stamp"
     want = _source_stamp(deps, flags)

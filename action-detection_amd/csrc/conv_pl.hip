@@ -1,0 +1,576 @@
+// Implicit-GEMM convolution on planes tensors (planes.h): forward conv + frozen-BN + ReLU and the data gradient of the
+// backbone layers behind /root/reference/ssn_models.py:266,298 with fp32-class accuracy on v_mfma_f32_32x32x16_f16,
+// gfx950.  Same arithmetic as conv_x6.hip (two f16 terms per operand, three partial products per k16 step, fp32
+// accumulation, power-of-two operand scales) -- but the activation operand ARRIVES split: the K loop of this kernel
+// contains no VALU work at all.
+//
+//   * K runs in slabs of 16 channels x one tap (taps innermost), i.e. one MFMA k-step.  A slab's B tile is
+//     [plane][k-half][BN pixels][16 B] in LDS, filled by LDS-DMA: one instruction = 64 pixels x 8 channels of one
+//     plane (1 KiB), gathered per lane (a lane = one output pixel; taps outside the image and pixels past the end
+//     carry an out-of-range offset and deposit zeros), so stride-2 layers, unpadded layers and any kh x kw taps (runtime)
+//     take the same path -- no guard bytes in front of tensors, no padded pixel enumeration, no zero rows.
+//   * A (weights): the packed image of conv_x6.hip (ssn_conv_x6_pack_* : row = 2 planes x 2 k-halves x 16 B,
+//     chunk-swizzled, amax behind the rows), copied 1 KiB per instruction.
+//   * Fragments: ONE ds_read_b128 per (tile, plane) for either operand, conflict-free; a wave keeps two register sets
+//     and reads slab t+1 while it multiplies slab t; the DMA runs two slabs ahead in a 3-slot ring; one s_barrier per
+//     slab; no branches in the loop (slabs past the end are issued with every offset out of range).
+//   * Epilogue: affine + ReLU (or accumulate + the fused ReLU / frozen-BN backward of the producer), multiplied by the
+//     OUTPUT tensor's scale, clamped to the f16 range, split into the two planes and stored 8 bytes (4 channels) per
+//     lane, plane and 8-row group; the largest magnitude goes to the output tensor's amax slot.
+#include "planes.h"
+
+namespace {
+
+using namespace pl;
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+constexpr int APITCH = 16;    // dwords per packed weight row (conv_x6_kernel.h)
+
+struct PlConvArgs {
+    const void* x_hi;     // planes of the gather source at the slice's first channel group
+    const void* x_lo;
+    const uint32_t* ap;   // packed split weights [nslab][M][APITCH], then [amax, 0, 0, 0]
+    const float* x_scale; // scale slot of the source tensor
+    const float* y_scale; // scale slot of the output tensor
+    float* y_amax;        // amax slot of the output tensor (nullptr: not recorded)
+    void* y_hi;
+    void* y_lo;
+    const float* scale;   // per output channel (forward): folded BN scale / shift, or nullptr
+    const float* shift;
+    int N, C, H, W;       // gather-source dims (C = channels read, multiple of 8)
+    uint32_t x_img_bytes; // bytes per image of one source plane (all channel groups of the tensor)
+    uint32_t x_grp_bytes; // bytes per channel group of one image: H * W * 16
+    int M;                // output channels written (multiple of 8)
+    int Ho, Wo;           // enumerated pixel grid
+    uint32_t y_img_bytes, y_grp_bytes;
+    int P;                // N * Ho * Wo
+    int kh, kw, stride, pad_h, pad_w;
+    int relu, accumulate;
+    int raw_from;             // output rows >= raw_from take no affine and no ReLU
+    int row_split, row_gap;   // forward: output rows >= row_split are stored row_gap channels further up (multiples of 32 / 8)
+    int k_split, k_gap;       // source channels >= k_split sit k_gap channels further up its tensor (multiples of 16 / 8)
+    const void* mask_hi;      // dgrad: hi plane of the forward activation whose ReLU / frozen-BN backward is fused (or null)
+    const float* mask_scale;  // per dx channel; NaN = not a ReLU output
+    uint32_t mask_img_bytes;
+    int n_ptiles, n_mtiles, ngroups;   // ngroups = ceil(C / 16)
+    uint32_t x_bytes, a_bytes, y_bytes, mask_bytes;   // per plane
+    // sub-sampled output (stride-2 dgrad as four stride-1 problems, one per parity class of the input pixel): the
+    // enumerated pixel (u, v) is stored at (2u + sub_a, 2v + sub_b) of planes sub_W wide.  sub_W == 0: dense output.
+    int sub_a, sub_b, sub_W;
+    FastDiv div_hw, div_w, div_mt;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PL_DMA_B128(rsrc_, dst_, voff_, soff_) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_, SSN_LDS_PTR(dst_), 16, voff_, soff_, 0, 0)
+#else
+#define PL_DMA_B128(rsrc_, dst_, voff_, soff_) ((void)(dst_), (void)(voff_), (void)(soff_))
+#endif
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(PlConvArgs p) {
+    constexpr int NW = 4;
+    constexpr int NT = 256;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(BN % 64 == 0 && BN <= 256, "tile width 64 / 128 / 256 pixels");
+    constexpr int SEGS = BN / 64;              // 64-pixel DMA pieces per (plane, k-half) row
+    constexpr int A_PIECES = BM / 16;          // 1 KiB pieces of the BM x 64 B weight tile
+    constexpr int NA = (A_PIECES + NW - 1) / NW;
+    constexpr int A_STAGE = NA * NW * 256;     // dwords
+    constexpr int PK = BN * 4;                 // dwords of one (plane, k-half) row of the B tile
+    constexpr int B_STAGE = 4 * PK;
+    constexpr int STAGE = A_STAGE + B_STAGE;
+    constexpr int NSTAGE = 3;
+    constexpr int NB = 4 * SEGS / NW;          // B pieces per wave and slab
+    constexpr int NLOAD = NA + NB;
+
+    __shared__ __attribute__((aligned(1024))) uint32_t lds[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const uint32_t nblk = (uint32_t)p.n_ptiles * (uint32_t)p.n_mtiles;
+    const uint32_t logical = xcd_remap(blockIdx.x, nblk);
+    uint32_t ptile, mtile;
+    fd_divmod(logical, p.div_mt, ptile, mtile);
+    const int m0 = (int)mtile * BM;
+    const int p0 = (int)ptile * BN;
+    const int KK = p.kh * p.kw;
+
+    // ---- B gather state: this lane fetches pixel seg * 64 + lane of the tile (one lane = one pixel, 16 B = 8 channels) ----
+    const int seg = wave % SEGS;
+    uint32_t gbase;      // byte offset of the tap-(0,0) input pixel inside a plane (may wrap below zero)
+    uint32_t gmask = 0;  // bit t: tap t reads inside the image
+    {
+        const int gp = p0 + seg * 64 + lane;
+        const bool gvalid = gp < p.P;
+        uint32_t n, hw, ho, wo;
+        fd_divmod((uint32_t)(gvalid ? gp : 0), p.div_hw, n, hw);
+        fd_divmod(hw, p.div_w, ho, wo);
+        const int h0 = (MODE == MODE_FWD) ? (int)ho * p.stride - p.pad_h : (int)ho + p.pad_h;
+        const int w0 = (MODE == MODE_FWD) ? (int)wo * p.stride - p.pad_w : (int)wo + p.pad_w;
+        int t = 0;
+        for (int r = 0; r < p.kh; ++r)
+            for (int s = 0; s < p.kw; ++s, ++t) {
+                const int hi = (MODE == MODE_FWD) ? h0 + r : h0 - r;
+                const int wi = (MODE == MODE_FWD) ? w0 + s : w0 - s;
+                if (gvalid && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W)) gmask |= 1u << t;
+            }
+        gbase = n * p.x_img_bytes + (uint32_t)((h0 * p.W + w0) * 16);
+    }
+
+    // ---- A copy: wave w moves 1 KiB pieces (q * NW + w) of the tile ----
+    uint32_t aoff[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        const int f = (q * NW + wave) * 64 + lane;   // 16-byte chunk of the tile
+        aoff[q] = (f < BM * 4 && m0 + f / 4 < p.M) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : PL_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc[2] = {pl_rsrc(p.x_hi, p.x_bytes), pl_rsrc(p.x_lo, p.x_bytes)};
+    const __amdgpu_buffer_rsrc_t arsrc = pl_rsrc(p.ap, p.a_bytes);
+    const uint32_t a_step = (uint32_t)(p.M * APITCH) * 4u;
+    const int nslab = p.ngroups * KK;
+    const bool c_half = (p.C & 8) != 0;   // the last slab holds 8 channels only
+
+    // Slab order: taps OUTERMOST, channel groups innermost (slab u = tap * ngroups + g reads packed weight slab g * KK + tap):
+    // the tap displacement, its validity bit and hence the per-lane gather offset only change once per ngroups slabs, so the
+    // producer's per-slab state is three scalar additions.  Producer state = the slab that is fetched next.
+    int pf_g = 0, pf_tap = 0, pf_col = 0;
+    uint32_t pf_d = 0;      // (r * W + s) * 16 of the tap
+    uint32_t pf_x = 0;      // + 2 channel groups per slab
+    uint32_t pf_a = 0;      // + KK weight slabs per slab
+    const uint32_t row_wrap = (uint32_t)(p.W - p.kw) * 16u, group_step = 2u * p.x_grp_bytes, a_gstep = a_step * (uint32_t)KK;
+    const int gap_g = p.k_gap ? p.k_split / 16 : -1;   // channel group in front of which the source has a gap
+    const uint32_t gap_bytes = (uint32_t)(p.k_gap / 8) * p.x_grp_bytes;
+    uint32_t cur_vo = (gmask & 1u) ? gbase : PL_OOB;   // this lane's gather offset for the producer's tap
+    uint32_t cur_dead = 0u;
+    uint32_t d_vo, d_so, d_aso, d_dead;
+    uint32_t *d_b, *d_a;
+    bool d_tail;
+    auto issue_begin = [&](uint32_t st_off) {   // st_off = dword offset of the destination ring slot
+        d_dead = cur_dead;
+        d_vo = cur_vo;
+        d_tail = (pf_g == p.ngroups - 1) && c_half;
+        d_so = pf_x;
+        d_b = lds + st_off + A_STAGE + seg * 256;
+        d_aso = pf_a;
+        d_a = lds + st_off + wave * 256;
+        pf_a += a_gstep;
+        pf_x += group_step;
+        ++pf_g;
+        if (pf_g == gap_g) pf_x += gap_bytes;
+        if (pf_g == p.ngroups) {      // next tap (past the last one: every offset out of range -- the ring runs ahead of the loop)
+            pf_g = 0;
+            pf_x = 0;
+            ++pf_tap;
+            pf_a = a_step * (uint32_t)pf_tap;
+            pf_d += 16u;
+            if (++pf_col == p.kw) {
+                pf_col = 0;
+                pf_d += row_wrap;
+            }
+            const uint32_t cand = (MODE == MODE_FWD) ? gbase + pf_d : gbase - pf_d;
+            const bool live = pf_tap < KK;
+            cur_vo = (live && ((gmask >> pf_tap) & 1u)) ? cand : PL_OOB;
+            cur_dead = live ? 0u : PL_OOB;
+        }
+    };
+    auto issue_piece = [&](int k) {   // k is a compile-time constant at every call site
+        if (k < NB) {
+            const int pk = (wave + k * NW) / SEGS;   // wave-uniform: 2 * plane + k-half
+            const int plane = pk >> 1, khalf = pk & 1;
+            uint32_t v = d_vo;
+            if (d_tail && khalf) v = PL_OOB;
+            PL_DMA_B128(xrsrc[plane], d_b + pk * PK, v, d_so + (khalf ? p.x_grp_bytes : 0u));
+        } else {
+            PL_DMA_B128(arsrc, d_a + (k - NB) * NW * 256, aoff[k - NB] | d_dead, d_aso);
+        }
+    };
+    auto issue = [&](uint32_t st_off) {
+        issue_begin(st_off);
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) issue_piece(k);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0);
+    issue(STAGE);
+    issue(2 * STAGE);
+
+    // operand scales (powers of two, exact)
+    const float sa = f16_scale_of(__builtin_bit_cast(float, p.ap[p.a_bytes >> 2]));
+    const float sb = *p.x_scale;
+    const float so = *p.y_scale;
+    const float inv = so / (sa * sb);     // accumulator -> scaled output units
+
+    // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 2) & 3)
+    const int swz = (li >> 2) & 3;
+    int achunk[2];
+#pragma unroll
+    for (int pn = 0; pn < 2; ++pn) achunk[pn] = ((2 * pn + lh) ^ swz) * 4;
+    const int arow = (wm * TM * 32 + li) * APITCH;
+    const int bcol = A_STAGE + lh * PK + (wn * TN * 32 + li) * 4;
+
+    struct Frags {
+        f16x8 af[2][TM];
+        f16x8 bf[2][TN];
+    };
+    Frags fr0, fr1;
+    constexpr int NREAD = 2 * TN + 2 * TM;
+    const uint32_t* rd_base;
+    auto read_begin = [&](uint32_t st_off) { rd_base = lds + st_off; };
+    auto read_step = [&](Frags& f, int k) {   // k is a compile-time constant at every call site
+        if (k < 2 * TN) {
+            const int pn = k / TN, j = k % TN;
+            f.bf[pn][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(rd_base + bcol + pn * 2 * PK + j * 128));
+        } else {
+            const int q = k - 2 * TN, pn = q / TM, i = q % TM;
+            f.af[pn][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(rd_base + arow + i * 32 * APITCH + achunk[pn]));
+        }
+    };
+    // Three partial products per accumulator tile: w_lo x_hi, w_hi x_hi, w_hi x_lo; between the MFMAs of slab t: the LDS
+    // reads of slab t+1 (other register set) and the DMA pieces of slab t+3.
+    auto mfma = [&](const Frags& f, uint32_t dma_stage, Frags& nxt) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 0, 1};
+        constexpr int NM = 3 * TM * TN;
+        constexpr int EVERY = NM / NLOAD > 0 ? NM / NLOAD : 1;
+        issue_begin(dma_stage);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.af[PA[c]][i], f.bf[PB[c]][j], acc[i][j], 0, 0, 0);
+                    const int idx = (c * TM + i) * TN + j;
+#pragma unroll
+                    for (int k = idx * NREAD / NM; k < (idx + 1) * NREAD / NM; ++k) read_step(nxt, k);
+                    if ((idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) issue_piece((idx + 1) / EVERY - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+        for (int k = NM / EVERY; k < NLOAD; ++k) issue_piece(k);
+    };
+
+    SSN_WAIT_VMCNT(2 * NLOAD);
+    __builtin_amdgcn_s_barrier();
+    read_begin(0);
+#pragma unroll
+    for (int k = 0; k < NREAD; ++k) read_step(fr0, k);
+    uint32_t s_cur = 0, s_n1 = STAGE, s_n2 = 2 * STAGE;   // ring slots of slabs t, t+1, t+2
+    auto half = [&](Frags& cur, Frags& nxt) {
+        SSN_WAIT_VMCNT(NLOAD);   // this wave's pieces of slab t+1 (slab t+2's may still be in flight)
+        SSN_WAIT_LGKM0();        // ... and its reads of slab t are back
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_begin(s_n1);
+        mfma(cur, s_cur, nxt);
+        const uint32_t o = s_cur;
+        s_cur = s_n1;
+        s_n1 = s_n2;
+        s_n2 = o;
+    };
+    // two slabs per trip (the register sets swap roles); an odd slab count runs one all-zero slab at the end
+    for (int t = 0; t < nslab; t += 2) {
+        half(fr0, fr1);
+        half(fr1, fr0);
+    }
+    SSN_WAIT_LGKM0();
+    SSN_WAIT_VMCNT(0);   // the out-of-range tail pieces still write (zeros) into the ring the epilogue is about to reuse
+
+    // ---- epilogue ----
+    __syncthreads();
+    float* ch = reinterpret_cast<float*>(lds);
+    // ch[0,BM) = multiplier, ch[BM,2BM) = shift (scaled), ch[2BM,3BM) = mask scale (NaN: pass through), ch[3BM,4BM) = floor
+    for (int r = tid; r < BM; r += NT) {
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const bool aff = ok && p.scale && m < p.raw_from;
+        ch[r] = aff ? p.scale[m + (m >= p.row_split ? p.row_gap : 0)] * inv : inv;
+        ch[BM + r] = aff ? p.shift[m] * so : 0.f;
+        ch[2 * BM + r] = (ok && p.mask_scale) ? p.mask_scale[m] : __builtin_nanf("");
+        ch[3 * BM + r] = (p.relu && m < p.raw_from) ? 0.f : -PL_F16_MAX;
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t yrsrc[2] = {pl_rsrc(p.y_hi, p.y_bytes), pl_rsrc(p.y_lo, p.y_bytes)};
+    const __amdgpu_buffer_rsrc_t orsrc[2] = {pl_rsrc(p.y_hi, p.accumulate ? p.y_bytes : 0u),
+                                             pl_rsrc(p.y_lo, p.accumulate ? p.y_bytes : 0u)};
+    const __amdgpu_buffer_rsrc_t mrsrc = pl_rsrc(p.mask_hi ? p.mask_hi : p.y_hi, p.mask_hi ? p.mask_bytes : 0u);
+    uint32_t yoff[TN], moff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pp = p0 + (wn * TN + j) * 32 + li;
+        uint32_t n, hw;
+        fd_divmod((uint32_t)(pp < p.P ? pp : 0), p.div_hw, n, hw);
+        if (p.sub_W) {
+            uint32_t u, v;
+            fd_divmod(hw, p.div_w, u, v);
+            hw = (2u * u + (uint32_t)p.sub_a) * (uint32_t)p.sub_W + 2u * v + (uint32_t)p.sub_b;
+        }
+        yoff[j] = pp < p.P ? n * p.y_img_bytes + hw * 16u + 8u * (uint32_t)lh : PL_OOB;
+        moff[j] = pp < p.P ? n * p.mask_img_bytes + hw * 16u + 8u * (uint32_t)lh : PL_OOB;
+    }
+    const int row0 = wm * TM * 32;
+    const bool rmw = p.accumulate || p.mask_hi;
+    float vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float cmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = m0 + row0 + i * 32;                       // first output row of this MFMA tile
+            const int gap = (mrow >= p.row_split) ? p.row_gap : 0;     // wave-uniform channel displacement
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sr = row0 + i * 32 + 8 * q + 4 * lh;          // this lane's first of 4 consecutive tile rows
+                const f32x4 mul = *reinterpret_cast<const f32x4*>(ch + sr);
+                const f32x4 add = *reinterpret_cast<const f32x4*>(ch + BM + sr);
+                const f32x4 flo = *reinterpret_cast<const f32x4*>(ch + 3 * BM + sr);
+                const bool rows_ok = mrow + 8 * q < p.M;
+                const uint32_t goff = (uint32_t)((mrow + gap) / 8 + q) * p.y_grp_bytes;
+                const uint32_t vo = rows_ok ? yoff[j] : PL_OOB;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * mul[e] + add[e];
+                if (rmw) {
+                    const u32x2 ohi = __builtin_amdgcn_raw_buffer_load_b64(orsrc[0], vo, goff, 0);
+                    const u32x2 olo = __builtin_amdgcn_raw_buffer_load_b64(orsrc[1], vo, goff, 0);
+                    const u32x2 mk = __builtin_amdgcn_raw_buffer_load_b64(
+                        mrsrc, rows_ok ? moff[j] : PL_OOB, (uint32_t)(mrow / 8 + q) * p.y_grp_bytes, 0);
+                    const f32x4 msc = *reinterpret_cast<const f32x4*>(ch + 2 * BM + sr);
+                    float old[4];
+                    pl_join4(ohi, olo, old);
+                    const float mv[4] = {f16_pair_lo(mk[0]), f16_pair_hi(mk[0]), f16_pair_lo(mk[1]), f16_pair_hi(mk[1])};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] += old[e];
+                        v[e] = (msc[e] != msc[e]) ? v[e] : (mv[e] > 0.f ? v[e] * msc[e] : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = pl_clamp_floor(v[e], flo[e]);
+                    cmax = fmaxf(cmax, fabsf(v[e]));
+                }
+                u32x2 hi, lo;
+                pl_split4(v, hi, lo);
+                pl_store_b64(hi, yrsrc[0], vo, goff);
+                pl_store_b64(lo, yrsrc[1], vo, goff);
+            }
+        }
+        vmax = fmaxf(vmax, yoff[j] != PL_OOB ? cmax : 0.f);
+    }
+    amax_emit(p.y_amax, vmax / so);
+}
+#undef PL_DMA_B128
+
+int g_pl_default_tile = -1;
+
+template <int MODE, int WM, int WN, int TM, int TN>
+int launch_cfg(PlConvArgs& a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
+    a.n_ptiles = (a.P + BN - 1) / BN;
+    const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
+    hipLaunchKernelGGL((conv_pl_kernel<MODE, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("conv_pl");
+    return SSN_OK;
+}
+
+// Tile ids (rows x pixels), 4 waves each:
+//   0 128x128 (2x2 waves of 64x64)   1 64x128   2 128x64   3 64x64   4 192x128   5 256x128   6 128x256
+//   7 96x128 (1x4 waves of 96x32)    8 160x128 (1x4)    9 32x128 (1x4)   10 64x256 (2x2 of 32x128)   11 192x64
+constexpr int PL_NCFG = 12;
+const int kPlBM[PL_NCFG] = {128, 64, 128, 64, 192, 256, 128, 96, 160, 32, 64, 192};
+const int kPlBN[PL_NCFG] = {128, 128, 64, 64, 128, 128, 256, 128, 128, 128, 256, 64};
+
+template <int MODE>
+int launch_tile(PlConvArgs& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_cfg<MODE, 2, 2, 2, 2>(a, stream);
+        case 1: return launch_cfg<MODE, 2, 2, 1, 2>(a, stream);
+        case 2: return launch_cfg<MODE, 2, 2, 2, 1>(a, stream);
+        case 3: return launch_cfg<MODE, 2, 2, 1, 1>(a, stream);
+        case 4: return launch_cfg<MODE, 2, 2, 3, 2>(a, stream);
+        case 5: return launch_cfg<MODE, 2, 2, 4, 2>(a, stream);
+        case 6: return launch_cfg<MODE, 2, 2, 2, 4>(a, stream);
+        case 7: return launch_cfg<MODE, 1, 4, 3, 1>(a, stream);
+        case 8: return launch_cfg<MODE, 1, 4, 5, 1>(a, stream);
+        case 9: return launch_cfg<MODE, 1, 4, 1, 1>(a, stream);
+        case 10: return launch_cfg<MODE, 2, 2, 1, 4>(a, stream);
+        case 11: return launch_cfg<MODE, 2, 2, 3, 1>(a, stream);
+    }
+    ssn_set_error("conv_pl: unknown tile config %d", cfg);
+    return SSN_ERR_ARG;
+}
+
+// fewest padded rows x columns, then the larger tile (slots = 512 workgroup slots: prefer a grid that fills them)
+int default_tile(int M, long P) {
+    double best = 1e300;
+    int bc = 0;
+    for (int c = 0; c < PL_NCFG; ++c) {
+        if (c == 5 || c == 6 || c == 10) continue;      // the register-heavy tiles: autotuner only
+        const long mt = (M + kPlBM[c] - 1) / kPlBM[c], pt = (P + kPlBN[c] - 1) / kPlBN[c];
+        const double padded = (double)(mt * kPlBM[c]) * (double)(pt * kPlBN[c]);
+        const double small = (kPlBM[c] * kPlBN[c] >= 128 * 128) ? 1.0 : (kPlBM[c] * kPlBN[c] >= 64 * 128 ? 1.1 : 1.3);
+        const long blocks = mt * pt;
+        const double fill = blocks < 256 ? 256.0 / (double)blocks : 1.0;      // fewer workgroups than CUs: pay for the idle ones
+        const double cost = padded * small * fill;
+        if (cost < best) {
+            best = cost;
+            bc = c;
+        }
+    }
+    return bc;
+}
+
+int fill_common(PlConvArgs& a, const void* x_hi, const void* x_lo, const uint32_t* ap, void* y_hi, void* y_lo, int N, int C,
+                int H, int W, long x_img_groups, int M, int Ho, int Wo, long y_img_groups, int kh, int kw,
+                const float* x_scale, const float* y_scale, float* y_amax, int k_gap, int row_gap, const char* what) {
+    SSN_CHECK_ARG(x_hi && x_lo && ap && y_hi && y_lo && x_scale && y_scale, "%s: null pointer", what);
+    SSN_CHECK_ARG(C > 0 && C % 8 == 0 && M > 0 && M % 8 == 0, "%s: channel counts must be multiples of 8 (C %d, M %d)", what, C, M);
+    SSN_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= 32, "%s: %dx%d taps unsupported", what, kh, kw);
+    a.x_hi = x_hi;
+    a.x_lo = x_lo;
+    a.ap = ap;
+    a.y_hi = y_hi;
+    a.y_lo = y_lo;
+    a.x_scale = x_scale;
+    a.y_scale = y_scale;
+    a.y_amax = y_amax;
+    a.N = N;
+    a.C = C;
+    a.H = H;
+    a.W = W;
+    a.M = M;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.kh = kh;
+    a.kw = kw;
+    a.P = N * Ho * Wo;
+    a.ngroups = (C + 15) / 16;
+    const long xg = (long)H * W * 16, yg = (long)Ho * Wo * 16;
+    const long xb = (long)N * x_img_groups * xg, yb = (long)N * y_img_groups * yg;
+    const long ab = (long)a.ngroups * kh * kw * M * APITCH * 4;
+    SSN_CHECK_ARG(x_img_groups >= (C + k_gap) / 8 && y_img_groups >= (M + row_gap) / 8, "%s: slice wider than its tensor", what);
+    SSN_CHECK_ARG(xb < (1l << 31) && yb < (1l << 31) && ab < (1l << 31) && (long)N * Ho * Wo < (1l << 31),
+                  "%s: operand plane larger than 2 GiB (buffer addressing)", what);
+    a.x_grp_bytes = (uint32_t)xg;
+    a.y_grp_bytes = (uint32_t)yg;
+    a.x_img_bytes = (uint32_t)(x_img_groups * xg);
+    a.y_img_bytes = (uint32_t)(y_img_groups * yg);
+    // (the descriptors start at the slice's first group: the bytes behind the last image's slice are never addressed)
+    a.x_bytes = (uint32_t)((long)(N - 1) * a.x_img_bytes + (long)((C + k_gap) / 8) * xg);
+    a.y_bytes = (uint32_t)((long)(N - 1) * a.y_img_bytes + (long)((M + row_gap) / 8) * yg);
+    a.a_bytes = (uint32_t)ab;
+    a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
+    a.div_w = make_fastdiv((uint32_t)Wo);
+    a.sub_a = a.sub_b = a.sub_W = 0;
+    a.mask_hi = nullptr;
+    a.mask_scale = nullptr;
+    a.mask_img_bytes = 0;
+    a.mask_bytes = 0;
+    a.k_split = 0;
+    a.k_gap = 0;
+    a.row_split = 0x7fffffff;
+    a.row_gap = 0;
+    a.raw_from = 0x7fffffff;
+    a.scale = a.shift = nullptr;
+    a.relu = a.accumulate = 0;
+    return SSN_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int ssn_conv_pl_tiles(void) { return PL_NCFG; }
+
+// Forward convolution + frozen-BN affine + ReLU on planes tensors (replaces cuDNN conv + BN(eval) + ReLU behind
+// /root/reference/ssn_models.py:266).  x_*/y_*: plane pointers at the first channel group of the source / destination
+// slice; *_img_groups: channel groups (C / 8) of the whole tensors.  w_packed: ssn_conv_x6_pack_* forward operand.
+extern "C" int ssn_conv_pl_fwd(const void* x_hi, const void* x_lo, const float* w_packed, const float* scale,
+                               const float* shift, void* y_hi, void* y_lo, int N, int Cin, int H, int W,
+                               long x_img_groups, int Cout, int Ho, int Wo, long y_img_groups, int kh, int kw, int stride,
+                               int pad_h, int pad_w, int relu, int tile_cfg, const float* x_scale, const float* y_scale,
+                               float* y_amax, int raw_from, int row_split, int row_gap, hipStream_t stream) {
+    PlConvArgs a;
+    int rc = fill_common(a, x_hi, x_lo, (const uint32_t*)w_packed, y_hi, y_lo, N, Cin, H, W, x_img_groups, Cout, Ho, Wo,
+                         y_img_groups, kh, kw, x_scale, y_scale, y_amax, 0, row_gap, "conv pl fwd");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(stride == 1 || stride == 2, "conv pl fwd: stride %d unsupported", stride);
+    SSN_CHECK_ARG(!row_gap || (row_split % 32 == 0 && row_gap % 8 == 0 && row_split > 0 && row_split < Cout),
+                  "conv pl fwd: a row split must be a multiple of 32 inside (0, M), the gap a multiple of 8");
+    a.stride = stride;
+    a.pad_h = pad_h;
+    a.pad_w = pad_w;
+    a.scale = scale;
+    a.shift = shift;
+    a.relu = relu;
+    a.raw_from = raw_from > 0 ? raw_from : 0x7fffffff;
+    if (row_gap) {
+        a.row_split = row_split;
+        a.row_gap = row_gap;
+    }
+    const int cfg = tile_cfg >= 0 ? tile_cfg : (g_pl_default_tile >= 0 ? g_pl_default_tile : default_tile(Cout, a.P));
+    return launch_tile<MODE_FWD>(a, cfg, stream);
+}
+
+// Data gradient of a stride-1 convolution (any kh x kw taps): dx = sum over taps of w^T dy, as a gather over dy with
+// padding (pad_h, pad_w) of the FORWARD layer.  wt_packed: the transposed operand (pack mode 1).  accumulate: dx += ;
+// mask_hi / mask_scale: fuse dx <- dx * (x > 0) * mask_scale[c] (ReLU + frozen-BN backward of the layer that produced x;
+// mask_hi = hi plane of x at dx's slice, mask_img_groups = groups of x's tensor).
+// taps_reversed: wt_packed is the transposed, tap-reversed operand (pack mode 2: rectangular-tap layers).
+extern "C" int ssn_conv_pl_dgrad(const void* dy_hi, const void* dy_lo, const float* wt_packed, void* dx_hi, void* dx_lo,
+                                 int N, int Cout, int Ho, int Wo, long dy_img_groups, int Cin, int H, int W,
+                                 long dx_img_groups, int kh, int kw, int pad_h, int pad_w, int accumulate,
+                                 const void* mask_hi, long mask_img_groups, const float* mask_scale, int tile_cfg,
+                                 const float* dy_scale, const float* dx_scale, float* dx_amax, int k_split, int k_gap,
+                                 int taps_reversed, hipStream_t stream) {
+    PlConvArgs a;
+    // dgrad runs on the grid of dx: "source" = dy (C = Cout channels, Ho x Wo), "output" = dx (M = Cin, H x W)
+    int rc = fill_common(a, dy_hi, dy_lo, (const uint32_t*)wt_packed, dx_hi, dx_lo, N, Cout, Ho, Wo, dy_img_groups, Cin, H, W,
+                         dx_img_groups, kh, kw, dy_scale, dx_scale, dx_amax, k_gap, 0, "conv pl dgrad");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(!k_gap || (k_split % 16 == 0 && k_gap % 8 == 0 && k_split > 0 && k_split < Cout && Cout % 16 == 0),
+                  "conv pl dgrad: a channel split must be a multiple of 16 inside (0, C)");
+    a.stride = 1;
+    a.pad_h = pad_h;
+    a.pad_w = pad_w;
+    a.accumulate = accumulate;
+    a.k_split = k_split;
+    a.k_gap = k_gap;
+    if (mask_hi && mask_scale) {
+        a.mask_hi = mask_hi;
+        a.mask_scale = mask_scale;
+        const long mg = (long)H * W * 16;
+        SSN_CHECK_ARG(mask_img_groups >= Cin / 8 && (long)N * mask_img_groups * mg < (1l << 31), "conv pl dgrad: bad mask tensor");
+        a.mask_img_bytes = (uint32_t)(mask_img_groups * mg);
+        a.mask_bytes = (uint32_t)((long)(N - 1) * a.mask_img_bytes + (long)(Cin / 8) * mg);
+    }
+    const int cfg = tile_cfg >= 0 ? tile_cfg : (g_pl_default_tile >= 0 ? g_pl_default_tile : default_tile(Cin, a.P));
+    if (taps_reversed) {
+        // the operand was packed transposed AND tap-reversed (ssn_conv_x6_pack_dgrad_rect / pack_rect_multi mode 2): the data
+        // gradient is then the forward correlation of dy with it, padding k - 1 - pad
+        a.pad_h = kh - 1 - pad_h;
+        a.pad_w = kw - 1 - pad_w;
+        return launch_tile<MODE_FWD>(a, cfg, stream);
+    }
+    return launch_tile<MODE_DGRAD>(a, cfg, stream);
+}

@@ -1,0 +1,182 @@
+"""Planes tensors (csrc/planes.h) on the host side: allocation, channel slices, scale / amax slots, and thin wrappers over
+the C-ABI entry points that read or write them.
+
+A planes tensor holds an fp32 activation as two f16 terms of ``x * scale`` in the channel-blocked NC8HW8 layout the
+matrix cores consume directly.  ``PlaneTensor`` owns the two planes (one ``torch.float16`` tensor ``[2, N, G, H*W, 8]``)
+and the association with its two slots: ``scale`` (a power of two, fixed while a step runs) and ``amax`` (the largest
+magnitude the step's producers stored).  ``SlotPool`` owns the slots of an executor and the update between steps.
+"""
+import torch
+
+from . import _lib
+from .kernels import _p, _stream
+
+
+class SlotPool:
+    """amax / scale slots of a set of planes tensors, plus the two status words the update kernel maintains:
+    flag[0] = a tensor outgrew its scale (values were clamped), flag[1] = number of scales changed since the last reset."""
+
+    def __init__(self, n, device):
+        self.device = device
+        self.amax = torch.zeros(n, device=device, dtype=torch.float32)
+        self.scale = torch.ones(n, device=device, dtype=torch.float32)
+        self.flag = torch.zeros(2, device=device, dtype=torch.int32)
+        self.used = 0
+
+    def take(self):
+        i = self.used
+        if i >= self.amax.numel():
+            raise RuntimeError("slot pool exhausted")
+        self.used += 1
+        return i
+
+    def update(self, exact=False, first=0, count=None):
+        """scale <- f(amax) for slots [first, first + count), amax <- 0."""
+        lib = _lib.get_lib()
+        count = self.used - first if count is None else count
+        if count <= 0:
+            return
+        lib.call("ssn_pl_scales_update", self.amax.data_ptr() + 4 * first, self.scale.data_ptr() + 4 * first,
+                 _p(self.flag), int(count), int(bool(exact)), _stream(lib, self.amax))
+
+
+class PlaneTensor:
+    """[N, C, H, W] activation as hi / lo f16 planes (C padded to a multiple of 8)."""
+
+    def __init__(self, n, c, h, w, device, pool=None, slot=None):
+        self.n, self.c, self.h, self.w = int(n), int(c), int(h), int(w)
+        self.g = (self.c + 7) // 8
+        self.data = torch.empty((2, self.n, self.g, self.h * self.w, 8), device=device, dtype=torch.float16)
+        if pool is None:
+            pool = SlotPool(1, device)
+        self.pool = pool
+        self.slot = pool.take() if slot is None else slot
+
+    @property
+    def device(self):
+        return self.data.device
+
+    @property
+    def scale(self):
+        return self.pool.scale[self.slot:self.slot + 1]
+
+    @property
+    def amax(self):
+        return self.pool.amax[self.slot:self.slot + 1]
+
+    @property
+    def scale_ptr(self):
+        return self.pool.scale.data_ptr() + 4 * self.slot
+
+    @property
+    def amax_ptr(self):
+        return self.pool.amax.data_ptr() + 4 * self.slot
+
+    def plane_ptr(self, plane, c0=0):
+        assert c0 % 8 == 0
+        return self.data[plane].data_ptr() + (c0 // 8) * self.h * self.w * 16
+
+    def zero_(self):
+        self.data.zero_()
+        return self
+
+
+class PSlice:
+    """Channels [c0, c0 + c) of a PlaneTensor (c0 a multiple of 8)."""
+
+    def __init__(self, t, c0=0, c=None):
+        self.t, self.c0 = t, int(c0)
+        self.c = t.c - self.c0 if c is None else int(c)
+        assert self.c0 % 8 == 0 and self.c0 + self.c <= t.g * 8
+
+    @property
+    def hi(self):
+        return self.t.plane_ptr(0, self.c0)
+
+    @property
+    def lo(self):
+        return self.t.plane_ptr(1, self.c0)
+
+    @property
+    def n(self):
+        return self.t.n
+
+    @property
+    def hw(self):
+        return self.t.h, self.t.w
+
+    @property
+    def groups(self):
+        return self.t.g
+
+
+def pfull(t):
+    return PSlice(t, 0, t.c)
+
+
+def _lib_for(t):
+    lib = _lib.get_lib()
+    if not lib.is_emulator and not t.data.is_cuda:
+        raise RuntimeError("SSN HIP ops need HIP (cuda) tensors; there is no CPU fallback")
+    return lib
+
+
+def _st(lib, t):
+    return _stream(lib, t.data)
+
+
+def from_f32(x, dst=None, pool=None, s2d=False, exact=True):
+    """fp32 NCHW tensor (or ChanSlice-like [N, C, H, W] contiguous tensor) -> planes.  exact: measure max |x| first and
+    derive the scale from it (two passes: what the caller's frames and test inputs get); otherwise the destination's
+    current scale is used and its amax slot raised (the delayed protocol)."""
+    from . import kernels as K
+    n, c, h, w = x.shape
+    if dst is None:
+        dst = PlaneTensor(n, 4 * c if s2d else c, h // 2 if s2d else h, w // 2 if s2d else w, x.device, pool)
+    t = dst.t if isinstance(dst, PSlice) else dst
+    sl = dst if isinstance(dst, PSlice) else pfull(dst)
+    lib = _lib_for(t)
+    if exact:
+        t.amax.zero_()
+        K.tensor_amax(x, t.amax)
+        t.pool.update(exact=True, first=t.slot, count=1)
+    lib.call("ssn_pl_from_f32", _p(x), c * h * w, sl.hi, sl.lo, n, c, h, w, t.g, int(bool(s2d)), t.scale_ptr,
+             None if exact else t.amax_ptr, _st(lib, t))
+    return dst
+
+
+def to_f32(src, out=None):
+    """planes (PlaneTensor / PSlice) -> fp32 NCHW tensor."""
+    sl = src if isinstance(src, PSlice) else pfull(src)
+    t = sl.t
+    lib = _lib_for(t)
+    if out is None:
+        out = torch.empty((t.n, sl.c, t.h, t.w), device=t.device, dtype=torch.float32)
+    lib.call("ssn_pl_to_f32", sl.hi, sl.lo, t.g, _p(out), sl.c * t.h * t.w, t.n, sl.c, t.h * t.w, t.scale_ptr, _st(lib, t))
+    return out
+
+
+def conv_fwd(x, w_packed, scale, shift, y, kh, kw, stride, pad_h, pad_w, relu=True, tile_cfg=-1, raw_from=0, row_split=0,
+             row_gap=0):
+    """y <- relu?(scale * conv(x) + shift) on planes slices.  w_packed: kernels.pack_weights_multi(x6=True) /
+    pack_weights_rect / pack_rect_multi forward operand (the packed image is shared with the fp32-layout split kernels)."""
+    lib = _lib_for(x.t)
+    h, w = x.hw
+    ho, wo = y.hw
+    lib.call("ssn_conv_pl_fwd", x.hi, x.lo, _p(w_packed), _p(scale), _p(shift), y.hi, y.lo, x.n, x.c, h, w, x.groups, y.c, ho,
+             wo, y.groups, kh, kw, stride, pad_h, pad_w, int(bool(relu)), tile_cfg, x.t.scale_ptr, y.t.scale_ptr, y.t.amax_ptr,
+             int(raw_from), int(row_split), int(row_gap), _st(lib, x.t))
+
+
+def conv_dgrad(dy, wt_packed, dx, kh, kw, pad_h, pad_w, accumulate=False, tile_cfg=-1, mask=None, mask_scale=None, k_split=0,
+               k_gap=0, taps_reversed=False):
+    """dx (+)= conv_transpose(dy) on planes slices (stride 1).  mask: PSlice of the forward activation at dx's channels +
+    mask_scale [dx.c]: fuse the ReLU / frozen-BN backward into the store.  taps_reversed: wt_packed is the transposed,
+    tap-reversed operand (kernels.pack_dgrad_rect / pack_rect_multi(dgrad=True)); otherwise pack mode 1."""
+    lib = _lib_for(dy.t)
+    ho, wo = dy.hw
+    h, w = dx.hw
+    lib.call("ssn_conv_pl_dgrad", dy.hi, dy.lo, _p(wt_packed), dx.hi, dx.lo, dy.n, dy.c, ho, wo, dy.groups, dx.c, h, w,
+             dx.groups, kh, kw, pad_h, pad_w, int(bool(accumulate)), mask.hi if mask is not None else None,
+             mask.groups if mask is not None else 0, _p(mask_scale), tile_cfg, dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr,
+             int(k_split), int(k_gap), int(bool(taps_reversed)), _st(lib, dy.t))

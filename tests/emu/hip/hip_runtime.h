@@ -421,6 +421,50 @@ static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned int v, __amdgp
     const uint64_t o = (uint64_t)voff + soff;
     if (o + 4 <= r.bytes) memcpy(const_cast<char*>(r.base) + o, &v, 4);
 }
+static inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u32x2 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
+                                                         int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    for (int d = 0; d < 2; ++d)
+        if (o + 4 * d + 4 <= r.bytes) {
+            const unsigned int w = v[d];
+            memcpy(const_cast<char*>(r.base) + o + 4 * d, &w, 4);
+        }
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff,
+                                                          int) {
+    const uint64_t o = (uint64_t)voff + soff;
+    for (int d = 0; d < 4; ++d)
+        if (o + 4 * d + 4 <= r.bytes) {
+            const unsigned int w = v[d];
+            memcpy(const_cast<char*>(r.base) + o + 4 * d, &w, 4);
+        }
+}
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {
+    const float lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+}
+static inline int atomicOr(int* p, int v) {
+    int o = *p;
+    *p = o | v;
+    return o;
+}
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read): every lane supplies the address of 4 consecutive 16-bit elements (one
+// row piece); inside each group of 16 lanes, lanes 4j..4j+3 supply row j (16 elements), and lane c of the group receives
+// column c of rows 0..3 (element j = row j).
+static inline emu_u32x2 emu_ds_read_tr16_b64(const void* addr) {
+    uint32_t u[2];
+    memcpy(u, addr, 8);
+    auto* buf = emu::wave_exchange(u, 2);
+    const int lane = emu::g_cur->lane, grp = lane & ~15, c = lane & 15;
+    unsigned short e[4];
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t* src = buf[grp + 4 * j + (c >> 2)];
+        const uint32_t d = src[(c & 3) >> 1];
+        e[j] = (unsigned short)((c & 1) ? (d >> 16) : (d & 0xFFFFu));
+    }
+    return emu_u32x2{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
+}
+#define SSN_DS_READ_TR16_B64(ptr) emu_ds_read_tr16_b64(ptr)
 // LDS-DMA: every lane deposits `size` bytes at (wave-uniform lds base) + lane * size
 #define SSN_LDS_PTR(p) ((void*)(p))
 #define SSN_WAIT_VMCNT(n) ((void)0)

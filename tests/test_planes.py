@@ -1,0 +1,182 @@
+"""Planes tensors (csrc/planes.h) and the kernels that read / write them, against float64 torch references of the same ops.
+
+Every test runs through the host emulator build of the kernel sources (CPU tier, small shapes) and, with ``-m gpu``, through
+libssn_hip.so at the backbone's layer shapes.  Tolerances are relative to the largest magnitude of the reference and are
+those of the fp32-layout split kernels (two f16 terms per operand = 22 significant bits, fp32 accumulation).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import action_detection_amd  # noqa: F401
+from action_detection_amd import kernels as K
+from action_detection_amd import planes as P
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def test_planes_roundtrip_and_scales(backend):
+    g = torch.Generator().manual_seed(0)
+    for (n, c, h, w) in [(2, 8, 5, 7), (1, 20, 4, 4), (3, 3, 6, 6)]:
+        x = torch.randn(n, c, h, w, generator=g) * 37.0
+        t = P.from_f32(backend.put(x))
+        assert t.g == (c + 7) // 8
+        s = t.scale.cpu().item()
+        amax = x.abs().max().item()
+        assert 2 ** 14 <= amax * s < 2 ** 15, "exact scale puts the maximum just below 2^15"
+        back = P.to_f32(t).cpu()
+        assert rel_err(back, x) < 2.0 ** -21
+        # padding channels are zero
+        raw = t.data.cpu().float().view(2, n, t.g, h * w, 8)
+        if c % 8:
+            assert (raw[:, :, -1, :, c % 8:] == 0).all()
+    # space-to-depth view of the stem input
+    x = torch.randn(2, 3, 8, 6, generator=g)
+    t = P.from_f32(backend.put(x), s2d=True)
+    back = P.to_f32(t).cpu()
+    ref = torch.zeros(2, 12, 4, 3)
+    for c in range(3):
+        for a in range(2):
+            for b in range(2):
+                ref[:, (c * 2 + a) * 2 + b] = x[:, c, a::2, b::2]
+    assert rel_err(back, ref) < 2.0 ** -21
+
+
+def test_scales_update_protocol(backend):
+    pool = P.SlotPool(4, backend.device)
+    pool.used = 4
+    pool.amax.copy_(torch.tensor([3.0, 0.0, 1e-6, 5000.0]))
+    pool.scale.copy_(torch.tensor([1.0, 7.0, 1.0, 16.0]))
+    pool.update()
+    s = pool.scale.cpu()
+    assert 2 ** 12 <= 3.0 * s[0] < 2 ** 13 and s[1] == 7.0 and 2 ** 12 <= 1e-6 * s[2] < 2 ** 13
+    assert s[3] != 16.0 and 2 ** 12 <= 5000.0 * s[3] < 2 ** 13      # 5000 * 16 > 65504: re-derived, and flagged
+    assert pool.flag.cpu()[0].item() == 1 and pool.flag.cpu()[1].item() == 3
+    assert (pool.amax.cpu() == 0).all()
+    # hysteresis: a maximum that still sits inside [2^10, 2^14) of the current scale keeps it
+    pool.flag.zero_()
+    pool.amax.copy_(torch.tensor([5.0, 0.0, 0.4e-6, 5000.0]))
+    pool.update()
+    assert torch.equal(pool.scale.cpu(), s) and pool.flag.cpu()[1].item() == 0
+
+
+CASES_SMALL = [
+    # N, Cin, H, W, Cout, kh, kw, stride, ph, pw
+    (2, 16, 9, 9, 40, 3, 3, 1, 1, 1), (1, 16, 7, 7, 96, 1, 1, 1, 0, 0), (2, 8, 10, 10, 32, 3, 3, 2, 1, 1),
+    (1, 24, 6, 8, 64, 1, 1, 1, 0, 0), (2, 16, 5, 5, 72, 5, 5, 1, 2, 2), (1, 32, 8, 8, 48, 1, 7, 1, 0, 3),
+    (1, 16, 9, 9, 32, 3, 3, 1, 0, 0), (1, 16, 12, 12, 64, 4, 4, 1, 2, 2), (2, 16, 9, 9, 32, 3, 3, 2, 0, 0),
+]
+CASES_GPU = [
+    (9, 64, 56, 56, 192, 3, 3, 1, 1, 1), (18, 192, 28, 28, 224, 1, 1, 1, 0, 0), (18, 128, 28, 28, 160, 3, 3, 2, 1, 1),
+    (18, 576, 14, 14, 512, 1, 1, 1, 0, 0), (18, 160, 14, 14, 192, 3, 3, 1, 1, 1), (36, 1056, 7, 7, 832, 1, 1, 1, 0, 0),
+    (36, 224, 7, 7, 224, 3, 3, 1, 1, 1), (4, 16, 112, 112, 64, 4, 4, 1, 2, 2), (4, 48, 35, 35, 64, 5, 5, 1, 2, 2),
+    (4, 128, 17, 17, 128, 1, 7, 1, 0, 3), (4, 128, 17, 17, 128, 7, 1, 1, 3, 0), (4, 32, 37, 37, 64, 3, 3, 1, 0, 0),
+]
+
+
+def _pack_fwd(w, backend):
+    cout, cin, kh, kw = w.shape
+    if kh == kw and kh in (1, 3):
+        return K.pack_weights_multi([([backend.put(w)], 0)], x6=True)[0]
+    return K.pack_weights_rect(backend.put(w))
+
+
+def test_conv_pl_forward(backend):
+    """conv + folded BN + ReLU on planes vs float64; every tile config on the first case."""
+    g = torch.Generator().manual_seed(1)
+    cases = CASES_GPU if backend.is_gpu else CASES_SMALL
+    ntiles = int(action_detection_amd._lib.get_lib().cdll.ssn_conv_pl_tiles())
+    for ci, (n, cin, h, wd, cout, kh, kw, s, ph, pw) in enumerate(cases):
+        x = torch.randn(n, cin, h, wd, generator=g) * 3.0
+        w = torch.randn(cout, cin, kh, kw, generator=g) * (2.0 / (cin * kh * kw)) ** 0.5
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g) * 0.1
+        ref = F.relu(F.conv2d(x.double(), w.double(), None, s, (ph, pw)) * scale.double().view(1, -1, 1, 1)
+                     + shift.double().view(1, -1, 1, 1))
+        ho, wo = ref.shape[2], ref.shape[3]
+        xp = P.from_f32(backend.put(x))
+        wp = _pack_fwd(w, backend)
+        c0, ctot = 16, cout + 48
+        for tile in (range(ntiles) if ci == 0 else [-1]):
+            y = P.PlaneTensor(n, ctot, ho, wo, backend.device)
+            y.data.fill_(7.0)
+            # the delayed protocol: first pass with a guessed scale records the maximum, the update derives the scale,
+            # the second pass stores with it
+            for _ in range(2):
+                P.conv_fwd(P.pfull(xp), wp, backend.put(scale), backend.put(shift), P.PSlice(y, c0, cout), kh, kw, s, ph, pw,
+                           True, tile)
+                assert abs(y.amax.cpu().item() - ref.abs().max().item()) <= 1e-4 * ref.abs().max().item()
+                y.pool.update()
+            got = P.to_f32(P.PSlice(y, c0, cout)).cpu()
+            assert rel_err(got, ref) < 3e-6, (n, cin, h, cout, kh, kw, s, tile)
+            raw = y.data.cpu().float()
+            assert (raw[:, :, :c0 // 8] == 7.0).all() and (raw[:, :, (c0 + cout) // 8:] == 7.0).all(), "wrote outside its slice"
+
+
+def test_conv_pl_raw_rows_and_row_gap(backend):
+    """Fused block-input launch: rows >= raw_from take no affine / ReLU, rows >= row_split land row_gap channels further up."""
+    g = torch.Generator().manual_seed(2)
+    n, cin, h, cout = (4, 192, 28, 224) if backend.is_gpu else (1, 16, 6, 96)
+    split, gap, raw_from = (64, 192, 192) if backend.is_gpu else (32, 64, 64)
+    x = torch.randn(n, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    ctot = split + gap + (cout - split)
+    scale = torch.rand(ctot, generator=g) + 0.5       # indexed by destination channel
+    shift = torch.randn(cout, generator=g) * 0.1      # indexed by launch row
+    z = F.conv2d(x.double(), w.double())
+    ref = torch.zeros(n, ctot, h, h, dtype=torch.float64)
+    for m in range(cout):
+        d = m if m < split else m + gap
+        if m < raw_from:
+            ref[:, d] = F.relu(z[:, m] * scale[d].double() + shift[m].double())
+        else:
+            ref[:, d] = z[:, m]
+    xp = P.from_f32(backend.put(x))
+    wp = _pack_fwd(w, backend)
+    y = P.PlaneTensor(n, ctot, h, h, backend.device).zero_()
+    for _ in range(2):
+        P.conv_fwd(P.pfull(xp), wp, backend.put(scale), backend.put(shift), P.PSlice(y, 0, cout), 1, 1, 1, 0, 0, True, -1,
+                   raw_from=raw_from, row_split=split, row_gap=gap)
+        y.pool.update()
+    got = P.to_f32(y).cpu()
+    assert rel_err(got, ref) < 3e-6
+
+
+def test_conv_pl_dgrad(backend):
+    """Data gradient (stride 1) on planes vs autograd in float64: plain, accumulating, and with the fused ReLU / BN mask."""
+    g = torch.Generator().manual_seed(3)
+    cases = [c for c in (CASES_GPU if backend.is_gpu else CASES_SMALL) if c[7] == 1]
+    for (n, cin, h, wd, cout, kh, kw, s, ph, pw) in cases:
+        x = torch.randn(n, cin, h, wd, generator=g, dtype=torch.float64).requires_grad_()
+        w = torch.randn(cout, cin, kh, kw, generator=g) * 0.1
+        y = F.conv2d(x, w.double(), None, 1, (ph, pw))
+        gy = torch.randn(y.shape, generator=g) * 1e-3
+        y.backward(gy.double())
+        dref = x.grad
+        rev = not (kh == kw and kh in (1, 3))
+        if not rev:
+            wt = K.pack_weights_multi([([backend.put(w)], 1)], x6=True)[0]
+        else:
+            wt = K.pack_dgrad_rect(backend.put(w))
+        gp = P.from_f32(backend.put(gy))
+        dx = P.PlaneTensor(n, cin, h, wd, backend.device)
+        for _ in range(2):
+            P.conv_dgrad(P.pfull(gp), wt, P.pfull(dx), kh, kw, ph, pw, taps_reversed=rev)
+            dx.pool.update()
+        assert rel_err(P.to_f32(dx), dref) < 3e-6, ("dgrad", n, cin, h, cout, kh, kw)
+        # accumulate on top of itself, then the mask: dx <- (dx + dgrad) * (act > 0) * mscale
+        act = torch.randn(n, cin, h, wd, generator=g).clamp(min=0)
+        msc = torch.randn(cin, generator=g)
+        msc[::5] = float("nan")          # channels that are not ReLU outputs pass through
+        actp = P.from_f32(backend.put(act))
+        for _ in range(2):
+            P.conv_dgrad(P.pfull(gp), wt, P.pfull(dx), kh, kw, ph, pw, taps_reversed=rev)      # dx = d
+            P.conv_dgrad(P.pfull(gp), wt, P.pfull(dx), kh, kw, ph, pw, accumulate=True, mask=P.pfull(actp),
+                         mask_scale=backend.put(msc), taps_reversed=rev)                                          # dx = mask(2 d)
+            dx.pool.update()
+        m = torch.where(torch.isnan(msc).view(1, -1, 1, 1), torch.ones_like(act),
+                        (act > 0).float() * torch.nan_to_num(msc).view(1, -1, 1, 1)).double()
+        assert rel_err(P.to_f32(dx), 2 * dref * m) < 4e-6, ("dgrad mask", n, cin, h, cout, kh, kw)
