@@ -19,7 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "bn_train.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip", "conv_pl.hip", "planes_ops.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "bn_train.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip", "conv_pl.hip", "planes_ops.hip", "wgrad_pl.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -99,6 +99,15 @@ _SIGS = {
     "ssn_pl_to_f32": "pplpliiipp",
     "ssn_conv_pl_fwd": "pppppppiiiiliiiliiiiiiipppiiip",
     "ssn_conv_pl_dgrad": "pppppiiiiliiiliiiiiplpipppiiip",
+    "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiip",
+    "ssn_conv_pl_dgrad_s2": "pppppiiiiliiiliiplpipppp",
+    "ssn_pl_maxpool_fwd": "pplpplpiiiiiiiiipppp",
+    "ssn_pl_maxpool_bwd": "pplpppliiiiiiiiiiplppppp",
+    "ssn_pl_avgpool_affine": "pplpplppiiiiiiipppp",
+    "ssn_pl_relu_bn_bwd": "pplplpiiippp",
+    "ssn_pl_gap_fwd": "pplpiiipp",
+    "ssn_pl_gap_bwd": "pppliiiplpppp",
+    "ssn_pl_channel_sum": "pplpiiipplp",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double,
        "u": ctypes.c_ulonglong}
@@ -107,7 +116,7 @@ EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_w
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_packed_floats_dgrad_rect", "ssn_conv_wgrad_x6_rect_workspace_bytes", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
-                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles"])
+                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes"])
 
 
 class SsnLibrary:
@@ -140,6 +149,10 @@ class SsnLibrary:
         self.cdll.ssn_detections_workspace_bytes.argtypes = [ctypes.c_int] * 2
         self.cdll.ssn_conv_pick_tile.restype = ctypes.c_int
         self.cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
+        self.cdll.ssn_pl_channel_sum_workspace_bytes.restype = ctypes.c_long
+        self.cdll.ssn_pl_channel_sum_workspace_bytes.argtypes = [ctypes.c_int]
+        self.cdll.ssn_conv_wgrad_pl_workspace_bytes.restype = ctypes.c_long
+        self.cdll.ssn_conv_wgrad_pl_workspace_bytes.argtypes = [ctypes.c_int] * 8
         self._fn = {}
         for name, sig in _SIGS.items():
             fn = getattr(self.cdll, name)

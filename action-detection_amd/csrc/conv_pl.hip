@@ -58,8 +58,17 @@ struct PlConvArgs {
     // sub-sampled output (stride-2 dgrad as four stride-1 problems, one per parity class of the input pixel): the
     // enumerated pixel (u, v) is stored at (2u + sub_a, 2v + sub_b) of planes sub_W wide.  sub_W == 0: dense output.
     int sub_a, sub_b, sub_W;
+    unsigned long long* trace;   // tooling only: per-block phase timestamps (tools/ablate_conv_pl.py), normally null
+    int dbg;                     // tooling only: ablation switches (1: no B fetch, 2: no A fetch, 4: no fragment reads, 8: no stores)
     FastDiv div_hw, div_w, div_mt;
 };
+
+// tooling build only (tools/build_trace_lib.sh: -DPL_ABLATE): runtime ablation switches; compiled out of the product
+#ifdef PL_ABLATE
+#define PL_DBG(bit) (p.dbg & (bit))
+#else
+#define PL_DBG(bit) 0
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PL_DMA_B128(rsrc_, dst_, voff_, soff_) \
@@ -101,6 +110,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     const int m0 = (int)mtile * BM;
     const int p0 = (int)ptile * BN;
     const int KK = p.kh * p.kw;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (p.trace) tr0 = __builtin_readcyclecounter();
 
     // ---- B gather state: this lane fetches pixel seg * 64 + lane of the tile (one lane = one pixel, 16 B = 8 channels) ----
     const int seg = wave % SEGS;
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
                 if (gvalid && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W)) gmask |= 1u << t;
             }
         gbase = n * p.x_img_bytes + (uint32_t)((h0 * p.W + w0) * 16);
+        if (PL_DBG(1)) gmask = 0;
     }
 
     // ---- A copy: wave w moves 1 KiB pieces (q * NW + w) of the tile ----
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
         const int f = (q * NW + wave) * 64 + lane;   // 16-byte chunk of the tile
-        aoff[q] = (f < BM * 4 && m0 + f / 4 < p.M) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : PL_OOB;
+        aoff[q] = (f < BM * 4 && m0 + f / 4 < p.M && !PL_DBG(2)) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : PL_OOB;
     }
     const __amdgpu_buffer_rsrc_t xrsrc[2] = {pl_rsrc(p.x_hi, p.x_bytes), pl_rsrc(p.x_lo, p.x_bytes)};
     const __amdgpu_buffer_rsrc_t arsrc = pl_rsrc(p.ap, p.a_bytes);
@@ -258,7 +270,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.af[PA[c]][i], f.bf[PB[c]][j], acc[i][j], 0, 0, 0);
                     const int idx = (c * TM + i) * TN + j;
 #pragma unroll
-                    for (int k = idx * NREAD / NM; k < (idx + 1) * NREAD / NM; ++k) read_step(nxt, k);
+                    for (int k = idx * NREAD / NM; k < (idx + 1) * NREAD / NM; ++k)
+                        if (!PL_DBG(4)) read_step(nxt, k);
                     if ((idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) issue_piece((idx + 1) / EVERY - 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -266,6 +279,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
         for (int k = NM / EVERY; k < NLOAD; ++k) issue_piece(k);
     };
 
+    if (p.trace) tr1 = __builtin_readcyclecounter();
     SSN_WAIT_VMCNT(2 * NLOAD);
     __builtin_amdgcn_s_barrier();
     read_begin(0);
@@ -291,6 +305,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     }
     SSN_WAIT_LGKM0();
     SSN_WAIT_VMCNT(0);   // the out-of-range tail pieces still write (zeros) into the ring the epilogue is about to reuse
+    if (p.trace) tr2 = __builtin_readcyclecounter();
 
     // ---- epilogue ----
     __syncthreads();
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
                 const f32x4 flo = *reinterpret_cast<const f32x4*>(ch + 3 * BM + sr);
                 const bool rows_ok = mrow + 8 * q < p.M;
                 const uint32_t goff = (uint32_t)((mrow + gap) / 8 + q) * p.y_grp_bytes;
-                const uint32_t vo = rows_ok ? yoff[j] : PL_OOB;
+                const uint32_t vo = (rows_ok && !PL_DBG(8)) ? yoff[j] : PL_OOB;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * mul[e] + add[e];
@@ -376,10 +391,21 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
         vmax = fmaxf(vmax, yoff[j] != PL_OOB ? cmax : 0.f);
     }
     amax_emit(p.y_amax, vmax / so);
+    if (p.trace && tid == 0) {
+        unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+        t[0] = tr0;
+        t[1] = tr1;
+        t[2] = tr2;
+        t[3] = __builtin_readcyclecounter();
+        t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+    }
 }
 #undef PL_DMA_B128
 
 int g_pl_default_tile = -1;
+int g_pl_dbg = 0;
+unsigned long long* g_pl_trace = nullptr;
 
 template <int MODE, int WM, int WN, int TM, int TN>
 int launch_cfg(PlConvArgs& a, hipStream_t stream) {
@@ -494,6 +520,8 @@ int fill_common(PlConvArgs& a, const void* x_hi, const void* x_lo, const uint32_
     a.raw_from = 0x7fffffff;
     a.scale = a.shift = nullptr;
     a.relu = a.accumulate = 0;
+    a.dbg = g_pl_dbg;
+    a.trace = g_pl_trace;
     return SSN_OK;
 }
 
@@ -501,6 +529,14 @@ int fill_common(PlConvArgs& a, const void* x_hi, const void* x_lo, const uint32_
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int ssn_conv_pl_tiles(void) { return PL_NCFG; }
+extern "C" void ssn_conv_pl_debug_flags(int flags) { g_pl_dbg = flags; }
+extern "C" void ssn_conv_pl_debug_trace(unsigned long long* buf) { g_pl_trace = buf; }
+extern "C" int ssn_conv_pl_tile_shape(int cfg, int* bm, int* bn) {
+    if (cfg < 0 || cfg >= PL_NCFG) return SSN_ERR_ARG;
+    *bm = kPlBM[cfg];
+    *bn = kPlBN[cfg];
+    return SSN_OK;
+}
 
 // Forward convolution + frozen-BN affine + ReLU on planes tensors (replaces cuDNN conv + BN(eval) + ReLU behind
 // /root/reference/ssn_models.py:266).  x_*/y_*: plane pointers at the first channel group of the source / destination
@@ -573,4 +609,52 @@ extern "C" int ssn_conv_pl_dgrad(const void* dy_hi, const void* dy_lo, const flo
         return launch_tile<MODE_FWD>(a, cfg, stream);
     }
     return launch_tile<MODE_DGRAD>(a, cfg, stream);
+}
+
+// Data gradient of a 3x3 / stride-2 convolution (pad 1 on an even input, or pad 0) on planes slices: four stride-1 launches,
+// one per parity class of the input pixel, each a (1 + a) x (1 + b)-tap gather over dy stored at the class's pixels of dx
+// (no tap is multiplied that does not contribute).  wt_packed: ssn_conv_x6_pack_dgrad_s2 (four sections).
+extern "C" int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const float* wt_packed, void* dx_hi, void* dx_lo, int N,
+                                    int Cout, int Ho, int Wo, long dy_img_groups, int Cin, int H, int W, long dx_img_groups,
+                                    int pad, int accumulate, const void* mask_hi, long mask_img_groups, const float* mask_scale,
+                                    int tile_cfg, const float* dy_scale, const float* dx_scale, float* dx_amax,
+                                    hipStream_t stream) {
+    SSN_CHECK_ARG((pad == 1 && H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2) ||
+                      (pad == 0 && H >= 3 && W >= 3 && Ho == (H - 3) / 2 + 1 && Wo == (W - 3) / 2 + 1),
+                  "conv pl dgrad s2: needs a 3x3 / stride-2 convolution with pad 1 and even input size, or pad 0 (%dx%d -> %dx%d, pad %d)",
+                  H, W, Ho, Wo, pad);
+    long off = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ca = cls >> 1, cb = cls & 1, kh = 1 + ca, kw = 1 + cb;
+        const int sub_a = pad ? ca : 1 - ca, sub_b = pad ? cb : 1 - cb;     // parity of the class's input rows / columns
+        const int gh = pad ? Ho : (H - sub_a + 1) / 2, gw = pad ? Wo : (W - sub_b + 1) / 2;
+        PlConvArgs a;
+        // source = dy, enumerated grid = the class's pixels (u, v); the output geometry is patched to dx's dense planes below
+        int rc = fill_common(a, dy_hi, dy_lo, (const uint32_t*)wt_packed + off, dx_hi, dx_lo, N, Cout, Ho, Wo, dy_img_groups, Cin, gh,
+                             gw, dx_img_groups, kh, kw, dy_scale, dx_scale, dx_amax, 0, 0, "conv pl dgrad s2");
+        if (rc != SSN_OK) return rc;
+        const long yg = (long)H * W * 16;
+        SSN_CHECK_ARG((long)N * dx_img_groups * yg < (1l << 31), "conv pl dgrad s2: dx plane larger than 2 GiB");
+        a.y_grp_bytes = (uint32_t)yg;
+        a.y_img_bytes = (uint32_t)(dx_img_groups * yg);
+        a.y_bytes = (uint32_t)((long)(N - 1) * a.y_img_bytes + (long)(Cin / 8) * yg);
+        a.stride = 1;
+        a.pad_h = pad ? 0 : ca;
+        a.pad_w = pad ? 0 : cb;
+        a.accumulate = accumulate;
+        a.sub_a = sub_a;
+        a.sub_b = sub_b;
+        a.sub_W = W;
+        if (mask_hi && mask_scale) {
+            a.mask_hi = mask_hi;
+            a.mask_scale = mask_scale;
+            a.mask_img_bytes = (uint32_t)(mask_img_groups * yg);
+            a.mask_bytes = (uint32_t)((long)(N - 1) * a.mask_img_bytes + (long)(Cin / 8) * yg);
+        }
+        const int cfg = tile_cfg >= 0 ? tile_cfg : (g_pl_default_tile >= 0 ? g_pl_default_tile : default_tile(Cin, a.P));
+        rc = launch_tile<MODE_FWD>(a, cfg, stream);
+        if (rc != SSN_OK) return rc;
+        off += (long)a.ngroups * kh * kw * Cin * APITCH + 4;
+    }
+    return SSN_OK;
 }

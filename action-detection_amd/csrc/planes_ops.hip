@@ -90,6 +90,305 @@ __global__ __launch_bounds__(256) void pl_to_f32_kernel(const void* hi, const vo
     }
 }
 
+// ---- pooling on planes: one thread = one (image, channel group, pixel) = 8 channels, 16-byte accesses per plane ----
+struct PoolArgs {
+    const void* x_hi;     // input slice (forward: activation; backward: output gradient)
+    const void* x_lo;
+    void* y_hi;           // output slice
+    void* y_lo;
+    unsigned char* argmax;   // max pool: window-local index per output element, [N][G][Ho Wo][8] bytes (compact, slice-local)
+    const float* x_scale;
+    const float* y_scale;
+    float* y_amax;
+    const float* aff_scale;  // avgpool_affine: per channel (of the slice) scale / shift; backward: mask scale (NaN = pass through)
+    const float* aff_shift;
+    const void* mask_hi;     // backward: hi plane of the forward activation whose ReLU / frozen-BN backward is fused (or null)
+    long x_img_groups, y_img_groups, mask_img_groups;
+    int N, G;                // images, channel groups of the slice
+    int H, W;                // spatial size of the pool's INPUT tensor
+    int Ho, Wo;              // ... and of its OUTPUT tensor
+    int k, s, pad;
+    int relu, accumulate;
+};
+
+__device__ __forceinline__ void load8(const void* hi, const void* lo, long o, float (&v)[8]) {
+    pl_join8(reinterpret_cast<const u32x4*>(hi)[o], reinterpret_cast<const u32x4*>(lo)[o], v);
+}
+
+// max pool forward (ceil_mode windows computed by the host; taps outside the image are skipped; first maximum in scan
+// order wins, as torch: gradients then route identically through the exact-zero ties behind every ReLU)
+__global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
+    const long total = (long)p.N * p.G * p.Ho * p.Wo;
+    const float r = *p.y_scale / *p.x_scale;
+    float vmax = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int wo = (int)(idx % p.Wo);
+        const int ho = (int)((idx / p.Wo) % p.Ho);
+        const long ng = idx / ((long)p.Wo * p.Ho);
+        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+        const long ibase = ((long)n * p.x_img_groups + g) * p.H * p.W;
+        float best[8];
+        unsigned char arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            best[e] = -__builtin_inff();
+            arg[e] = 0;
+        }
+        for (int dr = 0; dr < p.k; ++dr) {
+            const int h = ho * p.s - p.pad + dr;
+            if ((unsigned)h >= (unsigned)p.H) continue;
+            for (int ds = 0; ds < p.k; ++ds) {
+                const int w = wo * p.s - p.pad + ds;
+                if ((unsigned)w >= (unsigned)p.W) continue;
+                float v[8];
+                load8(p.x_hi, p.x_lo, ibase + (long)h * p.W + w, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > best[e]) {
+                        best[e] = v[e];
+                        arg[e] = (unsigned char)(dr * p.k + ds);
+                    }
+            }
+        }
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            out[e] = pl_clamp(best[e] * r);
+            vmax = fmaxf(vmax, fabsf(out[e]));
+        }
+        u32x4 hi, lo;
+        pl_split8(out, hi, lo);
+        const long o = ((long)n * p.y_img_groups + g) * p.Ho * p.Wo + (long)ho * p.Wo + wo;
+        reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
+        reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
+        if (p.argmax) {
+            uint32_t a0 = arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((uint32_t)arg[3] << 24);
+            uint32_t a1 = arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((uint32_t)arg[7] << 24);
+            reinterpret_cast<u32x2*>(p.argmax)[idx] = u32x2{a0, a1};
+        }
+    }
+    amax_emit(p.y_amax, vmax / *p.y_scale);
+}
+
+// finish a gradient element group: (+ old), fused ReLU / frozen-BN backward of the producer, clamp, amax, split, store
+__device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, long o, long mo, int c0) {
+    if (p.accumulate) {
+        float old[8];
+        load8(p.y_hi, p.y_lo, o, old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += old[e];
+    }
+    if (p.mask_hi) {
+        const u32x4 mk = reinterpret_cast<const u32x4*>(p.mask_hi)[mo];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = p.aff_scale[c0 + e];
+            const float m = (e & 1) ? f16_pair_hi(mk[e >> 1]) : f16_pair_lo(mk[e >> 1]);
+            v[e] = (sc != sc) ? v[e] : (m > 0.f ? v[e] * sc : 0.f);
+        }
+    }
+    float vmax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = pl_clamp(v[e]);
+        vmax = fmaxf(vmax, fabsf(v[e]));
+    }
+    u32x4 hi, lo;
+    pl_split8(v, hi, lo);
+    reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
+    reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
+    return vmax;
+}
+
+// max pool backward in gather form: input pixel (h, w) collects the output gradients of the windows whose argmax it is
+// (x = output gradient [Ho x Wo], y = input gradient [H x W]); deterministic, no atomics
+__global__ __launch_bounds__(256) void pl_maxpool_bwd_kernel(PoolArgs p) {
+    const long total = (long)p.N * p.G * p.H * p.W;
+    const float r = *p.y_scale / *p.x_scale;
+    float vmax = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int w = (int)(idx % p.W);
+        const int h = (int)((idx / p.W) % p.H);
+        const long ng = idx / ((long)p.W * p.H);
+        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        // windows (ho, wo) with ho * s - pad <= h <= ho * s - pad + k - 1
+        int ho_lo = (h + p.pad - p.k + p.s) / p.s;   // ceil((h + pad - k + 1) / s) for non-negative numerators
+        if (h + p.pad - p.k + 1 <= 0) ho_lo = 0;
+        int wo_lo = (w + p.pad - p.k + p.s) / p.s;
+        if (w + p.pad - p.k + 1 <= 0) wo_lo = 0;
+        int ho_hi = (h + p.pad) / p.s, wo_hi = (w + p.pad) / p.s;
+        if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
+        if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const int local = (h - (ho * p.s - p.pad)) * p.k + (w - (wo * p.s - p.pad));
+                const long oo = (long)ho * p.Wo + wo;
+                const u32x2 am = reinterpret_cast<const u32x2*>(p.argmax)[((long)n * p.G + g) * p.Ho * p.Wo + oo];
+                float d[8];
+                load8(p.x_hi, p.x_lo, ((long)n * p.x_img_groups + g) * p.Ho * p.Wo + oo, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int a = (int)((am[e >> 2] >> (8 * (e & 3))) & 0xFFu);
+                    v[e] += (a == local) ? d[e] : 0.f;
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= r;
+        const long o = ((long)n * p.y_img_groups + g) * p.H * p.W + (long)h * p.W + w;
+        const long mo = ((long)n * p.mask_img_groups + g) * p.H * p.W + (long)h * p.W + w;
+        vmax = fmaxf(vmax, finish_grad8(v, p, o, mo, 8 * g));
+    }
+    amax_emit(p.y_amax, vmax / *p.y_scale);
+}
+
+// y = relu?(scale[c] * avgpool_kxk(x) + shift[c]), stride 1, zero padding counted (count_include_pad): the pool BEHIND its 1x1
+// projection (a 1x1 convolution commutes with the zero-padded average)
+__global__ __launch_bounds__(256) void pl_avgpool_affine_kernel(PoolArgs p) {
+    const long total = (long)p.N * p.G * p.H * p.W;
+    const float inv = 1.f / ((float)(p.k * p.k) * *p.x_scale), so = *p.y_scale;
+    float vmax = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int w = (int)(idx % p.W);
+        const int h = (int)((idx / p.W) % p.H);
+        const long ng = idx / ((long)p.W * p.H);
+        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+        const long ibase = ((long)n * p.x_img_groups + g) * p.H * p.W;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int dr = 0; dr < p.k; ++dr) {
+            const int hh = h - p.pad + dr;
+            if ((unsigned)hh >= (unsigned)p.H) continue;
+            for (int ds = 0; ds < p.k; ++ds) {
+                const int ww = w - p.pad + ds;
+                if ((unsigned)ww >= (unsigned)p.W) continue;
+                float v[8];
+                load8(p.x_hi, p.x_lo, ibase + (long)hh * p.W + ww, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+        }
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[e] * inv;
+            if (p.aff_scale) v = v * p.aff_scale[8 * g + e] + p.aff_shift[8 * g + e];
+            if (p.relu) v = fmaxf(v, 0.f);
+            out[e] = pl_clamp(v * so);
+            vmax = fmaxf(vmax, fabsf(out[e]));
+        }
+        u32x4 hi, lo;
+        pl_split8(out, hi, lo);
+        const long o = ((long)n * p.y_img_groups + g) * p.H * p.W + (long)h * p.W + w;
+        reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
+        reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
+    }
+    amax_emit(p.y_amax, vmax / so);
+}
+
+// in place: g <- g * (y > 0) * scale[c]  (NaN scale: channel passes through) -- the ReLU / frozen-BN backward of a slice whose
+// last writer could not fuse it
+__global__ __launch_bounds__(256) void pl_relu_bn_bwd_kernel(PoolArgs p) {
+    const long total = (long)p.N * p.G * p.H * p.W;
+    float vmax = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long q = idx % ((long)p.H * p.W);
+        const long ng = idx / ((long)p.H * p.W);
+        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+        const long o = ((long)n * p.y_img_groups + g) * p.H * p.W + q;
+        const long mo = ((long)n * p.mask_img_groups + g) * p.H * p.W + q;
+        float v[8];
+        load8(p.y_hi, p.y_lo, o, v);
+        vmax = fmaxf(vmax, finish_grad8(v, p, o, mo, 8 * g));
+    }
+    amax_emit(p.y_amax, vmax / *p.y_scale);
+}
+
+// global average pool: planes [N][G][HW][8] -> fp32 [N][C]
+__global__ __launch_bounds__(256) void pl_gap_fwd_kernel(const void* hi, const void* lo, long img_groups, float* out, int N, int G,
+                                                        int HW, const float* scale) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * G) return;
+    const int g = idx % G, n = idx / G;
+    const long base = ((long)n * img_groups + g) * HW;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int q = 0; q < HW; ++q) {
+        float v[8];
+        load8(hi, lo, base + q, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    const float inv = 1.f / ((float)HW * *scale);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[(long)n * G * 8 + 8 * g + e] = acc[e] * inv;
+}
+
+// global average pool backward: dx[n][c][q] = dy[n][c] / HW, with the fused ReLU / frozen-BN backward of the pooled tensor
+// (PoolArgs: aff_shift = dy fp32 [N][C], y = dx planes, mask as usual)
+__global__ __launch_bounds__(256) void pl_gap_bwd_kernel(PoolArgs p) {
+    const int HW = p.H * p.W;
+    const long total = (long)p.N * p.G * HW;
+    const float k = *p.y_scale / (float)HW;
+    float vmax = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long q = idx % HW;
+        const long ng = idx / HW;
+        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = p.aff_shift[(long)n * p.G * 8 + 8 * g + e] * k;
+        const long o = ((long)n * p.y_img_groups + g) * HW + q;
+        const long mo = ((long)n * p.mask_img_groups + g) * HW + q;
+        vmax = fmaxf(vmax, finish_grad8(v, p, o, mo, 8 * g));
+    }
+    amax_emit(p.y_amax, vmax / *p.y_scale);
+}
+
+// per-channel sums of a planes slice (bias gradient of a projection in front of its pool): two passes, fixed order
+constexpr int CS_SHARES = 32;
+__global__ __launch_bounds__(256) void pl_channel_sum_kernel(const void* hi, const void* lo, long img_groups, int N, int G, int HW,
+                                                            float* part) {
+    __shared__ float red[256][9];
+    const int g = blockIdx.x, share = blockIdx.y;
+    const long total = (long)N * HW;
+    const long per = (total + CS_SHARES - 1) / CS_SHARES;
+    const long begin = (long)share * per;
+    long end = begin + per;
+    if (end > total) end = total;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (long i = begin + threadIdx.x; i < end; i += 256) {
+        const long n = i / HW, q = i - n * HW;
+        float v[8];
+        load8(hi, lo, (n * img_groups + g) * HW + q, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + st][e];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) part[((long)share * G + g) * 8 + threadIdx.x] = red[0][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void pl_channel_sum_final_kernel(const float* part, float* out, int C, int G, const float* scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int sh = 0; sh < CS_SHARES; ++sh) s += part[(long)sh * G * 8 + c];
+    out[c] = s / *scale;
+}
+
 int grid_for(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -143,5 +442,159 @@ extern "C" int ssn_pl_to_f32(const void* hi, const void* lo, long img_groups, fl
     hipLaunchKernelGGL(pl_to_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream, hi, lo, img_groups, y, y_img_stride, N, C,
                        HW, scale);
     SSN_CHECK_LAUNCH("pl_to_f32");
+    return SSN_OK;
+}
+
+static int fill_pool(PoolArgs& a, const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups,
+                     int N, int C, int H, int W, int Ho, int Wo, int k, int s, int pad, const float* x_scale, const float* y_scale,
+                     float* y_amax, const char* what) {
+    SSN_CHECK_ARG(y_hi && y_lo && y_scale && N > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "%s: bad arguments", what);
+    a.x_hi = x_hi;
+    a.x_lo = x_lo;
+    a.y_hi = y_hi;
+    a.y_lo = y_lo;
+    a.argmax = nullptr;
+    a.x_scale = x_scale;
+    a.y_scale = y_scale;
+    a.y_amax = y_amax;
+    a.aff_scale = a.aff_shift = nullptr;
+    a.mask_hi = nullptr;
+    a.x_img_groups = x_img_groups;
+    a.y_img_groups = y_img_groups;
+    a.mask_img_groups = 0;
+    a.N = N;
+    a.G = C / 8;
+    a.H = H;
+    a.W = W;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.k = k;
+    a.s = s;
+    a.pad = pad;
+    a.relu = 0;
+    a.accumulate = 0;
+    return SSN_OK;
+}
+
+// Max pool forward on planes slices (C channels, a multiple of 8): x [N, C, H, W] -> y [N, C, Ho, Wo] (ceil-mode sizes from the
+// caller), argmax: uint8 [N][C/8][Ho*Wo][8] or null (inference).  Replaces nn.MaxPool2d of the backbone manifest.
+extern "C" int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo,
+                                  long y_img_groups, unsigned char* argmax, int N, int C, int H, int W, int Ho, int Wo, int k,
+                                  int s, int pad, const float* x_scale, const float* y_scale, float* y_amax, hipStream_t stream) {
+    PoolArgs a;
+    int rc = fill_pool(a, x_hi, x_lo, x_img_groups, y_hi, y_lo, y_img_groups, N, C, H, W, Ho, Wo, k, s, pad, x_scale, y_scale, y_amax,
+                       "pl maxpool fwd");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(x_hi && x_lo && x_scale && k >= 1 && k <= 15 && s >= 1, "pl maxpool fwd: bad arguments");
+    a.argmax = argmax;
+    hipLaunchKernelGGL(pl_maxpool_fwd_kernel, dim3(grid_for((long)N * a.G * Ho * Wo)), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("pl_maxpool_fwd");
+    return SSN_OK;
+}
+
+// Max pool backward: dy [N, C, Ho, Wo] + argmax -> dx [N, C, H, W] (+= with accumulate); mask_hi / mask_scale [C]: the fused
+// ReLU / frozen-BN backward of the layer that produced the pool's input (mask_hi = hi plane of that activation at dx's slice).
+extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_img_groups, const unsigned char* argmax,
+                                  void* dx_hi, void* dx_lo, long dx_img_groups, int N, int C, int H, int W, int Ho, int Wo, int k,
+                                  int s, int pad, int accumulate, const void* mask_hi, long mask_img_groups,
+                                  const float* mask_scale, const float* dy_scale, const float* dx_scale, float* dx_amax,
+                                  hipStream_t stream) {
+    PoolArgs a;
+    int rc = fill_pool(a, dy_hi, dy_lo, dy_img_groups, dx_hi, dx_lo, dx_img_groups, N, C, H, W, Ho, Wo, k, s, pad, dy_scale, dx_scale,
+                       dx_amax, "pl maxpool bwd");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(dy_hi && dy_lo && dy_scale && argmax, "pl maxpool bwd: bad arguments");
+    a.argmax = const_cast<unsigned char*>(argmax);
+    a.accumulate = accumulate;
+    if (mask_hi && mask_scale) {
+        a.mask_hi = mask_hi;
+        a.aff_scale = mask_scale;
+        a.mask_img_groups = mask_img_groups;
+    }
+    hipLaunchKernelGGL(pl_maxpool_bwd_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("pl_maxpool_bwd");
+    return SSN_OK;
+}
+
+// y = relu?(scale[c] * avgpool(x) + shift[c]) (k x k, stride 1, zero padding counted): forward of the pool behind its
+// projection (scale / shift null: plain average) -- and, with dy as x and no affine, its backward (the same stencil).
+extern "C" int ssn_pl_avgpool_affine(const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo,
+                                     long y_img_groups, const float* scale, const float* shift, int relu, int N, int C, int H,
+                                     int W, int k, int pad, const float* x_scale, const float* y_scale, float* y_amax,
+                                     hipStream_t stream) {
+    PoolArgs a;
+    int rc = fill_pool(a, x_hi, x_lo, x_img_groups, y_hi, y_lo, y_img_groups, N, C, H, W, H, W, k, 1, pad, x_scale, y_scale, y_amax,
+                       "pl avgpool affine");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(x_hi && x_lo && x_scale && 2 * pad == k - 1 && (!scale == !shift), "pl avgpool affine: bad arguments");
+    a.aff_scale = scale;
+    a.aff_shift = shift;
+    a.relu = relu;
+    hipLaunchKernelGGL(pl_avgpool_affine_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("pl_avgpool_affine");
+    return SSN_OK;
+}
+
+// in place: g <- g * (y > 0) * scale[c] on a planes slice (y_hi = hi plane of the activation at the same channels)
+extern "C" int ssn_pl_relu_bn_bwd(void* g_hi, void* g_lo, long g_img_groups, const void* y_hi, long y_img_groups,
+                                  const float* scale, int N, int C, int HW, const float* g_scale, float* g_amax,
+                                  hipStream_t stream) {
+    PoolArgs a;
+    int rc = fill_pool(a, nullptr, nullptr, 0, g_hi, g_lo, g_img_groups, N, C, HW, 1, HW, 1, 1, 1, 0, g_scale, g_scale, g_amax,
+                       "pl relu bn bwd");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(y_hi && scale, "pl relu bn bwd: bad arguments");
+    a.mask_hi = y_hi;
+    a.aff_scale = scale;
+    a.mask_img_groups = y_img_groups;
+    hipLaunchKernelGGL(pl_relu_bn_bwd_kernel, dim3(grid_for((long)N * a.G * HW)), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("pl_relu_bn_bwd");
+    return SSN_OK;
+}
+
+extern "C" int ssn_pl_gap_fwd(const void* x_hi, const void* x_lo, long x_img_groups, float* y, int N, int C, int HW,
+                              const float* x_scale, hipStream_t stream) {
+    SSN_CHECK_ARG(x_hi && x_lo && y && x_scale && C % 8 == 0, "pl gap fwd: bad arguments");
+    hipLaunchKernelGGL(pl_gap_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, stream, x_hi, x_lo, x_img_groups, y, N, C / 8,
+                       HW, x_scale);
+    SSN_CHECK_LAUNCH("pl_gap_fwd");
+    return SSN_OK;
+}
+
+// dx = dy / HW broadcast over the pixels, times (x > 0) * mask_scale[c] when the mask is given
+extern "C" int ssn_pl_gap_bwd(const float* dy, void* dx_hi, void* dx_lo, long dx_img_groups, int N, int C, int HW,
+                              const void* mask_hi, long mask_img_groups, const float* mask_scale, const float* dx_scale,
+                              float* dx_amax, hipStream_t stream) {
+    PoolArgs a;
+    int rc = fill_pool(a, nullptr, nullptr, 0, dx_hi, dx_lo, dx_img_groups, N, C, HW, 1, HW, 1, 1, 1, 0, dx_scale, dx_scale, dx_amax,
+                       "pl gap bwd");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(dy, "pl gap bwd: bad arguments");
+    a.aff_shift = dy;
+    if (mask_hi && mask_scale) {
+        a.mask_hi = mask_hi;
+        a.aff_scale = mask_scale;
+        a.mask_img_groups = mask_img_groups;
+    }
+    hipLaunchKernelGGL(pl_gap_bwd_kernel, dim3(grid_for((long)N * a.G * HW)), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("pl_gap_bwd");
+    return SSN_OK;
+}
+
+extern "C" long ssn_pl_channel_sum_workspace_bytes(int C) { return (long)CS_SHARES * ((C + 7) / 8) * 8 * (long)sizeof(float); }
+
+// out[c] = sum over images and pixels of a planes slice (fixed order: deterministic)
+extern "C" int ssn_pl_channel_sum(const void* g_hi, const void* g_lo, long g_img_groups, float* out, int N, int C, int HW,
+                                  const float* g_scale, void* workspace, long ws_bytes, hipStream_t stream) {
+    SSN_CHECK_ARG(g_hi && g_lo && out && g_scale && workspace && C % 8 == 0, "pl channel sum: bad arguments");
+    if (ws_bytes < ssn_pl_channel_sum_workspace_bytes(C)) {
+        ssn_set_error("pl channel sum: workspace too small");
+        return SSN_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(pl_channel_sum_kernel, dim3(C / 8, CS_SHARES), dim3(256), 0, stream, g_hi, g_lo, g_img_groups, N, C / 8, HW,
+                       (float*)workspace);
+    hipLaunchKernelGGL(pl_channel_sum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, out, C,
+                       C / 8, g_scale);
+    SSN_CHECK_LAUNCH("pl_channel_sum");
     return SSN_OK;
 }

@@ -180,3 +180,90 @@ def conv_dgrad(dy, wt_packed, dx, kh, kw, pad_h, pad_w, accumulate=False, tile_c
              dx.groups, kh, kw, pad_h, pad_w, int(bool(accumulate)), mask.hi if mask is not None else None,
              mask.groups if mask is not None else 0, _p(mask_scale), tile_cfg, dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr,
              int(k_split), int(k_gap), int(bool(taps_reversed)), _st(lib, dy.t))
+
+
+def wgrad_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile_cfg=-1):
+    return int(_lib.get_lib().cdll.ssn_conv_wgrad_pl_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile_cfg))
+
+
+def conv_wgrad(g, x, dw, db, kh, kw, stride, pad_h, pad_w, workspace, tile_cfg=-1, cin=None, g_row_split=0, g_row_gap=0):
+    """dw [Cout, Cin, kh, kw] (fp32), db [Cout] or None <- weight / bias gradient from the planes slices g (output gradient, final)
+    and x (the layer's input).  cin: real input channels when x's slice is zero-padded (the 12-channel stem)."""
+    lib = _lib_for(g.t)
+    h, w = x.hw
+    ho, wo = g.hw
+    cin = x.c if cin is None else cin
+    lib.call("ssn_conv_wgrad_pl", g.hi, g.lo, x.hi, x.lo, _p(dw), _p(db), x.n, cin, h, w, x.groups, g.c, ho, wo, g.groups, kh, kw,
+             stride, pad_h, pad_w, _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg, g.t.scale_ptr,
+             x.t.scale_ptr, int(g_row_split), int(g_row_gap), _st(lib, g.t))
+
+
+def conv_dgrad_s2(dy, wt_packed, dx, pad, accumulate=False, tile_cfg=-1, mask=None, mask_scale=None):
+    """dgrad of a 3x3 / stride-2 conv on planes slices (pad 1 on an even input, or pad 0).  wt_packed: kernels.pack_dgrad_s2(w)."""
+    lib = _lib_for(dy.t)
+    ho, wo = dy.hw
+    h, w = dx.hw
+    lib.call("ssn_conv_pl_dgrad_s2", dy.hi, dy.lo, _p(wt_packed), dx.hi, dx.lo, dy.n, dy.c, ho, wo, dy.groups, dx.c, h, w, dx.groups,
+             int(pad), int(bool(accumulate)), mask.hi if mask is not None else None, mask.groups if mask is not None else 0,
+             _p(mask_scale), tile_cfg, dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, _st(lib, dy.t))
+
+
+def maxpool_fwd(x, y, argmax, k, s, pad):
+    """x, y: PSlice with equal channel counts; argmax: uint8 tensor [N, C/8, Ho*Wo, 8] or None."""
+    lib = _lib_for(x.t)
+    h, w = x.hw
+    ho, wo = y.hw
+    lib.call("ssn_pl_maxpool_fwd", x.hi, x.lo, x.groups, y.hi, y.lo, y.groups, _p(argmax), x.n, x.c, h, w, ho, wo, k, s, pad,
+             x.t.scale_ptr, y.t.scale_ptr, y.t.amax_ptr, _st(lib, x.t))
+
+
+def maxpool_bwd(dy, argmax, dx, k, s, pad, accumulate=False, mask=None, mask_scale=None):
+    lib = _lib_for(dy.t)
+    h, w = dx.hw
+    ho, wo = dy.hw
+    lib.call("ssn_pl_maxpool_bwd", dy.hi, dy.lo, dy.groups, _p(argmax), dx.hi, dx.lo, dx.groups, dx.n, dx.c, h, w, ho, wo, k, s,
+             pad, int(bool(accumulate)), mask.hi if mask is not None else None, mask.groups if mask is not None else 0,
+             _p(mask_scale), dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, _st(lib, dy.t))
+
+
+def avgpool_affine(x, y, scale, shift, relu, k, pad):
+    """y = relu?(scale * avgpool_kxk(x) + shift), stride 1, count_include_pad (scale / shift None: the plain average -- also the
+    backward of that pool when x is the output gradient)."""
+    lib = _lib_for(x.t)
+    h, w = x.hw
+    lib.call("ssn_pl_avgpool_affine", x.hi, x.lo, x.groups, y.hi, y.lo, y.groups, _p(scale), _p(shift), int(bool(relu)), x.n, x.c,
+             h, w, k, pad, x.t.scale_ptr, y.t.scale_ptr, y.t.amax_ptr, _st(lib, x.t))
+
+
+def relu_bn_bwd(g, y, scale):
+    """in place on the planes slice g: g <- g * (y > 0) * scale[c] (NaN scale: pass through)."""
+    lib = _lib_for(g.t)
+    h, w = g.hw
+    lib.call("ssn_pl_relu_bn_bwd", g.hi, g.lo, g.groups, y.hi, y.groups, _p(scale), g.n, g.c, h * w, g.t.scale_ptr, g.t.amax_ptr,
+             _st(lib, g.t))
+
+
+def gap_fwd(x, out):
+    """planes slice [N, C, H, W] -> fp32 [N, C] mean over the pixels."""
+    lib = _lib_for(x.t)
+    h, w = x.hw
+    lib.call("ssn_pl_gap_fwd", x.hi, x.lo, x.groups, _p(out), x.n, x.c, h * w, x.t.scale_ptr, _st(lib, x.t))
+
+
+def gap_bwd(dy, dx, mask=None, mask_scale=None):
+    """fp32 [N, C] -> planes slice dx = dy / HW per pixel (times the fused ReLU / frozen-BN backward when mask is given)."""
+    lib = _lib_for(dx.t)
+    h, w = dx.hw
+    lib.call("ssn_pl_gap_bwd", _p(dy), dx.hi, dx.lo, dx.groups, dx.n, dx.c, h * w, mask.hi if mask is not None else None,
+             mask.groups if mask is not None else 0, _p(mask_scale), dx.t.scale_ptr, dx.t.amax_ptr, _st(lib, dx.t))
+
+
+def channel_sum_workspace_bytes(c):
+    return int(_lib.get_lib().cdll.ssn_pl_channel_sum_workspace_bytes(int(c)))
+
+
+def channel_sum(g, out, workspace):
+    lib = _lib_for(g.t)
+    h, w = g.hw
+    lib.call("ssn_pl_channel_sum", g.hi, g.lo, g.groups, _p(out), g.n, g.c, h * w, g.t.scale_ptr, _p(workspace),
+             workspace.numel() * workspace.element_size(), _st(lib, g.t))

@@ -180,3 +180,120 @@ def test_conv_pl_dgrad(backend):
         m = torch.where(torch.isnan(msc).view(1, -1, 1, 1), torch.ones_like(act),
                         (act > 0).float() * torch.nan_to_num(msc).view(1, -1, 1, 1)).double()
         assert rel_err(P.to_f32(dx), 2 * dref * m) < 4e-6, ("dgrad mask", n, cin, h, cout, kh, kw)
+
+
+def test_conv_pl_wgrad(backend):
+    """Weight + bias gradient on planes (LDS transpose reads) vs autograd in float64: every stride / tap shape, every tile."""
+    g = torch.Generator().manual_seed(4)
+    cases = CASES_GPU if backend.is_gpu else CASES_SMALL
+    ntiles = int(action_detection_amd._lib.get_lib().cdll.ssn_conv_wgrad_pl_tiles())
+    for ci, (n, cin, h, wd, cout, kh, kw, s, ph, pw) in enumerate(cases):
+        x = torch.randn(n, cin, h, wd, generator=g)
+        w = (torch.randn(cout, cin, kh, kw, generator=g, dtype=torch.float64) * 0.1).requires_grad_()
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x.double(), w, b, s, (ph, pw))
+        gy = torch.randn(y.shape, generator=g) * 1e-3
+        y.backward(gy.double())
+        ho, wo = y.shape[2], y.shape[3]
+        # the output gradient lives in a slice of a wider tensor, the input in a slice too
+        gt = P.PlaneTensor(n, cout + 16, ho, wo, backend.device).zero_()
+        P.from_f32(backend.put(gy), P.PSlice(gt, 8, cout))
+        xt = P.PlaneTensor(n, cin + 8, h, wd, backend.device).zero_()
+        P.from_f32(backend.put(x), P.PSlice(xt, 8, cin))
+        for tile in (range(ntiles) if ci in (0, 2) else [-1]):
+            ws = backend.put(torch.empty(P.wgrad_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile) // 4))
+            dw, db = backend.put(torch.full(w.shape, 9.0)), backend.put(torch.full((cout,), 9.0))
+            P.conv_wgrad(P.PSlice(gt, 8, cout), P.PSlice(xt, 8, cin), dw, db, kh, kw, s, ph, pw, ws, tile)
+            assert rel_err(dw, w.grad) < 5e-6, ("wgrad", n, cin, h, cout, kh, kw, s, tile)
+            assert rel_err(db, b.grad) < 5e-6, ("bias", n, cin, h, cout, kh, kw, s, tile)
+
+
+def _two_pass(fn, t):
+    """run a producer twice around a scale update (the delayed-scale protocol), leave the result of the second pass"""
+    fn()
+    t.pool.update()
+    fn()
+
+
+def test_conv_pl_dgrad_stride2(backend):
+    g = torch.Generator().manual_seed(5)
+    cases = [(4, 128, 28, 160, 1), (4, 96, 35, 96, 0)] if backend.is_gpu else [(2, 16, 8, 32, 1), (1, 16, 9, 40, 0), (1, 16, 10, 32, 0)]
+    for (n, cin, h, cout, pad) in cases:
+        x = torch.randn(n, cin, h, h, generator=g, dtype=torch.float64).requires_grad_()
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+        y = F.conv2d(x, w.double(), None, 2, pad)
+        gy = torch.randn(y.shape, generator=g) * 1e-2
+        y.backward(gy.double())
+        wt = K.pack_dgrad_s2(backend.put(w))
+        gp = P.from_f32(backend.put(gy))
+        act = torch.randn(n, cin, h, h, generator=g).clamp(min=0)
+        msc = torch.rand(cin, generator=g) + 0.5
+        actp = P.from_f32(backend.put(act))
+        dx = P.PlaneTensor(n, cin, h, h, backend.device).zero_()
+        _two_pass(lambda: P.conv_dgrad_s2(P.pfull(gp), wt, P.pfull(dx), pad, mask=P.pfull(actp), mask_scale=backend.put(msc)), dx)
+        ref = x.grad * (act > 0).double() * msc.double().view(1, -1, 1, 1)
+        assert rel_err(P.to_f32(dx), ref) < 4e-6, (n, cin, h, cout, pad)
+
+
+def test_planes_pools(backend):
+    """max pool (ceil mode, argmax routing), average pool behind a projection, global pool, ReLU/BN backward, channel sums."""
+    g = torch.Generator().manual_seed(6)
+    n, c = (6, 64) if backend.is_gpu else (2, 16)
+    for (h, k, s, pad) in [(12, 3, 2, 0), (7, 3, 1, 1), (9, 3, 2, 0)]:
+        x = torch.randn(n, c, h, h, generator=g).clamp(min=0)          # post-ReLU: many exact-zero ties
+        xd = x.double().requires_grad_()
+        ref, idx = F.max_pool2d(xd, k, s, pad, ceil_mode=True, return_indices=True)
+        ho = ref.shape[2]
+        xp = P.from_f32(backend.put(x))
+        y = P.PlaneTensor(n, c, ho, ho, backend.device)
+        am = backend.put(torch.zeros((n, c // 8, ho * ho, 8), dtype=torch.uint8))
+        _two_pass(lambda: P.maxpool_fwd(P.pfull(xp), P.pfull(y), am, k, s, pad), y)
+        assert rel_err(P.to_f32(y), ref) < 2.0 ** -21
+        gy = torch.randn(ref.shape, generator=g)
+        ref.backward(gy.double())
+        gp = P.from_f32(backend.put(gy))
+        dx = P.PlaneTensor(n, c, h, h, backend.device)
+        _two_pass(lambda: P.maxpool_bwd(P.pfull(gp), am, P.pfull(dx), k, s, pad), dx)
+        assert rel_err(P.to_f32(dx), xd.grad) < 2.0 ** -20, ("maxpool bwd", h, k, s, pad)
+        # accumulate + mask
+        msc = torch.rand(c, generator=g) + 0.5
+        msc[3] = float("nan")
+        base = torch.randn(n, c, h, h, generator=g)
+        P.from_f32(backend.put(base), dx)
+        dx.pool.scale.mul_(0.25)        # leave head-room for the sum (the executor's scale comes from the last step's maximum)
+        P.from_f32(backend.put(base), dx, exact=False)
+        P.maxpool_bwd(P.pfull(gp), am, P.pfull(dx), k, s, pad, accumulate=True, mask=P.pfull(xp), mask_scale=backend.put(msc))
+        m = torch.where(torch.isnan(msc).view(1, -1, 1, 1), torch.ones_like(x), (x > 0).float() * torch.nan_to_num(msc).view(1, -1, 1, 1))
+        assert rel_err(P.to_f32(dx), (base.double() + xd.grad) * m.double()) < 2.0 ** -19
+    # average pool behind the projection + its backward stencil
+    h = 7
+    z = torch.randn(n, c, h, h, generator=g)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    ref = F.relu(F.avg_pool2d(z.double(), 3, 1, 1, count_include_pad=True) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    zp = P.from_f32(backend.put(z))
+    y = P.PlaneTensor(n, c + 8, h, h, backend.device).zero_()
+    _two_pass(lambda: P.avgpool_affine(P.pfull(zp), P.PSlice(y, 8, c), backend.put(sc), backend.put(sh), True, 3, 1), y)
+    assert rel_err(P.to_f32(P.PSlice(y, 8, c)), ref) < 1e-6
+    dz = P.PlaneTensor(n, c, h, h, backend.device)
+    _two_pass(lambda: P.avgpool_affine(P.pfull(zp), P.pfull(dz), None, None, False, 3, 1), dz)
+    assert rel_err(P.to_f32(dz), F.avg_pool2d(z.double(), 3, 1, 1, count_include_pad=True)) < 1e-6
+    # relu / bn backward in place, channel sums, global pool
+    act = torch.randn(n, c, h, h, generator=g).clamp(min=0)
+    msc = torch.randn(c, generator=g)
+    gz = P.from_f32(backend.put(z))
+    P.relu_bn_bwd(P.pfull(gz), P.pfull(P.from_f32(backend.put(act))), backend.put(msc))
+    refm = z.double() * (act > 0).double() * msc.double().view(1, -1, 1, 1)
+    assert rel_err(P.to_f32(gz), refm) < 1e-6
+    out = backend.put(torch.empty(c))
+    ws = backend.put(torch.empty(P.channel_sum_workspace_bytes(c) // 4))
+    P.channel_sum(P.pfull(gz), out, ws)
+    assert rel_err(out, refm.sum(dim=(0, 2, 3))) < 2e-6
+    feat = backend.put(torch.empty(n, c))
+    P.gap_fwd(P.pfull(zp), feat)
+    assert rel_err(feat, z.double().mean(dim=(2, 3))) < 1e-6
+    dfeat = torch.randn(n, c, generator=g)
+    dxp = P.PlaneTensor(n, c, h, h, backend.device)
+    actp = P.from_f32(backend.put(act))
+    _two_pass(lambda: P.gap_bwd(backend.put(dfeat), P.pfull(dxp), mask=P.pfull(actp), mask_scale=backend.put(msc)), dxp)
+    refg = (dfeat.double() / (h * h)).view(n, c, 1, 1) * (act > 0).double() * msc.double().view(1, -1, 1, 1)
+    assert rel_err(P.to_f32(dxp), refg) < 1e-6
