@@ -42,6 +42,18 @@ def _load_tuned():
 _TUNED, _TUNED_N, _TUNED_MS = _load_tuned()
 
 
+def _load_tuned_pl():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles_pl.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+_TUNED_PL = _load_tuned_pl()
+
+
 def tuned_tile(kind, n, cin, cout, k, s, hin):
     """Tile config for a conv launch: the autotuned entry when the batch is comparable, else -1 (heuristic)."""
     if not _TUNED or n * 2 < _TUNED_N:
@@ -155,6 +167,12 @@ class BNInception(nn.Module):
         self.stem_s2d = os.environ.get("SSN_STEM_S2D", "1") != "0"
         # average-pool branches: pool BEHIND the 1x1 projection (see _move_avg_pools); False = the manifest's order
         self.pool_after_projection = os.environ.get("SSN_POOL_ORDER", "") != "manifest"
+        # "planes": activations and their gradients live as two f16 planes in the channel-blocked layout of the matrix cores,
+        # produced by the kernels that compute them (planes_exec.py; frozen BatchNorm only) -- "f32": fp32 NCHW tensors, every
+        # consumer converts its operands (the round-1/2 executor below, and the path of training-mode BatchNorm)
+        self.layout = os.environ.get("SSN_LAYOUT", "f32")
+        self._planes_states = {}
+        self.pl_tiles = {}            # (kind, cin, cout, kh, kw, s, hin) -> tile config of the planes kernels (autotuner)
 
     def _timed(self, family, lid, flops, fn):
         """Run one conv launch; with a profiler attached, bracket it with events on the current stream."""
@@ -396,9 +414,27 @@ class BNInception(nn.Module):
             i += 1
         return out
 
+    def _pl_tile(self, kind, op, n, shapes):
+        """Tile config of a planes-kernel launch: the autotuned table (tools/autotune_pl.py -> tuned_tiles_pl.json), else -1."""
+        kh, kw = op.get("kh", op["k"]), op.get("kw", op["k"])
+        key = "%s|%d|%d|%d|%d|%d|%d" % (kind, op["cin"], op["cout"], kh, kw, op["s"], shapes[op["src"]][1])
+        tab = _TUNED_PL.get("tiles", {})
+        if not tab or n * 2 < _TUNED_PL.get("n_images", 0):
+            return -1
+        return tab.get(key, -1)
+
+    def _use_planes(self, plan):
+        if self.layout != "planes" or self.conv_precision != "split":
+            return False
+        from . import planes_exec
+        return planes_exec.supported(self, plan)
+
     # ------------------------------------------------------------------ forward executor
     def _run_forward(self, x, keep):
         plan, shapes = self._plan(x)
+        if self._use_planes(plan):
+            from . import planes_exec
+            return planes_exec.run_forward(self, x, keep)
         n, dev = x.shape[0], x.device
         acts = {"data": x}
         argmax, tscale, wcat = {}, {}, {}
@@ -641,6 +677,9 @@ class BNInception(nn.Module):
         return self._ws
 
     def _run_backward(self, dfeat, saved, hook=True):
+        if len(saved) == 7:      # a forward of the planes executor
+            from . import planes_exec
+            return planes_exec.run_backward(self, dfeat, saved, hook)
         plan, shapes, acts, argmax, tscale, bnstat = saved
         bn_grads = {}    # training-mode BatchNorm layers: layer id -> (dgamma, dbeta)
         n, dev = dfeat.shape[0], dfeat.device

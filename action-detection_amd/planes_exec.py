@@ -1,0 +1,426 @@
+"""Backbone executor on planes tensors (csrc/planes.h): the launch plan of ``bninception.BNInception`` (same manifest, same
+plan transforms, same parameter surface and flat gradient layout) run on the kernels that keep every activation and every
+activation gradient as two f16 planes in the channel-blocked NC8HW8 layout -- the operand format of the matrix cores.
+
+What differs from the fp32-layout executor (bninception._run_forward / _run_backward):
+
+* producers split, consumers multiply: the convolution / pool epilogues emit the planes, so no kernel of the step converts
+  operands in its inner loop (the round-2 kernels spent 7-13 VALU per MFMA there);
+* scales are delayed (``planes.SlotPool``): a tensor's power-of-two scale for this step comes from the largest magnitude its
+  producers recorded in the previous step; the first step of an executor state is CALIBRATED by running the pass until no scale
+  moves any more (2-3 passes), and an overflow flag (a tensor outgrew its head-room; values were clamped) is raised for the host;
+* one stream: the launches of a step already fill the GPU (round 2 measured 1.5 % from four-stream overlap), so the planes path
+  keeps the whole step on the caller's stream -- one amax / scale slot per tensor suffices and results stay deterministic;
+* the ReLU / frozen-BN backward of a layer is fused into whichever launch writes its output gradient last and reads only the
+  SIGN of the activation's high plane (2 bytes per element instead of the 4 of an fp32 ``y``).
+
+Supported: frozen BatchNorm (the reference's default ``bn_mode='frozen'``; /root/reference/ssn_models.py:95-105) on the square /
+rectangular-tap plans.  Training-mode BatchNorm keeps the fp32-layout executor.
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from . import planes as P
+from .planes import PSlice, PlaneTensor
+
+
+class PlanesState:
+    """Scale / amax slots of one backbone (persistent across steps) and the calibration status."""
+
+    MAX_TENSORS = 512
+
+    def __init__(self, device):
+        self.pool = P.SlotPool(2 * self.MAX_TENSORS, device)
+        self.act_slot = {}      # activation tensor name -> slot
+        self.grad_slot = {}     # gradient tensor name -> slot
+        self.fwd_calibrated = False
+        self.bwd_calibrated = False
+        self.calibration_passes = [0, 0]
+
+    def slot(self, name, grad):
+        table = self.grad_slot if grad else self.act_slot
+        if name not in table:
+            # activations take the even slots, gradients the odd ones: both sets stay contiguous ranges for the update kernel
+            table[name] = 2 * len(table) + (1 if grad else 0)
+            assert table[name] < self.pool.amax.numel()
+            self.pool.used = max(self.pool.used, table[name] + 1)
+        return table[name]
+
+    def update(self):
+        """One launch over all slots (slots nobody wrote keep their scale)."""
+        self.pool.update(first=0, count=self.pool.used)
+
+    def overflowed(self):
+        return bool(self.pool.flag[0].item())
+
+
+def _state(net, x):
+    key = (x.device, x.shape[1], x.shape[2])
+    st = net._planes_states.get(key)
+    if st is None:
+        st = net._planes_states[key] = PlanesState(x.device)
+    return st
+
+
+def supported(net, plan):
+    if net._train_bn_ids():
+        return False
+    for op in plan:
+        if op["kind"] == "pool" and op["pool"] != "max":
+            return False
+        if op["kind"] == "bn_train":
+            return False
+        if op["kind"] == "conv" and (op["cout"] % 8 or (op["src"] != "data" and op["cin"] % 8)):
+            return False
+    return True
+
+
+def _conv_taps(op):
+    return op.get("kh", op["k"]), op.get("kw", op["k"]), op.get("ph", op["p"]), op.get("pw", op["p"])
+
+
+def _is_rect(op):
+    kh, kw, _, _ = _conv_taps(op)
+    return kh != kw or kh not in (1, 3, 7)
+
+
+def _fold_bn(net, plan, shapes, dev):
+    """tscale: per tensor folded-BN scale of every channel (NaN: not a conv+ReLU output); shift_of: per layer shift vectors."""
+    tscale, shift_of = {}, {}
+
+    def scale_slice(name, c0, c):
+        if name not in tscale:
+            tscale[name] = torch.full((shapes[name][0],), float("nan"), device=dev, dtype=torch.float32)
+        return tscale[name][c0:c0 + c]
+
+    shift_flat = torch.empty(sum(op["cout"] for op in plan if op["kind"] == "conv"), device=dev, dtype=torch.float32)
+    fold = ([], [], [], [], [], [], [], [])
+    soff = 0
+    for op in plan:
+        if op["kind"] != "conv":
+            continue
+        shift_of[op["lids"][0]] = shift_flat[soff:soff + op["cout"]]
+        for lid_, o_ in zip(op["lids"], [sum(op["couts"][:q]) for q in range(len(op["lids"]))]):
+            shift_of.setdefault(lid_, shift_flat[soff + o_:soff + o_ + getattr(net, lid_).out_channels])
+        off = 0
+        aff_dst, aff_c0 = op.get("final", (op["dst"], op["dst_c0"]))
+        for lid, c in zip(op["lids"], op["couts"]):
+            conv, bn = getattr(net, lid), getattr(net, lid + "_bn")
+            if "raw_from" in op and off >= op["raw_from"]:
+                sdst = scale_slice(op["proj_final"][0], op["proj_final"][1], c)
+            else:
+                sdst = scale_slice(aff_dst, aff_c0 + off + (op["row_gap"] if off >= op.get("row_split", 1 << 30) else 0), c)
+            for lst, v in zip(fold, (conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                     bn.eps, sdst, shift_flat[soff + off:soff + off + c])):
+                lst.append(v)
+            off += c
+        soff += op["cout"]
+    K.bn_fold_multi(*fold)
+    return tscale, shift_of, scale_slice
+
+
+def _pool_out(h, k, s, p):
+    """ceil-mode output size of the manifest's pools (torch rule: the last window must start inside the padded input)."""
+    o = -(-(h + 2 * p - k) // s) + 1
+    if (o - 1) * s >= h + p:
+        o -= 1
+    return o
+
+
+def run_forward(net, x, keep):
+    plan, shapes = net._plan(x)
+    n, dev = x.shape[0], x.device
+    st = _state(net, x)
+    tscale, shift_of, scale_slice = _fold_bn(net, plan, shapes, dev)
+
+    conv_ops = [op for op in plan if op["kind"] == "conv"]
+    for op in conv_ops:
+        op["rect"] = _is_rect(op)
+        op["s2d"] = (op["src"] == "data" and len(op["lids"]) == 1 and (op["k"], op["s"], op["p"]) == (7, 2, 3)
+                     and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and not op.get("raw"))
+        if op["src"] == "data" and not op["s2d"] and not op["rect"] and op["k"] not in (1, 3):
+            raise NotImplementedError("planes layout: first convolution %dx%d / stride %d" % (op["k"], op["k"], op["s"]))
+    packed = {}
+    for op in conv_ops:
+        if op["s2d"]:
+            packed[op["lids"][0]] = K.pack_weights_rect(K.s2d_weights(getattr(net, op["lids"][0]).weight.detach()))
+    rect_ops = [op for op in conv_ops if op["rect"] and not op["s2d"]]
+    packed.update(zip((op["lids"][0] for op in rect_ops),
+                      K.pack_rect_multi([getattr(net, op["lids"][0]).weight.detach() for op in rect_ops])))
+    sq_ops = [op for op in conv_ops if not op["rect"] and not op["s2d"]]
+    packed.update(zip((op["lids"][0] for op in sq_ops), K.pack_weights_multi(
+        [([getattr(net, lid).weight.detach() for lid in op["lids"]], 0) for op in sq_ops], x6=True)))
+
+    def launch_all(acts, argmax):
+        def get(name):
+            if name not in acts:
+                c, h, w = shapes[name]
+                acts[name] = PlaneTensor(n, c, h, w, dev, st.pool, st.slot(name, False))
+            return acts[name]
+
+        feat = None
+        for op in plan:
+            if op["kind"] == "conv":
+                cout, cin = op["cout"], op["cin"]
+                raw = bool(op.get("raw"))
+                shift = None if raw else shift_of[op["lids"][0]]
+                scale = None if raw else scale_slice(op["dst"], op["dst_c0"], cout + op.get("row_gap", 0))
+                kh, kw, ph, pw = _conv_taps(op)
+                dst = PSlice(get(op["dst"]), op["dst_c0"], cout)
+                wp = packed[op["lids"][0]]
+                if op["s2d"]:
+                    if "data_s2d" not in acts:
+                        acts["data_s2d"] = PlaneTensor(n, 4 * cin, x.shape[2] // 2, x.shape[3] // 2, dev, st.pool,
+                                                       st.slot("data_s2d", False))
+                        P.from_f32(x, acts["data_s2d"], s2d=True, exact=True)
+                    src = P.pfull(acts["data_s2d"])
+                    P.conv_fwd(PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, True,
+                               net._pl_tile("fwd", op, n, shapes))
+                else:
+                    if op["src"] == "data":
+                        if "data" not in acts:
+                            acts["data"] = PlaneTensor(n, cin, x.shape[2], x.shape[3], dev, st.pool, st.slot("data", False))
+                            P.from_f32(x, acts["data"], exact=True)
+                        src = PSlice(acts["data"], 0, acts["data"].g * 8)
+                    else:
+                        src = PSlice(acts[op["src"]], op["src_c0"], cin)
+                    P.conv_fwd(src, wp, scale, shift, dst, kh, kw, op["s"], ph, pw, not raw, net._pl_tile("fwd", op, n, shapes),
+                               raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0))
+            elif op["kind"] == "pool":
+                c = op["c"]
+                out = PSlice(get(op["dst"]), op["dst_c0"], c)
+                _, ho, wo = shapes[op["dst"]]
+                am = None
+                if keep:
+                    am = argmax.get(op["lid"])
+                    if am is None:
+                        am = argmax[op["lid"]] = torch.empty((n, c // 8, ho * wo, 8), device=dev, dtype=torch.uint8)
+                P.maxpool_fwd(PSlice(acts[op["src"]], 0, c), out, am, op["k"], op["s"], op["p"])
+            elif op["kind"] == "pool_aff":
+                c = op["c"]
+                P.avgpool_affine(PSlice(acts[op["src"]], op.get("src_c0", 0), c), PSlice(get(op["dst"]), op["dst_c0"], c),
+                                 scale_slice(op["dst"], op["dst_c0"], c), shift_of[op["conv"]], True, op["k"], op["p"])
+            else:
+                feat = torch.empty((n, op["c"]), device=dev, dtype=torch.float32)
+                P.gap_fwd(PSlice(acts[op["src"]], 0, op["c"]), feat)
+        return feat
+
+    # delayed scales: this pass stores with the scales derived from the previous pass's maxima
+    acts, argmax = {}, {}
+    if not st.fwd_calibrated:
+        # first pass of this state: no history.  Activations start at 1/4 (head-room up to 2.6e5), then the pass is repeated
+        # until no scale moves (each pass fixes every tensor whose inputs were already right)
+        st.pool.scale[0::2] = 0.25
+        feat = launch_all(acts, argmax)
+        for it in range(12):
+            st.pool.flag.zero_()
+            st.update()
+            moved, over = st.pool.flag[1].item(), st.pool.flag[0].item()
+            st.calibration_passes[0] = it + 1
+            if not moved and not over:
+                break
+            feat = launch_all(acts, argmax)
+        else:
+            raise RuntimeError("planes executor: forward scales did not settle")
+        st.pool.flag.zero_()
+        st.fwd_calibrated = True
+    else:
+        st.update()
+        feat = launch_all(acts, argmax)
+    saved = (plan, shapes, acts, argmax, tscale, packed, st) if keep else None
+    return feat, saved
+
+
+def run_backward(net, dfeat, saved, hook=True):
+    plan, shapes, acts, argmax, tscale, packed_fwd, st = saved
+    n, dev = dfeat.shape[0], dfeat.device
+    layout, total = net.flat_grad_layout(plan)
+    lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
+    flat = torch.empty(total, device=dev, dtype=torch.float32)
+
+    # workspace: split-K slabs of the largest weight gradient, channel-sum scratch
+    ws_bytes = 0
+    for op in plan:
+        if op["kind"] != "conv":
+            continue
+        kh, kw, _, _ = _conv_taps(op)
+        _, ho, wo = shapes[op["dst"]]
+        if op.get("s2d"):
+            ws_bytes = max(ws_bytes, P.wgrad_workspace_bytes(n, 4 * op["cin"], op["cout"], ho, wo, 4, 4, net._pl_tile("wgrad", op, n, shapes)))
+        else:
+            ws_bytes = max(ws_bytes, P.wgrad_workspace_bytes(n, op["cin"], op["cout"], ho, wo, kh, kw, net._pl_tile("wgrad", op, n, shapes)))
+    ws = net._workspace(ws_bytes, dev)
+    cs_ws = torch.empty(P.channel_sum_workspace_bytes(max(op["cout"] for op in plan if op["kind"] == "conv")) // 4, device=dev,
+                        dtype=torch.float32)
+
+    dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
+    dg_s2 = {op["lids"][0]: (len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3 and op["s"] == 2) for op in dg_ops}
+    packed_dg = {}
+    for op in dg_ops:
+        if dg_s2[op["lids"][0]]:
+            packed_dg[op["lids"][0]] = K.pack_dgrad_s2(getattr(net, op["lids"][0]).weight.detach())
+        elif op["s"] != 1:
+            raise NotImplementedError("planes layout: data gradient of a %dx%d / stride-%d convolution" % (op["k"], op["k"], op["s"]))
+    rect_ops = [op for op in dg_ops if op["rect"]]
+    packed_dg.update(zip((op["lids"][0] for op in rect_ops),
+                         K.pack_rect_multi([getattr(net, op["lids"][0]).weight.detach() for op in rect_ops], dgrad=True)))
+    sq_ops = [op for op in dg_ops if not op["rect"] and not dg_s2[op["lids"][0]]]
+    packed_dg.update(zip((op["lids"][0] for op in sq_ops), K.pack_weights_multi(
+        [([getattr(net, lid).weight.detach() for lid in op["lids"]], 1) for op in sq_ops], x6=True)))
+
+    def src_key(op):
+        return (op["src"], op.get("src_c0", 0))
+    last_writer = {}
+    for idx in range(len(plan) - 1, -1, -1):
+        last_writer[src_key(plan[idx])] = idx
+    first_conv = net._conv_ids[0]
+
+    def launch_all(grads, fire_hook):
+        masked, inited = {}, set()
+        pending_end = total
+
+        def gbuf(name):
+            if name not in grads:
+                c, h, w = shapes[name]
+                grads[name] = PlaneTensor(n, c, h, w, dev, st.pool, st.slot(name, True))
+            return grads[name]
+
+        def mask_args(idx, op, width):
+            key = src_key(op)
+            if last_writer.get(key) == idx and key[0] in tscale and key[0] != "data":
+                masked.setdefault(key[0], []).append((key[1], key[1] + width))
+                return PSlice(acts[key[0]], key[1], width), tscale[key[0]][key[1]:key[1] + width]
+            return None, None
+
+        def is_masked(name, c0, c):
+            covered = sum(max(0, min(hi, c0 + c) - max(lo, c0)) for lo, hi in masked.get(name, []))
+            assert covered in (0, c), "partially finalised gradient slice %s[%d:%d]" % (name, c0, c0 + c)
+            return covered == c
+
+        for idx in range(len(plan) - 1, -1, -1):
+            op = plan[idx]
+            if op["kind"] == "gap":
+                c = op["c"]
+                key = (op["src"], 0)
+                assert key not in inited
+                fuse = op["src"] in tscale
+                P.gap_bwd(dfeat, PSlice(gbuf(op["src"]), 0, c), mask=PSlice(acts[op["src"]], 0, c) if fuse else None,
+                          mask_scale=tscale[op["src"]][0:c] if fuse else None)
+                if fuse:
+                    masked.setdefault(op["src"], []).append((0, c))
+                inited.add(key)
+            elif op["kind"] == "pool":
+                c = op["c"]
+                key = (op["src"], 0)
+                my, ms = mask_args(idx, op, c)
+                P.maxpool_bwd(PSlice(grads[op["dst"]], op["dst_c0"], c), argmax[op["lid"]], PSlice(gbuf(op["src"]), 0, c), op["k"],
+                              op["s"], op["p"], accumulate=key in inited, mask=my, mask_scale=ms)
+                inited.add(key)
+            elif op["kind"] == "pool_aff":
+                c = op["c"]
+                g = PSlice(grads[op["dst"]], op["dst_c0"], c)
+                if not is_masked(op["dst"], op["dst_c0"], c):
+                    P.relu_bn_bwd(g, PSlice(acts[op["dst"]], op["dst_c0"], c), tscale[op["dst"]][op["dst_c0"]:op["dst_c0"] + c])
+                    masked.setdefault(op["dst"], []).append((op["dst_c0"], op["dst_c0"] + c))
+                P.avgpool_affine(g, PSlice(gbuf(op["src"]), op.get("src_c0", 0), c), None, None, False, op["k"], op["p"])
+                inited.add((op["src"], op.get("src_c0", 0)))
+            else:
+                cout, cin, s = op["cout"], op["cin"], op["s"]
+                lids = op["lids"]
+                raw = bool(op.get("raw"))
+                c_aff, gap, split = op.get("raw_from", cout), op.get("row_gap", 0), op.get("row_split", cout)
+                ranges = [(0, min(split, c_aff))] + ([(split + gap, c_aff - split)] if c_aff > split else [])
+                if "row_gap" in op:
+                    offs = [sum(op["couts"][:q]) for q in range(len(lids))]
+                    ranges = [(o_ + (gap if o_ >= split else 0), c_) for o_, c_ in zip(offs, op["couts"]) if o_ < c_aff]
+                for r0, rc in ([] if raw else ranges):
+                    if not is_masked(op["dst"], op["dst_c0"] + r0, rc):
+                        P.relu_bn_bwd(PSlice(grads[op["dst"]], op["dst_c0"] + r0, rc), PSlice(acts[op["dst"]], op["dst_c0"] + r0, rc),
+                                      tscale[op["dst"]][op["dst_c0"] + r0:op["dst_c0"] + r0 + rc])
+                wo, wn, bo, bn = lay[lids[0]]
+                for extra in lids[1:]:
+                    wo2, wn2, bo2, bn2 = lay[extra]
+                    assert wo2 == wo + wn and bo2 == bo + bn
+                    wn, bn = wn + wn2, bn + bn2
+                kh, kw, ph, pw = _conv_taps(op)
+                dw = flat[wo:wo + wn].view(cout, cin, kh, kw)
+                db = flat[bo:bo + bn]
+                gs = PSlice(grads[op["dst"]], op["dst_c0"], cout)      # the launch's rows (a gap is described separately)
+                wcfg = net._pl_tile("wgrad", op, n, shapes)
+                if op.get("s2d"):
+                    xs = acts["data_s2d"]
+                    dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
+                    P.conv_wgrad(gs, PSlice(xs, 0, xs.g * 8), dw2, db, 4, 4, 1, 2, 2, ws, wcfg, cin=4 * cin)
+                    K.s2d_weights_bwd(dw2, dw)
+                else:
+                    xin = PSlice(acts[op["src"]], op["src_c0"], cin) if op["src"] != "data" else PSlice(acts["data"], 0, acts["data"].g * 8)
+                    P.conv_wgrad(gs, xin, dw, db, kh, kw, s, ph, pw, ws, wcfg, cin=cin, g_row_split=op.get("row_split", 0),
+                                 g_row_gap=op.get("row_gap", 0))
+                if raw or "raw_from" in op:
+                    # the (projection's) bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's backward
+                    fin = op["proj_final"] if "raw_from" in op else op["final"]
+                    cp = cout - op.get("raw_from", 0)
+                    P.channel_sum(PSlice(grads[fin[0]], fin[1], cp), db[op.get("raw_from", 0):], cs_ws)
+                if op["src"] != "data":
+                    wt = packed_dg[lids[0]]
+                    key = src_key(op)
+                    acc_flag = key in inited
+                    my, ms = mask_args(idx, op, cin)
+                    dx = PSlice(gbuf(op["src"]), op["src_c0"], cin)
+                    tcfg = net._pl_tile("dgrad", op, n, shapes)
+                    if dg_s2[lids[0]]:
+                        P.conv_dgrad_s2(gs, wt, dx, op["p"], acc_flag, tcfg, mask=my, mask_scale=ms)
+                    else:
+                        # (a fused block-input launch reads its rows behind the split k_gap channels further up dy's tensor)
+                        P.conv_dgrad(gs, wt, dx, kh, kw, ph, pw, acc_flag, tcfg, mask=my, mask_scale=ms,
+                                     k_split=op.get("row_split", 0), k_gap=op.get("row_gap", 0), taps_reversed=op["rect"])
+                    inited.add(key)
+                closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
+                                or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
+                if fire_hook and net.grad_ready_hook is not None and closes_block:
+                    net.grad_ready_hook.range_ready(flat, wo, pending_end)
+                    pending_end = wo
+        if fire_hook and net.grad_ready_hook is not None:
+            if pending_end > 0:
+                net.grad_ready_hook.range_ready(flat, 0, pending_end)
+            net.grad_ready_hook.finish()
+
+    grads = {}
+    fire = hook
+    if not st.bwd_calibrated:
+        # no history: every gradient tensor starts from the magnitude of the incoming feature gradient spread over the 7x7 pool
+        # (2^11 at that magnitude: f16 then covers 2^-25 .. 2^5 of it), then passes until no scale moves
+        amax0 = float(dfeat.abs().max().item())
+        hw = 1
+        for op in plan:
+            if op["kind"] == "gap":
+                hw = shapes[op["src"]][1] * shapes[op["src"]][2]
+        s0 = 2.0 ** math.floor(math.log2(2048.0 / max(amax0 / hw, 1e-30))) if amax0 > 0 else 1.0
+        st.pool.scale[1::2] = s0
+        for it in range(12):
+            launch_all(grads, False)
+            st.pool.flag.zero_()
+            st.update()
+            moved, over = st.pool.flag[1].item(), st.pool.flag[0].item()
+            st.calibration_passes[1] = it + 1
+            if not moved and not over:
+                break
+        else:
+            raise RuntimeError("planes executor: gradient scales did not settle")
+        st.pool.flag.zero_()
+        st.bwd_calibrated = True
+        if hook and net.grad_ready_hook is not None:      # the last pass stands; hand its gradients to the reducer
+            net.grad_ready_hook.range_ready(flat, 0, total)
+            net.grad_ready_hook.finish()
+    else:
+        # (the update at the head of this step's forward already derived the gradient scales from the last backward)
+        launch_all(grads, fire)
+    out = []
+    for lid in net._conv_ids:
+        conv = getattr(net, lid)
+        wo, wn, bo, bn = lay[lid]
+        out.append(flat[wo:wo + wn].view_as(conv.weight) if conv.weight.requires_grad else None)
+        out.append(flat[bo:bo + bn] if conv.bias.requires_grad else None)
+    return out, flat
