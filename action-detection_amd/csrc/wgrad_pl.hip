@@ -249,7 +249,268 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
             }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 layers (two thirds of the weight-gradient work): ALL NINE TAPS in one workgroup.
+//
+// The one-tap kernel above streams dY and X once per (tile, tap): nine times the L2 -> LDS traffic of the layer, which is what
+// bounds it (measured: 2.1 GB per launch on the 192 -> 192 layer of the 14 x 14 stage = the whole 0.2 ms).  Here a workgroup
+// keeps nine accumulator sets and feeds them from ONE copy of the operands: the reduction index runs over PADDED pixel slots
+//        slot = n * SP + hp * Wp + wp,   Wp = W + 1, SP = (H + 1) * Wp     (row 0 / column 0 of every image = zero border,
+//                                                                          shared with the previous row / image)
+// so that the input pixel of tap (r, s) for the output pixel at `slot` is simply slot + (r - 1) * Wp + (s - 1) -- a constant
+// displacement of the transposed LDS read, no masks: whatever falls off the image lands on a border slot, and border slots
+// hold zeros on both operands (their DMA offsets are out of range).  Price: (H + 1)(W + 1) / HW more k-steps (1.15 at 14 x 14).
+// A chunk = 64 slots of dY and the 64 + 2 (Wp + 1) slots of X around them, double-buffered; 4 k-steps x 9 taps x 3 products per
+// chunk and barrier; waves 0/1 fetch the planes of dY, waves 2/3 those of X.
+template <int TM, int TC, int XP>
+__global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(WgPlArgs p) {
+    constexpr int KK = 9, NS = 64, KSC = NS / 16;
+    constexpr int BM = 2 * TM * 32, BC = 2 * TC * 32;
+    constexpr int FA = BM / 32, FB = BC / 32;
+    constexpr int A_BYTES = FA * 2 * KSC * 1024;     // [frag][plane][64 slots][32 ch]
+    constexpr int X_BYTES = FB * 2 * XP * 1024;      // [frag][plane][XP * 16 slots][32 ch]
+    constexpr int STAGE = A_BYTES + X_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int wm = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const uint32_t tiles = (uint32_t)p.n_mtiles * (uint32_t)p.n_ctiles;
+    const uint32_t logical = xcd_remap(blockIdx.x, tiles * (uint32_t)p.splits);
+    uint32_t z, tile, mt, ct;
+    fd_divmod(logical, p.div_tiles, z, tile);
+    fd_divmod(tile, p.div_ct, mt, ct);
+    const int m0 = (int)mt * BM, c0 = (int)ct * BC;
+    const int Wp = p.W + 1, SP = (p.H + 1) * Wp;
+    const int D = Wp + 1;                              // slots of X in front of the chunk's first dY slot
+    const uint32_t T = (uint32_t)p.N * (uint32_t)SP;   // padded slots that can hold data
+
+    // ---- DMA role: operand (0 = dY, 1 = X) and plane ----
+    const int op = wave >> 1, plane = wave & 1;
+    const __amdgpu_buffer_rsrc_t rsrc = op ? pl_rsrc(plane ? p.x_lo : p.x_hi, p.x_bytes) : pl_rsrc(plane ? p.g_lo : p.g_hi, p.g_bytes);
+    const uint32_t grp_bytes = op ? p.x_grp_bytes : p.g_grp_bytes;
+    const uint32_t img_bytes = op ? p.x_img_bytes : p.g_img_bytes;
+    const int dsl = lane >> 2;
+    const uint32_t lane_grp = (uint32_t)(lane & 3) * grp_bytes;
+    constexpr int NF = FA > FB ? FA : FB;
+    uint32_t frag_so[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int ch = (op ? c0 : m0) + f * 32;
+        const int gap = (!op && ch >= p.g_row_split) ? p.g_row_gap : 0;
+        frag_so[f] = (uint32_t)((ch + gap) / 8) * grp_bytes;
+    }
+    const int ck_begin = (int)z * p.ksteps_per_split;          // (chunks per split)
+    const int total_ck = (int)((T + NS - 1) / NS);
+    int ck_end = ck_begin + p.ksteps_per_split;
+    if (ck_end > total_ck) ck_end = total_ck;
+
+    // byte offset of the pixel behind padded slot `sl` inside a plane of this wave's operand, or out of range (border / past the end)
+    auto slot_offset = [&](int sl) -> uint32_t {
+        const bool in = (uint32_t)sl < T;
+        uint32_t n, u, hp, wp;
+        fd_divmod((uint32_t)(in ? sl : 0), p.div_hw, n, u);     // div_hw = SP
+        fd_divmod(u, p.div_w, hp, wp);                          // div_w = Wp
+        const bool real = in && hp >= 1u && wp >= 1u;
+        return real ? n * img_bytes + ((hp - 1u) * (uint32_t)p.W + (wp - 1u)) * 16u + lane_grp : PL_OOB;
+    };
+    auto issue = [&](int ck, int buf) {
+        unsigned char* base = lds + buf * STAGE;
+        const bool live = ck < ck_end;
+        if (op == 0) {
+#pragma unroll
+            for (int sg = 0; sg < KSC; ++sg) {
+                const uint32_t vo = live ? slot_offset(ck * NS + sg * 16 + dsl) : PL_OOB;
+#pragma unroll
+                for (int f = 0; f < FA; ++f)
+                    WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + ((f * 2 + plane) * KSC + sg) * 1024), vo, frag_so[f]);
+            }
+        } else {
+#pragma unroll
+            for (int sg = 0; sg < XP; ++sg) {
+                const uint32_t vo = live ? slot_offset(ck * NS - D + sg * 16 + dsl) : PL_OOB;
+#pragma unroll
+                for (int f = 0; f < FB; ++f)
+                    WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + A_BYTES + ((f * 2 + plane) * XP + sg) * 1024), vo, frag_so[f]);
+            }
+        }
+    };
+
+    f32x16 acc[KK][TM][TC];
+    f32x16 accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+    }
+    const bool do_bias = wave_uniform((ct == 0 && wc == 0) ? 1 : 0) != 0;
+
+    // transposed reads (see the one-tap kernel): byte offset of this lane inside a [16 slots][32 ch] k-step block
+    const int l16 = lane & 15, sg16 = (lane >> 4) & 1;
+    const int lane_rd = (8 * lh + (l16 >> 2)) * 64 + sg16 * 32 + (l16 & 3) * 8;
+    int tapoff[KK];      // byte displacement of tap t inside the X rows: (D + (r - 1) Wp + (s - 1)) * 64
+#pragma unroll
+    for (int t = 0; t < KK; ++t) tapoff[t] = (D + (t / 3 - 1) * Wp + (t % 3 - 1)) * 64;
+    const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u});
+
+    auto rd_frag = [&](const unsigned char* src) -> f16x8 {
+        const u32x2 r0 = SSN_DS_READ_TR16_B64(src);
+        const u32x2 r1 = SSN_DS_READ_TR16_B64(src + 256);
+        return __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
+    };
+
+    issue(ck_begin, 0);
+    int buf = 0;
+    for (int ck = ck_begin; ck < ck_end; ++ck) {
+        SSN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();          // chunk ck is complete in `buf`; everybody is done reading the other buffer
+        issue(ck + 1, buf ^ 1);
+        const unsigned char* ab = lds + buf * STAGE + lane_rd;
+        const unsigned char* xb = ab + A_BYTES;
+        f16x8 af[2][TM], bf[2][2][TC];         // bf[set][plane][j]
+#pragma unroll
+        for (int pn = 0; pn < 2; ++pn)
+#pragma unroll
+            for (int j = 0; j < TC; ++j) bf[0][pn][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn) * XP * 1024 + tapoff[0]);
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+#pragma unroll
+            for (int pn = 0; pn < 2; ++pn)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[pn][i] = rd_frag(ab + (((wm * TM + i) * 2 + pn) * KSC + ks) * 1024);
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const int cur = (ks * KK + t) & 1;
+                // fragments of the next (k-step, tap) into the other register set while this tap multiplies
+                const int nt = (t + 1 == KK) ? 0 : t + 1, nks = (t + 1 == KK) ? ks + 1 : ks;
+                if (nks < KSC) {
+#pragma unroll
+                    for (int pn = 0; pn < 2; ++pn)
+#pragma unroll
+                        for (int j = 0; j < TC; ++j)
+                            bf[cur ^ 1][pn][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn) * XP * 1024 + nks * 1024 + tapoff[nt]);
+                }
+                constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_hi + g_hi x_lo
+                constexpr int PB[3] = {0, 0, 1};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TC; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA[c]][i], bf[cur][PB[c]][j], acc[t][i][j], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], ones, accb[i], 0, 0, 0);
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], ones, accb[i], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    SSN_WAIT_VMCNT(0);
+
+    const float inv = 1.f / (*p.g_scale * *p.x_scale);
+    float* out = p.part + (long)z * p.M * p.ldp;
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+        const int ci = c0 + (wc * TC + j) * 32 + li;
+        if (ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) {
+#pragma unroll
+                    for (int t = 0; t < KK; ++t) out[(long)m * p.ldp + ci * KK + t] = acc[t][i][j][r] * inv;
+                }
+            }
+    }
+    if (do_bias && li == 0) {
+        const float ginv = 1.f / *p.g_scale;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) out[(long)m * p.ldp + p.K] = accb[i][r] * ginv;
+            }
+    }
+}
+
 #undef WG_DMA_B128
+
+template <int TM, int TC, int XP>
+int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {
+    constexpr int BM = 2 * TM * 32, BC = 2 * TC * 32;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.n_ctiles = (a.Cin + BC - 1) / BC;
+    const unsigned tiles = (unsigned)a.n_mtiles * (unsigned)a.n_ctiles;
+    a.div_tiles = make_fastdiv(tiles);
+    a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
+    hipLaunchKernelGGL((wgrad_pl9_kernel<TM, TC, XP>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("wgrad_pl9");
+    return SSN_OK;
+}
+
+// nine-tap tile configs (output channels x input channels): 0: 64 x 64   1: 128 x 64   2: 64 x 128
+constexpr int N9 = 3;
+const int k9BM[N9] = {64, 128, 64};
+const int k9BC[N9] = {64, 64, 128};
+const int k9Occ[N9] = {1, 1, 1};
+
+template <int XP>
+int launch_wgpl9_xp(WgPlArgs& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_wgpl9<1, 1, XP>(a, stream);
+        case 1: return launch_wgpl9<2, 1, XP>(a, stream);
+        case 2: return launch_wgpl9<1, 2, XP>(a, stream);
+    }
+    ssn_set_error("conv_wgrad_pl (nine taps): unknown tile config %d", cfg);
+    return SSN_ERR_ARG;
+}
+// X pieces (16 slots each) per chunk: 64 + 2 (W + 2) slots
+int xp_for(int W) { return (64 + 2 * (W + 2) + 15) / 16; }
+int launch_wgpl9_tile(WgPlArgs& a, int cfg, hipStream_t stream) {
+    const int xp = xp_for(a.W);
+    if (xp <= 6) return launch_wgpl9_xp<6>(a, cfg, stream);
+    if (xp <= 8) return launch_wgpl9_xp<8>(a, cfg, stream);
+    return launch_wgpl9<1, 1, 12>(a, stream);   // wide rows: only the 64 x 64 tile fits two buffers into the LDS
+}
+int pick_tile9(int M, int Cin, int W) {
+    if (xp_for(W) > 8) return 0;
+    double best = 1e300;
+    int bc = 0;
+    for (int c = 0; c < N9; ++c) {
+        const double padded = (double)((M + k9BM[c] - 1) / k9BM[c]) * k9BM[c] * (double)((Cin + k9BC[c] - 1) / k9BC[c]) * k9BC[c];
+        const double small = c == 0 ? 1.1 : 1.0;
+        if (padded * small < best) {
+            best = padded * small;
+            bc = c;
+        }
+    }
+    return bc;
+}
+void plan9(int M, int Cin, long slots, int cfg, int* splits, int* chunks_per_split) {
+    const long tiles = (long)((M + k9BM[cfg] - 1) / k9BM[cfg]) * ((Cin + k9BC[cfg] - 1) / k9BC[cfg]);
+    const long chunks = (slots + 63) / 64;
+    plan_split_k(tiles, chunks, k9Occ[cfg], 4, 2, 0.005 + (double)M * Cin * 9 * 1.7e-6, splits, chunks_per_split);
+}
+bool nine_tap_layer(int kh, int kw, int stride, int pad_h, int pad_w, int H, int W, int Ho, int Wo) {
+    return kh == 3 && kw == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == H && Wo == W && W + 2 <= 58;
+}
 
 template <int WM, int WC, int TM, int TC>
 int launch_wgpl(WgPlArgs& a, hipStream_t stream) {
@@ -327,6 +588,19 @@ extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, 
 extern "C" int ssn_conv_wgrad_pl_tiles(void) { return NCFG; }
 
 extern "C" long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int tile_cfg) {
+    if (tile_cfg >= 100 || (tile_cfg < 0 && kh == 3 && kw == 3)) {
+        // (nine-tap kernel; a 3x3 layer that turns out not to qualify at launch needs at most the one-tap kernel's slabs below)
+        const int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, Wo);
+        int splits9, cps9;
+        plan9(Cout, Cin, (long)N * (Ho + 1) * (Wo + 1), c9 < N9 ? c9 : 0, &splits9, &cps9);
+        const long need9 = (long)splits9 * Cout * ((long)Cin * 9 + 1) * (long)sizeof(float);
+        if (tile_cfg >= 100) return need9;
+        const int cfg1 = fix_cfg(-1, Cout, Cin);
+        int s1, k1;
+        plan(Cout, Cin, 9, (long)N * Ho * Wo, cfg1, &s1, &k1);
+        const long need1 = (long)s1 * Cout * ((long)Cin * 9 + 1) * (long)sizeof(float);
+        return need9 > need1 ? need9 : need1;
+    }
     const int cfg = fix_cfg(tile_cfg, Cout, Cin);
     int splits, kps;
     plan(Cout, Cin, kh * kw, (long)N * Ho * Wo, cfg, &splits, &kps);
@@ -383,6 +657,24 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
     a.x_bytes = (uint32_t)xb;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
+    // tile_cfg >= 100: the nine-tap kernel with tile tile_cfg - 100; < 0: it for every layer that qualifies
+    if ((tile_cfg >= 100 || tile_cfg < 0) && nine_tap_layer(kh, kw, stride, pad_h, pad_w, H, W, Ho, Wo)) {
+        int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, W);
+        SSN_CHECK_ARG(c9 < N9, "conv wgrad pl: unknown nine-tap tile %d", c9);
+        if (xp_for(W) > 8) c9 = 0;
+        plan9(Cout, Cin, (long)N * (H + 1) * (W + 1), c9, &a.splits, &a.ksteps_per_split);
+        const long need9 = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
+        if (ws_bytes < need9) {
+            ssn_set_error("conv wgrad pl: workspace %ld < %ld bytes", ws_bytes, need9);
+            return SSN_ERR_WORKSPACE;
+        }
+        a.div_hw = make_fastdiv((uint32_t)((H + 1) * (W + 1)));
+        a.div_w = make_fastdiv((uint32_t)(W + 1));
+        const int rc9 = launch_wgpl9_tile(a, c9, stream);
+        if (rc9 != SSN_OK) return rc9;
+        return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
+    }
+    SSN_CHECK_ARG(tile_cfg < 100, "conv wgrad pl: the nine-tap kernel takes 3x3 / stride 1 / pad 1 layers only");
     const int cfg = fix_cfg(tile_cfg, Cout, Cin);
     plan(Cout, Cin, kh * kw, a.P, cfg, &a.splits, &a.ksteps_per_split);
     const long need = (long)a.splits * Cout * a.ldp * (long)sizeof(float);

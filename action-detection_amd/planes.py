@@ -43,7 +43,7 @@ class SlotPool:
 class PlaneTensor:
     """[N, C, H, W] activation as hi / lo f16 planes (C padded to a multiple of 8)."""
 
-    def __init__(self, n, c, h, w, device, pool=None, slot=None):
+    def __init__(self, n, c, h, w, device, pool=None, slot=None, scale_store=None):
         self.n, self.c, self.h, self.w = int(n), int(c), int(h), int(w)
         self.g = (self.c + 7) // 8
         self.data = torch.empty((2, self.n, self.g, self.h * self.w, 8), device=device, dtype=torch.float16)
@@ -51,6 +51,9 @@ class PlaneTensor:
             pool = SlotPool(1, device)
         self.pool = pool
         self.slot = pool.take() if slot is None else slot
+        # where this tensor's scale is read from: the pool's live array, or a snapshot of it taken when the pass that wrote
+        # the tensor started (the pool's entry moves on with the next pass; data already stored must keep its scale)
+        self.scale_store = pool.scale if scale_store is None else scale_store
 
     @property
     def device(self):
@@ -58,7 +61,7 @@ class PlaneTensor:
 
     @property
     def scale(self):
-        return self.pool.scale[self.slot:self.slot + 1]
+        return self.scale_store[self.slot:self.slot + 1]
 
     @property
     def amax(self):
@@ -66,7 +69,7 @@ class PlaneTensor:
 
     @property
     def scale_ptr(self):
-        return self.pool.scale.data_ptr() + 4 * self.slot
+        return self.scale_store.data_ptr() + 4 * self.slot
 
     @property
     def amax_ptr(self):
@@ -140,6 +143,8 @@ def from_f32(x, dst=None, pool=None, s2d=False, exact=True):
         t.amax.zero_()
         K.tensor_amax(x, t.amax)
         t.pool.update(exact=True, first=t.slot, count=1)
+        if t.scale_store is not t.pool.scale:
+            t.scale_store[t.slot:t.slot + 1].copy_(t.pool.scale[t.slot:t.slot + 1])
     lib.call("ssn_pl_from_f32", _p(x), c * h * w, sl.hi, sl.lo, n, c, h, w, t.g, int(bool(s2d)), t.scale_ptr,
              None if exact else t.amax_ptr, _st(lib, t))
     return dst

@@ -154,10 +154,14 @@ def run_forward(net, x, keep):
         [([getattr(net, lid).weight.detach() for lid in op["lids"]], 0) for op in sq_ops], x6=True)))
 
     def launch_all(acts, argmax):
+        # the scales this pass stores with, frozen: the pool's entries move on with the next pass (another sub-batch, an
+        # evaluation forward), while this pass's tensors may still be read by its backward
+        snap = st.pool.scale.clone()
+
         def get(name):
             if name not in acts:
                 c, h, w = shapes[name]
-                acts[name] = PlaneTensor(n, c, h, w, dev, st.pool, st.slot(name, False))
+                acts[name] = PlaneTensor(n, c, h, w, dev, st.pool, st.slot(name, False), snap)
             return acts[name]
 
         feat = None
@@ -170,24 +174,26 @@ def run_forward(net, x, keep):
                 kh, kw, ph, pw = _conv_taps(op)
                 dst = PSlice(get(op["dst"]), op["dst_c0"], cout)
                 wp = packed[op["lids"][0]]
+                flops = 2.0 * n * shapes[op["dst"]][1] * shapes[op["dst"]][2] * cout * cin * kh * kw
                 if op["s2d"]:
                     if "data_s2d" not in acts:
                         acts["data_s2d"] = PlaneTensor(n, 4 * cin, x.shape[2] // 2, x.shape[3] // 2, dev, st.pool,
-                                                       st.slot("data_s2d", False))
+                                                       st.slot("data_s2d", False), snap)
                         P.from_f32(x, acts["data_s2d"], s2d=True, exact=True)
                     src = P.pfull(acts["data_s2d"])
-                    P.conv_fwd(PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, True,
-                               net._pl_tile("fwd", op, n, shapes))
+                    net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
+                        PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, True, net._pl_tile("fwd", op, n, shapes)))
                 else:
                     if op["src"] == "data":
                         if "data" not in acts:
-                            acts["data"] = PlaneTensor(n, cin, x.shape[2], x.shape[3], dev, st.pool, st.slot("data", False))
+                            acts["data"] = PlaneTensor(n, cin, x.shape[2], x.shape[3], dev, st.pool, st.slot("data", False), snap)
                             P.from_f32(x, acts["data"], exact=True)
                         src = PSlice(acts["data"], 0, acts["data"].g * 8)
                     else:
                         src = PSlice(acts[op["src"]], op["src_c0"], cin)
-                    P.conv_fwd(src, wp, scale, shift, dst, kh, kw, op["s"], ph, pw, not raw, net._pl_tile("fwd", op, n, shapes),
-                               raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0))
+                    net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
+                        src, wp, scale, shift, dst, kh, kw, op["s"], ph, pw, not raw, net._pl_tile("fwd", op, n, shapes),
+                        raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0)))
             elif op["kind"] == "pool":
                 c = op["c"]
                 out = PSlice(get(op["dst"]), op["dst_c0"], c)
@@ -221,6 +227,7 @@ def run_forward(net, x, keep):
             st.calibration_passes[0] = it + 1
             if not moved and not over:
                 break
+            acts = {}
             feat = launch_all(acts, argmax)
         else:
             raise RuntimeError("planes executor: forward scales did not settle")
@@ -349,15 +356,21 @@ def run_backward(net, dfeat, saved, hook=True):
                 db = flat[bo:bo + bn]
                 gs = PSlice(grads[op["dst"]], op["dst_c0"], cout)      # the launch's rows (a gap is described separately)
                 wcfg = net._pl_tile("wgrad", op, n, shapes)
+                flops = 2.0 * n * shapes[op["dst"]][1] * shapes[op["dst"]][2] * cout * cin * kh * kw
                 if op.get("s2d"):
                     xs = acts["data_s2d"]
                     dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
-                    P.conv_wgrad(gs, PSlice(xs, 0, xs.g * 8), dw2, db, 4, 4, 1, 2, 2, ws, wcfg, cin=4 * cin)
-                    K.s2d_weights_bwd(dw2, dw)
+
+                    def run_wgrad():
+                        P.conv_wgrad(gs, PSlice(xs, 0, xs.g * 8), dw2, db, 4, 4, 1, 2, 2, ws, wcfg, cin=4 * cin)
+                        K.s2d_weights_bwd(dw2, dw)
                 else:
                     xin = PSlice(acts[op["src"]], op["src_c0"], cin) if op["src"] != "data" else PSlice(acts["data"], 0, acts["data"].g * 8)
-                    P.conv_wgrad(gs, xin, dw, db, kh, kw, s, ph, pw, ws, wcfg, cin=cin, g_row_split=op.get("row_split", 0),
-                                 g_row_gap=op.get("row_gap", 0))
+
+                    def run_wgrad():
+                        P.conv_wgrad(gs, xin, dw, db, kh, kw, s, ph, pw, ws, wcfg, cin=cin, g_row_split=op.get("row_split", 0),
+                                     g_row_gap=op.get("row_gap", 0))
+                net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad)
                 if raw or "raw_from" in op:
                     # the (projection's) bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's backward
                     fin = op["proj_final"] if "raw_from" in op else op["final"]
@@ -371,11 +384,13 @@ def run_backward(net, dfeat, saved, hook=True):
                     dx = PSlice(gbuf(op["src"]), op["src_c0"], cin)
                     tcfg = net._pl_tile("dgrad", op, n, shapes)
                     if dg_s2[lids[0]]:
-                        P.conv_dgrad_s2(gs, wt, dx, op["p"], acc_flag, tcfg, mask=my, mask_scale=ms)
+                        net._timed("conv_dgrad_pl", lids[0], flops,
+                                   lambda: P.conv_dgrad_s2(gs, wt, dx, op["p"], acc_flag, tcfg, mask=my, mask_scale=ms))
                     else:
                         # (a fused block-input launch reads its rows behind the split k_gap channels further up dy's tensor)
-                        P.conv_dgrad(gs, wt, dx, kh, kw, ph, pw, acc_flag, tcfg, mask=my, mask_scale=ms,
-                                     k_split=op.get("row_split", 0), k_gap=op.get("row_gap", 0), taps_reversed=op["rect"])
+                        net._timed("conv_dgrad_pl", lids[0], flops, lambda: P.conv_dgrad(
+                            gs, wt, dx, kh, kw, ph, pw, acc_flag, tcfg, mask=my, mask_scale=ms, k_split=op.get("row_split", 0),
+                            k_gap=op.get("row_gap", 0), taps_reversed=op["rect"]))
                     inited.add(key)
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))

@@ -309,9 +309,13 @@ def main():
                    "collectives": (args.collectives if use_dist else "none"),
                    "ranks": (dist.get_world_size() if use_dist else 1),
                    "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if use_dist else None),
-                   "conv_precision": ("fp32 in/out; 1x1/3x3 multiplies = 3 f16-MFMA products of per-tensor scaled 2-way f16 "
-                                      "operand splits (22 of 24 significand bits per operand, fp32 accumulation: "
-                                      "fp32-class error, tests/test_kernels.py K-sweep), 7x7 stem on the exact-f32 MFMA"
+                   "layout": model.base_model.layout,
+                   "conv_precision": ("fp32 parameters / features / gradients; every convolution multiply = 3 f16-MFMA products of "
+                                      "per-tensor power-of-two-scaled 2-way f16 operand splits (22 of 24 significand bits per "
+                                      "operand, fp32 accumulation: fp32-class error, tests/test_kernels.py K-sweep), the 7x7 "
+                                      "stem through its space-to-depth form on the same kernels"
+                                      + ("; activations and their gradients are STORED as the two f16 planes (delayed scales)"
+                                         if model.base_model.layout == "planes" else "")
                                       if args.precision == "split" else "exact-f32 MFMA everywhere")},
         "final_loss": float(loss.item()),
     }
@@ -335,7 +339,15 @@ def main():
             # dominant kernel: conv_x6_kernel (forward + dgrad launches of the 1x1/3x3 layers).  Every fp32
             # multiply is 3 f16 MFMA products, so its matrix-pipe ceiling in ALGORITHMIC flops is f16 dense / 3.
             x6_fl, x6_ms, x6_n = agg(("conv_fwd_x6", "conv_dgrad_x6"))
-            if x6_n:
+            pl_fl, pl_ms, pl_n = agg(("conv_fwd_pl", "conv_dgrad_pl"))
+            if pl_n:     # planes layout: the operands arrive split (csrc/conv_pl.hip); same arithmetic, same ceiling
+                x6_n = pl_n
+                dom_name = ("conv_pl_kernel (implicit GEMM on planes tensors: activations / gradients stored as 2 f16 terms by "
+                            "their producers, 3 v_mfma_f32_32x32x16_f16 per k16 step, no operand conversion in the K loop; "
+                            "fwd + dgrad launches)")
+                dom_fl, dom_ms, dom_n, dom_peak = pl_fl, pl_ms, pl_n, X6_PEAK_TFLOPS
+                pmc_keys = ("conv_pl_kernel_fwd", "conv_pl_kernel_dgrad")
+            elif x6_n:
                 dom_name = ("conv_x6_kernel (implicit GEMM, fp32 operands scaled per tensor and split into 2 f16 terms, 3 "
                             "v_mfma_f32_32x32x16_f16 per k16 step; fwd + dgrad launches)")
                 dom_fl, dom_ms, dom_n, dom_peak = x6_fl, x6_ms, x6_n, X6_PEAK_TFLOPS
@@ -373,12 +385,12 @@ def main():
             det = {}
             for k, f in sorted(fam.items()):
                 tf = f[0] / (f[1] * 1e-3) / 1e12
-                own = X6_PEAK_TFLOPS if k.endswith("_x6") else F32_MFMA_PEAK_TFLOPS
+                own = X6_PEAK_TFLOPS if k.endswith(("_x6", "_pl")) else F32_MFMA_PEAK_TFLOPS
                 det[k] = {"tflops": round(tf, 3), "frac_of_own_mfma_peak": round(tf / own, 4),
                           "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
                           "ms_per_step": round(f[1] / args.steps, 3), "launches_per_step": f[2] // args.steps}
             for grp in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
-                fl, ms, n = agg((grp + "_x6", grp + "_f32"))
+                fl, ms, n = agg((grp + "_x6", grp + "_f32", grp + "_pl"))
                 if n:
                     det[grp + "_all"] = {"tflops": round(fl / (ms * 1e-3) / 1e12, 3),
                                          "frac_of_f32_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),

@@ -200,7 +200,10 @@ def test_conv_pl_wgrad(backend):
         P.from_f32(backend.put(gy), P.PSlice(gt, 8, cout))
         xt = P.PlaneTensor(n, cin + 8, h, wd, backend.device).zero_()
         P.from_f32(backend.put(x), P.PSlice(xt, 8, cin))
-        for tile in (range(ntiles) if ci in (0, 2) else [-1]):
+        tiles = list(range(ntiles)) if ci in (0, 2) else [-1]
+        if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1):
+            tiles += [100, 101, 102]          # the nine-tap kernel's tiles
+        for tile in tiles:
             ws = backend.put(torch.empty(P.wgrad_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile) // 4))
             dw, db = backend.put(torch.full(w.shape, 9.0)), backend.put(torch.full((cout,), 9.0))
             P.conv_wgrad(P.PSlice(gt, 8, cout), P.PSlice(xt, 8, cin), dw, db, kh, kw, s, ph, pw, ws, tile)
