@@ -102,7 +102,7 @@ _SIGS = {
     "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiip",
     "ssn_conv_pl_dgrad_s2": "pppppiiiiliiiliiplpipppp",
     "ssn_pl_maxpool_fwd": "pplpplpiiiiiiiiipppp",
-    "ssn_pl_maxpool_bwd": "pplpppliiiiiiiiiiplppppp",
+    "ssn_pl_maxpool_bwd": "pplpppl" + "i" * 10 + "plppppplp",
     "ssn_pl_avgpool_affine": "pplpplppiiiiiiipppp",
     "ssn_pl_relu_bn_bwd": "pplplpiiippp",
     "ssn_pl_gap_fwd": "pplpiiipp",

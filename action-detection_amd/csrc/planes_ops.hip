@@ -109,6 +109,8 @@ struct PoolArgs {
     int Ho, Wo;              // ... and of its OUTPUT tensor
     int k, s, pad;
     int relu, accumulate;
+    float* y_f32;            // backward kernels: store fp32 NCHW here instead of planes (a gradient only a fp32-layout kernel reads)
+    long y_f32_img_stride;
 };
 
 __device__ __forceinline__ void load8(const void* hi, const void* lo, long o, float (&v)[8]) {
@@ -188,6 +190,17 @@ __device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, 
         }
     }
     float vmax = 0.f;
+    if (p.y_f32) {      // fp32 NCHW output (y_scale is 1): o = (n * y_img_groups + g) * HW + q with y_img_groups = G
+        const long hw = (long)p.H * p.W;
+        const long q = o % hw, ng = o / hw;
+        const long n = ng / p.y_img_groups;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            vmax = fmaxf(vmax, fabsf(v[e]));
+            p.y_f32[n * p.y_f32_img_stride + (long)(c0 + e) * hw + q] = v[e];
+        }
+        return vmax;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         v[e] = pl_clamp(v[e]);
@@ -448,7 +461,7 @@ extern "C" int ssn_pl_to_f32(const void* hi, const void* lo, long img_groups, fl
 static int fill_pool(PoolArgs& a, const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups,
                      int N, int C, int H, int W, int Ho, int Wo, int k, int s, int pad, const float* x_scale, const float* y_scale,
                      float* y_amax, const char* what) {
-    SSN_CHECK_ARG(y_hi && y_lo && y_scale && N > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "%s: bad arguments", what);
+    SSN_CHECK_ARG(y_scale && N > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "%s: bad arguments", what);
     a.x_hi = x_hi;
     a.x_lo = x_lo;
     a.y_hi = y_hi;
@@ -473,6 +486,8 @@ static int fill_pool(PoolArgs& a, const void* x_hi, const void* x_lo, long x_img
     a.pad = pad;
     a.relu = 0;
     a.accumulate = 0;
+    a.y_f32 = nullptr;
+    a.y_f32_img_stride = 0;
     return SSN_OK;
 }
 
@@ -494,16 +509,24 @@ extern "C" int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img
 
 // Max pool backward: dy [N, C, Ho, Wo] + argmax -> dx [N, C, H, W] (+= with accumulate); mask_hi / mask_scale [C]: the fused
 // ReLU / frozen-BN backward of the layer that produced the pool's input (mask_hi = hi plane of that activation at dx's slice).
+// dx_f32 != null: dx is written as fp32 NCHW there instead (dx_scale -> 1.0): the gradient of the stem's output, which only the
+// fp32-layout weight-gradient kernel of the 3-channel first layer reads.
 extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_img_groups, const unsigned char* argmax,
                                   void* dx_hi, void* dx_lo, long dx_img_groups, int N, int C, int H, int W, int Ho, int Wo, int k,
                                   int s, int pad, int accumulate, const void* mask_hi, long mask_img_groups,
                                   const float* mask_scale, const float* dy_scale, const float* dx_scale, float* dx_amax,
-                                  hipStream_t stream) {
+                                  float* dx_f32, long dx_f32_img_stride, hipStream_t stream) {
     PoolArgs a;
     int rc = fill_pool(a, dy_hi, dy_lo, dy_img_groups, dx_hi, dx_lo, dx_img_groups, N, C, H, W, Ho, Wo, k, s, pad, dy_scale, dx_scale,
                        dx_amax, "pl maxpool bwd");
     if (rc != SSN_OK) return rc;
-    SSN_CHECK_ARG(dy_hi && dy_lo && dy_scale && argmax, "pl maxpool bwd: bad arguments");
+    SSN_CHECK_ARG(dy_hi && dy_lo && dy_scale && argmax && ((dx_hi && dx_lo) || dx_f32), "pl maxpool bwd: bad arguments");
+    if (dx_f32) {       // fp32 NCHW output: dx_scale must point at 1.0, no accumulation (nothing to read back in this layout)
+        SSN_CHECK_ARG(!accumulate, "pl maxpool bwd: fp32 output cannot accumulate");
+        a.y_f32 = dx_f32;
+        a.y_f32_img_stride = dx_f32_img_stride;
+        a.y_img_groups = C / 8;
+    }
     a.argmax = const_cast<unsigned char*>(argmax);
     a.accumulate = accumulate;
     if (mask_hi && mask_scale) {

@@ -376,44 +376,48 @@ __global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(
         issue(ck + 1, buf ^ 1);
         const unsigned char* ab = lds + buf * STAGE + lane_rd;
         const unsigned char* xb = ab + A_BYTES;
-        f16x8 af[2][TM], bf[2][2][TC];         // bf[set][plane][j]
-#pragma unroll
-        for (int pn = 0; pn < 2; ++pn)
-#pragma unroll
-            for (int j = 0; j < TC; ++j) bf[0][pn][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn) * XP * 1024 + tapoff[0]);
-#pragma unroll
-        for (int ks = 0; ks < KSC; ++ks) {
+        // 36 (k-step, tap) steps per chunk, fully unrolled; the X fragments run TWO steps ahead of the MFMAs in three rotating
+        // register sets and the dY fragments one k-step ahead in two (one wave per SIMD at the larger tiles: nobody else
+        // hides the ~100+ cycles of an LDS round trip)
+        constexpr int NSTEP = KSC * KK;
+        f16x8 af[2][2][TM], bf[3][2][TC];      // af[set][plane][i], bf[set][plane][j]
+        auto read_b = [&](int step, int set) {
+            const int ks = step / KK, t = step % KK;
 #pragma unroll
             for (int pn = 0; pn < 2; ++pn)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[pn][i] = rd_frag(ab + (((wm * TM + i) * 2 + pn) * KSC + ks) * 1024);
+                for (int j = 0; j < TC; ++j)
+                    bf[set][pn][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn) * XP * 1024 + ks * 1024 + tapoff[t]);
+        };
+        auto read_a = [&](int ks, int set) {
 #pragma unroll
-            for (int t = 0; t < KK; ++t) {
-                const int cur = (ks * KK + t) & 1;
-                // fragments of the next (k-step, tap) into the other register set while this tap multiplies
-                const int nt = (t + 1 == KK) ? 0 : t + 1, nks = (t + 1 == KK) ? ks + 1 : ks;
-                if (nks < KSC) {
+            for (int pn = 0; pn < 2; ++pn)
 #pragma unroll
-                    for (int pn = 0; pn < 2; ++pn)
+                for (int i = 0; i < TM; ++i) af[set][pn][i] = rd_frag(ab + (((wm * TM + i) * 2 + pn) * KSC + ks) * 1024);
+        };
+        read_a(0, 0);
+        read_b(0, 0);
+        read_b(1, 1);
 #pragma unroll
-                        for (int j = 0; j < TC; ++j)
-                            bf[cur ^ 1][pn][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn) * XP * 1024 + nks * 1024 + tapoff[nt]);
-                }
-                constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_hi + g_hi x_lo
-                constexpr int PB[3] = {0, 0, 1};
+        for (int step = 0; step < NSTEP; ++step) {
+            const int ks = step / KK, t = step % KK;
+            if (t == 1 && ks + 1 < KSC) read_a(ks + 1, (ks + 1) & 1);
+            if (step + 2 < NSTEP) read_b(step + 2, (step + 2) % 3);
+            constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_hi + g_hi x_lo
+            constexpr int PB[3] = {0, 0, 1};
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TC; ++j)
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[PA[c]][i], bf[cur][PB[c]][j], acc[t][i][j], 0, 0, 0);
-            }
-            if (do_bias) {
+                    for (int j = 0; j < TC; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][PA[c]][i], bf[step % 3][PB[c]][j], acc[t][i][j],
+                                                                              0, 0, 0);
+            if (t == KK - 1 && do_bias) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][i], ones, accb[i], 0, 0, 0);
-                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][i], ones, accb[i], 0, 0, 0);
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][0][i], ones, accb[i], 0, 0, 0);
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][1][i], ones, accb[i], 0, 0, 0);
                 }
             }
         }
@@ -503,10 +507,12 @@ int pick_tile9(int M, int Cin, int W) {
     }
     return bc;
 }
-void plan9(int M, int Cin, long slots, int cfg, int* splits, int* chunks_per_split) {
+void plan9(int M, int Cin, long slots, int cfg, int W, int* splits, int* chunks_per_split) {
     const long tiles = (long)((M + k9BM[cfg] - 1) / k9BM[cfg]) * ((Cin + k9BC[cfg] - 1) / k9BC[cfg]);
     const long chunks = (slots + 63) / 64;
-    plan_split_k(tiles, chunks, k9Occ[cfg], 4, 2, 0.005 + (double)M * Cin * 9 * 1.7e-6, splits, chunks_per_split);
+    // the 64 x 64 tile on rows of <= 14 pixels: 80 KiB of LDS, two workgroups per CU
+    const int occ = (cfg == 0 && xp_for(W) <= 6) ? 2 : k9Occ[cfg];
+    plan_split_k(tiles, chunks, occ, 4, 2, 0.005 + (double)M * Cin * 9 * 1.7e-6, splits, chunks_per_split);
 }
 bool nine_tap_layer(int kh, int kw, int stride, int pad_h, int pad_w, int H, int W, int Ho, int Wo) {
     return kh == 3 && kw == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == H && Wo == W && W + 2 <= 58;
@@ -592,7 +598,7 @@ extern "C" long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int 
         // (nine-tap kernel; a 3x3 layer that turns out not to qualify at launch needs at most the one-tap kernel's slabs below)
         const int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, Wo);
         int splits9, cps9;
-        plan9(Cout, Cin, (long)N * (Ho + 1) * (Wo + 1), c9 < N9 ? c9 : 0, &splits9, &cps9);
+        plan9(Cout, Cin, (long)N * (Ho + 1) * (Wo + 1), c9 < N9 ? c9 : 0, Wo, &splits9, &cps9);
         const long need9 = (long)splits9 * Cout * ((long)Cin * 9 + 1) * (long)sizeof(float);
         if (tile_cfg >= 100) return need9;
         const int cfg1 = fix_cfg(-1, Cout, Cin);
@@ -662,7 +668,7 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
         int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, W);
         SSN_CHECK_ARG(c9 < N9, "conv wgrad pl: unknown nine-tap tile %d", c9);
         if (xp_for(W) > 8) c9 = 0;
-        plan9(Cout, Cin, (long)N * (H + 1) * (W + 1), c9, &a.splits, &a.ksteps_per_split);
+        plan9(Cout, Cin, (long)N * (H + 1) * (W + 1), c9, W, &a.splits, &a.ksteps_per_split);
         const long need9 = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
         if (ws_bytes < need9) {
             ssn_set_error("conv wgrad pl: workspace %ld < %ld bytes", ws_bytes, need9);

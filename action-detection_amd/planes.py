@@ -223,12 +223,32 @@ def maxpool_fwd(x, y, argmax, k, s, pad):
 
 
 def maxpool_bwd(dy, argmax, dx, k, s, pad, accumulate=False, mask=None, mask_scale=None):
+    """dx: PSlice, or an fp32 NCHW tensor [N, C, H, W] with an amax slot attached (kernels.attach_amax): the gradient is then
+    written in the fp32 layout (for a consumer on the fp32-layout kernels)."""
     lib = _lib_for(dy.t)
-    h, w = dx.hw
     ho, wo = dy.hw
-    lib.call("ssn_pl_maxpool_bwd", dy.hi, dy.lo, dy.groups, _p(argmax), dx.hi, dx.lo, dx.groups, dx.n, dx.c, h, w, ho, wo, k, s,
-             pad, int(bool(accumulate)), mask.hi if mask is not None else None, mask.groups if mask is not None else 0,
-             _p(mask_scale), dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, _st(lib, dy.t))
+    if isinstance(dx, PSlice):
+        h, w = dx.hw
+        lib.call("ssn_pl_maxpool_bwd", dy.hi, dy.lo, dy.groups, _p(argmax), dx.hi, dx.lo, dx.groups, dx.n, dx.c, h, w, ho, wo, k,
+                 s, pad, int(bool(accumulate)), mask.hi if mask is not None else None, mask.groups if mask is not None else 0,
+                 _p(mask_scale), dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, None, 0, _st(lib, dy.t))
+        return
+    n, c, h, w = dx.shape
+    assert not accumulate and dx.is_contiguous() and dx.dtype == torch.float32
+    one = _ones(dx.device)
+    lib.call("ssn_pl_maxpool_bwd", dy.hi, dy.lo, dy.groups, _p(argmax), None, None, 0, n, c, h, w, ho, wo, k, s, pad, 0,
+             mask.hi if mask is not None else None, mask.groups if mask is not None else 0, _p(mask_scale), dy.t.scale_ptr,
+             _p(one), _p(getattr(dx, "_ssn_amax", None)), _p(dx), c * h * w, _st(lib, dy.t))
+
+
+_ONES = {}
+
+
+def _ones(device):
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones(1, device=device, dtype=torch.float32)
+    return t
 
 
 def avgpool_affine(x, y, scale, shift, relu, k, pad):

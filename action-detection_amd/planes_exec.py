@@ -180,6 +180,8 @@ def run_forward(net, x, keep):
                         acts["data_s2d"] = PlaneTensor(n, 4 * cin, x.shape[2] // 2, x.shape[3] // 2, dev, st.pool,
                                                        st.slot("data_s2d", False), snap)
                         P.from_f32(x, acts["data_s2d"], s2d=True, exact=True)
+                        if keep:     # the stem's weight gradient runs on the fp32-layout kernel (3 real channels: see run_backward)
+                            acts["data_s2d_f32"] = K.space_to_depth2(x)
                     src = P.pfull(acts["data_s2d"])
                     net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
                         PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, True, net._pl_tile("fwd", op, n, shapes)))
@@ -256,6 +258,7 @@ def run_backward(net, dfeat, saved, hook=True):
         _, ho, wo = shapes[op["dst"]]
         if op.get("s2d"):
             ws_bytes = max(ws_bytes, P.wgrad_workspace_bytes(n, 4 * op["cin"], op["cout"], ho, wo, 4, 4, net._pl_tile("wgrad", op, n, shapes)))
+            ws_bytes = max(ws_bytes, K.wgrad_x6_workspace_bytes(n, 4 * op["cin"], op["cout"], ho, wo, 4))
         else:
             ws_bytes = max(ws_bytes, P.wgrad_workspace_bytes(n, op["cin"], op["cout"], ho, wo, kh, kw, net._pl_tile("wgrad", op, n, shapes)))
     ws = net._workspace(ws_bytes, dev)
@@ -283,6 +286,13 @@ def run_backward(net, dfeat, saved, hook=True):
     for idx in range(len(plan) - 1, -1, -1):
         last_writer[src_key(plan[idx])] = idx
     first_conv = net._conv_ids[0]
+    # the stem's output tensor, when a max pool (and nothing else) reads it: its gradient is produced in the fp32 layout
+    stem_out = None
+    for op in plan:
+        if op["kind"] == "conv" and op.get("s2d") and "data_s2d_f32" in acts:
+            readers = [q for q in plan if q.get("src") == op["dst"]]
+            if len(readers) == 1 and readers[0]["kind"] == "pool" and readers[0]["pool"] == "max" and op["dst_c0"] == 0:
+                stem_out = op["dst"]
 
     def launch_all(grads, fire_hook):
         masked, inited = {}, set()
@@ -322,8 +332,17 @@ def run_backward(net, dfeat, saved, hook=True):
                 c = op["c"]
                 key = (op["src"], 0)
                 my, ms = mask_args(idx, op, c)
-                P.maxpool_bwd(PSlice(grads[op["dst"]], op["dst_c0"], c), argmax[op["lid"]], PSlice(gbuf(op["src"]), 0, c), op["k"],
-                              op["s"], op["p"], accumulate=key in inited, mask=my, mask_scale=ms)
+                if op["src"] == stem_out:
+                    # the stem's output gradient has ONE consumer, the weight gradient of a 3- (12-) channel layer, which the
+                    # planes kernels would pad to 32 input channels: it goes to the fp32-layout split kernel, in its layout
+                    assert key not in inited
+                    _, h_, w_ = shapes[op["src"]]
+                    grads["__stem_f32__"] = K.attach_amax(K.guarded_empty((n, c, h_, w_), dev))
+                    P.maxpool_bwd(PSlice(grads[op["dst"]], op["dst_c0"], c), argmax[op["lid"]], grads["__stem_f32__"], op["k"],
+                                  op["s"], op["p"], mask=my, mask_scale=ms)
+                else:
+                    P.maxpool_bwd(PSlice(grads[op["dst"]], op["dst_c0"], c), argmax[op["lid"]], PSlice(gbuf(op["src"]), 0, c),
+                                  op["k"], op["s"], op["p"], accumulate=key in inited, mask=my, mask_scale=ms)
                 inited.add(key)
             elif op["kind"] == "pool_aff":
                 c = op["c"]
@@ -354,10 +373,19 @@ def run_backward(net, dfeat, saved, hook=True):
                 kh, kw, ph, pw = _conv_taps(op)
                 dw = flat[wo:wo + wn].view(cout, cin, kh, kw)
                 db = flat[bo:bo + bn]
-                gs = PSlice(grads[op["dst"]], op["dst_c0"], cout)      # the launch's rows (a gap is described separately)
                 wcfg = net._pl_tile("wgrad", op, n, shapes)
                 flops = 2.0 * n * shapes[op["dst"]][1] * shapes[op["dst"]][2] * cout * cin * kh * kw
-                if op.get("s2d"):
+                gs = None if (op.get("s2d") and "__stem_f32__" in grads) else PSlice(grads[op["dst"]], op["dst_c0"], cout)
+                if op.get("s2d") and "__stem_f32__" in grads:
+                    dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
+                    g32, xs32 = grads["__stem_f32__"], acts["data_s2d_f32"]
+                    from .bninception import tuned_tile
+                    ocfg = tuned_tile("wgrad6s2d", n, cin, cout, op["k"], op["s"], shapes[op["src"]][1])
+
+                    def run_wgrad():
+                        K.conv_wgrad_x6(K.full(g32), K.full(xs32), dw2, db, 4, 2, ws, ocfg)
+                        K.s2d_weights_bwd(dw2, dw)
+                elif op.get("s2d"):
                     xs = acts["data_s2d"]
                     dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
 

@@ -1,0 +1,147 @@
+"""Tile tables of the planes kernels (conv_pl forward / dgrad, wgrad_pl one-tap and nine-tap) for the launch plans of the
+backbones at the bench batch: every launch shape of the plan is timed with every tile config on the MI355X and the fastest
+is written to action-detection_amd/tuned_tiles_pl.json (read by bninception.BNInception._pl_tile).
+
+    python tools/autotune_pl.py [n_images] [BNInception|InceptionV3]
+"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import action_detection_amd as pkg  # noqa: E402
+from action_detection_amd import _lib, kernels as K, planes as P  # noqa: E402
+
+OUT = os.path.join(ROOT, "action-detection_amd", "tuned_tiles_pl.json")
+
+
+def timeit(fn, reps=12, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
+    arch = sys.argv[2] if len(sys.argv) > 2 else "BNInception"
+    pkg.build()
+    dev = torch.device("cuda:0")
+    lib = _lib.get_lib()
+    nfwd = int(lib.cdll.ssn_conv_pl_tiles())
+    nwg = int(lib.cdll.ssn_conv_wgrad_pl_tiles())
+    shapes_done = {}
+    plans = []
+    if arch == "BNInception":
+        from action_detection_amd.bninception import BNInception
+        for cin in (3, 10):
+            net = BNInception(in_channels=cin)
+            plans.append(net._plan(torch.zeros(1, cin, 224, 224)))
+    else:
+        from action_detection_amd.inceptionv3 import InceptionV3
+        net = InceptionV3()
+        plans.append(net._plan(torch.zeros(1, 3, 299, 299)))
+    try:
+        with open(OUT) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        table = {}
+    tiles, ms = table.get("tiles", {}), table.get("ms", {})
+    g = torch.Generator().manual_seed(0)
+    for plan, shapes in plans:
+        for op in plan:
+            if op["kind"] != "conv":
+                continue
+            kh, kw = op.get("kh", op["k"]), op.get("kw", op["k"])
+            ph, pw = op.get("ph", op["p"]), op.get("pw", op["p"])
+            cin, cout, s = op["cin"], op["cout"], op["s"]
+            hin = shapes[op["src"]][1]
+            _, ho, wo = shapes[op["dst"]]
+            key = "%d|%d|%d|%d|%d|%d" % (cin, cout, kh, kw, s, hin)
+            if key in shapes_done:
+                continue
+            shapes_done[key] = True
+            stem = op["src"] == "data" and (kh, s) == (7, 2)
+            if stem:       # the space-to-depth form: 4x4 taps on 4C (padded to 16) channels at half the size
+                xc, xh, k_, s_, p_ = 4 * cin, hin // 2, 4, 1, 2
+            else:
+                xc, xh, k_, s_, p_ = cin, hin, kh, s, ph
+            rect = (kh != kw) or kh not in (1, 3, 7)
+            x = torch.randn(n, xc, xh, xh, generator=g).clamp(min=0).to(dev)
+            w = (torch.randn(cout, xc, k_, k_ if not rect else kw, generator=g) * 0.05).to(dev)
+            sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+            xp = P.from_f32(x)
+            xs = P.PSlice(xp, 0, xp.g * 8)
+            yp = P.PlaneTensor(n, cout, ho, wo, dev)
+            if rect or stem:
+                wp = K.pack_weights_rect(w)
+            else:
+                wp = K.pack_weights_multi([([w], 0)], x6=True)[0]
+            kw_ = k_ if not rect else kw
+            pw_ = p_ if not rect else pw
+            # ---- forward
+            res = {}
+            for t in range(nfwd):
+                fn = lambda: P.conv_fwd(xs, wp, sc, sh, P.pfull(yp), k_, kw_, s_, p_, pw_, True, t)  # noqa: E731
+                fn()
+                yp.pool.update()
+                res[t] = timeit(fn)
+            best = min(res, key=res.get)
+            tiles["fwd|" + key], ms["fwd|" + key] = best, round(res[best], 4)
+            line = "%-28s fwd tile %2d %.4f ms" % (key, best, res[best])
+            # ---- dgrad (not for the first layer)
+            gy = (torch.randn(n, cout, ho, wo, generator=g) * 1e-3).to(dev)
+            gp = P.from_f32(gy)
+            if op["src"] != "data":
+                dxp = P.PlaneTensor(n, cin, hin, hin, dev)
+                msc = torch.ones(cin, device=dev)
+                res = {}
+                if s == 2:
+                    wt = K.pack_dgrad_s2(w)
+                    mk = lambda t: (lambda: P.conv_dgrad_s2(P.pfull(gp), wt, P.pfull(dxp), ph, False, t, mask=P.pfull(xp), mask_scale=msc))  # noqa: E731
+                elif rect:
+                    wt = K.pack_dgrad_rect(w)
+                    mk = lambda t: (lambda: P.conv_dgrad(P.pfull(gp), wt, P.pfull(dxp), kh, kw, ph, pw, False, t, mask=P.pfull(xp),  # noqa: E731
+                                                         mask_scale=msc, taps_reversed=True))
+                else:
+                    wt = K.pack_weights_multi([([w], 1)], x6=True)[0]
+                    mk = lambda t: (lambda: P.conv_dgrad(P.pfull(gp), wt, P.pfull(dxp), kh, kw, ph, pw, False, t, mask=P.pfull(xp),  # noqa: E731
+                                                         mask_scale=msc))
+                for t in range(nfwd):
+                    fn = mk(t)
+                    fn()
+                    dxp.pool.update()
+                    res[t] = timeit(fn)
+                best = min(res, key=res.get)
+                tiles["dgrad|" + key], ms["dgrad|" + key] = best, round(res[best], 4)
+                line += " | dgrad tile %2d %.4f ms" % (best, res[best])
+            # ---- wgrad
+            dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
+            res = {}
+            cand = list(range(nwg)) + ([100, 101, 102] if (k_, kw_, s_, p_, pw_) == (3, 3, 1, 1, 1) and ho == xh else [])
+            for t in cand:
+                ws = torch.empty(P.wgrad_workspace_bytes(n, xc, cout, ho, wo, k_, kw_, t) // 4 + 4, device=dev)
+                res[t] = timeit(lambda: P.conv_wgrad(P.pfull(gp), xs, dw, db, k_, kw_, s_, p_, pw_, ws, t, cin=xc))
+            best = min(res, key=res.get)
+            tiles["wgrad|" + key], ms["wgrad|" + key] = best, round(res[best], 4)
+            line += " | wgrad tile %3d %.4f ms" % (best, res[best])
+            print(line, flush=True)
+    for path in (OUT, os.path.join(ROOT, "gpurun_out", "tuned_tiles_pl.json")):      # (gpurun_out/ is what travels back from the GPU box)
+        if os.path.isdir(os.path.dirname(path)):
+            with open(path, "w") as f:
+                json.dump({"n_images": n, "tiles": tiles, "ms": ms}, f, indent=0, sort_keys=True)
+    print("wrote", OUT, "fwd %.3f dgrad %.3f wgrad %.3f ms (one launch per distinct shape)" % tuple(
+        sum(v for k, v in ms.items() if k.startswith(p + "|")) for p in ("fwd", "dgrad", "wgrad")))
+
+
+if __name__ == "__main__":
+    main()
