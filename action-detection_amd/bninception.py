@@ -170,7 +170,8 @@ class BNInception(nn.Module):
         # "planes": activations and their gradients live as two f16 planes in the channel-blocked layout of the matrix cores,
         # produced by the kernels that compute them (planes_exec.py; frozen BatchNorm only) -- "f32": fp32 NCHW tensors, every
         # consumer converts its operands (the round-1/2 executor below, and the path of training-mode BatchNorm)
-        self.layout = os.environ.get("SSN_LAYOUT", "f32")
+        # Default: planes for BN-Inception (the benchmarked backbone; frozen BatchNorm), fp32 for the Inception-v3 subclass.
+        self.layout = os.environ.get("SSN_LAYOUT", "planes" if type(self).__name__ == "BNInception" else "f32")
         self._planes_states = {}
         self.pl_tiles = {}            # (kind, cin, cout, kh, kw, s, hin) -> tile config of the planes kernels (autotuner)
 

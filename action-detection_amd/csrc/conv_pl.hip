@@ -343,52 +343,87 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     const int row0 = wm * TM * 32;
     const bool rmw = p.accumulate || p.mask_hi;
     float vmax = 0.f;
+    // per accumulator tile (i, j) and 8-row group q: output channel group offset, row validity
+    auto goff_of = [&](int i, int q) {
+        const int mrow = m0 + row0 + i * 32;
+        const int gap = (mrow >= p.row_split) ? p.row_gap : 0;     // wave-uniform channel displacement
+        return (uint32_t)((mrow + gap) / 8 + q) * p.y_grp_bytes;
+    };
+    auto finish = [&](int i, int j, int q, const u32x2& ohi, const u32x2& olo, const u32x2& mk, float& cmax) {
+        const int mrow = m0 + row0 + i * 32;
+        const int sr = row0 + i * 32 + 8 * q + 4 * lh;          // this lane's first of 4 consecutive tile rows
+        const f32x4 mul = *reinterpret_cast<const f32x4*>(ch + sr);
+        const f32x4 add = *reinterpret_cast<const f32x4*>(ch + BM + sr);
+        const f32x4 flo = *reinterpret_cast<const f32x4*>(ch + 3 * BM + sr);
+        const bool rows_ok = mrow + 8 * q < p.M;
+        const uint32_t vo = (rows_ok && !PL_DBG(8)) ? yoff[j] : PL_OOB;
+        float v[4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        float cmax = 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * mul[e] + add[e];
+        if (rmw) {
+            const f32x4 msc = *reinterpret_cast<const f32x4*>(ch + 2 * BM + sr);
+            float old[4];
+            pl_join4(ohi, olo, old);
+            const float mv[4] = {f16_pair_lo(mk[0]), f16_pair_hi(mk[0]), f16_pair_lo(mk[1]), f16_pair_hi(mk[1])};
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mrow = m0 + row0 + i * 32;                       // first output row of this MFMA tile
-            const int gap = (mrow >= p.row_split) ? p.row_gap : 0;     // wave-uniform channel displacement
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int sr = row0 + i * 32 + 8 * q + 4 * lh;          // this lane's first of 4 consecutive tile rows
-                const f32x4 mul = *reinterpret_cast<const f32x4*>(ch + sr);
-                const f32x4 add = *reinterpret_cast<const f32x4*>(ch + BM + sr);
-                const f32x4 flo = *reinterpret_cast<const f32x4*>(ch + 3 * BM + sr);
-                const bool rows_ok = mrow + 8 * q < p.M;
-                const uint32_t goff = (uint32_t)((mrow + gap) / 8 + q) * p.y_grp_bytes;
-                const uint32_t vo = (rows_ok && !PL_DBG(8)) ? yoff[j] : PL_OOB;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * mul[e] + add[e];
-                if (rmw) {
-                    const u32x2 ohi = __builtin_amdgcn_raw_buffer_load_b64(orsrc[0], vo, goff, 0);
-                    const u32x2 olo = __builtin_amdgcn_raw_buffer_load_b64(orsrc[1], vo, goff, 0);
-                    const u32x2 mk = __builtin_amdgcn_raw_buffer_load_b64(
-                        mrsrc, rows_ok ? moff[j] : PL_OOB, (uint32_t)(mrow / 8 + q) * p.y_grp_bytes, 0);
-                    const f32x4 msc = *reinterpret_cast<const f32x4*>(ch + 2 * BM + sr);
-                    float old[4];
-                    pl_join4(ohi, olo, old);
-                    const float mv[4] = {f16_pair_lo(mk[0]), f16_pair_hi(mk[0]), f16_pair_lo(mk[1]), f16_pair_hi(mk[1])};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] += old[e];
-                        v[e] = (msc[e] != msc[e]) ? v[e] : (mv[e] > 0.f ? v[e] * msc[e] : 0.f);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = pl_clamp_floor(v[e], flo[e]);
-                    cmax = fmaxf(cmax, fabsf(v[e]));
-                }
-                u32x2 hi, lo;
-                pl_split4(v, hi, lo);
-                pl_store_b64(hi, yrsrc[0], vo, goff);
-                pl_store_b64(lo, yrsrc[1], vo, goff);
+            for (int e = 0; e < 4; ++e) {
+                v[e] += old[e];
+                v[e] = (msc[e] != msc[e]) ? v[e] : (mv[e] > 0.f ? v[e] * msc[e] : 0.f);
             }
         }
-        vmax = fmaxf(vmax, yoff[j] != PL_OOB ? cmax : 0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = pl_clamp_floor(v[e], flo[e]);
+            cmax = fmaxf(cmax, fabsf(v[e]));
+        }
+        u32x2 hi, lo;
+        pl_split4(v, hi, lo);
+        const uint32_t goff = goff_of(i, q);
+        pl_store_b64(hi, yrsrc[0], vo, goff);
+        pl_store_b64(lo, yrsrc[1], vo, goff);
+    };
+    if (!rmw) {
+        const u32x2 z2 = u32x2{0u, 0u};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cmax = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) finish(i, j, q, z2, z2, z2, cmax);
+            vmax = fmaxf(vmax, yoff[j] != PL_OOB ? cmax : 0.f);
+        }
+    } else {
+        // read-modify-write / masked: the operands of tile g + 1 are requested before tile g is stored (the stores alias the
+        // loads as far as the compiler knows, so without this every group would wait out a full memory round trip)
+        constexpr int NG = TM * TN;
+        u32x2 ohi[2][4], olo[2][4], mk[2][4];
+        auto fetch = [&](int g, int b) {
+            const int j = g / TM, i = g % TM;
+            const int mrow = m0 + row0 + i * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool rows_ok = mrow + 8 * q < p.M;
+                const uint32_t goff = goff_of(i, q);
+                ohi[b][q] = __builtin_amdgcn_raw_buffer_load_b64(orsrc[0], rows_ok ? yoff[j] : PL_OOB, goff, 0);
+                olo[b][q] = __builtin_amdgcn_raw_buffer_load_b64(orsrc[1], rows_ok ? yoff[j] : PL_OOB, goff, 0);
+                mk[b][q] = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, rows_ok ? moff[j] : PL_OOB,
+                                                               (uint32_t)(mrow / 8 + q) * p.y_grp_bytes, 0);
+            }
+        };
+        fetch(0, 0);
+        float cmax = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+            const int j = g / TM, i = g % TM;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) finish(i, j, q, ohi[g & 1][q], olo[g & 1][q], mk[g & 1][q], cmax);
+            if (i == TM - 1) {
+                vmax = fmaxf(vmax, yoff[j] != PL_OOB ? cmax : 0.f);
+                cmax = 0.f;
+            }
+        }
     }
     amax_emit(p.y_amax, vmax / so);
     if (p.trace && tid == 0) {

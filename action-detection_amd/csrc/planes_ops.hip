@@ -119,7 +119,9 @@ __device__ __forceinline__ void load8(const void* hi, const void* lo, long o, fl
 
 // max pool forward (ceil_mode windows computed by the host; taps outside the image are skipped; first maximum in scan
 // order wins, as torch: gradients then route identically through the exact-zero ties behind every ReLU)
+template <int KT, int ST>
 __global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
+    const int pk = KT ? KT : p.k, ps = ST ? ST : p.s;
     const long total = (long)p.N * p.G * p.Ho * p.Wo;
     const float r = *p.y_scale / *p.x_scale;
     float vmax = 0.f;
@@ -136,20 +138,46 @@ __global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
             best[e] = -__builtin_inff();
             arg[e] = 0;
         }
-        for (int dr = 0; dr < p.k; ++dr) {
-            const int h = ho * p.s - p.pad + dr;
-            if ((unsigned)h >= (unsigned)p.H) continue;
-            for (int ds = 0; ds < p.k; ++ds) {
-                const int w = wo * p.s - p.pad + ds;
-                if ((unsigned)w >= (unsigned)p.W) continue;
+        if constexpr (KT > 0) {
+            // all taps of the window in flight at once (taps outside the image re-read the window's first valid pixel and are
+            // kept out of the comparison)
+            u32x4 thi[KT * KT], tlo[KT * KT];
+            bool ok[KT * KT];
+#pragma unroll
+            for (int t = 0; t < KT * KT; ++t) {
+                const int h = ho * ps - p.pad + t / KT, w = wo * ps - p.pad + t % KT;
+                ok[t] = ((unsigned)h < (unsigned)p.H) && ((unsigned)w < (unsigned)p.W);
+                const long o = ibase + (ok[t] ? (long)h * p.W + w : 0);
+                thi[t] = reinterpret_cast<const u32x4*>(p.x_hi)[o];
+                tlo[t] = reinterpret_cast<const u32x4*>(p.x_lo)[o];
+            }
+#pragma unroll
+            for (int t = 0; t < KT * KT; ++t) {
                 float v[8];
-                load8(p.x_hi, p.x_lo, ibase + (long)h * p.W + w, v);
+                pl_join8(thi[t], tlo[t], v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (v[e] > best[e]) {
+                    if (ok[t] && v[e] > best[e]) {
                         best[e] = v[e];
-                        arg[e] = (unsigned char)(dr * p.k + ds);
+                        arg[e] = (unsigned char)t;
                     }
+            }
+        } else {
+            for (int dr = 0; dr < pk; ++dr) {
+                const int h = ho * ps - p.pad + dr;
+                if ((unsigned)h >= (unsigned)p.H) continue;
+                for (int ds = 0; ds < pk; ++ds) {
+                    const int w = wo * ps - p.pad + ds;
+                    if ((unsigned)w >= (unsigned)p.W) continue;
+                    float v[8];
+                    load8(p.x_hi, p.x_lo, ibase + (long)h * p.W + w, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (v[e] > best[e]) {
+                            best[e] = v[e];
+                            arg[e] = (unsigned char)(dr * pk + ds);
+                        }
+                }
             }
         }
         float out[8];
@@ -215,6 +243,7 @@ __device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, 
 
 // max pool backward in gather form: input pixel (h, w) collects the output gradients of the windows whose argmax it is
 // (x = output gradient [Ho x Wo], y = input gradient [H x W]); deterministic, no atomics
+template <int KT, int ST>
 __global__ __launch_bounds__(256) void pl_maxpool_bwd_kernel(PoolArgs p) {
     const long total = (long)p.N * p.G * p.H * p.W;
     const float r = *p.y_scale / *p.x_scale;
@@ -235,19 +264,48 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_kernel(PoolArgs p) {
         int ho_hi = (h + p.pad) / p.s, wo_hi = (w + p.pad) / p.s;
         if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
         if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
-        for (int ho = ho_lo; ho <= ho_hi; ++ho)
-            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                const int local = (h - (ho * p.s - p.pad)) * p.k + (w - (wo * p.s - p.pad));
-                const long oo = (long)ho * p.Wo + wo;
-                const u32x2 am = reinterpret_cast<const u32x2*>(p.argmax)[((long)n * p.G + g) * p.Ho * p.Wo + oo];
+        if constexpr (KT > 0) {
+            // at most NW x NW windows contain a pixel: fetch all of them at once (windows that do not exist are masked out)
+            constexpr int NWN = (KT + ST - 1) / ST;
+            u32x2 am[NWN * NWN];
+            u32x4 dhi[NWN * NWN], dlo[NWN * NWN];
+            int local[NWN * NWN];
+#pragma unroll
+            for (int t = 0; t < NWN * NWN; ++t) {
+                const int ho = ho_lo + t / NWN, wo = wo_lo + t % NWN;
+                const bool ok = ho <= ho_hi && wo <= wo_hi;
+                local[t] = ok ? (h - (ho * ST - p.pad)) * KT + (w - (wo * ST - p.pad)) : 255;
+                const long oo = ok ? (long)ho * p.Wo + wo : 0;
+                am[t] = reinterpret_cast<const u32x2*>(p.argmax)[((long)n * p.G + g) * p.Ho * p.Wo + oo];
+                const long o = ((long)n * p.x_img_groups + g) * p.Ho * p.Wo + oo;
+                dhi[t] = reinterpret_cast<const u32x4*>(p.x_hi)[o];
+                dlo[t] = reinterpret_cast<const u32x4*>(p.x_lo)[o];
+            }
+#pragma unroll
+            for (int t = 0; t < NWN * NWN; ++t) {
                 float d[8];
-                load8(p.x_hi, p.x_lo, ((long)n * p.x_img_groups + g) * p.Ho * p.Wo + oo, d);
+                pl_join8(dhi[t], dlo[t], d);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int a = (int)((am[e >> 2] >> (8 * (e & 3))) & 0xFFu);
-                    v[e] += (a == local) ? d[e] : 0.f;
+                    const int a = (int)((am[t][e >> 2] >> (8 * (e & 3))) & 0xFFu);
+                    v[e] += (a == local[t]) ? d[e] : 0.f;
                 }
             }
+        } else {
+            for (int ho = ho_lo; ho <= ho_hi; ++ho)
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    const int local = (h - (ho * p.s - p.pad)) * p.k + (w - (wo * p.s - p.pad));
+                    const long oo = (long)ho * p.Wo + wo;
+                    const u32x2 am = reinterpret_cast<const u32x2*>(p.argmax)[((long)n * p.G + g) * p.Ho * p.Wo + oo];
+                    float d[8];
+                    load8(p.x_hi, p.x_lo, ((long)n * p.x_img_groups + g) * p.Ho * p.Wo + oo, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int a = (int)((am[e >> 2] >> (8 * (e & 3))) & 0xFFu);
+                        v[e] += (a == local) ? d[e] : 0.f;
+                    }
+                }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= r;
         const long o = ((long)n * p.y_img_groups + g) * p.H * p.W + (long)h * p.W + w;
@@ -502,7 +560,13 @@ extern "C" int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img
     if (rc != SSN_OK) return rc;
     SSN_CHECK_ARG(x_hi && x_lo && x_scale && k >= 1 && k <= 15 && s >= 1, "pl maxpool fwd: bad arguments");
     a.argmax = argmax;
-    hipLaunchKernelGGL(pl_maxpool_fwd_kernel, dim3(grid_for((long)N * a.G * Ho * Wo)), dim3(256), 0, stream, a);
+    const dim3 grid(grid_for((long)N * a.G * Ho * Wo));
+    if (k == 3 && s == 2)
+        hipLaunchKernelGGL((pl_maxpool_fwd_kernel<3, 2>), grid, dim3(256), 0, stream, a);
+    else if (k == 3 && s == 1)
+        hipLaunchKernelGGL((pl_maxpool_fwd_kernel<3, 1>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((pl_maxpool_fwd_kernel<0, 0>), grid, dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("pl_maxpool_fwd");
     return SSN_OK;
 }
@@ -534,7 +598,13 @@ extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_
         a.aff_scale = mask_scale;
         a.mask_img_groups = mask_img_groups;
     }
-    hipLaunchKernelGGL(pl_maxpool_bwd_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
+    const dim3 grid(grid_for((long)N * a.G * H * W));
+    if (k == 3 && s == 2)
+        hipLaunchKernelGGL((pl_maxpool_bwd_kernel<3, 2>), grid, dim3(256), 0, stream, a);
+    else if (k == 3 && s == 1)
+        hipLaunchKernelGGL((pl_maxpool_bwd_kernel<3, 1>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((pl_maxpool_bwd_kernel<0, 0>), grid, dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("pl_maxpool_bwd");
     return SSN_OK;
 }
