@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define SSN_ERR_WORKSPACE (-3)
 
 const char* ssn_last_error(void);
-int ssn_abi_version(void);   /* 4 */
+int ssn_abi_version(void);   /* 5 */
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
@@ -386,6 +386,77 @@ int ssn_add_inplace(float* dst, const float* src, long n, hipStream_t stream);
  * the pixel: ssn_conv_wgrad_x6_rect(kh, kw, pad 0, 0) on (out, x).  The values are g's: out shares g's amax slot. */
 int ssn_embed_planes(const float* g, float* out, int N, int C, int Ho, int Wo, long g_img_stride, int H, int W,
                      long out_img_stride, hipStream_t stream);
+
+/* ================================================================== planes tensors (ABI 5)
+ * The MFMA-native activation format of the split-precision path (csrc/planes.h): an fp32 activation x of the backbone behind
+ * /root/reference/ssn_models.py:266,298 is kept as TWO f16 terms of x * s -- hi = f16(x s), lo = f16(x s - hi), s a power of
+ * two per tensor -- in the channel-blocked layout
+ *     plane (hi | lo)  |  image n  |  channel group g = c / 8  |  pixel q  |  channel c % 8        (f16; 16 bytes per pixel & group)
+ * produced by the kernel that computes x (conv / pool epilogues), so that no consumer converts operands in its inner loop.
+ * Pointers `*_hi` / `*_lo` address the two planes at the first channel group of a channel slice (slices start at multiples of 8
+ * channels), `*_img_groups` = channel groups (C / 8) of the whole tensor.  Scales are "delayed": `*_scale` points at the
+ * tensor's scale slot, fixed while a step runs and derived from the magnitude recorded in the previous step;
+ * `*_amax` at its amax slot, raised by every producer (ssn_pl_scales_update turns one into the other between steps and flags
+ * tensors that outgrew their head-room).  Packed weights are those of ssn_conv_x6_pack_*. */
+int ssn_pl_scales_update(float* amax, float* scale, int* flag, int n, int exact, hipStream_t stream);
+/* fp32 NCHW <-> planes (the caller's frames, test inputs, the fp32 feature boundary); s2d: the space-to-depth view of the stem. */
+int ssn_pl_from_f32(const float* x, long x_img_stride, void* hi, void* lo, int N, int C, int H, int W, long img_groups, int s2d,
+                    const float* scale, float* amax, hipStream_t stream);
+int ssn_pl_to_f32(const void* hi, const void* lo, long img_groups, float* y, long y_img_stride, int N, int C, int HW,
+                  const float* scale, hipStream_t stream);
+/* conv + frozen-BN affine + ReLU (cuDNN conv / BN(eval) / ReLU behind ssn_models.py:266) on planes slices: any kh x kw taps,
+ * stride 1 / 2; raw_from / row_split / row_gap as ssn_conv_x6_fwd (fused launch on an Inception block input). */
+int ssn_conv_pl_fwd(const void* x_hi, const void* x_lo, const float* w_packed, const float* scale, const float* shift, void* y_hi,
+                    void* y_lo, int N, int Cin, int H, int W, long x_img_groups, int Cout, int Ho, int Wo, long y_img_groups, int kh,
+                    int kw, int stride, int pad_h, int pad_w, int relu, int tile_cfg, const float* x_scale, const float* y_scale,
+                    float* y_amax, int raw_from, int row_split, int row_gap, hipStream_t stream);
+/* data gradient (loss.backward(), ssn_train.py:236) of a stride-1 layer; mask_hi / mask_scale fuse the ReLU + frozen-BN backward
+ * of the layer that produced the input (only the SIGN of its high plane is read); taps_reversed: pack mode 2 operand. */
+int ssn_conv_pl_dgrad(const void* dy_hi, const void* dy_lo, const float* wt_packed, void* dx_hi, void* dx_lo, int N, int Cout,
+                      int Ho, int Wo, long dy_img_groups, int Cin, int H, int W, long dx_img_groups, int kh, int kw, int pad_h,
+                      int pad_w, int accumulate, const void* mask_hi, long mask_img_groups, const float* mask_scale, int tile_cfg,
+                      const float* dy_scale, const float* dx_scale, float* dx_amax, int k_split, int k_gap, int taps_reversed,
+                      hipStream_t stream);
+/* ... of a 3x3 / stride-2 layer (pad 1 on an even input, or pad 0): four parity-class launches (ssn_conv_x6_pack_dgrad_s2). */
+int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const float* wt_packed, void* dx_hi, void* dx_lo, int N, int Cout,
+                         int Ho, int Wo, long dy_img_groups, int Cin, int H, int W, long dx_img_groups, int pad, int accumulate,
+                         const void* mask_hi, long mask_img_groups, const float* mask_scale, int tile_cfg, const float* dy_scale,
+                         const float* dx_scale, float* dx_amax, hipStream_t stream);
+/* weight + bias gradient (cuDNN wgrad behind ssn_train.py:236): the reduction index is the pixel, so the operands are read
+ * with the LDS transpose read; tile_cfg >= 100 / < 0: the nine-tap kernel for 3x3 / stride 1 / pad 1 layers. */
+int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void* x_hi, const void* x_lo, float* dw, float* db, int N, int Cin,
+                      int H, int W, long x_img_groups, int Cout, int Ho, int Wo, long g_img_groups, int kh, int kw, int stride,
+                      int pad_h, int pad_w, void* workspace, long ws_bytes, int tile_cfg, const float* g_scale,
+                      const float* x_scale, int g_row_split, int g_row_gap, hipStream_t stream);
+long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int tile_cfg);
+int ssn_conv_wgrad_pl_tiles(void);
+int ssn_conv_pl_tiles(void);
+int ssn_conv_pl_tile_shape(int cfg, int* bm, int* bn);
+void ssn_conv_pl_debug_flags(int flags);                    /* tooling (tools/ablate_conv_pl.py) */
+void ssn_conv_pl_debug_trace(unsigned long long* buf);
+/* nn.MaxPool2d(ceil_mode) of the backbone manifest forward / backward (uint8 window-local argmax, torch's tie rule; dx_f32:
+ * write the input gradient as fp32 NCHW instead), the 3x3 average pool behind its 1x1 projection (+ affine + ReLU; without
+ * affine: its backward stencil), the ReLU / frozen-BN backward of a slice, global average pool forward / backward, and the
+ * per-channel sums that give a projection's bias gradient. */
+int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups,
+                       unsigned char* argmax, int N, int C, int H, int W, int Ho, int Wo, int k, int s, int pad,
+                       const float* x_scale, const float* y_scale, float* y_amax, hipStream_t stream);
+int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_img_groups, const unsigned char* argmax, void* dx_hi,
+                       void* dx_lo, long dx_img_groups, int N, int C, int H, int W, int Ho, int Wo, int k, int s, int pad,
+                       int accumulate, const void* mask_hi, long mask_img_groups, const float* mask_scale, const float* dy_scale,
+                       const float* dx_scale, float* dx_amax, float* dx_f32, long dx_f32_img_stride, hipStream_t stream);
+int ssn_pl_avgpool_affine(const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups,
+                          const float* scale, const float* shift, int relu, int N, int C, int H, int W, int k, int pad,
+                          const float* x_scale, const float* y_scale, float* y_amax, hipStream_t stream);
+int ssn_pl_relu_bn_bwd(void* g_hi, void* g_lo, long g_img_groups, const void* y_hi, long y_img_groups, const float* scale, int N,
+                       int C, int HW, const float* g_scale, float* g_amax, hipStream_t stream);
+int ssn_pl_gap_fwd(const void* x_hi, const void* x_lo, long x_img_groups, float* y, int N, int C, int HW, const float* x_scale,
+                   hipStream_t stream);
+int ssn_pl_gap_bwd(const float* dy, void* dx_hi, void* dx_lo, long dx_img_groups, int N, int C, int HW, const void* mask_hi,
+                   long mask_img_groups, const float* mask_scale, const float* dx_scale, float* dx_amax, hipStream_t stream);
+long ssn_pl_channel_sum_workspace_bytes(int C);
+int ssn_pl_channel_sum(const void* g_hi, const void* g_lo, long g_img_groups, float* out, int N, int C, int HW,
+                       const float* g_scale, void* workspace, long ws_bytes, hipStream_t stream);
 
 #ifdef __cplusplus
 }
