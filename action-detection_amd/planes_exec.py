@@ -454,9 +454,11 @@ def run_backward(net, dfeat, saved, hook=True):
             raise RuntimeError("planes executor: gradient scales did not settle")
         st.pool.flag.zero_()
         st.bwd_calibrated = True
-        if hook and net.grad_ready_hook is not None:      # the last pass stands; hand its gradients to the reducer
-            net.grad_ready_hook.range_ready(flat, 0, total)
-            net.grad_ready_hook.finish()
+        if hook and net.grad_ready_hook is not None:
+            # the last pass stands numerically; with a gradient reducer attached the pass is run once more so that it sees the
+            # block-by-block ready ranges it overlaps its all-reduces with (first step of a state only)
+            grads = {}
+            launch_all(grads, True)
     else:
         # (the update at the head of this step's forward already derived the gradient scales from the last backward)
         launch_all(grads, fire)
