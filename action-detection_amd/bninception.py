@@ -62,7 +62,7 @@ def tuned_tile(kind, n, cin, cout, k, s, hin):
 
 
 def x6_wins(kind, cin, cout, k, s, hin):
-    """bf16-split ("x6") kernel or the exact-f32 MFMA kernel for this layer?  x6 unless the f32 one measured faster."""
+    """Split-operand ("x6": 2 x f16, 3 products) kernel or the exact-f32 MFMA kernel for this layer?  x6 unless f32 measured faster."""
     key = "|%d|%d|%d|%d|%d" % (cin, cout, k, s, hin)
     t6, t32 = _TUNED_MS.get(kind + "6" + key), _TUNED_MS.get(kind + key)
     return t6 is None or t32 is None or t6 <= t32
@@ -97,6 +97,8 @@ class _BackboneFn(torch.autograd.Function):
             f, s = net._run_forward(x[i0:i1], keep=need_grad)
             feats.append(f)
             saved.append(s)
+        if net.debug_keep_saved:      # tests: lets the caller export the forward's ReLU / max-pool decisions (export_decisions)
+            net._last_saved = saved
         ctx.net = net
         ctx.saved = saved if need_grad else None
         ctx.bounds = bounds
@@ -172,6 +174,8 @@ class BNInception(nn.Module):
         # consumer converts its operands (the round-1/2 executor below, and the path of training-mode BatchNorm)
         # Default: planes for BN-Inception (the benchmarked backbone; frozen BatchNorm), fp32 for the Inception-v3 subclass.
         self.layout = os.environ.get("SSN_LAYOUT", "planes" if type(self).__name__ == "BNInception" else "f32")
+        self.debug_keep_saved = False
+        self._last_saved = None
         self._planes_states = {}
         self.pl_tiles = {}            # (kind, cin, cout, kh, kw, s, hin) -> tile config of the planes kernels (autotuner)
 
@@ -423,6 +427,33 @@ class BNInception(nn.Module):
         if not tab or n * 2 < _TUNED_PL.get("n_images", 0):
             return -1
         return tab.get(key, -1)
+
+    def export_decisions(self):
+        """The discrete decisions of the last forward (debug_keep_saved = True; one chunk): ({layer id: bool [N, C, H, W] = "the
+        ReLU behind this layer passed the element" as the BACKWARD of this executor sees it}, {pool id: int64 [N, C, Ho, Wo] =
+        window-local index dr * k + ds of the maximum}).  tests/test_model_gpu.py runs the float64 oracle with exactly these
+        decisions forced, which makes the loss smooth in the comparison: gradients must then agree to rounding."""
+        saved = self._last_saved[0]
+        if len(saved) == 7:
+            from . import planes_exec
+            return planes_exec.export_decisions(self, saved)
+        plan, shapes, acts, argmax, _tscale, _bn = saved
+        relu, pool = {}, {}
+        for op in plan:
+            if op["kind"] == "conv":
+                off = 0
+                for lid, c in zip(op["lids"], op["couts"]):
+                    if "raw_from" in op and off >= op["raw_from"]:
+                        name, c0 = op["proj_final"]
+                    elif op.get("raw"):
+                        name, c0 = op["final"]
+                    else:
+                        name, c0 = op["dst"], op["dst_c0"] + off + (op["row_gap"] if off >= op.get("row_split", 1 << 30) else 0)
+                    relu[lid] = acts[name][:, c0:c0 + c] > 0
+                    off += c
+            elif op["kind"] == "pool" and op["pool"] == "max":
+                pool[op["lid"]] = argmax[op["lid"]].long()
+        return relu, pool
 
     def _use_planes(self, plan):
         if self.layout != "planes" or self.conv_precision != "split":

@@ -469,3 +469,32 @@ def run_backward(net, dfeat, saved, hook=True):
         out.append(flat[wo:wo + wn].view_as(conv.weight) if conv.weight.requires_grad else None)
         out.append(flat[bo:bo + bn] if conv.bias.requires_grad else None)
     return out, flat
+
+
+def export_decisions(net, saved):
+    """bninception.BNInception.export_decisions for a planes forward: the ReLU decision is the sign of the HIGH plane (what the
+    fused backward epilogues read), the pool decision the stored window-local argmax."""
+    plan, shapes, acts, argmax, _tscale, _packed, _st = saved
+
+    def hi_nchw(name):
+        t = acts[name]
+        return t.data[0].permute(0, 1, 3, 2).reshape(t.n, t.g * 8, t.h, t.w)
+
+    relu, pool = {}, {}
+    for op in plan:
+        if op["kind"] == "conv":
+            off = 0
+            for lid, c in zip(op["lids"], op["couts"]):
+                if "raw_from" in op and off >= op["raw_from"]:
+                    name, c0 = op["proj_final"]
+                elif op.get("raw"):
+                    name, c0 = op["final"]
+                else:
+                    name, c0 = op["dst"], op["dst_c0"] + off + (op["row_gap"] if off >= op.get("row_split", 1 << 30) else 0)
+                relu[lid] = hi_nchw(name)[:, c0:c0 + c] > 0
+                off += c
+        elif op["kind"] == "pool":
+            am = argmax[op["lid"]]
+            _, ho, wo = shapes[op["dst"]]
+            pool[op["lid"]] = am.permute(0, 1, 3, 2).reshape(am.shape[0], am.shape[1] * 8, ho, wo).long()
+    return relu, pool

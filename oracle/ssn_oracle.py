@@ -83,17 +83,38 @@ class OracleBNInception(nn.Module):
             cin = (c1 or 0) + c3 + db + (pp if pp else cin)
         self.fc = nn.Linear(cin, num_classes)
 
+    # Mask-forced evaluation (gradient referee of tests/test_model_gpu.py): with `forced = (relu, pools)` -- {layer id: bool mask},
+    # [window-local argmax per max pool, in forward order] taken from ANOTHER implementation's forward -- every ReLU multiplies by
+    # the given mask and every max pool picks the given element.  The network is then smooth in its weights, so two correct
+    # implementations must agree on the gradients to rounding (no "which side of zero did this unit land on" term).
+    forced = None
+
     def _cbr(self, name, x):
         conv = getattr(self, name)
         bn = getattr(self, name + "_bn")
-        return F.relu(bn(conv(x)))
+        z = bn(conv(x))
+        if self.forced is not None:
+            return z * self.forced[0][name].to(z.dtype)
+        return F.relu(z)
+
+    def _maxpool(self, x, k, s, p):
+        if self.forced is None:
+            return F.max_pool2d(x, k, s, p, ceil_mode=True)
+        local = self.forced[1][self._pool_i]
+        self._pool_i += 1
+        n, c, h, w = x.shape
+        ho, wo = local.shape[2], local.shape[3]
+        hh = torch.arange(ho).view(1, 1, ho, 1) * s - p + local // k
+        ww = torch.arange(wo).view(1, 1, 1, wo) * s - p + local % k
+        return x.flatten(2).gather(2, (hh * w + ww).flatten(2)).view(n, c, ho, wo)
 
     def features(self, x):
+        self._pool_i = 0
         x = self._cbr("conv1_7x7_s2", x)
-        x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+        x = self._maxpool(x, 3, 2, 0)
         x = self._cbr("conv2_3x3_reduce", x)
         x = self._cbr("conv2_3x3", x)
-        x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+        x = self._maxpool(x, 3, 2, 0)
         for (nm, c1, r3, c3, rd, da, db, pk, pp, st) in INCEPTION_ROWS:
             p = "inception_%s_" % nm
             outs = []
@@ -107,10 +128,10 @@ class OracleBNInception(nn.Module):
                 if pk == "avg":
                     q = F.avg_pool2d(x, 3, 1, 1, ceil_mode=True, count_include_pad=True)
                 else:
-                    q = F.max_pool2d(x, 3, 1, 1, ceil_mode=True)
+                    q = self._maxpool(x, 3, 1, 1)
                 outs.append(self._cbr(p + "pool_proj", q))
             else:
-                outs.append(F.max_pool2d(x, 3, 2, 0, ceil_mode=True))
+                outs.append(self._maxpool(x, 3, 2, 0))
             x = torch.cat(outs, 1)
         x = F.avg_pool2d(x, x.shape[-1], 1, 0, ceil_mode=True, count_include_pad=True)
         return x.flatten(1)

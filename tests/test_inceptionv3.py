@@ -128,9 +128,11 @@ def test_inceptionv3_backbone_backward_gpu(hip_library):
     assert ferr < 1e-4
     assert len(errs) == 2 * 94
     # 4 images and a random linear loss: this configuration is dominated by units that take the other ReLU / max-pool branch
-    # (torch's own fp32 path is 5e-4 / 1.2e-2 off float64); the split kernels' forward error is ~3x an fp32 FMA chain's, so
-    # proportionally more units sit within rounding of their threshold.  The tight bounds are the kernel tests (2e-6 / 5e-5)
-    # and the emulated whole-backbone run above (2e-5 on every tensor).
+    # (torch's own fp32 path is 5e-4 / 1.2e-2 off float64).  The split kernels' forward error is that of an fp32 FMA chain
+    # (K sweep against float64, profiles/r2_ksweep_f16x3.txt: 1.4-2.7e-7 on signed data where the exact-f32 MFMA kernel has
+    # 2.2-3.3e-7, 3.5e-7 ... 1.7e-6 on all-positive data where it has 3.5e-7 ... 3.3e-6), so which units sit within rounding of
+    # their threshold is an accident of the summation order, not of the operand split.  The tight bounds are the kernel tests
+    # (2e-6 / 5e-5) and the emulated whole-backbone run above (2e-5 on every tensor).
     assert e.median() <= 3.0 * ec.median() + 1e-5 and e.max() <= max(2.0 * ec.max(), 5e-3)
     # one launch per layer (no reduce pairs, no block-input merges) against the fused plan: same arithmetic, other launches
     fused = {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None}

@@ -407,8 +407,9 @@ X6_CASES_GPU = [
 
 
 def test_conv_x6_fwd_and_dgrad(backend):
-    """bf16-split ("x6") convolution kernels against fp64 torch: the split is exact and only three partial products
-    below 2^-24 |ab| are dropped, so the SAME tolerances as the f32-MFMA kernels apply (2e-5 / 5e-5 relative)."""
+    """Split-operand ("x6": two f16 terms per operand, three products) convolution kernels against fp64 torch: 22 of 24
+    significand bits per operand and one dropped product below 2^-22 |ab|, so the SAME tolerances as the f32-MFMA kernels apply
+    (2e-5 / 5e-5 relative)."""
     g = torch.Generator().manual_seed(20)
     for (n, cin, h, cout, k, s, p, tile) in (X6_CASES_GPU if backend.is_gpu else X6_CASES_SMALL):
         x = torch.randn(n, cin, h, h, generator=g)
@@ -448,7 +449,7 @@ def test_conv_x6_fwd_and_dgrad(backend):
 
 def test_conv_x6_is_fp32_accurate(backend):
     """The x6 kernel must be in the accuracy class of the exact-f32 MFMA kernel (measured against fp64), orders of
-    magnitude away from a plain bf16 product."""
+    magnitude away from a plain f16 / bf16 product."""
     g = torch.Generator().manual_seed(21)
     n, cin, h, cout = (4, 256, 14, 128) if backend.is_gpu else (1, 64, 6, 32)
     x = torch.randn(n, cin, h, h, generator=g)
@@ -598,7 +599,7 @@ def test_conv_x6_fused_pair_and_mask(backend):
 
 
 def test_conv_wgrad_x6(backend):
-    """bf16-split weight gradient (+ fp32 bias gradient) vs torch autograd in fp64; tolerance as the f32 kernel (5e-5)."""
+    """Split-operand (2 x f16) weight gradient (+ fp32 bias gradient) vs torch autograd in fp64; tolerance as the f32 kernel (5e-5)."""
     g = torch.Generator().manual_seed(30)
     cases = ([(6, 24, 14, 80, 3, -1), (4, 64, 28, 96, 1, -1), (3, 40, 56, 64, 3, 2), (5, 576, 14, 224, 1, -1),
               (2, 20, 14, 33, 3, 0), (2, 16, 28, 100, 3, 1), (2, 64, 14, 130, 1, 3), (2, 16, 14, 96, 3, 4),

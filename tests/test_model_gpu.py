@@ -33,10 +33,12 @@ def losses(out, v):
             ClassWiseRegressionLoss()(out[4], out[5], out[6]))
 
 
-@pytest.mark.parametrize("modality,cfg,v", [("RGB", (1, 1, 1), 4), ("Flow", (1, (1, 2), 1), 2)])
-def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v):
-    """RGB: BASELINE config 2 at FULL size (4 videos = 32 proposals = 288 frames of 224^2); Flow: a 2-video slice of
-    config 3.  Logits / losses 1e-4 against the fp32 CPU oracle; gradients against the oracle AND a float64 referee.
+@pytest.mark.parametrize("modality,cfg,v,neg", [("RGB", (1, 1, 1), 4, 0.0), ("Flow", (1, (1, 2), 1), 4, 0.0),
+                                                ("Flow", (1, 1, 1), 2, 0.25)])
+def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v, neg):
+    """BASELINE configs 2 (RGB) and 3 (Flow) at FULL size (4 videos = 32 proposals = 288 frames of 224^2), and a Flow slice
+    with a quarter of the frozen-BN scales negative.  Logits / losses 1e-4 against the fp32 CPU oracle; gradients against the
+    oracle, a float64 referee, and -- the tight check -- a MASK-FORCED float64 referee (below).
 
     Why the gradient check is a distribution and not a per-tensor bound: the loss is only piecewise smooth in the
     weights -- a ReLU (or max-pool) unit whose pre-activation is within rounding of zero takes a different branch in
@@ -45,7 +47,8 @@ def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v):
     (profiles/r2_grad_flip_diag.txt; identical numbers with the exact-f32 MFMA kernels, so it is not a property of the
     operand split).  Which units flip is an accident of rounding; how MANY tensors are affected and how close the bulk
     is to float64 is what a correct implementation controls, and that is what is asserted."""
-    m, o = build(modality, cfg)
+    m, o = build(modality, cfg, negative_gamma_frac=neg)
+    m.base_model.debug_keep_saved = True
     batch = make_batch(v, modality, 20, seed=5)
     out = m(*[t.cuda() for t in batch])
     ref = o(*batch)
@@ -84,6 +87,28 @@ def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v):
     assert e_hip.max() < 5e-3
     assert e_hip.median() <= 2.0 * e_cpu.median() + 1e-5, (e_hip.median(), e_cpu.median())
     assert int((e_hip > 1e-3).sum()) <= int((e_cpu > 1e-3).sum()) + max(6, len(e_hip) // 50)
+
+    # ---- the tight check: float64 referee with the HIP forward's discrete decisions forced ----
+    # The statistical statement above is all that can be said against an INDEPENDENT forward (units within rounding of zero
+    # land on different sides).  Forcing the oracle to take the ReLU / max-pool decisions the HIP forward took (the sign its
+    # backward kernels read, the argmax its pools stored) removes that term: what is left is a smooth function of the weights,
+    # and every gradient tensor must agree with float64 to rounding -- 5e-5 relative per tensor, at the full batch.
+    relu, pools = m.base_model.export_decisions()
+    o64.base_model.forced = ({k: t.cpu() for k, t in relu.items()}, [t.cpu() for t in pools.values()])
+    o64.zero_grad(set_to_none=True)
+    out_m = o64(*b64)
+    for i in (0, 2, 4):
+        assert rel_err(out[i], out_m[i]) < 2e-6, ("forced forward", i, rel_err(out[i], out_m[i]))
+    O.ssn_total_loss(out_m, v)[0].backward()
+    worst = ("", 0.0)
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), o64.named_parameters()):
+        if p2.grad is None:
+            continue
+        e = rel_err(p1.grad, p2.grad)
+        if e > worst[1]:
+            worst = (n1, e)
+    print("gradients vs mask-forced float64 referee: worst %s %.2e" % worst)
+    assert worst[1] < 5e-5, worst
 
 
 def test_negative_bn_gammas(hip_library):

@@ -54,4 +54,4 @@ for lid, (cin, cout, k, s, hi, ho) in info.items():
         else:
             row += ["       -", "     -"]
     print("%-34s %5d %5d %2d %2d %4d | %-4d %s %s | %s %s | %s %s" % ((lid, cin, cout, k, s, ho, tile) + tuple(row)))
-print("totals ms:", tot, "(* = bf16-split x6 kernel, otherwise exact-f32 MFMA kernel)")
+print("totals ms:", tot, "(* = split-operand (2 x f16, 3 products) x6 kernel, otherwise exact-f32 MFMA kernel)")
