@@ -35,7 +35,7 @@ def _scale_inplace(t, coef):
 class GradReducer:
     """Bucketed, overlapped gradient averaging for ``SSN`` across ``torch.distributed`` ranks."""
 
-    def __init__(self, model, process_group=None, min_bucket_elems=1 << 20):
+    def __init__(self, model, process_group=None, min_bucket_elems=1 << 20, deferred=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model = model
@@ -45,6 +45,11 @@ class GradReducer:
         # the RCCL + hipGraph-capture path the multi-GPU runs take)
         self.force = os.environ.get("SSN_FORCE_ALLREDUCE") == "1"
         self.min_bucket = min_bucket_elems
+        # deferred: no collective inside the backward; the caller sums everything afterwards with reduce_all() -- ONE
+        # all-reduce of the backbone's flat gradient buffer in place plus one bucket for the heads (the "separate" mode of
+        # bench.py: graph(forward + backward) -> eager RCCL all-reduces -> graph(optimizer), nothing captured)
+        self.deferred = deferred
+        self._deferred_flat = None
         self._handles = []
         self._flat = None
         self._pend = None  # (start, end) of ranges reported but not yet launched
@@ -53,6 +58,9 @@ class GradReducer:
 
     # --- protocol used by BNInception._run_backward
     def range_ready(self, flat, start, end):
+        if self.deferred:
+            self._deferred_flat = flat
+            return
         if self._flat is None:
             self._flat = flat
             self.launched = []
@@ -74,6 +82,8 @@ class GradReducer:
 
     def finish(self):
         """Called at the end of the backbone backward, before autograd consumes the gradients."""
+        if self.deferred:
+            return
         if self._pend is not None:
             self._launch()
         for h in self._handles:
@@ -82,6 +92,36 @@ class GradReducer:
         if self._flat is not None and (self.world > 1 or self.force):
             _scale_inplace(self._flat, 1.0 / self.world)
         self._flat = None
+
+    def reduce_all(self, average=False):
+        """Deferred mode, after loss.backward(): SUM (average=True: mean) of every gradient over the ranks.  The backbone's
+        parameter gradients are views of the executor's flat buffer (autograd adopts them without a copy), so that buffer is
+        reduced in place -- no gather / scatter of the 42 MB; anything that does not alias it (the three heads) goes in one
+        small bucket."""
+        if self.world == 1 and not self.force:
+            return
+        flat = self._deferred_flat
+        rest = []
+        lo = hi = None
+        if flat is not None:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        for p in self.model.parameters():
+            if p.grad is None:
+                continue
+            if flat is not None and lo <= p.grad.data_ptr() < hi and p.grad.is_contiguous():
+                continue                       # lives in the flat buffer
+            rest.append(p)
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if average:
+                _scale_inplace(flat, 1.0 / self.world)
+        if rest:
+            bucket = torch.cat([p.grad.reshape(-1) for p in rest])
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+            if average:
+                _scale_inplace(bucket, 1.0 / self.world)
+            torch._foreach_copy_([p.grad for p in rest], [c.view_as(p.grad) for c, p in zip(bucket.split([p.grad.numel() for p in rest]), rest)])
+        self.last_reduce = (0 if flat is None else flat.numel(), sum(p.grad.numel() for p in rest))
 
     # --- heads
     def head_parameters(self):

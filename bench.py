@@ -74,6 +74,7 @@ def parse():
                          "every kernel runs alone and rocprofv3's per-kernel durations are free of mutual slow-down")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly from Python instead of replaying one captured hipGraph per step")
+    ap.add_argument("--frame-size", type=int, default=224, help=argparse.SUPPRESS)      # tests: emulator mode only
     return ap.parse_args()
 
 
@@ -122,15 +123,30 @@ def main():
         return self_launch(args.gpus)
     if world != args.gpus:
         raise SystemExit("--gpus %d but the launcher set WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    # TEST TOOLING (tests/test_bench_selflaunch.py, CPU tier): SSN_BENCH_EMULATOR=1 runs the control flow of this script --
+    # self-launch, rendezvous, step loop, collectives, fences, rank-0 JSON -- on the host emulator build of the kernels over gloo,
+    # with a stand-in backbone; it measures nothing and says so in the JSON.  Without it there is no CPU path.
+    emulator = os.environ.get("SSN_BENCH_EMULATOR") == "1"
+    if emulator:
+        from action_detection_amd import _lib as _lib_
+        _lib_.use_library_for_testing(_lib_.SsnLibrary(os.path.join(ROOT, "tests", "emu", "libssn_emu.so"), is_emulator=True))
+        os.environ["SSN_BENCH_BACKEND"] = "gloo"
+        args.no_graph = args.no_kernel_events = True
+        args.cpu_baseline_videos = 0
+        torch.cuda.synchronize = lambda *a, **k: None
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     if os.environ.get("SSN_BENCH_ONE_DEVICE") == "1":   # tooling: several ranks on one GPU (control-flow check with gloo)
         local_rank = 0
-    if local_rank >= torch.cuda.device_count():
+    if not emulator and local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: this box has %d GPU(s); --gpus %d needs one GPU per rank (SSN_BENCH_ONE_DEVICE=1 "
                          "SSN_BENCH_BACKEND=gloo shares GPU 0 for a control-flow check)"
                          % (rank, torch.cuda.device_count(), args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if emulator:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("SSN_FORCE_ALLREDUCE") == "1"
     backend = None
     if use_dist:
@@ -149,12 +165,17 @@ def main():
     from action_detection_amd.ssn_models import SSN
     from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic, make_batch
 
-    pkg.build()
+    if not emulator:
+        pkg.build()
     v = args.videos_per_gpu
     torch.manual_seed(1234 + rank)
     model = SSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1))
     init_backbone_synthetic(model.base_model)  # same weights on every rank (same seed)
     init_heads_synthetic(model, std=0.001)
+    if emulator:      # stand-in backbone (pixels -> 1024 features through one trainable matrix): the emulated one takes minutes per frame
+        proj = torch.nn.Parameter(torch.randn(3 * 4 * 4, 1024) * 0.01)
+        model.base_model.register_parameter("stub_proj", proj)
+        model.base_model.features = lambda x: torch.nn.functional.adaptive_avg_pool2d(x, 4).flatten(1) @ proj
     model.base_model.conv_precision = args.precision
     if args.single_stream:
         model.base_model.overlap_wgrad = False
@@ -163,9 +184,9 @@ def main():
     policies = model.get_optim_policies()
     opt = SSNSGD(policies, lr=0.001, momentum=0.9, weight_decay=5e-4)
     overlapped = use_dist and args.collectives == "overlapped"
-    reducer = GradReducer(model) if overlapped else None
+    reducer = GradReducer(model, deferred=not overlapped) if use_dist else None
     act_crit, comp_crit, reg_crit = ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss()
-    batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank)]
+    batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank, input_size=args.frame_size)]
     global_comp_rows = 7 * v * world
     params = [p for g in opt.param_groups for p in g["params"]]
 
@@ -177,11 +198,9 @@ def main():
         return loss
 
     def allreduce_grads():
-        """'separate' mode: one RCCL all-reduce (sum) of all gradients; the 1/world lands in the SGD kernel."""
-        grads = [p.grad for p in params if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])          # 42 MB gather / scatter: bookkeeping copies
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        """'separate' mode: RCCL all-reduce (sum) of the backbone's flat gradient buffer IN PLACE (the parameter gradients are
+        views of it) plus one small bucket for the three heads; the 1/world lands in the SGD kernel."""
+        reducer.reduce_all(average=False)
 
     def update():
         opt.step(grad_scale=(1.0 / world) if (use_dist and not overlapped) else 1.0)
@@ -300,7 +319,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not emulator else "synthetic; HOST EMULATOR CONTROL-FLOW RUN with a stand-in backbone -- not a measurement",
         "config": {"workload": "BNInception %s SSN, %d videos x 8 proposals x 9 segments per GPU (224x224), "
                                "fwd + losses + bwd + SGD, THUMOS14 shape (C=%d, stpp [1,1,1], dropout 0.8)"
                                % (args.modality, v, args.num_class),

@@ -79,18 +79,13 @@ def _worker(rank, world, port, mode, size, v_per_rank, out_dir):
     losses = _step(m, crit, batch, rows)
     red.reduce_heads()
     res["overlapped"] = (losses, _grads(m), list(red.launched))
-    # (2) separate: plain backward, then ONE flat all-reduce (sum) and the 1/world of the optimiser step
+    # (2) separate (bench.py's default): plain backward, then the product's deferred reducer -- ONE all-reduce of the backbone's
+    # flat gradient buffer in place (the parameter gradients are views of it) + one bucket for the heads
     m2, crit2 = _model_and_losses(dev)
+    red2 = GradReducer(m2, deferred=True)
     losses2 = _step(m2, crit2, batch, rows)
-    ps = [p for p in m2.parameters() if p.grad is not None]
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat /= world
-    off = 0
-    for p in ps:
-        p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
-        off += p.grad.numel()
-    res["separate"] = (losses2, _grads(m2), None)
+    red2.reduce_all(average=True)
+    res["separate"] = (losses2, _grads(m2), red2.last_reduce)
     lt = torch.tensor(losses, dtype=torch.float64)
     dist.all_reduce(lt)                      # rank average of the per-rank losses = the gathered-batch losses
     res["mean_losses"] = (lt / world).tolist()
@@ -119,6 +114,9 @@ def _run(mode, size, v_per_rank, tmp_path, tol):
             assert err < tol, (which, n, err)
             if err > worst[1]:
                 worst = (which + ":" + n, err)
+    n_flat, n_rest = ranks[0]["separate"][2]
+    # the whole backbone went through the flat buffer in place; only the three heads needed the gather / scatter bucket
+    assert n_flat > 10_000_000 and n_rest < 300_000, (n_flat, n_rest)
     buckets = ranks[0]["overlapped"][2]
     assert len(buckets) >= 2 and buckets[-1][0] == 0, buckets           # tail-first buckets down to offset 0
     assert all(a[0] == b[1] for a, b in zip(buckets, buckets[1:])), buckets
