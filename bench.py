@@ -74,7 +74,17 @@ def parse():
                          "every kernel runs alone and rocprofv3's per-kernel durations are free of mutual slow-down")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel eagerly from Python instead of replaying one captured hipGraph per step")
-    ap.add_argument("--frame-size", type=int, default=224, help=argparse.SUPPRESS)      # tests: emulator mode only
+    ap.add_argument("--frame-size", type=int, default=0, help=argparse.SUPPRESS)      # tests: emulator mode only
+    ap.add_argument("--arch", default="BNInception", choices=["BNInception", "InceptionV3"],
+                    help="backbone: BNInception (the headline metric, BASELINE.json configs[1-3]) or InceptionV3 (299x299; the "
+                         "reference trains / tests on it with --arch InceptionV3, /root/reference/ssn_models.py:133-139)")
+    ap.add_argument("--mode", default="train", choices=["train", "dense-test"],
+                    help="train: the loop body of ssn_train.py:205-253 (default); dense-test: the per-video loop of "
+                         "ssn_test.py:66-92 (BASELINE.json configs[4]: every sampled frame x 10 crops through the backbone, "
+                         "re-organised STPP over the proposals), N > 1 = independent replicas")
+    ap.add_argument("--ticks", type=int, default=600, help="dense-test: sampled frames per video")
+    ap.add_argument("--proposals", type=int, default=50, help="dense-test: proposals per video")
+    ap.add_argument("--tick-batch", type=int, default=60, help="dense-test: ticks per backbone call (the reference uses 4)")
     return ap.parse_args()
 
 
@@ -114,6 +124,130 @@ def self_launch(n):
         raise SystemExit(rc)
 
 
+def dense_test_main(args, world, rank, local_rank):
+    """--mode dense-test: the per-video loop of /root/reference/ssn_test.py:66-92 (BASELINE.json configs[4]) on synthetic
+    ActivityNet-1.2-shape videos resident in HBM: `--ticks` sampled frames x 10 crops through the backbone in large tick
+    batches, crop mean, folded test_fc, re-organised STPP over `--proposals` proposals, regression de-normalisation.  One "step" =
+    one video.  N > 1: independent replicas (the reference's worker queue, ssn_test.py:145-159), no collective in the data path."""
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    if os.environ.get("SSN_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = os.environ.get("SSN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    import numpy as np
+    import action_detection_amd as pkg
+    from action_detection_amd.dense_test import DenseTester
+    from action_detection_amd.ssn_models import SSN
+    from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic
+    pkg.build()
+    num_class, crops = 100, 10
+    torch.manual_seed(0)
+    net = SSN(num_class, 2, 5, 2, "RGB", base_model=args.arch, test_mode=True, stpp_cfg=(1, 1, 1))
+    size = net.input_size
+    gflop_per_frame = {"BNInception": 4.063152128, "InceptionV3": 2 * 5.711168096}[args.arch]   # 2 * conv MACs
+    init_backbone_synthetic(net.base_model)
+    init_heads_synthetic(net, std=0.01)
+    net.prepare_test_fc()
+    net.to(dev).eval()
+    tester = DenseTester(net, num_class, stats=np.array([[0.0, 0.0], [1.0, 1.0]]), tick_batch=args.tick_batch)
+    g = torch.Generator().manual_seed(1 + rank)
+    batch = (torch.randint(0, 256, (crops * args.tick_batch, 3, size, size), generator=g).float() - 110.0).to(dev)
+    n_calls = (args.ticks + args.tick_batch - 1) // args.tick_batch
+    ticks_total = n_calls * args.tick_batch
+    rs = np.random.RandomState(rank)
+    starts = rs.randint(0, ticks_total - 8, size=args.proposals)
+    lens = rs.randint(2, ticks_total // 3, size=args.proposals)
+    pt = np.stack([np.maximum(starts - lens // 2, 0), starts, np.minimum(starts + lens, ticks_total),
+                   np.minimum(starts + lens + lens // 2, ticks_total)], axis=1).astype(np.int64)
+    sc = rs.rand(args.proposals, 2)
+
+    def one_video():
+        return tester.score_video((batch for _ in range(n_calls)), ticks_total, torch.from_numpy(pt), torch.from_numpy(sc),
+                                  num_crop=crops)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        one_video()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_video()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = ticks_total * crops * args.steps * world
+    result = {
+        "metric": "dense-test frames/sec (ssn_test.py per-video loop, %s RGB %dx%d, C=%d)" % (args.arch, size, size, num_class),
+        "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "videos_per_s": round(args.steps * world / elapsed, 3),
+        "config": {"workload": "%s RGB SSN dense testing, ActivityNet-1.2 shape: %d ticks x %d crops per video (%dx%d), %d proposals, "
+                               "backbone in tick batches of %d, crop mean, folded test_fc (out %d), re-organised STPP, de-normalised "
+                               "regression; one step = one video, N > 1 = independent replicas"
+                               % (args.arch, ticks_total, crops, size, size, args.proposals, args.tick_batch, net.test_fc.out_features),
+                   "parallelism": "replicas%d" % world, "layout": net.base_model.layout},
+    }
+    if rank == 0:
+        # roofline of the dominant kernel family: the forward convolutions of one more video, HIP events per launch
+        prof = []
+        net.base_model.profiler = prof
+        overlap, lanes = net.base_model.overlap_wgrad, net.base_model.branch_streams
+        net.base_model.branch_streams = False
+        one_video()
+        torch.cuda.synchronize()
+        net.base_model.profiler = None
+        net.base_model.branch_streams = lanes
+        fl = sum(p[2] for p in prof)
+        ms = sum(p[3].elapsed_time(p[4]) for p in prof)
+        if prof and ms > 0:
+            tf = fl / (ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "kernel": "forward convolution launches (%s)" % "/".join(sorted({p[0] for p in prof})),
+                                  "achieved": round(tf, 3), "peak": round(X6_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+                                  "frac": round(tf / X6_PEAK_TFLOPS, 4), "traffic": None,
+                                  "peak_note": "algorithmic fp32 flops (2*MACs); peak = 2500 TF dense f16 MFMA / 3 products per multiply",
+                                  "launches": len(prof), "conv_ms_per_video": round(ms, 3),
+                                  "whole_video_fwd_tflops": round(ticks_total * crops * gflop_per_frame * 1e9 * args.steps * world
+                                                                  / elapsed / 1e12, 2)}
+        if args.cpu_baseline_videos > 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import ssn_oracle as O
+            oracle = O.OracleSSN(num_class, 2, 5, 2, "RGB", test_mode=True, stpp_cfg=(1, 1, 1), base_model=args.arch)
+            oracle.load_state_dict({k: t_.cpu() for k, t_ in net.state_dict().items() if not k.startswith("test_fc")})
+            oracle.prepare_test_fc()
+            oracle.eval()
+            nb = 2
+            cb = batch.view(crops, args.tick_batch, 3, size, size)[:, :4].reshape(-1, 3, size, size).cpu()
+            cpt = np.clip(pt, 0, 4 * nb)
+            c0 = time.perf_counter()
+            O.dense_test_video(oracle, (cb for _ in range(nb)), 4 * nb, cpt, sc, num_class, num_crop=crops,
+                               stats=np.array([[0.0, 0.0], [1.0, 1.0]]))
+            ct = time.perf_counter() - c0
+            result["cpu_baseline"] = {"value": round(4 * nb * crops / ct, 2), "unit": "frames/s", "cores": torch.get_num_threads(),
+                                      "kind": "port", "sample": "oracle/ssn_oracle.py dense_test_video: %d ticks x %d crops, the "
+                                      "reference's batching (4 ticks per call), %.1f s" % (4 * nb, crops, ct)}
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,6 +257,8 @@ def main():
         return self_launch(args.gpus)
     if world != args.gpus:
         raise SystemExit("--gpus %d but the launcher set WORLD_SIZE=%d" % (args.gpus, world))
+    if args.mode == "dense-test":
+        return dense_test_main(args, world, rank, local_rank)
     # TEST TOOLING (tests/test_bench_selflaunch.py, CPU tier): SSN_BENCH_EMULATOR=1 runs the control flow of this script --
     # self-launch, rendezvous, step loop, collectives, fences, rank-0 JSON -- on the host emulator build of the kernels over gloo,
     # with a stand-in backbone; it measures nothing and says so in the JSON.  Without it there is no CPU path.
@@ -169,7 +305,8 @@ def main():
         pkg.build()
     v = args.videos_per_gpu
     torch.manual_seed(1234 + rank)
-    model = SSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1))
+    model = SSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1), base_model=args.arch)
+    frame = args.frame_size or model.input_size
     init_backbone_synthetic(model.base_model)  # same weights on every rank (same seed)
     init_heads_synthetic(model, std=0.001)
     if emulator:      # stand-in backbone (pixels -> 1024 features through one trainable matrix): the emulated one takes minutes per frame
@@ -186,7 +323,7 @@ def main():
     overlapped = use_dist and args.collectives == "overlapped"
     reducer = GradReducer(model, deferred=not overlapped) if use_dist else None
     act_crit, comp_crit, reg_crit = ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss()
-    batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank, input_size=args.frame_size)]
+    batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank, input_size=frame)]
     global_comp_rows = 7 * v * world
     params = [p for g in opt.param_groups for p in g["params"]]
 
@@ -307,8 +444,16 @@ def main():
 
     proposals = 8 * v * world * args.steps
     value = proposals / elapsed
+    if args.arch == "InceptionV3":      # algorithmic conv work from the manifest (2 * MACs; no data gradient for the first layer)
+        from action_detection_amd.inceptionv3_spec import build_manifest as _bm, conv_macs as _cm
+        _ops, _shapes = _bm(3, frame)
+        _first = next(op for op in _ops if op[0] == "conv")
+        fwd_gflop_img = 2.0 * _cm(_ops, _shapes) / 1e9
+        conv1_dgrad_gflop_img = 2.0 * _shapes[_first[3]][1] * _shapes[_first[3]][2] * _first[5] * _first[6] * _first[7] * _first[8] / 1e9
+    else:
+        fwd_gflop_img, conv1_dgrad_gflop_img = FWD_GFLOP_PER_IMAGE[args.modality], CONV1_DGRAD_GFLOP_PER_IMAGE[args.modality]
     result = {
-        "metric": "proposals/sec (9-seg BNInception SSN fwd+bwd)",
+        "metric": "proposals/sec (9-seg %s SSN fwd+bwd)" % args.arch,
         "value": round(value, 3),
         "unit": "proposals/s",
         "n_gpus": world,
@@ -320,9 +465,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if not emulator else "synthetic; HOST EMULATOR CONTROL-FLOW RUN with a stand-in backbone -- not a measurement",
-        "config": {"workload": "BNInception %s SSN, %d videos x 8 proposals x 9 segments per GPU (224x224), "
+        "config": {"workload": "%s %s SSN, %d videos x 8 proposals x 9 segments per GPU (%dx%d), "
                                "fwd + losses + bwd + SGD, THUMOS14 shape (C=%d, stpp [1,1,1], dropout 0.8)"
-                               % (args.modality, v, args.num_class),
+                               % (args.arch, args.modality, v, frame, frame, args.num_class),
                    "global_batch_proposals": 8 * v * world, "images_per_gpu": 72 * v,
                    "parallelism": "dp%d" % world, "launch": launch,
                    "collectives": (args.collectives if use_dist else "none"),
@@ -416,7 +561,7 @@ def main():
                                          "ms_per_step": round(ms / args.steps, 3)}
             det["conv_ms_per_step"] = round(sum(f[1] for f in fam.values()) / args.steps, 3)
             # fwd + dgrad + wgrad = 3 x forward flops minus the data gradient of conv1, which is never computed
-            step_gflop = (3 * FWD_GFLOP_PER_IMAGE[args.modality] - CONV1_DGRAD_GFLOP_PER_IMAGE[args.modality]) * 72 * v
+            step_gflop = (3 * fwd_gflop_img - conv1_dgrad_gflop_img) * 72 * v
             det["step_algorithmic_gflop"] = round(step_gflop, 1)
             det["whole_step_tflops"] = round(step_gflop * 1e9 / (elapsed / args.steps) / 1e12, 2)
             det["whole_step_frac_of_f32_mfma_peak"] = round(det["whole_step_tflops"] / F32_MFMA_PEAK_TFLOPS, 4)
@@ -450,13 +595,13 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import ssn_oracle as O
             cv = args.cpu_baseline_videos
-            oracle = O.OracleSSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1))
+            oracle = O.OracleSSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1), base_model=args.arch)
             sd = {k: t.detach().cpu() for k, t in model.state_dict().items()}
             oracle.load_state_dict(sd)
             oracle.train()
             # the identical tensors the GPU was timed on (rank 0's batch) when the sample is the full per-GPU batch
             cb = ([t.detach().cpu() for t in batch] if cv == v
-                  else make_batch(cv, args.modality, args.num_class, seed=10_000))
+                  else make_batch(cv, args.modality, args.num_class, seed=10_000, input_size=frame))
             times = []
             for rep in range(1 + max(1, args.cpu_baseline_reps)):     # first repetition = warm-up (allocator, threads)
                 c0 = time.perf_counter()
