@@ -87,6 +87,7 @@ class TrainingBatchPrefetcher(object):
         self._q = queue.Queue(maxsize=self.depth)
         self._stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._stop = False
+        self._done = None
         self._thread = threading.Thread(target=self._produce, daemon=True)
         self._thread.start()
 
@@ -99,10 +100,22 @@ class TrainingBatchPrefetcher(object):
                     break
                 slot = self._slots[i % self.depth]
                 i += 1
-                self._q.put(("ok", self._stage(slot, item)))     # blocks while `depth` batches are waiting
-            self._q.put(("end", None))
+                if not self._put(("ok", self._stage(slot, item))):     # waits while `depth` batches are queued
+                    return
+            self._put(("end", None))
         except BaseException as e:      # surfaced on the consumer's thread
-            self._q.put(("err", e))
+            self._put(("err", e))
+
+    def _put(self, item):
+        """queue.put that gives up when close() was called (a producer blocked on a full queue must be able to exit)."""
+        import queue
+        while not self._stop:
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def _stage(self, slot, item):
         frames, scaling, target, reg_target, prop_type = item
@@ -113,7 +126,8 @@ class TrainingBatchPrefetcher(object):
         small = [torch.as_tensor(t) for t in (scaling, target, reg_target, prop_type)]
         if not self.cuda:
             out = self.transform.crop(frames.reshape(v * n_img, h, w, c), 0, 0, False)
-            return (out.reshape(v, n_img * c, h, w),) + tuple(t.to(self.device) for t in small), None
+            ch, cw = out.shape[-2], out.shape[-1]      # the transform's crop size (the frames may be larger)
+            return (out.reshape(v, n_img * c, ch, cw),) + tuple(t.to(self.device) for t in small), None
         if slot["pinned"] is None or slot["pinned"].shape != frames.shape:
             slot["pinned"] = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
             slot["dev"] = torch.empty(frames.shape, dtype=torch.uint8, device=self.device)
@@ -124,7 +138,8 @@ class TrainingBatchPrefetcher(object):
             slot["dev"].copy_(slot["pinned"], non_blocking=True)    # (the device buffer is only touched on this stream)
             slot["uploaded"] = torch.cuda.Event()
             slot["uploaded"].record(self._stream)
-            out = self.transform.crop(slot["dev"].reshape(v * n_img, h, w, c), 0, 0, False).reshape(v, n_img * c, h, w)
+            out = self.transform.crop(slot["dev"].reshape(v * n_img, h, w, c), 0, 0, False)
+            out = out.reshape(v, n_img * c, out.shape[-2], out.shape[-1])      # the transform's crop size
             rest = tuple(t.pin_memory().to(self.device, non_blocking=True) for t in small)
             ready = torch.cuda.Event()
             ready.record(self._stream)
@@ -135,10 +150,14 @@ class TrainingBatchPrefetcher(object):
         return self
 
     def __next__(self):
+        if self._done is not None:          # exhausted / failed / closed: every further next() says so again
+            raise self._done
         kind, payload = self._q.get()
         if kind == "end":
+            self._done = StopIteration()
             raise StopIteration
         if kind == "err":
+            self._done = StopIteration()
             raise payload
         batch, ready = payload
         if ready is not None:
@@ -148,4 +167,15 @@ class TrainingBatchPrefetcher(object):
         return batch
 
     def close(self):
+        """Stop the producer thread and release its staging buffers (safe to call more than once)."""
+        import queue
         self._stop = True
+        if self._done is None:
+            self._done = StopIteration()
+        while True:                          # unblock a producer waiting on the full queue, drop what it staged
+            try:
+                self._q.get_nowait()
+            except queue.Empty:
+                break
+        self._thread.join(timeout=5.0)
+        self._slots = []

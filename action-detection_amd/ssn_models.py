@@ -277,19 +277,22 @@ class SSN(torch.nn.Module):
         cache = getattr(self, "_indexer_cache", None)
         capturing = prop_type.is_cuda and torch.cuda.is_current_stream_capturing()
         if capturing:
+            # (`_version` counts in-place writes: a prop_type buffer modified since the eager forward that read it would
+            # silently bake stale row indices -- and gather sizes -- into the graph)
             key = (prop_type.data_ptr(), tuple(prop_type.shape), str(dev))
-            if cache is None or cache[0] != key:
-                raise RuntimeError("hipGraph capture of SSN.forward needs one eager forward with the same prop_type "
-                                   "tensor first (its proposal-type pattern is baked into the captured graph)")
+            if cache is None or cache[0] != key or cache[3] != prop_type._version:
+                raise RuntimeError("hipGraph capture of SSN.forward needs one eager forward with the same, unmodified "
+                                   "prop_type tensor first (its proposal-type pattern is baked into the captured graph; "
+                                   "re-capture whenever the pattern changes)")
             return cache[2]
         type_host = prop_type.detach().reshape(-1).cpu()
         if cache is not None and cache[0][2] == str(dev) and torch.equal(cache[1], type_host):
-            self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), cache[1], cache[2])
+            self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), cache[1], cache[2], prop_type._version)
             return cache[2]
         idx = (torch.nonzero((type_host == 0) | (type_host == 2)).reshape(-1).to(dev),
                torch.nonzero((type_host == 0) | (type_host == 1)).reshape(-1).to(dev),
                torch.nonzero(type_host == 0).reshape(-1).to(dev))
-        self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), type_host.clone(), idx)
+        self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), type_host.clone(), idx, prop_type._version)
         return idx
 
     def test_forward(self, input):

@@ -202,8 +202,8 @@ class GroupNormalize(object):
         c = tensor.size(0)
         mean = torch.tensor(self.mean * (c // len(self.mean)), dtype=tensor.dtype).view(-1, 1, 1)
         std = torch.tensor(self.std * (c // len(self.std)), dtype=tensor.dtype).view(-1, 1, 1)
-        k = mean.shape[0]                    # the reference's zip() stops at the shorter list
-        tensor[:k].sub_(mean).div_(std)
+        k = min(mean.shape[0], std.shape[0])     # the reference's zip(tensor, rep_mean, rep_std) stops at the shortest list
+        tensor[:k].sub_(mean[:k]).div_(std[:k])
         return tensor
 
 
