@@ -45,10 +45,12 @@ def main():
         from action_detection_amd.bninception import BNInception
         for cin in (3, 10):
             net = BNInception(in_channels=cin)
+            net.eval()      # frozen BatchNorm (what SSN.train() leaves): the plan with the fused block-input launches
             plans.append(net._plan(torch.zeros(1, cin, 224, 224)))
     else:
         from action_detection_amd.inceptionv3 import InceptionV3
         net = InceptionV3()
+        net.eval()
         plans.append(net._plan(torch.zeros(1, 3, 299, 299)))
     try:
         with open(OUT) as f:

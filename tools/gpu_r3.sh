@@ -12,7 +12,7 @@ if has bench; then timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; 
 if has flow; then timeout 600 python bench.py --modality Flow --cpu-baseline-videos 0 > $O/bench_flow.json 2>/dev/null; cut -c1-200 $O/bench_flow.json; fi
 if has dist1; then
   for m in separate overlapped; do
-    SSN_FORCE_ALLREDUCE=1 timeout 600 python bench.py --collectives $m --cpu-baseline-videos 0 --no-kernel-events > $O/bench_dist1_$m.json 2> $O/bench_dist1_$m.err
+    SSN_FORCE_ALLREDUCE=1 timeout 600 python bench.py --collectives $m --cpu-baseline-videos 0 --no-kernel-events 2> $O/bench_dist1_$m.err | grep '^{' > $O/bench_dist1_$m.json   # (RCCL prints its banner on stdout)
     cut -c1-200 $O/bench_dist1_$m.json; tail -2 $O/bench_dist1_$m.err
   done
 fi
