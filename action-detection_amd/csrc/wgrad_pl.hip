@@ -263,9 +263,12 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
 // hold zeros on both operands (their DMA offsets are out of range).  Price: (H + 1)(W + 1) / HW more k-steps (1.15 at 14 x 14).
 // A chunk = 64 slots of dY and the 64 + 2 (Wp + 1) slots of X around them, double-buffered; 4 k-steps x 9 taps x 3 products per
 // chunk and barrier; waves 0/1 fetch the planes of dY, waves 2/3 those of X.
-template <int TM, int TC, int XP>
-__global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(WgPlArgs p) {
-    constexpr int KK = 9, NS = 64, KSC = NS / 16;
+// KK = 1 (1x1 layers): the same chunked pipeline without borders or halo -- 64 plain pixel slots per chunk, 4 k-steps per barrier
+// instead of the one-tap kernel's single one, register tiles up to 64 x 64 per wave.
+template <int KK, int TM, int TC, int XP>
+__global__ __launch_bounds__(256, (KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) void wgrad_pl9_kernel(WgPlArgs p) {
+    constexpr int NS = 64, KSC = NS / 16;
+    static_assert(KK == 1 || KK == 9, "1x1 or 3x3");
     constexpr int BM = 2 * TM * 32, BC = 2 * TC * 32;
     constexpr int FA = BM / 32, FB = BC / 32;
     constexpr int A_BYTES = FA * 2 * KSC * 1024;     // [frag][plane][64 slots][32 ch]
@@ -284,8 +287,9 @@ __global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(
     fd_divmod(logical, p.div_tiles, z, tile);
     fd_divmod(tile, p.div_ct, mt, ct);
     const int m0 = (int)mt * BM, c0 = (int)ct * BC;
-    const int Wp = p.W + 1, SP = (p.H + 1) * Wp;
-    const int D = Wp + 1;                              // slots of X in front of the chunk's first dY slot
+    constexpr int BORDER = KK > 1 ? 1 : 0;             // zero row / column in front of every image row (3x3); none for 1x1
+    const int Wp = p.W + BORDER, SP = (p.H + BORDER) * Wp;
+    const int D = BORDER * (Wp + 1);                   // slots of X in front of the chunk's first dY slot
     const uint32_t T = (uint32_t)p.N * (uint32_t)SP;   // padded slots that can hold data
 
     // ---- DMA role: operand (0 = dY, 1 = X) and plane ----
@@ -314,8 +318,8 @@ __global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(
         uint32_t n, u, hp, wp;
         fd_divmod((uint32_t)(in ? sl : 0), p.div_hw, n, u);     // div_hw = SP
         fd_divmod(u, p.div_w, hp, wp);                          // div_w = Wp
-        const bool real = in && hp >= 1u && wp >= 1u;
-        return real ? n * img_bytes + ((hp - 1u) * (uint32_t)p.W + (wp - 1u)) * 16u + lane_grp : PL_OOB;
+        const bool real = in && hp >= (uint32_t)BORDER && wp >= (uint32_t)BORDER;
+        return real ? n * img_bytes + ((hp - BORDER) * (uint32_t)p.W + (wp - BORDER)) * 16u + lane_grp : PL_OOB;
     };
     auto issue = [&](int ck, int buf) {
         unsigned char* base = lds + buf * STAGE;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(
     const int lane_rd = (8 * lh + (l16 >> 2)) * 64 + sg16 * 32 + (l16 & 3) * 8;
     int tapoff[KK];      // byte displacement of tap t inside the X rows: (D + (r - 1) Wp + (s - 1)) * 64
 #pragma unroll
-    for (int t = 0; t < KK; ++t) tapoff[t] = (D + (t / 3 - 1) * Wp + (t % 3 - 1)) * 64;
+    for (int t = 0; t < KK; ++t) tapoff[t] = KK > 1 ? (D + (t / 3 - 1) * Wp + (t % 3 - 1)) * 64 : 0;
     const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u});
 
     auto rd_frag = [&](const unsigned char* src) -> f16x8 {
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             const int ks = step / KK, t = step % KK;
-            if (t == 1 && ks + 1 < KSC) read_a(ks + 1, (ks + 1) & 1);
+            if (t == (KK > 1 ? 1 : 0) && ks + 1 < KSC) read_a(ks + 1, (ks + 1) & 1);
             if (step + 2 < NSTEP) read_b(step + 2, (step + 2) % 3);
             constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_hi + g_hi x_lo
             constexpr int PB[3] = {0, 0, 1};
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256, (TM * TC >= 2) ? 1 : 2) void wgrad_pl9_kernel(
 
 #undef WG_DMA_B128
 
-template <int TM, int TC, int XP>
+template <int KK, int TM, int TC, int XP>
 int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {
     constexpr int BM = 2 * TM * 32, BC = 2 * TC * 32;
     a.n_mtiles = (a.M + BM - 1) / BM;
@@ -464,7 +468,7 @@ int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {
     const unsigned tiles = (unsigned)a.n_mtiles * (unsigned)a.n_ctiles;
     a.div_tiles = make_fastdiv(tiles);
     a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
-    hipLaunchKernelGGL((wgrad_pl9_kernel<TM, TC, XP>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((wgrad_pl9_kernel<KK, TM, TC, XP>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("wgrad_pl9");
     return SSN_OK;
 }
@@ -478,9 +482,9 @@ const int k9Occ[N9] = {1, 1, 1};
 template <int XP>
 int launch_wgpl9_xp(WgPlArgs& a, int cfg, hipStream_t stream) {
     switch (cfg) {
-        case 0: return launch_wgpl9<1, 1, XP>(a, stream);
-        case 1: return launch_wgpl9<2, 1, XP>(a, stream);
-        case 2: return launch_wgpl9<1, 2, XP>(a, stream);
+        case 0: return launch_wgpl9<9, 1, 1, XP>(a, stream);
+        case 1: return launch_wgpl9<9, 2, 1, XP>(a, stream);
+        case 2: return launch_wgpl9<9, 1, 2, XP>(a, stream);
     }
     ssn_set_error("conv_wgrad_pl (nine taps): unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -491,8 +495,32 @@ int launch_wgpl9_tile(WgPlArgs& a, int cfg, hipStream_t stream) {
     const int xp = xp_for(a.W);
     if (xp <= 6) return launch_wgpl9_xp<6>(a, cfg, stream);
     if (xp <= 8) return launch_wgpl9_xp<8>(a, cfg, stream);
-    return launch_wgpl9<1, 1, 12>(a, stream);   // wide rows: only the 64 x 64 tile fits two buffers into the LDS
+    return launch_wgpl9<9, 1, 1, 12>(a, stream);   // wide rows: only the 64 x 64 tile fits two buffers into the LDS
 }
+// chunked 1x1 tile configs (tile_cfg 200 + i): 0: 64 x 64   1: 128 x 64   2: 64 x 128   3: 128 x 128
+constexpr int N1 = 4;
+const int k1BM[N1] = {64, 128, 64, 128};
+const int k1BC[N1] = {64, 64, 128, 128};
+const int k1Occ[N1] = {2, 1, 1, 1};
+int launch_wgpl1_tile(WgPlArgs& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_wgpl9<1, 1, 1, 4>(a, stream);
+        case 1: return launch_wgpl9<1, 2, 1, 4>(a, stream);
+        case 2: return launch_wgpl9<1, 1, 2, 4>(a, stream);
+        case 3: return launch_wgpl9<1, 2, 2, 4>(a, stream);
+    }
+    ssn_set_error("conv_wgrad_pl (chunked 1x1): unknown tile config %d", cfg);
+    return SSN_ERR_ARG;
+}
+void plan1(int M, int Cin, long slots, int cfg, int* splits, int* chunks_per_split) {
+    const long tiles = (long)((M + k1BM[cfg] - 1) / k1BM[cfg]) * ((Cin + k1BC[cfg] - 1) / k1BC[cfg]);
+    const long chunks = (slots + 63) / 64;
+    plan_split_k(tiles, chunks, k1Occ[cfg], 4, 2, 0.005 + (double)M * Cin * 1.7e-6, splits, chunks_per_split);
+}
+bool chunked_1x1_layer(int kh, int kw, int stride, int pad_h, int pad_w) {
+    return kh == 1 && kw == 1 && stride == 1 && pad_h == 0 && pad_w == 0;
+}
+
 int pick_tile9(int M, int Cin, int W) {
     if (xp_for(W) > 8) return 0;
     double best = 1e300;
@@ -594,6 +622,11 @@ extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, 
 extern "C" int ssn_conv_wgrad_pl_tiles(void) { return NCFG; }
 
 extern "C" long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int tile_cfg) {
+    if (tile_cfg >= 200) {
+        int s1, c1;
+        plan1(Cout, Cin, (long)N * Ho * Wo, (tile_cfg - 200) < N1 ? tile_cfg - 200 : 0, &s1, &c1);
+        return (long)s1 * Cout * ((long)Cin + 1) * (long)sizeof(float);
+    }
     if (tile_cfg >= 100 || (tile_cfg < 0 && kh == 3 && kw == 3)) {
         // (nine-tap kernel; a 3x3 layer that turns out not to qualify at launch needs at most the one-tap kernel's slabs below)
         const int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, Wo);
@@ -663,6 +696,23 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
     a.x_bytes = (uint32_t)xb;
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
+    // tile_cfg >= 200: the chunked 1x1 kernel with tile tile_cfg - 200
+    if (tile_cfg >= 200) {
+        SSN_CHECK_ARG(chunked_1x1_layer(kh, kw, stride, pad_h, pad_w) && tile_cfg - 200 < N1,
+                      "conv wgrad pl: the chunked kernel (tile %d) takes 1x1 / stride-1 layers only", tile_cfg);
+        const int c1 = tile_cfg - 200;
+        plan1(Cout, Cin, a.P, c1, &a.splits, &a.ksteps_per_split);
+        const long need1 = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
+        if (ws_bytes < need1) {
+            ssn_set_error("conv wgrad pl: workspace %ld < %ld bytes", ws_bytes, need1);
+            return SSN_ERR_WORKSPACE;
+        }
+        a.div_hw = make_fastdiv((uint32_t)(H * W));
+        a.div_w = make_fastdiv((uint32_t)W);
+        const int rc1 = launch_wgpl1_tile(a, c1, stream);
+        if (rc1 != SSN_OK) return rc1;
+        return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
+    }
     // tile_cfg >= 100: the nine-tap kernel with tile tile_cfg - 100; < 0: it for every layer that qualifies
     if ((tile_cfg >= 100 || tile_cfg < 0) && nine_tap_layer(kh, kw, stride, pad_h, pad_w, H, W, Ho, Wo)) {
         int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, W);

@@ -203,6 +203,8 @@ def test_conv_pl_wgrad(backend):
         tiles = list(range(ntiles)) if ci in (0, 2) else [-1]
         if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1):
             tiles += [100, 101, 102]          # the nine-tap kernel's tiles
+        if (kh, kw, s, ph, pw) == (1, 1, 1, 0, 0):
+            tiles += [200, 201, 202, 203]     # the chunked 1x1 kernel's tiles
         for tile in tiles:
             ws = backend.put(torch.empty(P.wgrad_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile) // 4))
             dw, db = backend.put(torch.full(w.shape, 9.0)), backend.put(torch.full((cout,), 9.0))
@@ -242,7 +244,7 @@ def test_planes_pools(backend):
     """max pool (ceil mode, argmax routing), average pool behind a projection, global pool, ReLU/BN backward, channel sums."""
     g = torch.Generator().manual_seed(6)
     n, c = (6, 64) if backend.is_gpu else (2, 16)
-    for (h, k, s, pad) in [(12, 3, 2, 0), (7, 3, 1, 1), (9, 3, 2, 0)]:
+    for (h, k, s, pad) in [(12, 3, 2, 0), (7, 3, 1, 1), (9, 3, 2, 0), (10, 3, 2, 1), (11, 3, 2, 1)]:
         x = torch.randn(n, c, h, h, generator=g).clamp(min=0)          # post-ReLU: many exact-zero ties
         xd = x.double().requires_grad_()
         ref, idx = F.max_pool2d(xd, k, s, pad, ceil_mode=True, return_indices=True)
