@@ -17,6 +17,13 @@ import re
 import sys
 
 FAMILIES = [  # (family, regex on the kernel name, wide 16-byte reads?)
+    ("conv_pl_kernel_fwd", r"conv_pl_kernel<0,", True),
+    ("conv_pl_kernel_dgrad", r"conv_pl_kernel<1,", True),
+    ("wgrad_pl9_kernel", r"wgrad_pl9_kernel", True),
+    ("wgrad_pl_kernel", r"wgrad_pl_kernel", True),
+    ("pl_maxpool_fwd_kernel", r"pl_maxpool_fwd_kernel", True),
+    ("pl_maxpool_bwd_kernel", r"pl_maxpool_bwd", True),
+    ("pl_avgpool_affine_kernel", r"pl_avgpool_affine_kernel", True),
     ("conv_x6_kernel_fwd", r"conv_x6_kernel<\d+,\s*\d+,\s*\d+,\s*0,", True),
     ("conv_x6_kernel_dgrad", r"conv_x6_kernel<\d+,\s*\d+,\s*\d+,\s*1,", True),
     ("wgrad_x6_kernel", r"wgrad_x6_kernel", True),
@@ -43,6 +50,7 @@ def family_of(name):
 def main():
     root, out = sys.argv[1], sys.argv[2]
     sums = {}      # family -> counter -> [sum, n]
+    clock = {}     # family -> [sum of GRBM_GUI_ACTIVE / 8, sum of dispatch durations in ns]
     for path in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
@@ -52,6 +60,10 @@ def main():
                 c = sums.setdefault(fam, {}).setdefault(row["Counter_Name"], [0.0, 0])
                 c[0] += float(row["Counter_Value"])
                 c[1] += 1
+                if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                    k = clock.setdefault(fam, [0.0, 0.0])
+                    k[0] += float(row["Counter_Value"]) / 8.0
+                    k[1] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
     wide = {fam: w for fam, _, w in FAMILIES}
     res = {}
     for fam, cs in sums.items():
@@ -75,6 +87,20 @@ def main():
                     r[key] = round(tot(cname) / wc, 4)
         if gui and per("GRBM_GUI_ACTIVE"):
             r["gpu_active_cycles_per_launch"] = round(per("GRBM_GUI_ACTIVE"))
+        if fam in clock and clock[fam][1] > 0:
+            # shader clock the kernels of this family actually ran at (GRBM_GUI_ACTIVE counts per XCD; the chip clocks to its
+            # power budget: MI355X_MICROARCH.md, "DVFS give-back")
+            r["effective_clock_ghz"] = round(clock[fam][0] / clock[fam][1], 3)
+        mf = per("SQ_INSTS_MFMA")
+        if mf:
+            other = sum(per(cn) or 0.0 for cn in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"))
+            valu = per("SQ_INSTS_VALU")
+            # (counted like the round-2 review did: SQ_INSTS_VALU taken as the non-matrix vector instructions)
+            if valu is not None:
+                r["non_mfma_insts_per_mfma"] = round(other / mf, 2)
+                r["valu_per_mfma"] = round(valu / mf, 2)
+            if per("SQ_INSTS_SALU") is not None:
+                r["salu_per_mfma"] = round(per("SQ_INSTS_SALU") / mf, 2)
         lds_act, lds_conf = tot("SQ_LDS_IDX_ACTIVE"), tot("SQ_LDS_BANK_CONFLICT")
         if lds_act:
             r["lds_bank_conflict_frac"] = round(lds_conf / lds_act, 4)
