@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     constexpr int PK = BN * 4;                 // dwords of one (plane, k-half) row of the B tile
     constexpr int B_STAGE = 4 * PK;
     constexpr int STAGE = A_STAGE + B_STAGE;
-    constexpr int NSTAGE = 3;
+    // ring depth: 4 slots (the DMA runs three slabs ahead) wherever two co-resident workgroups still fit the 160 KiB of LDS --
+    // one slab of MFMAs (0.4-1.2k cycles) covers less of a loaded L2 / HBM round trip than two did for the fp32-layout kernels,
+    // whose slabs carried twice the VALU work -- else 3
+    constexpr bool ONE_WAVE = (TM * TN >= 8);
+    constexpr int NSTAGE = (STAGE * 4 * 4 * (ONE_WAVE ? 1 : 2) <= 163840) ? 4 : 3;
     constexpr int NB = 4 * SEGS / NW;          // B pieces per wave and slab
     constexpr int NLOAD = NA + NB;
 
@@ -217,9 +221,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue(0);
-    issue(STAGE);
-    issue(2 * STAGE);
+#pragma unroll
+    for (int st = 0; st < NSTAGE; ++st) issue(st * STAGE);
 
     // operand scales (powers of two, exact)
     const float sa = f16_scale_of(__builtin_bit_cast(float, p.ap[p.a_bytes >> 2]));
@@ -280,23 +283,28 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     };
 
     if (p.trace) tr1 = __builtin_readcyclecounter();
-    SSN_WAIT_VMCNT(2 * NLOAD);
+    SSN_WAIT_VMCNT((NSTAGE - 1) * NLOAD);
     __builtin_amdgcn_s_barrier();
     read_begin(0);
 #pragma unroll
     for (int k = 0; k < NREAD; ++k) read_step(fr0, k);
-    uint32_t s_cur = 0, s_n1 = STAGE, s_n2 = 2 * STAGE;   // ring slots of slabs t, t+1, t+2
+    uint32_t s_cur = 0, s_n1 = STAGE, s_n2 = 2 * STAGE, s_n3 = 3 * STAGE;   // ring slots of slabs t, t+1, t+2 (, t+3)
     auto half = [&](Frags& cur, Frags& nxt) {
-        SSN_WAIT_VMCNT(NLOAD);   // this wave's pieces of slab t+1 (slab t+2's may still be in flight)
+        SSN_WAIT_VMCNT((NSTAGE - 2) * NLOAD);   // this wave's pieces of slab t+1 (the later slabs' may still be in flight)
         SSN_WAIT_LGKM0();        // ... and its reads of slab t are back
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_begin(s_n1);
-        mfma(cur, s_cur, nxt);
+        mfma(cur, s_cur, nxt);   // (refills the slot of slab t, whose fragments are in registers, with slab t + NSTAGE)
         const uint32_t o = s_cur;
         s_cur = s_n1;
         s_n1 = s_n2;
-        s_n2 = o;
+        if (NSTAGE == 4) {
+            s_n2 = s_n3;
+            s_n3 = o;
+        } else {
+            s_n2 = o;
+        }
     };
     // two slabs per trip (the register sets swap roles); an odd slab count runs one all-zero slab at the end
     for (int t = 0; t < nslab; t += 2) {

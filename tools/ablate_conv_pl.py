@@ -69,8 +69,26 @@ for name, cin, cout, k, h, tiles in CASES:
         torch.cuda.synchronize()
         lib.cdll.ssn_conv_pl_debug_trace(ctypes.c_void_p(0))
         t = tr.cpu().numpy().reshape(nblk, 8)
+        t = t[t[:, 0] > 0]
         nslab = ((cin + 15) // 16) * k * k
         t_full = timeit(fn)
+        # tick rate of the cycle counter, blocks in flight (sum of block lifetimes / kernel span) and per-CU co-residency
+        span = float(t[:, 3].max() - t[:, 0].min())
+        conc = float((t[:, 3] - t[:, 0]).sum()) / span
+        cu = (t[:, 5] & 0xF) * 4096 + ((t[:, 4] >> 8) & 0xFFF)       # XCC id | (CU, SH, SE) bits of HW_ID
+        order = np.argsort(t[:, 0])
+        peak = {}
+        live = {}
+        for i in order:
+            c = int(cu[i])
+            lst = [e for e in live.get(c, []) if e > t[i, 0]]
+            lst.append(t[i, 3])
+            live[c] = lst
+            peak[c] = max(peak.get(c, 0), len(lst))
+        pk = np.array(list(peak.values()))
+        print("    traced blocks %d of %d; span %.0f ticks = %.4f ms -> %.2f GHz tick rate; blocks in flight %.0f (%.2f per CU of %d CUs "
+              "seen); peak co-resident blocks per CU: mean %.2f max %d" % (len(t), nblk, span, t_full, span / (t_full * 1e6), conc,
+                                                                           conc / len(peak), len(peak), pk.mean(), pk.max()))
         print("%s tile %d (%dx%d, %d blocks, %d slabs) %.1f TF | %s" % (name, tile, bm.value, bn.value, nblk, nslab,
                                                                        flops / t_full / 1e9, " | ".join(res)))
         print("    per block: prologue %.0f  loop %.0f (%.0f / slab)  epilogue %.0f  total %.0f cycles; kernel span %.0f" % (
