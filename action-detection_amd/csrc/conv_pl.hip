@@ -114,8 +114,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     const int m0 = (int)mtile * BM;
     const int p0 = (int)ptile * BN;
     const int KK = p.kh * p.kw;
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-    if (p.trace) tr0 = __builtin_readcyclecounter();
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, trr = 0;
+    if (p.trace) {
+        tr0 = __builtin_readcyclecounter();
+        trr = __builtin_amdgcn_s_memrealtime();     // the constant 100 MHz counter: calibrates the tick of the cycle counter
+    }
 
     // ---- B gather state: this lane fetches pixel seg * 64 + lane of the tile (one lane = one pixel, 16 B = 8 channels) ----
     const int seg = wave % SEGS;
@@ -442,6 +445,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
         t[3] = __builtin_readcyclecounter();
         t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
         t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+        t[6] = trr;
+        t[7] = __builtin_amdgcn_s_memrealtime();
     }
 }
 #undef PL_DMA_B128

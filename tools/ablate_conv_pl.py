@@ -72,25 +72,40 @@ for name, cin, cout, k, h, tiles in CASES:
         t = t[t[:, 0] > 0]
         nslab = ((cin + 15) // 16) * k * k
         t_full = timeit(fn)
-        # tick rate of the cycle counter, blocks in flight (sum of block lifetimes / kernel span) and per-CU co-residency
-        span = float(t[:, 3].max() - t[:, 0].min())
-        conc = float((t[:, 3] - t[:, 0]).sum()) / span
-        cu = (t[:, 5] & 0xF) * 4096 + ((t[:, 4] >> 8) & 0xFFF)       # XCC id | (CU, SH, SE) bits of HW_ID
-        order = np.argsort(t[:, 0])
-        peak = {}
-        live = {}
-        for i in order:
-            c = int(cu[i])
-            lst = [e for e in live.get(c, []) if e > t[i, 0]]
-            lst.append(t[i, 3])
-            live[c] = lst
-            peak[c] = max(peak.get(c, 0), len(lst))
-        pk = np.array(list(peak.values()))
-        print("    traced blocks %d of %d; span %.0f ticks = %.4f ms -> %.2f GHz tick rate; blocks in flight %.0f (%.2f per CU of %d CUs "
-              "seen); peak co-resident blocks per CU: mean %.2f max %d" % (len(t), nblk, span, t_full, span / (t_full * 1e6), conc,
-                                                                           conc / len(peak), len(peak), pk.mean(), pk.max()))
+        # per CU (XCC id | SE, SH, CU bits of HW_ID): tick of the cycle counter against the 100 MHz real-time counter, how many
+        # blocks were co-resident, and how much of the kernel's duration the CU held at least one / two blocks
+        # (cycle counters of different XCDs are not synchronised: nothing is compared across CUs except real-time stamps)
+        cu = (t[:, 5] & 0xF) * 256 + ((t[:, 4] >> 8) & 0xFF)
+        rt0, rt1 = t[:, 6].astype(np.float64), t[:, 7].astype(np.float64)
+        life_rt = rt1 - rt0
+        big = life_rt > 0
+        tick_ghz = float(((t[big, 3] - t[big, 0]) / life_rt[big]).mean() * 0.1)
+        kern_us = float(rt1.max() - rt0.min()) * 0.01
+        first_us = (rt0 - rt0.min()) * 0.01
+        peaks, busy1, busy2, nper = [], [], [], []
+        for c in np.unique(cu):
+            sel = np.where(cu == c)[0]
+            ev = sorted([(rt0[i], 1) for i in sel] + [(rt1[i], -1) for i in sel])
+            live = peak = 0
+            b1 = b2 = 0.0
+            last = ev[0][0]
+            for when, d in ev:
+                if live >= 1:
+                    b1 += when - last
+                if live >= 2:
+                    b2 += when - last
+                last = when
+                live += d
+                peak = max(peak, live)
+            peaks.append(peak); busy1.append(b1 * 0.01); busy2.append(b2 * 0.01); nper.append(len(sel))
+        peaks, busy1, busy2, nper = map(np.array, (peaks, busy1, busy2, nper))
+        print("    traced blocks %d of %d on %d CUs (%d..%d per CU); cycle-counter tick %.3f GHz; kernel %.1f us by real-time stamps "
+              "(%.1f us by events); block start spread: median %.1f us, last %.1f us; per CU: peak co-resident mean %.2f max %d, "
+              ">=1 block %.1f us, >=2 blocks %.1f us" % (len(t), nblk, len(peaks), nper.min(), nper.max(), tick_ghz, kern_us,
+                                                        t_full * 1e3, float(np.median(first_us)), float(first_us.max()),
+                                                        peaks.mean(), peaks.max(), busy1.mean(), busy2.mean()))
         print("%s tile %d (%dx%d, %d blocks, %d slabs) %.1f TF | %s" % (name, tile, bm.value, bn.value, nblk, nslab,
                                                                        flops / t_full / 1e9, " | ".join(res)))
-        print("    per block: prologue %.0f  loop %.0f (%.0f / slab)  epilogue %.0f  total %.0f cycles; kernel span %.0f" % (
+        print("    per block: prologue %.0f  loop %.0f (%.0f / slab)  epilogue %.0f  total %.0f ticks" % (
             (t[:, 1] - t[:, 0]).mean(), (t[:, 2] - t[:, 1]).mean(), (t[:, 2] - t[:, 1]).mean() / nslab, (t[:, 3] - t[:, 2]).mean(),
-            (t[:, 3] - t[:, 0]).mean(), float(t[:, 3].max() - t[:, 0].min())), flush=True)
+            (t[:, 3] - t[:, 0]).mean()), flush=True)
