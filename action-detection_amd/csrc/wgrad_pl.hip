@@ -31,6 +31,8 @@ struct WgPlArgs {
     const void* x_hi;   // X planes at the slice's first channel group
     const void* x_lo;
     float* part;        // [splits][M][ldp]
+    unsigned long long* trace;   // tooling only (tools/trace_wgrad_pl.py): per-block phase timestamps, normally null
+    int dbg;                     // tooling only (-DPL_ABLATE builds): 1: fetch nothing, 2: X fragments of every third step only, 4: no fetch instructions
     const float* g_scale;
     const float* x_scale;
     int g_row_split, g_row_gap;   // rows m >= g_row_split of dY sit g_row_gap channels further up its tensor
@@ -43,8 +45,40 @@ struct WgPlArgs {
     uint32_t g_img_bytes, g_grp_bytes, x_img_bytes, x_grp_bytes;
     uint32_t g_bytes, x_bytes;    // per plane
     int splits, ksteps_per_split;
+    uint32_t magic_wp;            // nine-tap / chunked kernels: ceil(2^32 / padded row length)
     int n_mtiles, n_ctiles;
     FastDiv div_hw, div_w, div_tiles, div_ct, div_kk;
+};
+
+
+#ifdef PL_ABLATE
+#define WG_DBG(bit) (p.dbg & (bit))
+#else
+#define WG_DBG(bit) 0
+#endif
+
+// tooling: phase stamps of a block (cycle counter at start / loop start / loop end / end, HW_ID, XCC_ID, 100 MHz real time at start / end)
+struct WgTrace {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
+    __device__ void begin(const WgPlArgs& p) {
+        if (p.trace) {
+            t0 = __builtin_readcyclecounter();
+            r0 = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+    __device__ void mark1(const WgPlArgs& p) { if (p.trace) t1 = __builtin_readcyclecounter(); }
+    __device__ void mark2(const WgPlArgs& p) { if (p.trace) t2 = __builtin_readcyclecounter(); }
+    __device__ void end(const WgPlArgs& p) {
+        if (p.trace && threadIdx.x == 0) {
+            unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+            t[0] = t0; t[1] = t1; t[2] = t2;
+            t[3] = __builtin_readcyclecounter();
+            t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+            t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+            t[6] = r0;
+            t[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -62,12 +96,17 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
     constexpr int NPW = FA > FB ? FA : FB;        // DMA instructions per wave and k-step (the surplus ones are dummies)
     constexpr int PIECE = 256;                    // dwords of one fragment-plane
     constexpr int STAGE = 2 * (FA + FB) * PIECE;  // [dY: frag][plane] then [X: frag][plane]
+    // ring depth 3 (the k-step in registers + two in flight).  Deeper rings (4 - 6 slots, as many as the LDS share of a workgroup
+    // holds) were measured 8 - 10 % SLOWER on the 1x1 block-input layers, with the fetch switched off too: what the fetch costs
+    // this loop is not latency (tools/trace_wgrad_pl.py)
     constexpr int NSTAGE = 3;
     static_assert(WM * WC == 4, "4 waves");
 
     __shared__ __attribute__((aligned(1024))) uint32_t lds[NSTAGE * STAGE + PIECE];   // + the dummy piece
 
     const int tid = threadIdx.x;
+    WgTrace trc;
+    trc.begin(p);
     const int lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int wm = wave / WC, wc = wave % WC;
     const int li = lane & 31, lh = lane >> 5;
@@ -121,7 +160,7 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
 #pragma unroll
         for (int f = 0; f < NPW; ++f) {
             const bool real = f < myF;      // wave-uniform
-            WG_DMA_B128(rsrc, real ? base + f * 2 * PIECE : lds + NSTAGE * STAGE, real ? vo : PL_OOB, frag_so[f]);
+            WG_DMA_B128(rsrc, real ? base + f * 2 * PIECE : lds + NSTAGE * STAGE, (real && !WG_DBG(1)) ? vo : PL_OOB, frag_so[f]);
         }
     };
 
@@ -138,9 +177,8 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
     }
     const bool do_bias = wave_uniform((ct == 0 && tap == 0 && wc == 0) ? 1 : 0) != 0;
 
-    issue(ks_begin, 0);
-    issue(ks_begin + 1, STAGE);
-    issue(ks_begin + 2, 2 * STAGE);
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) issue(ks_begin + i, i * STAGE);
 
     // transposed fragment reads: lane (channel li, k-half lh) <- slots 8 lh + 0..7 of its channel, as two reads of 4 slots:
     // inside a 16-lane group, lane 4 j + q supplies channels 4 q .. 4 q + 3 of slot j
@@ -194,32 +232,37 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
         }
     };
 
-    SSN_WAIT_VMCNT(2 * NPW);
+    static_assert((NSTAGE - 1) * NPW <= 63, "vmcnt range");
+    SSN_WAIT_VMCNT((NSTAGE - 1) * NPW);
     __builtin_amdgcn_s_barrier();
     read_begin(0);
 #pragma unroll
     for (int k = 0; k < NREAD; ++k) read_step(fr0, k);
-    uint32_t s_cur = 0, s_n1 = STAGE, s_n2 = 2 * STAGE;
+    uint32_t st[NSTAGE];      // ring slots, oldest first: st[0] holds the k-step now in registers (free for the next fetch)
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) st[i] = (uint32_t)(i * STAGE);
     int ks = ks_begin;
     auto half = [&](Frags& cur, Frags& nxt) {
-        SSN_WAIT_VMCNT(NPW);
+        SSN_WAIT_VMCNT((NSTAGE - 2) * NPW);
         SSN_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        read_begin(s_n1);
-        mfma(cur, ks + 3, s_cur, nxt);
+        read_begin(st[1]);
+        mfma(cur, ks + NSTAGE, st[0], nxt);
         ++ks;
-        const uint32_t o = s_cur;
-        s_cur = s_n1;
-        s_n1 = s_n2;
-        s_n2 = o;
+        const uint32_t o = st[0];
+#pragma unroll
+        for (int i = 0; i + 1 < NSTAGE; ++i) st[i] = st[i + 1];
+        st[NSTAGE - 1] = o;
     };
+    trc.mark1(p);
     for (int t = 0; t < nks; t += 2) {
         half(fr0, fr1);
         half(fr1, fr0);
     }
     SSN_WAIT_LGKM0();
     SSN_WAIT_VMCNT(0);
+    trc.mark2(p);
 
     // ---- partial slab store: part[z][m][ci * KK + tap] ----
     const float inv = 1.f / (*p.g_scale * *p.x_scale);
@@ -248,6 +291,7 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
                 if (m < p.M) out[(long)m * p.ldp + p.K] = accb[i][r] * ginv;
             }
     }
+    trc.end(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -265,10 +309,17 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
 // chunk and barrier; waves 0/1 fetch the planes of dY, waves 2/3 those of X.
 // KK = 1 (1x1 layers): the same chunked pipeline without borders or halo -- 64 plain pixel slots per chunk, 4 k-steps per barrier
 // instead of the one-tap kernel's single one, register tiles up to 64 x 64 per wave.
-template <int KK, int TM, int TC, int XP>
-__global__ __launch_bounds__(256, (KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) void wgrad_pl9_kernel(WgPlArgs p) {
+// KG = 2: EIGHT waves -- two groups of four, each with its own accumulators over the same output tile, splitting the four
+// k-steps of every chunk between them (partial slabs z * 2 + group).  For the layers whose LDS footprint leaves room for one
+// workgroup per CU only: a lone wave per SIMD keeps the matrix pipe 45 % busy in this loop (nobody covers its LDS round
+// trips and DMA address arithmetic), two waves per SIMD 80 % (tools/trace_wgrad_pl.py).
+template <int KK, int TM, int TC, int XP, int KG = 1>
+__global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) void wgrad_pl9_kernel(WgPlArgs p) {
     constexpr int NS = 64, KSC = NS / 16;
+    constexpr int KSG = KSC / KG;                      // k-steps of a chunk per wave group
     static_assert(KK == 1 || KK == 9, "1x1 or 3x3");
+    static_assert(KG == 1 || KG == 2, "one or two wave groups");
+    static_assert(XP % KG == 0, "X pieces split evenly between the wave groups");
     constexpr int BM = 2 * TM * 32, BC = 2 * TC * 32;
     constexpr int FA = BM / 32, FB = BC / 32;
     constexpr int A_BYTES = FA * 2 * KSC * 1024;     // [frag][plane][64 slots][32 ch]
@@ -277,7 +328,10 @@ __global__ __launch_bounds__(256, (KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) 
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    WgTrace trc;
+    trc.begin(p);
+    const int lane = tid & 63, wave8 = wave_uniform(tid >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;     // grp: which k-steps of a chunk (and which share of the DMA pieces)
     const int wm = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -312,35 +366,44 @@ __global__ __launch_bounds__(256, (KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) 
     int ck_end = ck_begin + p.ksteps_per_split;
     if (ck_end > total_ck) ck_end = total_ck;
 
-    // byte offset of the pixel behind padded slot `sl` inside a plane of this wave's operand, or out of range (border / past the end)
-    auto slot_offset = [&](int sl) -> uint32_t {
-        const bool in = (uint32_t)sl < T;
-        uint32_t n, u, hp, wp;
-        fd_divmod((uint32_t)(in ? sl : 0), p.div_hw, n, u);     // div_hw = SP
-        fd_divmod(u, p.div_w, hp, wp);                          // div_w = Wp
-        const bool real = in && hp >= (uint32_t)BORDER && wp >= (uint32_t)BORDER;
-        return real ? n * img_bytes + ((hp - BORDER) * (uint32_t)p.W + (wp - BORDER)) * 16u + lane_grp : PL_OOB;
-    };
-    auto issue = [&](int ck, int buf) {
+    // ---- operand fetch: piece q of this wave = 16 slots x 32 channels x FA (FB) fragments of its plane.  Each lane walks ONE slot
+    // per piece through the padded pixel space, 64 slots further per chunk: (position inside the padded image, byte offset of
+    // the image) are carried in registers and advanced with a compare-and-wrap, the row / column split is one mulhi with
+    // p.magic_wp = ceil(2^32 / Wp) (exact below 2^16) -- a dozen VALU per piece where two 64-bit fast divisions took forty.
+    constexpr int NPMAX = (XP > KSC ? XP : KSC) / KG;
+    const int npieces = wave_uniform(op ? XP / KG : KSC / KG);
+    const int lane_slot0 = (op ? -D : 0) + dsl;                   // slot of this lane in piece sg of chunk 0: lane_slot0 + 16 sg
+    const uint32_t adv_img = (uint32_t)(NS / SP) * img_bytes, adv_u = (uint32_t)(NS % SP);
+    uint32_t pu[NPMAX], pn[NPMAX];
+#pragma unroll
+    for (int q = 0; q < NPMAX; ++q) {
+        const int sl = ck_begin * NS + lane_slot0 + (q * KG + grp) * 16;
+        uint32_t n, u;
+        fd_divmod((uint32_t)(sl < 0 ? sl + SP : sl), p.div_hw, n, u);       // div_hw = SP;  D <= SP: one image back at most
+        pu[q] = u;
+        pn[q] = (n - (sl < 0 ? 1u : 0u)) * img_bytes;                      // (wraps for the slots in front of image 0: never used)
+    }
+    auto issue_piece = [&](int ck, int buf, int q) {    // piece q of chunk ck -> buffer buf; the lane's state moves on to chunk ck + 1
+        if (q >= npieces || (WG_DBG(4) && ck > ck_begin)) return;
+        const int sg = q * KG + grp;
+        const int sl = ck * NS + lane_slot0 + sg * 16;
+        const uint32_t hp = __umulhi(pu[q], p.magic_wp), wp = pu[q] - hp * (uint32_t)Wp;
+        const bool real = ck < ck_end && (uint32_t)sl < T && hp >= (uint32_t)BORDER && wp >= (uint32_t)BORDER && !WG_DBG(1);
+        const uint32_t vo = real ? pn[q] + ((hp - BORDER) * (uint32_t)p.W + (wp - BORDER)) * 16u + lane_grp : PL_OOB;
         unsigned char* base = lds + buf * STAGE;
-        const bool live = ck < ck_end;
         if (op == 0) {
 #pragma unroll
-            for (int sg = 0; sg < KSC; ++sg) {
-                const uint32_t vo = live ? slot_offset(ck * NS + sg * 16 + dsl) : PL_OOB;
-#pragma unroll
-                for (int f = 0; f < FA; ++f)
-                    WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + ((f * 2 + plane) * KSC + sg) * 1024), vo, frag_so[f]);
-            }
+            for (int f = 0; f < FA; ++f)
+                WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + ((f * 2 + plane) * KSC + sg) * 1024), vo, frag_so[f]);
         } else {
 #pragma unroll
-            for (int sg = 0; sg < XP; ++sg) {
-                const uint32_t vo = live ? slot_offset(ck * NS - D + sg * 16 + dsl) : PL_OOB;
-#pragma unroll
-                for (int f = 0; f < FB; ++f)
-                    WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + A_BYTES + ((f * 2 + plane) * XP + sg) * 1024), vo, frag_so[f]);
-            }
+            for (int f = 0; f < FB; ++f)
+                WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + A_BYTES + ((f * 2 + plane) * XP + sg) * 1024), vo, frag_so[f]);
         }
+        uint32_t u = pu[q] + adv_u, im = pn[q] + adv_img;
+        const bool wrap = u >= (uint32_t)SP;
+        pu[q] = wrap ? u - (uint32_t)SP : u;
+        pn[q] = wrap ? im + img_bytes : im;
     };
 
     f32x16 acc[KK][TM][TC];
@@ -372,41 +435,60 @@ __global__ __launch_bounds__(256, (KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) 
         return __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
     };
 
-    issue(ck_begin, 0);
+#pragma unroll
+    for (int q = 0; q < NPMAX; ++q) issue_piece(ck_begin, 0, q);
     int buf = 0;
+    trc.mark1(p);
     for (int ck = ck_begin; ck < ck_end; ++ck) {
         SSN_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();          // chunk ck is complete in `buf`; everybody is done reading the other buffer
-        issue(ck + 1, buf ^ 1);
-        const unsigned char* ab = lds + buf * STAGE + lane_rd;
+        const unsigned char* ab = lds + buf * STAGE + lane_rd + grp * (KSG * 1024);   // this group's k-steps of the chunk
         const unsigned char* xb = ab + A_BYTES;
-        // 36 (k-step, tap) steps per chunk, fully unrolled; the X fragments run TWO steps ahead of the MFMAs in three rotating
-        // register sets and the dY fragments one k-step ahead in two (one wave per SIMD at the larger tiles: nobody else
-        // hides the ~100+ cycles of an LDS round trip)
-        constexpr int NSTEP = KSC * KK;
-        f16x8 af[2][2][TM], bf[3][2][TC];      // af[set][plane][i], bf[set][plane][j]
+        // KSG x KK (k-step, tap) steps per chunk, taken in PAIRS: the three products of a step accumulate into the same registers,
+        // and a matrix instruction that waits for its predecessor's result runs at half the pipe's rate -- alternating the
+        // products of two steps (two taps = two accumulator sets) keeps consecutive instructions independent.  The X fragments
+        // run one pair ahead of the MFMAs (four rotating register sets), the dY fragments one k-step ahead; the fetch of the
+        // next chunk goes out one piece per pair, its address arithmetic in the shadow of the MFMAs.
+        constexpr int NSTEP = KSG * KK, NPAIR = NSTEP / 2;
+        static_assert(NSTEP % 2 == 0, "steps come in pairs");
+        constexpr int NA = KK == 1 ? 4 : 2;    // 1x1: every step is its own k-step
+        f16x8 af[NA][2][TM], bf[4][2][TC];     // af[set][plane][i], bf[set][plane][j]
         auto read_b = [&](int step, int set) {
             const int ks = step / KK, t = step % KK;
 #pragma unroll
-            for (int pn = 0; pn < 2; ++pn)
+            for (int pn_ = 0; pn_ < 2; ++pn_)
 #pragma unroll
                 for (int j = 0; j < TC; ++j)
-                    bf[set][pn][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn) * XP * 1024 + ks * 1024 + tapoff[t]);
+                    bf[set][pn_][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn_) * XP * 1024 + ks * 1024 + tapoff[t]);
         };
         auto read_a = [&](int ks, int set) {
 #pragma unroll
-            for (int pn = 0; pn < 2; ++pn)
+            for (int pn_ = 0; pn_ < 2; ++pn_)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[set][pn][i] = rd_frag(ab + (((wm * TM + i) * 2 + pn) * KSC + ks) * 1024);
+                for (int i = 0; i < TM; ++i) af[set][pn_][i] = rd_frag(ab + (((wm * TM + i) * 2 + pn_) * KSC + ks) * 1024);
         };
         read_a(0, 0);
+        if (KK == 1) read_a(1, 1);
         read_b(0, 0);
         read_b(1, 1);
 #pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-            const int ks = step / KK, t = step % KK;
-            if (t == (KK > 1 ? 1 : 0) && ks + 1 < KSC) read_a(ks + 1, (ks + 1) & 1);
-            if (step + 2 < NSTEP) read_b(step + 2, (step + 2) % 3);
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            const int s0 = 2 * pr, s1 = s0 + 1;
+            const int ks0 = s0 / KK, t0 = s0 % KK, ks1 = s1 / KK, t1 = s1 % KK;
+            if (KK == 1) {
+                if (ks0 + 2 < KSG) read_a(ks0 + 2, (ks0 + 2) % NA);
+                if (ks1 + 2 < KSG) read_a(ks1 + 2, (ks1 + 2) % NA);
+            } else {
+                if (t0 == 1 && ks0 + 1 < KSG) read_a(ks0 + 1, (ks0 + 1) % NA);
+                if (t1 == 1 && ks1 + 1 < KSG) read_a(ks1 + 1, (ks1 + 1) % NA);
+            }
+            if (s0 + 2 < NSTEP && !(WG_DBG(2) && (s0 + 2) % 3)) read_b(s0 + 2, (s0 + 2) % 4);
+            if (s1 + 2 < NSTEP && !(WG_DBG(2) && (s1 + 2) % 3)) read_b(s1 + 2, (s1 + 2) % 4);
+            // (all pieces within the first third of the chunk: what bounds the lone-workgroup layers is the fetch itself)
+            constexpr int PPP = (NPMAX + 5) / 6;
+#pragma unroll
+            for (int e = 0; e < PPP; ++e)
+                if (pr * PPP + e < NPMAX) issue_piece(ck + 1, buf ^ 1, pr * PPP + e);
             constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_hi + g_hi x_lo
             constexpr int PB[3] = {0, 0, 1};
 #pragma unroll
@@ -414,23 +496,36 @@ __global__ __launch_bounds__(256, (KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) 
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TC; ++j)
-                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][PA[c]][i], bf[step % 3][PB[c]][j], acc[t][i][j],
-                                                                              0, 0, 0);
-            if (t == KK - 1 && do_bias) {
+                    for (int j = 0; j < TC; ++j) {
+                        acc[t0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks0 % NA][PA[c]][i], bf[s0 % 4][PB[c]][j], acc[t0][i][j],
+                                                                               0, 0, 0);
+                        acc[t1][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks1 % NA][PA[c]][i], bf[s1 % 4][PB[c]][j], acc[t1][i][j],
+                                                                               0, 0, 0);
+                    }
+            if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][0][i], ones, accb[i], 0, 0, 0);
-                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][1][i], ones, accb[i], 0, 0, 0);
+                for (int e = 0; e < 2; ++e) {
+                    const int ks = e ? ks1 : ks0, t = e ? t1 : t0;
+                    if (t != KK - 1) continue;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks % NA][0][i], ones, accb[i], 0, 0, 0);
+                        accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks % NA][1][i], ones, accb[i], 0, 0, 0);
+                    }
                 }
             }
+        }
+        if (NPMAX > NPAIR * ((NPMAX + 5) / 6)) {
+#pragma unroll
+            for (int q = NPAIR * ((NPMAX + 5) / 6); q < NPMAX; ++q) issue_piece(ck + 1, buf ^ 1, q);
         }
         buf ^= 1;
     }
     SSN_WAIT_VMCNT(0);
+    trc.mark2(p);
 
     const float inv = 1.f / (*p.g_scale * *p.x_scale);
-    float* out = p.part + (long)z * p.M * p.ldp;
+    float* out = p.part + ((long)z * KG + grp) * p.M * p.ldp;
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
         const int ci = c0 + (wc * TC + j) * 32 + li;
@@ -456,11 +551,12 @@ __global__ __launch_bounds__(256, (KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) 
                 if (m < p.M) out[(long)m * p.ldp + p.K] = accb[i][r] * ginv;
             }
     }
+    trc.end(p);
 }
 
 #undef WG_DMA_B128
 
-template <int KK, int TM, int TC, int XP>
+template <int KK, int TM, int TC, int XP, int KG = 1>
 int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {
     constexpr int BM = 2 * TM * 32, BC = 2 * TC * 32;
     a.n_mtiles = (a.M + BM - 1) / BM;
@@ -468,16 +564,19 @@ int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {
     const unsigned tiles = (unsigned)a.n_mtiles * (unsigned)a.n_ctiles;
     a.div_tiles = make_fastdiv(tiles);
     a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
-    hipLaunchKernelGGL((wgrad_pl9_kernel<KK, TM, TC, XP>), dim3(tiles * (unsigned)a.splits), dim3(256), 0, stream, a);
+    a.magic_wp = 0xFFFFFFFFu / (uint32_t)(a.W + (KK > 1 ? 1 : 0)) + 1u;
+    hipLaunchKernelGGL((wgrad_pl9_kernel<KK, TM, TC, XP, KG>), dim3(tiles * (unsigned)a.splits), dim3(256 * KG), 0, stream, a);
     SSN_CHECK_LAUNCH("wgrad_pl9");
     return SSN_OK;
 }
 
 // nine-tap tile configs (output channels x input channels): 0: 64 x 64   1: 128 x 64   2: 64 x 128
-constexpr int N9 = 3;
-const int k9BM[N9] = {64, 128, 64};
-const int k9BC[N9] = {64, 64, 128};
-const int k9Occ[N9] = {1, 1, 1};
+// 3: 64 x 64 with eight waves (two groups splitting the k-steps of each chunk: twice the partial slabs)
+constexpr int N9 = 4;
+const int k9BM[N9] = {64, 128, 64, 64};
+const int k9BC[N9] = {64, 64, 128, 64};
+const int k9Occ[N9] = {1, 1, 1, 1};
+const int k9KG[N9] = {1, 1, 1, 2};
 
 template <int XP>
 int launch_wgpl9_xp(WgPlArgs& a, int cfg, hipStream_t stream) {
@@ -485,6 +584,7 @@ int launch_wgpl9_xp(WgPlArgs& a, int cfg, hipStream_t stream) {
         case 0: return launch_wgpl9<9, 1, 1, XP>(a, stream);
         case 1: return launch_wgpl9<9, 2, 1, XP>(a, stream);
         case 2: return launch_wgpl9<9, 1, 2, XP>(a, stream);
+        case 3: return launch_wgpl9<9, 1, 1, XP, 2>(a, stream);
     }
     ssn_set_error("conv_wgrad_pl (nine taps): unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -495,7 +595,8 @@ int launch_wgpl9_tile(WgPlArgs& a, int cfg, hipStream_t stream) {
     const int xp = xp_for(a.W);
     if (xp <= 6) return launch_wgpl9_xp<6>(a, cfg, stream);
     if (xp <= 8) return launch_wgpl9_xp<8>(a, cfg, stream);
-    return launch_wgpl9<9, 1, 1, 12>(a, stream);   // wide rows: only the 64 x 64 tile fits two buffers into the LDS
+    // wide rows: only the 64 x 64 tiles fit two buffers into the LDS
+    return cfg == 3 ? launch_wgpl9<9, 1, 1, 12, 2>(a, stream) : launch_wgpl9<9, 1, 1, 12>(a, stream);
 }
 // chunked 1x1 tile configs (tile_cfg 200 + i): 0: 64 x 64   1: 128 x 64   2: 64 x 128   3: 128 x 128
 constexpr int N1 = 4;
@@ -525,7 +626,7 @@ int pick_tile9(int M, int Cin, int W) {
     if (xp_for(W) > 8) return 0;
     double best = 1e300;
     int bc = 0;
-    for (int c = 0; c < N9; ++c) {
+    for (int c = 0; c < 3; ++c) {
         const double padded = (double)((M + k9BM[c] - 1) / k9BM[c]) * k9BM[c] * (double)((Cin + k9BC[c] - 1) / k9BC[c]) * k9BC[c];
         const double small = c == 0 ? 1.1 : 1.0;
         if (padded * small < best) {
@@ -539,7 +640,7 @@ void plan9(int M, int Cin, long slots, int cfg, int W, int* splits, int* chunks_
     const long tiles = (long)((M + k9BM[cfg] - 1) / k9BM[cfg]) * ((Cin + k9BC[cfg] - 1) / k9BC[cfg]);
     const long chunks = (slots + 63) / 64;
     // the 64 x 64 tile on rows of <= 14 pixels: 80 KiB of LDS, two workgroups per CU
-    const int occ = (cfg == 0 && xp_for(W) <= 6) ? 2 : k9Occ[cfg];
+    const int occ = (cfg == 0 && xp_for(W) <= 6) ? 2 : k9Occ[cfg];     // (config 3: one workgroup of eight waves)
     plan_split_k(tiles, chunks, occ, 4, 2, 0.005 + (double)M * Cin * 9 * 1.7e-6, splits, chunks_per_split);
 }
 bool nine_tap_layer(int kh, int kw, int stride, int pad_h, int pad_w, int H, int W, int Ho, int Wo) {
@@ -615,7 +716,14 @@ int fix_cfg(int tile_cfg, int M, int Cin) {
     return (tile_cfg >= 0 && tile_cfg < NCFG) ? tile_cfg : pick_tile(M, Cin);
 }
 
+unsigned long long* g_wg_trace = nullptr;
+int g_wg_dbg = 0;
+
 }  // namespace
+
+// tooling (tools/trace_wgrad_pl.py): per-block phase stamps of the next launches into buf (8 qwords per block), null = off
+extern "C" void ssn_conv_wgrad_pl_debug_trace(unsigned long long* buf) { g_wg_trace = buf; }
+extern "C" void ssn_conv_wgrad_pl_debug_flags(int flags) { g_wg_dbg = flags; }
 
 extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
 
@@ -632,7 +740,7 @@ extern "C" long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int 
         const int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, Wo);
         int splits9, cps9;
         plan9(Cout, Cin, (long)N * (Ho + 1) * (Wo + 1), c9 < N9 ? c9 : 0, Wo, &splits9, &cps9);
-        const long need9 = (long)splits9 * Cout * ((long)Cin * 9 + 1) * (long)sizeof(float);
+        const long need9 = (long)splits9 * k9KG[c9 < N9 ? c9 : 0] * Cout * ((long)Cin * 9 + 1) * (long)sizeof(float);
         if (tile_cfg >= 100) return need9;
         const int cfg1 = fix_cfg(-1, Cout, Cin);
         int s1, k1;
@@ -665,6 +773,8 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
     a.x_hi = x_hi;
     a.x_lo = x_lo;
     a.part = (float*)workspace;
+    a.trace = g_wg_trace;
+    a.dbg = g_wg_dbg;
     a.g_scale = g_scale;
     a.x_scale = x_scale;
     a.g_row_split = g_row_gap ? g_row_split : 0x7fffffff;
@@ -717,9 +827,9 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
     if ((tile_cfg >= 100 || tile_cfg < 0) && nine_tap_layer(kh, kw, stride, pad_h, pad_w, H, W, Ho, Wo)) {
         int c9 = tile_cfg >= 100 ? tile_cfg - 100 : pick_tile9(Cout, Cin, W);
         SSN_CHECK_ARG(c9 < N9, "conv wgrad pl: unknown nine-tap tile %d", c9);
-        if (xp_for(W) > 8) c9 = 0;
+        if (xp_for(W) > 8 && c9 != 3) c9 = 0;
         plan9(Cout, Cin, (long)N * (H + 1) * (W + 1), c9, W, &a.splits, &a.ksteps_per_split);
-        const long need9 = (long)a.splits * Cout * a.ldp * (long)sizeof(float);
+        const long need9 = (long)a.splits * k9KG[c9] * Cout * a.ldp * (long)sizeof(float);
         if (ws_bytes < need9) {
             ssn_set_error("conv wgrad pl: workspace %ld < %ld bytes", ws_bytes, need9);
             return SSN_ERR_WORKSPACE;
@@ -728,7 +838,7 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
         a.div_w = make_fastdiv((uint32_t)(W + 1));
         const int rc9 = launch_wgpl9_tile(a, c9, stream);
         if (rc9 != SSN_OK) return rc9;
-        return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
+        return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits * k9KG[c9], stream);
     }
     SSN_CHECK_ARG(tile_cfg < 100, "conv wgrad pl: the nine-tap kernel takes 3x3 / stride 1 / pad 1 layers only");
     const int cfg = fix_cfg(tile_cfg, Cout, Cin);

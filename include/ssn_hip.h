@@ -434,6 +434,8 @@ int ssn_conv_pl_tiles(void);
 int ssn_conv_pl_tile_shape(int cfg, int* bm, int* bn);
 void ssn_conv_pl_debug_flags(int flags);                    /* tooling (tools/ablate_conv_pl.py) */
 void ssn_conv_pl_debug_trace(unsigned long long* buf);
+void ssn_conv_wgrad_pl_debug_trace(unsigned long long* buf); /* tooling (tools/trace_wgrad_pl.py) */
+void ssn_conv_wgrad_pl_debug_flags(int flags);
 /* nn.MaxPool2d(ceil_mode) of the backbone manifest forward / backward (uint8 window-local argmax, torch's tie rule; dx_f32:
  * write the input gradient as fp32 NCHW instead), the 3x3 average pool behind its 1x1 projection (+ affine + ReLU; without
  * affine: its backward stencil), the ReLU / frozen-BN backward of a slice, global average pool forward / backward, and the

@@ -368,6 +368,7 @@ static inline uint32_t __builtin_amdgcn_perm(uint32_t s0, uint32_t s1, uint32_t 
     return out;
 }
 #define __builtin_amdgcn_s_getreg(x) 0
+#define __builtin_amdgcn_s_memrealtime() 0ull
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)   /* only used on wave-uniform values */
 struct __amdgpu_buffer_rsrc_t {

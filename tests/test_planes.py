@@ -202,7 +202,7 @@ def test_conv_pl_wgrad(backend):
         P.from_f32(backend.put(x), P.PSlice(xt, 8, cin))
         tiles = list(range(ntiles)) if ci in (0, 2) else [-1]
         if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1):
-            tiles += [100, 101, 102]          # the nine-tap kernel's tiles
+            tiles += [100, 101, 102, 103]     # the nine-tap kernel's tiles
         if (kh, kw, s, ph, pw) == (1, 1, 1, 0, 0):
             tiles += [200, 201, 202, 203]     # the chunked 1x1 kernel's tiles
         for tile in tiles:

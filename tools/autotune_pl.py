@@ -58,6 +58,7 @@ def main():
     except (OSError, ValueError):
         table = {}
     tiles, ms = table.get("tiles", {}), table.get("ms", {})
+    kinds = os.environ.get("KINDS", "fwd,dgrad,wgrad").split(",")      # KINDS=wgrad: re-tune the weight gradients only
     g = torch.Generator().manual_seed(0)
     for plan, shapes in plans:
         for op in plan:
@@ -92,18 +93,20 @@ def main():
             pw_ = p_ if not rect else pw
             # ---- forward
             res = {}
-            for t in range(nfwd):
+            for t in (range(nfwd) if "fwd" in kinds else []):
                 fn = lambda: P.conv_fwd(xs, wp, sc, sh, P.pfull(yp), k_, kw_, s_, p_, pw_, True, t)  # noqa: E731
                 fn()
                 yp.pool.update()
                 res[t] = timeit(fn)
-            best = min(res, key=res.get)
-            tiles["fwd|" + key], ms["fwd|" + key] = best, round(res[best], 4)
-            line = "%-28s fwd tile %2d %.4f ms" % (key, best, res[best])
+            line = "%-28s" % key
+            if res:
+                best = min(res, key=res.get)
+                tiles["fwd|" + key], ms["fwd|" + key] = best, round(res[best], 4)
+                line += " fwd tile %2d %.4f ms" % (best, res[best])
             # ---- dgrad (not for the first layer)
             gy = (torch.randn(n, cout, ho, wo, generator=g) * 1e-3).to(dev)
             gp = P.from_f32(gy)
-            if op["src"] != "data":
+            if op["src"] != "data" and "dgrad" in kinds:
                 dxp = P.PlaneTensor(n, cin, hin, hin, dev)
                 msc = torch.ones(cin, device=dev)
                 res = {}
@@ -127,9 +130,12 @@ def main():
                 tiles["dgrad|" + key], ms["dgrad|" + key] = best, round(res[best], 4)
                 line += " | dgrad tile %2d %.4f ms" % (best, res[best])
             # ---- wgrad
+            if "wgrad" not in kinds:
+                print(line, flush=True)
+                continue
             dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
             res = {}
-            cand = list(range(nwg)) + ([100, 101, 102] if (k_, kw_, s_, p_, pw_) == (3, 3, 1, 1, 1) and ho == xh else [])
+            cand = list(range(nwg)) + ([100, 101, 102, 103] if (k_, kw_, s_, p_, pw_) == (3, 3, 1, 1, 1) and ho == xh else [])
             cand += [200, 201, 202, 203] if (k_, kw_, s_, p_, pw_) == (1, 1, 1, 0, 0) else []
             for t in cand:
                 ws = torch.empty(P.wgrad_workspace_bytes(n, xc, cout, ho, wo, k_, kw_, t) // 4 + 4, device=dev)

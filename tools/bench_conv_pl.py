@@ -123,7 +123,7 @@ def main():
             gp, xp = P.from_f32(gy), P.from_f32(x)
             nt = int(_lib.get_lib().cdll.ssn_conv_wgrad_pl_tiles())
             res = {}
-            for tile in list(range(nt)) + ([100, 101, 102] if (k, s, p) == (3, 1, 1) else []):
+            for tile in list(range(nt)) + ([100, 101, 102, 103] if (k, s, p) == (3, 1, 1) else []):
                 ws2 = torch.empty(P.wgrad_workspace_bytes(n, cin, cout, ho, ho, k, k, tile) // 4, device=dev)
                 res[tile] = timeit(lambda: P.conv_wgrad(P.pfull(gp), P.pfull(xp), dw, db, k, k, s, p, p, ws2, tile))
             best = min(res, key=res.get)
