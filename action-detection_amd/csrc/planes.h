@@ -93,12 +93,19 @@ __device__ __forceinline__ void pl_store_b128(u32x4 v, __amdgpu_buffer_rsrc_t r,
 // gfx950 LDS transpose read: every lane supplies the address of 4 consecutive f16 (8-byte aligned); inside each group of 16
 // lanes, lanes 4j..4j+3 supply row j (16 elements) and lane c receives column c of rows 0..3.  (The host emulator of the
 // CPU test tier supplies its own definition.)
-#ifndef SSN_DS_READ_TR16_B64
+#ifndef SSN_DS_READ_TR16_B64_AT
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef short pl_v4i16 __attribute__((ext_vector_type(4)));
-#define SSN_DS_READ_TR16_B64(ptr) \
-    __builtin_bit_cast(pl::u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) pl_v4i16*)(ptr)))
+// ds_read_b64_tr_b16 of the LDS bytes at ptr + imm (imm: compile-time constant < 64 KiB).  INLINE ASM, not
+// __builtin_amdgcn_ds_read_tr16_b64_*: the compiler cannot tell what an LDS access through the builtin aliases, so it puts
+// `s_waitcnt vmcnt(0)` -- wait for EVERY LDS-DMA fetch in flight, the ones just issued for later k-steps included -- in front of
+// the first such read after each fetch instruction, which serialises fetch and compute (measured: the weight-gradient loops ran
+// 25 - 45 % of the matrix pipe).  The asm form is invisible to that bookkeeping, so the CALLER orders it against the DMA
+// (SSN_WAIT_VMCNT + barrier) and waits for the result (SSN_WAIT_LGKM0 + sched_barrier) before its first use.
+#define SSN_DS_READ_TR16_B64_AT(dst, ptr, imm)                                                                      \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                              \
+                 : "=v"(dst)                                                                                        \
+                 : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(ptr)), "n"(imm))
 #else
-#define SSN_DS_READ_TR16_B64(ptr) (pl::u32x2{0u, 0u})
+#define SSN_DS_READ_TR16_B64_AT(dst, ptr, imm) ((dst) = pl::u32x2{0u, 0u})
 #endif
 #endif

@@ -189,15 +189,24 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
     };
     Frags fr0, fr1;
     constexpr int NREAD = 2 * (TM + TC);
-    const uint32_t* rd_base;
-    auto read_begin = [&](uint32_t st_off) { rd_base = lds + st_off + lane_rd; };
+    // (asm reads, see planes.h: nothing the compiler orders or waits for -- the SSN_WAIT_LGKM0 at the head of every k-step does)
+    const uint32_t *rd_a, *rd_b;
+    auto read_begin = [&](uint32_t st_off) {
+        rd_a = lds + st_off + lane_rd + (wm * TM * 2) * PIECE;
+        rd_b = lds + st_off + lane_rd + (2 * FA + wc * TC * 2) * PIECE;
+    };
     auto read_step = [&](Frags& f, int k) {   // k is a compile-time constant at every call site
         const bool isb = k >= 2 * TM;
         const int kk = isb ? k - 2 * TM : k;
         const int pn = kk & 1, i = kk >> 1;
-        const uint32_t* src = rd_base + (isb ? (2 * FA + (wc * TC + i) * 2 + pn) : ((wm * TM + i) * 2 + pn)) * PIECE;
-        const u32x2 r0 = SSN_DS_READ_TR16_B64(src);
-        const u32x2 r1 = SSN_DS_READ_TR16_B64(src + 64);
+        u32x2 r0, r1;
+        if (isb) {
+            SSN_DS_READ_TR16_B64_AT(r0, rd_b, (i * 2 + pn) * PIECE * 4);
+            SSN_DS_READ_TR16_B64_AT(r1, rd_b, (i * 2 + pn) * PIECE * 4 + 256);
+        } else {
+            SSN_DS_READ_TR16_B64_AT(r0, rd_a, (i * 2 + pn) * PIECE * 4);
+            SSN_DS_READ_TR16_B64_AT(r1, rd_a, (i * 2 + pn) * PIECE * 4 + 256);
+        }
         const f16x8 v = __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
         if (isb)
             f.b[pn][i] = v;
@@ -429,11 +438,14 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
     for (int t = 0; t < KK; ++t) tapoff[t] = KK > 1 ? (D + (t / 3 - 1) * Wp + (t % 3 - 1)) * 64 : 0;
     const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u});
 
-    auto rd_frag = [&](const unsigned char* src) -> f16x8 {
-        const u32x2 r0 = SSN_DS_READ_TR16_B64(src);
-        const u32x2 r1 = SSN_DS_READ_TR16_B64(src + 256);
-        return __builtin_bit_cast(f16x8, u32x4{r0[0], r0[1], r1[0], r1[1]});
-    };
+    // (asm reads, see planes.h: the SSN_WAIT_LGKM0 at the head of every step pair is what waits for them)
+#define WG_RD_FRAG(dst_, base_, imm_)                                                \
+    do {                                                                             \
+        u32x2 r0_, r1_;                                                              \
+        SSN_DS_READ_TR16_B64_AT(r0_, base_, imm_);                                   \
+        SSN_DS_READ_TR16_B64_AT(r1_, base_, (imm_) + 256);                           \
+        dst_ = __builtin_bit_cast(f16x8, u32x4{r0_[0], r0_[1], r1_[0], r1_[1]});     \
+    } while (0)
 
 #pragma unroll
     for (int q = 0; q < NPMAX; ++q) issue_piece(ck_begin, 0, q);
@@ -442,8 +454,9 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
     for (int ck = ck_begin; ck < ck_end; ++ck) {
         SSN_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();          // chunk ck is complete in `buf`; everybody is done reading the other buffer
-        const unsigned char* ab = lds + buf * STAGE + lane_rd + grp * (KSG * 1024);   // this group's k-steps of the chunk
-        const unsigned char* xb = ab + A_BYTES;
+        // this wave's fragment rows of this group's k-steps of the chunk
+        const unsigned char* ab = lds + buf * STAGE + lane_rd + grp * (KSG * 1024) + wm * (TM * 2 * KSC * 1024);
+        const unsigned char* xb = lds + buf * STAGE + lane_rd + grp * (KSG * 1024) + A_BYTES + wc * (TC * 2 * XP * 1024);
         // KSG x KK (k-step, tap) steps per chunk, taken in PAIRS: the three products of a step accumulate into the same registers,
         // and a matrix instruction that waits for its predecessor's result runs at half the pipe's rate -- alternating the
         // products of two steps (two taps = two accumulator sets) keeps consecutive instructions independent.  The X fragments
@@ -455,17 +468,17 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
         f16x8 af[NA][2][TM], bf[4][2][TC];     // af[set][plane][i], bf[set][plane][j]
         auto read_b = [&](int step, int set) {
             const int ks = step / KK, t = step % KK;
+            const unsigned char* xt = xb + tapoff[t];
 #pragma unroll
             for (int pn_ = 0; pn_ < 2; ++pn_)
 #pragma unroll
-                for (int j = 0; j < TC; ++j)
-                    bf[set][pn_][j] = rd_frag(xb + ((wc * TC + j) * 2 + pn_) * XP * 1024 + ks * 1024 + tapoff[t]);
+                for (int j = 0; j < TC; ++j) WG_RD_FRAG(bf[set][pn_][j], xt, (j * 2 + pn_) * XP * 1024 + ks * 1024);
         };
         auto read_a = [&](int ks, int set) {
 #pragma unroll
             for (int pn_ = 0; pn_ < 2; ++pn_)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[set][pn_][i] = rd_frag(ab + (((wm * TM + i) * 2 + pn_) * KSC + ks) * 1024);
+                for (int i = 0; i < TM; ++i) WG_RD_FRAG(af[set][pn_][i], ab, ((i * 2 + pn_) * KSC + ks) * 1024);
         };
         read_a(0, 0);
         if (KK == 1) read_a(1, 1);
@@ -475,6 +488,8 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
         for (int pr = 0; pr < NPAIR; ++pr) {
             const int s0 = 2 * pr, s1 = s0 + 1;
             const int ks0 = s0 / KK, t0 = s0 % KK, ks1 = s1 / KK, t1 = s1 % KK;
+            SSN_WAIT_LGKM0();                       // the fragments of this pair (read during the previous one) are in
+            __builtin_amdgcn_sched_barrier(0);
             if (KK == 1) {
                 if (ks0 + 2 < KSG) read_a(ks0 + 2, (ks0 + 2) % NA);
                 if (ks1 + 2 < KSG) read_a(ks1 + 2, (ks1 + 2) % NA);
@@ -555,6 +570,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
 }
 
 #undef WG_DMA_B128
+#undef WG_RD_FRAG
 
 template <int KK, int TM, int TC, int XP, int KG = 1>
 int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {

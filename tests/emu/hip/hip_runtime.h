@@ -466,6 +466,7 @@ static inline emu_u32x2 emu_ds_read_tr16_b64(const void* addr) {
     return emu_u32x2{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
 }
 #define SSN_DS_READ_TR16_B64(ptr) emu_ds_read_tr16_b64(ptr)
+#define SSN_DS_READ_TR16_B64_AT(dst, ptr, imm) ((dst) = emu_ds_read_tr16_b64((const char*)(ptr) + (imm)))
 // LDS-DMA: every lane deposits `size` bytes at (wave-uniform lds base) + lane * size
 #define SSN_LDS_PTR(p) ((void*)(p))
 #define SSN_WAIT_VMCNT(n) ((void)0)
