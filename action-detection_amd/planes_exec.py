@@ -89,10 +89,16 @@ def _is_rect(op):
 def _fold_bn(net, plan, shapes, dev):
     """tscale: per tensor folded-BN scale of every channel (NaN: not a conv+ReLU output); shift_of: per layer shift vectors."""
     tscale, shift_of = {}, {}
+    # one NaN-filled buffer for the scale vectors of all tensors (one fill launch per forward, not one per tensor)
+    offs, o = {}, 0
+    for name_, v in shapes.items():
+        offs[name_] = o
+        o += (v[0] + 7) // 8 * 8          # (every vector starts 32-byte aligned, as separate allocations did)
+    flat = torch.full((o,), float("nan"), device=dev, dtype=torch.float32)
 
     def scale_slice(name, c0, c):
         if name not in tscale:
-            tscale[name] = torch.full((shapes[name][0],), float("nan"), device=dev, dtype=torch.float32)
+            tscale[name] = flat[offs[name]:offs[name] + shapes[name][0]]
         return tscale[name][c0:c0 + c]
 
     shift_flat = torch.empty(sum(op["cout"] for op in plan if op["kind"] == "conv"), device=dev, dtype=torch.float32)
