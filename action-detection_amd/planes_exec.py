@@ -92,6 +92,8 @@ def _fold_bn(net, plan, shapes, dev):
     # one NaN-filled buffer for the scale vectors of all tensors (one fill launch per forward, not one per tensor)
     offs, o = {}, 0
     for name_, v in shapes.items():
+        if not isinstance(v, tuple):      # (the plan's bookkeeping entries)
+            continue
         offs[name_] = o
         o += (v[0] + 7) // 8 * 8          # (every vector starts 32-byte aligned, as separate allocations did)
     flat = torch.full((o,), float("nan"), device=dev, dtype=torch.float32)
