@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
     amax_emit(p.y_amax, vmax / *p.y_scale);
 }
 
-// finish a gradient element group: (+ old), fused ReLU / frozen-BN backward of the producer, clamp, amax, split, store
-__device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, long o, long mo, int c0) {
+// finish a gradient element group: (+ old), fused ReLU / frozen-BN backward of the producer ...
+__device__ __forceinline__ void prep_grad8(float (&v)[8], const PoolArgs& p, long o, long mo, int c0) {
     if (p.accumulate) {
         float old[8];
         load8(p.y_hi, p.y_lo, o, old);
@@ -217,8 +217,11 @@ __device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, 
             v[e] = (sc != sc) ? v[e] : (m > 0.f ? v[e] * sc : 0.f);
         }
     }
+}
+// ... clamp, amax, split, store (planes), or the fp32 NCHW store (y_scale is 1): o = (n * y_img_groups + g) * HW + q, y_img_groups = G
+__device__ __forceinline__ float store_grad8(float (&v)[8], const PoolArgs& p, long o, int c0) {
     float vmax = 0.f;
-    if (p.y_f32) {      // fp32 NCHW output (y_scale is 1): o = (n * y_img_groups + g) * HW + q with y_img_groups = G
+    if (p.y_f32) {
         const long hw = (long)p.H * p.W;
         const long q = o % hw, ng = o / hw;
         const long n = ng / p.y_img_groups;
@@ -239,6 +242,10 @@ __device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, 
     reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
     reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
     return vmax;
+}
+__device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, long o, long mo, int c0) {
+    prep_grad8(v, p, o, mo, c0);
+    return store_grad8(v, p, o, c0);
 }
 
 // max pool backward in gather form: input pixel (h, w) collects the output gradients of the windows whose argmax it is
@@ -340,13 +347,16 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
             am[t] = reinterpret_cast<const u32x2*>(p.argmax)[((long)n * p.G + g) * p.Ho * p.Wo + oo];
             load8(p.x_hi, p.x_lo, ((long)n * p.x_img_groups + g) * p.Ho * p.Wo + oo, d[t]);
         }
+        float v[4][8];
+        bool live[4];
+        long oq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int h = 2 * i + (q >> 1), w = 2 * j + (q & 1);
-            if (h >= p.H || w >= p.W) continue;
-            float v[8];
+            live[q] = h < p.H && w < p.W;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int e = 0; e < 8; ++e) v[q][e] = 0.f;
+            if (!live[q]) continue;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ho = i + base_off + (t >> 1), wo = j + base_off + (t & 1);
@@ -355,14 +365,33 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int a = (int)((am[t][e >> 2] >> (8 * (e & 3))) & 0xFFu);
-                    v[e] += (a == local) ? d[t][e] : 0.f;
+                    v[q][e] += (a == local) ? d[t][e] : 0.f;
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= r;
-            const long o = ((long)n * p.y_img_groups + g) * p.H * p.W + (long)h * p.W + w;
+            for (int e = 0; e < 8; ++e) v[q][e] *= r;
+            oq[q] = ((long)n * p.y_img_groups + g) * p.H * p.W + (long)h * p.W + w;
             const long mo = ((long)n * p.mask_img_groups + g) * p.H * p.W + (long)h * p.W + w;
-            vmax = fmaxf(vmax, finish_grad8(v, p, o, mo, 8 * g));
+            prep_grad8(v[q], p, oq[q], mo, 8 * g);
+        }
+        if (p.y_f32 && (p.W & 1) == 0) {
+            // fp32 NCHW output (the stem's pool: 925 MB per step): the two pixels of a block row are neighbours in every channel
+            // plane -- one 8-byte store per channel and row, contiguous across the lanes of a wave
+            const long hw = (long)p.H * p.W;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (!live[2 * rr]) continue;          // (W even: the pair is live or dead together)
+                float* dst = p.y_f32 + (long)n * p.y_f32_img_stride + (long)(8 * g) * hw + (long)(2 * i + rr) * p.W + 2 * j;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    vmax = fmaxf(vmax, fmaxf(fabsf(v[2 * rr][e]), fabsf(v[2 * rr + 1][e])));
+                    *reinterpret_cast<float2*>(dst + (long)e * hw) = float2{v[2 * rr][e], v[2 * rr + 1][e]};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (live[q]) vmax = fmaxf(vmax, store_grad8(v[q], p, oq[q], 8 * g));
         }
     }
     amax_emit(p.y_amax, vmax / *p.y_scale);

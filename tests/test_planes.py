@@ -270,6 +270,12 @@ def test_planes_pools(backend):
         P.maxpool_bwd(P.pfull(gp), am, P.pfull(dx), k, s, pad, accumulate=True, mask=P.pfull(xp), mask_scale=backend.put(msc))
         m = torch.where(torch.isnan(msc).view(1, -1, 1, 1), torch.ones_like(x), (x > 0).float() * torch.nan_to_num(msc).view(1, -1, 1, 1))
         assert rel_err(P.to_f32(dx), (base.double() + xd.grad) * m.double()) < 2.0 ** -19
+        # the gradient written as fp32 NCHW (the stem's pool: its only reader is a weight gradient on the fp32-layout kernels),
+        # with the producer's ReLU / BN mask fused; even widths take the paired 8-byte stores of the 2 x 2 block kernel
+        dx32 = K.attach_amax(backend.put(torch.full((n, c, h, h), 7.0)))
+        P.maxpool_bwd(P.pfull(gp), am, dx32, k, s, pad, mask=P.pfull(xp), mask_scale=backend.put(msc))
+        assert rel_err(dx32, xd.grad * m.double()) < 2.0 ** -20, ("maxpool bwd fp32", h, k, s, pad)
+        assert abs(float(dx32._ssn_amax) - float((xd.grad * m.double()).abs().max())) <= 1e-6 * float(xd.grad.abs().max())
     # average pool behind the projection + its backward stencil
     h = 7
     z = torch.randn(n, c, h, h, generator=g)
