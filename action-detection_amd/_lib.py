@@ -42,6 +42,7 @@ _SIGS = {
     "ssn_conv_wgrad": "ppppiiiiliiiliiiplip",
     "ssn_conv_wgrad_x6": "ppppiiiililiiiplippiipp",
     "ssn_wgrad_reduce": "pppiiip",
+    "ssn_wgrad_reduce_taps": "pppiiiip",
     "ssn_conv_x6_pack_weights_multi": "ippppppppppppp",
     "ssn_conv_x6_fwd": "pppppiiiiliiiliiiiiippiiipp",
     "ssn_conv_x6_dgrad": "pppiiiiliiiliiiplpiippiipp",

@@ -238,9 +238,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     }
 }
 
-// dst[m*K + kk] = sum_z part[z][m][kk];  db[m] = sum_z part[z][m][K]
+// dst[m*K + kk] = sum_z part[z][m][kk];  db[m] = sum_z part[z][m][K].  taps > 1: the slabs' columns are TAP-MAJOR
+// (column t * (K / taps) + ci holds dW[m][ci][t]: what lets the nine-tap kernel store a tap's columns lane-contiguously)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* dw, float* db, int M, int K,
-                                                           int ldp, int splits) {
+                                                           int ldp, int splits, int taps) {
     const long total = (long)M * ldp;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         float s = 0.f;
@@ -255,10 +256,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
         for (; z < splits; ++z) s += part[(long)z * total + idx];
         const int m = (int)(idx / ldp);
         const int kk = (int)(idx - (long)m * ldp);
-        if (kk < K)
-            dw[(long)m * K + kk] = s;
-        else if (db)
+        if (kk < K) {
+            int col = kk;
+            if (taps > 1) {
+                const int cin = K / taps, t = kk / cin;
+                col = (kk - t * cin) * taps + t;
+            }
+            dw[(long)m * K + col] = s;
+        } else if (db) {
             db[m] = s;
+        }
     }
 }
 
@@ -325,14 +332,19 @@ void plan_wgrad(int M, int K, long P, int cfg, int* splits, int* chunks_per_spli
 }  // namespace
 
 // dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] (fixed order); shared with conv_wgrad_x6.hip
-extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream) {
+extern "C" int ssn_wgrad_reduce_taps(const float* part, float* dw, float* db, int M, int K, int splits, int taps,
+                                     hipStream_t stream) {
+    SSN_CHECK_ARG(part && dw && M > 0 && K > 0 && splits > 0 && taps >= 1 && K % taps == 0, "wgrad reduce: bad arguments");
     const long total = (long)M * (K + 1);
     long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, part, dw, db, M, K, K + 1,
-                       splits);
+                       splits, taps);
     SSN_CHECK_LAUNCH("wgrad_reduce");
     return SSN_OK;
+}
+extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream) {
+    return ssn_wgrad_reduce_taps(part, dw, db, M, K, splits, 1, stream);
 }
 
 extern "C" long ssn_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int ksize, int tile_cfg) {

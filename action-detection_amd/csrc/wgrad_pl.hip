@@ -17,7 +17,7 @@
 //   * waves 0/1 fetch the two planes of dY, waves 2/3 those of X; the DMA runs two k-steps ahead in a 3-slot ring, the
 //     transposed reads of k-step t+1 are dealt out between the MFMAs of k-step t (two register sets), one barrier per k-step.
 // A workgroup = (tile of output channels) x (tile of input channels) x ONE tap x (share of the pixel range); partial slabs
-// [split][co][ci * KK + tap (+ bias column)] are reduced in a fixed order by ssn_wgrad_reduce (deterministic).  The bias
+// [split][co][ci * KK + tap (+ bias column)] (nine-tap kernel: [tap * Cin + ci]) are reduced in a fixed order by ssn_wgrad_reduce (deterministic).  The bias
 // column is the product of the dY fragments with a fragment of ones (workgroups of the first input tile and tap only).
 #include "planes.h"
 
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < p.M) {
 #pragma unroll
-                    for (int t = 0; t < KK; ++t) out[(long)m * p.ldp + ci * KK + t] = acc[t][i][j][r] * inv;
+                    for (int t = 0; t < KK; ++t) out[(long)m * p.ldp + t * p.Cin + ci] = acc[t][i][j][r] * inv;   // tap-major: lanes = consecutive ci
                 }
             }
     }
@@ -742,6 +742,7 @@ extern "C" void ssn_conv_wgrad_pl_debug_trace(unsigned long long* buf) { g_wg_tr
 extern "C" void ssn_conv_wgrad_pl_debug_flags(int flags) { g_wg_dbg = flags; }
 
 extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
+extern "C" int ssn_wgrad_reduce_taps(const float* part, float* dw, float* db, int M, int K, int splits, int taps, hipStream_t stream);
 
 extern "C" int ssn_conv_wgrad_pl_tiles(void) { return NCFG; }
 
@@ -854,7 +855,7 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
         a.div_w = make_fastdiv((uint32_t)(W + 1));
         const int rc9 = launch_wgpl9_tile(a, c9, stream);
         if (rc9 != SSN_OK) return rc9;
-        return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits * k9KG[c9], stream);
+        return ssn_wgrad_reduce_taps(a.part, dw, db, Cout, a.K, a.splits * k9KG[c9], 9, stream);
     }
     SSN_CHECK_ARG(tile_cfg < 100, "conv wgrad pl: the nine-tap kernel takes 3x3 / stride 1 / pad 1 layers only");
     const int cfg = fix_cfg(tile_cfg, Cout, Cin);

@@ -199,6 +199,8 @@ int ssn_conv_wgrad_x6_rect(const float* g, const float* x, float* dw, float* db,
                            const float* x_amax, hipStream_t stream);
 /* second pass of both wgrad kernels: dw[m][kk] = sum_z part[z][m][kk], db[m] = sum_z part[z][m][K] */
 int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream);
+/* the same with TAP-MAJOR slab columns (column t * (K / taps) + ci holds dW[m][ci][t]): the nine-tap planes kernel's slabs */
+int ssn_wgrad_reduce_taps(const float* part, float* dw, float* db, int M, int K, int splits, int taps, hipStream_t stream);
 
 /* cuDNN wgrad (+ bias grad) replacement.  dw[co][ci][r][s] = sum_p g * x,  db[co] = sum_p g  (db may be NULL).
  * workspace: ssn_conv_wgrad_workspace_bytes() bytes of scratch for the split-K partial slabs. */
