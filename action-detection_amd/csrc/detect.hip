@@ -11,14 +11,19 @@ namespace {
 
 constexpr int DET_MAXN = 2048;   // candidates of one class (sorted and suppressed inside one workgroup)
 
-// combined[p][c] = softmax(act[p][off : off + n_sm])[c + 1 - off] * exp(comp[p][c]),  off = 0 (softmax over all C + 1
-// activity scores, then drop the background column) or 1 (softmax over the C class scores only)
+// combined[p][c] = softmax(act[p][off : off + n_sm])[c + 1 - off] * exp(comp[p][c]),  off = 0 (include_bg 1: softmax over all
+// C + 1 activity scores, then drop the background column) or 1 (include_bg 0: softmax over the C class scores only);
+// include_bg 2: NO softmax, the raw class scores act[p][c + 1] (the `--cls_scores` branch without --softmax_before_filter, :135)
 __global__ __launch_bounds__(256) void det_scores_kernel(const float* act, const float* comp, float* combined, int P, int C,
                                                          int include_bg) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
     const float* a = act + (long)p * (C + 1);
+    if (include_bg == 2) {
+        for (int c = lane; c < C; c += 64) combined[(long)p * C + c] = a[c + 1] * expf(comp[(long)p * C + c]);
+        return;
+    }
     const int lo = include_bg ? 0 : 1;
     float mx = -INFINITY;
     for (int c = lo + lane; c <= C; c += 64) mx = fmaxf(mx, a[c]);

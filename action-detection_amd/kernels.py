@@ -658,7 +658,8 @@ def frame_diff(x, new_length, channels=3):
 
 
 def detections(act, comp, reg, rel_prop, top_k, include_bg, nms_thresh, regress):
-    """One video: -> (combined [P, C] fp32, dets [C, max_det, 5] fp64, counts [C] int32).  See ssn_detections."""
+    """One video: -> (combined [P, C] fp32, dets [C, max_det, 5] fp64, counts [C] int32).  See ssn_detections
+    (include_bg: 0 softmax over the class scores, 1 / True over all C + 1 scores, 2 no softmax)."""
     lib = _check(act, comp, reg, rel_prop)
     p, c = comp.shape
     assert act.shape == (p, c + 1) and rel_prop.shape == (p, 2) and rel_prop.dtype == torch.float64
@@ -670,7 +671,7 @@ def detections(act, comp, reg, rel_prop, top_k, include_bg, nms_thresh, regress)
     ws_bytes = int(lib.cdll.ssn_detections_workspace_bytes(p, c))
     ws = torch.zeros((ws_bytes + 3) // 4, device=dev, dtype=torch.int32)
     lib.call("ssn_detections", _p(act), _p(comp), _p(reg), _p(rel_prop), _p(combined), _p(dets), _p(counts), _p(ws),
-             ws_bytes, p, c, max_det, int(top_k), int(bool(include_bg)), float(nms_thresh), int(bool(regress)),
+             ws_bytes, p, c, max_det, int(top_k), int(include_bg), float(nms_thresh), int(bool(regress)),
              _stream(lib, act))
     return combined, dets, counts
 

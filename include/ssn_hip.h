@@ -317,8 +317,8 @@ int ssn_frames_crop_normalize(const unsigned char* src, float* dst, int n_img, i
  * (eval_detection_results.py:91-128, 167-178; ops/utils.py:56-82).  act [P][C+1], comp [P][C], reg [P][C][2] or NULL
  * (fp32); rel_prop [P][2] fp64 normalised spans; combined [P][C] fp32 out; dets [C][max_det][5] fp64 = (start, end,
  * score, loc, dur) in descending score order, counts [C] int32; workspace: ssn_detections_workspace_bytes(P, C) bytes
- * of device scratch.  include_bg: softmax over all C+1 activity scores (the reference's top_k <= 0 branch) instead of
- * the C class scores; top_k <= 0 keeps every pair, otherwise EXACTLY top_k pairs are kept as np.argsort(...)[-top_k:]
+ * of device scratch.  include_bg 1: softmax over all C+1 activity scores (the reference's top_k <= 0 branch) instead of
+ * the C class scores (0); 2: no softmax, raw class scores (the --cls_scores branch without --softmax_before_filter, :135); top_k <= 0 keeps every pair, otherwise EXACTLY top_k pairs are kept as np.argsort(...)[-top_k:]
  * does (ties at the k-th score: the higher flat indices, i.e. a stable sort's choice).  Score ties inside a class:
  * higher proposal index first (scores.argsort()[::-1] of a stable sort).  Non-finite scores are ordered as numpy
  * orders them (NaN above +inf) and can never cause an out-of-range access.  Any P is accepted (P > 2048 sorts in the

@@ -413,6 +413,49 @@ def golden_detection():
     np.savez_compressed(os.path.join(OUT, "ref_detection.npz"), **out)
 
 
+def golden_detection_cls():
+    """The `--cls_scores` branch of eval_detection_results.py (:82-90, :130-144): detections only for the `--cls_top_k` classes
+    an external video-level classifier ranks highest, every proposal kept, fused score = (softmax(act)[:, 1:] with
+    `--softmax_before_filter`, else the raw class scores act[:, 1:]) * exp(comp); then temporal_nms and perform_regression as
+    in golden_detection.  The reference's own functions on seeded videos."""
+    import argparse
+    from ops import utils as ref_utils
+    out = {}
+    cases = [  # P, C, cls_top_k, softmax_bf, nms, no_regression, with_reg, seed
+        (40, 6, 1, False, 0.4, False, True, 1),       # the defaults: one class, raw activity scores
+        (35, 5, 2, True, 0.3, False, True, 2),        # --cls_top_k 2 --softmax_before_filter
+        (20, 4, 3, False, 0.5, True, False, 3),       # --no_regression, no regression scores in the pickle
+        (1, 3, 1, True, 0.5, False, True, 4),         # a single proposal
+    ]
+    for ci, (p, c, ktop, sbf, thr, no_reg, with_reg, seed) in enumerate(cases):
+        rs = np.random.RandomState(300 + seed)
+        start = rs.uniform(0, 0.8, p)
+        rel = np.stack([start, np.minimum(start + rs.uniform(0.02, 0.5, p), 1.0)], axis=1)
+        act = (rs.standard_normal((p, c + 1)) * 2).astype(np.float32)
+        comp = rs.standard_normal((p, c)).astype(np.float32)
+        reg = (rs.standard_normal((p, c, 2)) * 0.3).astype(np.float32) if with_reg else None
+        vcls = rs.standard_normal(c).astype(np.float32)        # the external classifier's scores of this video
+        ns = _reference_functions(os.path.join(REF, "eval_detection_results.py"),
+                                  ["gen_detection_results", "perform_regression"])
+        ns.update(np=np, os=os, softmax=ref_utils.softmax, num_class=c, top_k=0, cls_score_dict={"v": vcls}, softmax_bf=sbf,
+                  args=argparse.Namespace(cls_top_k=ktop), dataset_detections=[dict() for _ in range(c)])
+        ns["gen_detection_results"]("some/dir/v.mp4", (rel[None], act, comp, reg))
+        dets = [{k: ref_utils.temporal_nms(v, thr) for k, v in d.items()} for d in ns["dataset_detections"]]
+        if not no_reg:
+            dets = [{k: ns["perform_regression"](v) for k, v in d.items()} for d in dets]
+        combined = (ref_utils.softmax(act)[:, 1:] if sbf else act[:, 1:]) * np.exp(comp)
+        assert len(np.unique(combined.ravel())) == combined.size, "exact ties in fixture %d" % ci
+        rows = [d["some/dir/v.mp4"] if "some/dir/v.mp4" in d else np.zeros((0, 5)) for d in dets]
+        assert sum(len(r) > 0 for r in rows) == min(ktop, c)
+        out.update({"e%d_rel" % ci: rel, "e%d_act" % ci: act, "e%d_comp" % ci: comp, "e%d_vcls" % ci: vcls,
+                    "e%d_reg" % ci: reg if with_reg else np.zeros(0, np.float32),
+                    "e%d_cfg" % ci: np.array([p, c, ktop, int(sbf), int(no_reg), int(with_reg)], np.int64),
+                    "e%d_thr" % ci: np.array([thr]), "e%d_counts" % ci: np.array([len(r) for r in rows], np.int64),
+                    "e%d_dets" % ci: np.concatenate(rows, 0), "e%d_combined" % ci: combined.astype(np.float32)})
+    out["n_cases"] = np.array([len(cases)])
+    np.savez_compressed(os.path.join(OUT, "ref_detection_cls.npz"), **out)
+
+
 def golden_transforms():
     """transforms.py on PIL images: the test chain GroupOverSample -> Stack(roll) -> ToTorchFormatTensor(div=False) ->
     GroupNormalize (ssn_test.py:101-112, ssn_dataset.py:434-450) and the training augmentation
@@ -463,6 +506,9 @@ def main():
     assert os.path.isdir(REF), "this script needs /root/reference (build container only)"
     os.makedirs(OUT, exist_ok=True)
     install_shims()
+    if os.environ.get("GOLDEN_ONLY") == "detection_cls":      # (only this fixture: the others stay byte-identical)
+        golden_detection_cls()
+        return
     import ssn_models as ref_models
     from ops import ssn_ops as ref_ops
     golden_stpp(ref_ops)
@@ -478,6 +524,7 @@ def main():
     golden_binary(ref_binary, ref_ops)
     golden_proposal_io()
     golden_detection()
+    golden_detection_cls()
     golden_transforms()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

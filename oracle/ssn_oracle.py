@@ -618,9 +618,10 @@ class OracleSSN(nn.Module):
 
 
 def detections_for_video(rel_prop, act_scores, comp_scores, reg_scores, num_class, nms_threshold, top_k=0,
-                         no_regression=False):
-    """The per-video part of /root/reference/eval_detection_results.py: gen_detection_results (:91-128, the two
-    branches without external class scores), temporal_nms (ops/utils.py:56-82) and perform_regression (:167-178).
+                         no_regression=False, video_cls_score=None, cls_top_k=1, softmax_bf=False):
+    """The per-video part of /root/reference/eval_detection_results.py: gen_detection_results (:91-144: the two
+    branches without external class scores, and -- video_cls_score given -- the `--cls_scores` branch :130-144),
+    temporal_nms (ops/utils.py:56-82) and perform_regression (:167-178).
     -> {cls: float64 array [n, 5] = (start, end, score, loc, dur)}
 
     The reference calls ``np.argsort`` with numpy's default (unstable) sort, so WHICH of several exactly equal scores
@@ -655,7 +656,12 @@ def detections_for_video(rel_prop, act_scores, comp_scores, reg_scores, num_clas
         reg_scores = np.zeros((len(rel_prop), num_class, 2), dtype=np.float32)
     reg_scores = np.asarray(reg_scores).reshape((-1, num_class, 2))
     dets = {}
-    if top_k <= 0:
+    if video_cls_score is not None:       # :130-144 (top_k plays no role here; --softmax_before_filter = softmax_bf)
+        combined = (softmax(act_scores)[:, 1:] if softmax_bf else act_scores[:, 1:]) * np.exp(comp_scores)
+        for video_cls in np.argsort(np.asarray(video_cls_score), kind="stable")[-cls_top_k:]:
+            dets[int(video_cls)] = np.concatenate((rel_prop, combined[:, video_cls][:, None], reg_scores[:, video_cls, 0][:, None],
+                                                   reg_scores[:, video_cls, 1][:, None]), axis=1)
+    elif top_k <= 0:
         combined = softmax(act_scores)[:, 1:] * np.exp(comp_scores)
         for i in range(num_class):
             dets[i] = np.concatenate((rel_prop, combined[:, i][:, None], reg_scores[:, i, 0][:, None],

@@ -105,6 +105,59 @@ def test_product_matches_reference_functions(backend):
         assert_same(got, k["ref"])
 
 
+def golden_cls_cases():
+    d = np.load(os.path.join(GOLDEN, "ref_detection_cls.npz"))
+    for ci in range(int(d["n_cases"][0])):
+        p, c, ktop, sbf, no_reg, with_reg = (int(v) for v in d["e%d_cfg" % ci])
+        rows, ref, o = d["e%d_dets" % ci], {}, 0
+        for cls, n in enumerate(d["e%d_counts" % ci]):
+            if n:
+                ref[cls] = rows[o:o + n]
+            o += n
+        yield dict(rel=d["e%d_rel" % ci], act=d["e%d_act" % ci], comp=d["e%d_comp" % ci], vcls=d["e%d_vcls" % ci],
+                   reg=d["e%d_reg" % ci] if with_reg else None, c=c, ktop=ktop, sbf=bool(sbf), no_reg=bool(no_reg),
+                   thr=float(d["e%d_thr" % ci][0]), ref=ref, combined=d["e%d_combined" % ci])
+
+
+def test_cls_scores_branch_oracle_matches_reference_functions():
+    """`--cls_scores` (eval_detection_results.py:82-90, :130-144): the numpy restatement against the reference's own functions."""
+    n = 0
+    for k in golden_cls_cases():
+        got, comb = O.detections_for_video(k["rel"][None], k["act"], k["comp"], k["reg"], k["c"], k["thr"], 0, k["no_reg"],
+                                           video_cls_score=k["vcls"], cls_top_k=k["ktop"], softmax_bf=k["sbf"])
+        assert np.array_equal(comb.astype(np.float32), k["combined"])
+        assert_same(got, k["ref"], tol=0)
+        n += 1
+    assert n == 4
+
+
+def test_cls_scores_branch_product(backend):
+    """The HIP path on the `--cls_scores` branch: against the reference's own outputs (golden) and against the oracle on
+    seeded videos, with and without --softmax_before_filter, cls_top_k 1 ... all classes, top_k set (it must play no role)."""
+    for k in golden_cls_cases():
+        post = DetectionPostProcessor(k["c"], k["thr"], top_k=7, no_regression=k["no_reg"], cls_top_k=k["ktop"],
+                                      softmax_before_filter=k["sbf"])
+        got, comb = post.process_video(torch.from_numpy(k["rel"][None]), backend.put(torch.from_numpy(k["act"])),
+                                       backend.put(torch.from_numpy(k["comp"])),
+                                       backend.put(torch.from_numpy(k["reg"])) if k["reg"] is not None else None,
+                                       device=backend.device, video_cls_score=k["vcls"])
+        assert np.allclose(comb.cpu().numpy(), k["combined"], rtol=2e-6, atol=1e-30)
+        assert_same(got, k["ref"])
+    rs = np.random.RandomState(41)
+    for (p, c, ktop, sbf) in ([(400, 20, 3, False), (187, 100, 1, True)] if backend.is_gpu else []) + [(18, 5, 2, False), (14, 4, 4, True)]:
+        rel, act, comp, reg = synthetic_video(rs, p, c)
+        vcls = rs.standard_normal(c).astype(np.float32)
+        ref, ref_comb = O.detections_for_video(rel[None], act, comp, reg, c, 0.45, 0, False, video_cls_score=vcls, cls_top_k=ktop,
+                                               softmax_bf=sbf)
+        post = DetectionPostProcessor(c, 0.45, top_k=5, cls_top_k=ktop, softmax_before_filter=sbf)
+        got, comb = post.process_video(torch.from_numpy(rel[None]), backend.put(torch.from_numpy(act)),
+                                       backend.put(torch.from_numpy(comp)), backend.put(torch.from_numpy(reg)),
+                                       device=backend.device, video_cls_score=torch.from_numpy(vcls))
+        assert np.allclose(comb.cpu().numpy(), ref_comb, rtol=2e-6, atol=1e-30)
+        assert len(got) == ktop
+        assert_same(got, ref)
+
+
 def test_exact_ties_follow_a_stable_sort(backend):
     """Equal fused scores (duplicated proposals' scores): exactly top_k pairs survive, the higher flat indices of the
     ties at the k-th place; inside a class the higher proposal index is visited first."""
