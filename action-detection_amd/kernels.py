@@ -774,6 +774,17 @@ def sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale=1.0, first_st
              int(first_step), _stream(lib, ws[0]))
 
 
+def wgrad_reduce(part, dw, db, splits, taps=1):
+    """dw [M, K] (any trailing shape), db [M] or None <- sum over the `splits` partial slabs part [splits, M, K + 1] in a fixed
+    order (column K = bias).  taps > 1: the slabs' columns are tap-major (column t * (K / taps) + ci holds dW[m][ci][t]), the
+    layout of the nine-tap planes weight gradient."""
+    lib = _check(part, dw, db)
+    m = dw.shape[0]
+    k = dw.numel() // m
+    assert part.numel() >= splits * m * (k + 1)
+    lib.call("ssn_wgrad_reduce_taps", _p(part), _p(dw), _p(db), m, k, int(splits), int(taps), _stream(lib, part))
+
+
 def bn_fold_multi(biases, gammas, betas, means, variances, eps, scales, shifts):
     """ssn_bn_fold for many layers in one launch per 48 layers."""
     if not gammas:

@@ -213,6 +213,21 @@ def test_conv_pl_wgrad(backend):
             assert rel_err(db, b.grad) < 5e-6, ("bias", n, cin, h, cout, kh, kw, s, tile)
 
 
+def test_wgrad_reduce_tap_major(backend):
+    """Split-K slabs in the nine-tap kernel's tap-major column order are summed and permuted back to dW[m][ci][tap]."""
+    g = torch.Generator().manual_seed(9)
+    for (m, cin, taps, splits) in [(5, 7, 9, 3), (64, 40, 9, 11), (3, 4, 1, 8)]:
+        k = cin * taps
+        part = torch.randn(splits, m, k + 1, generator=g)
+        dw, db = backend.put(torch.full((m, cin, taps), 9.0)), backend.put(torch.full((m,), 9.0))
+        K.wgrad_reduce(backend.put(part), dw, db, splits, taps)
+        s = part.double().sum(0)
+        ref = s[:, :k].view(m, taps, cin).permute(0, 2, 1) if taps > 1 else s[:, :k].view(m, cin, 1)
+        assert rel_err(dw, ref) < 1e-6 and rel_err(db, s[:, k]) < 1e-6, (m, cin, taps, splits)
+        K.wgrad_reduce(backend.put(part), dw, None, splits, taps)         # (no bias gradient wanted)
+        assert rel_err(dw, ref) < 1e-6
+
+
 def _two_pass(fn, t):
     """run a producer twice around a scale update (the delayed-scale protocol), leave the result of the second pass"""
     fn()
