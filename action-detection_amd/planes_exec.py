@@ -10,7 +10,9 @@ What differs from the fp32-layout executor (bninception._run_forward / _run_back
   producers recorded in the previous step; the first step of an executor state is CALIBRATED by running the pass until no scale
   moves any more (2-3 passes), and an overflow flag (a tensor outgrew its head-room; values were clamped) is raised for the host;
 * one stream: the launches of a step already fill the GPU (round 2 measured 1.5 % from four-stream overlap), so the planes path
-  keeps the whole step on the caller's stream -- one amax / scale slot per tensor suffices and results stay deterministic;
+  keeps the whole step on the caller's stream -- one amax / scale slot per tensor suffices and results stay deterministic.
+  ``SSN_PL_OVERLAP_WGRAD=1`` (off by default) moves the weight gradients -- which write no planes tensor and no amax slot -- to a
+  side stream: measured 16.88 vs 17.05 ms per step on one box (+1.0 %), not yet run through the full GPU test tier;
 * the ReLU / frozen-BN backward of a layer is fused into whichever launch writes its output gradient last and reads only the
   SIGN of the activation's high plane (2 bytes per element instead of the 4 of an fp32 ``y``).
 
@@ -18,6 +20,7 @@ Supported: frozen BatchNorm (the reference's default ``bn_mode='frozen'``; /root
 rectangular-tap plans.  Training-mode BatchNorm keeps the fp32-layout executor.
 """
 import math
+import os
 
 import torch
 
@@ -75,6 +78,9 @@ def supported(net, plan):
         if op["kind"] == "conv" and (op["cout"] % 8 or (op["src"] != "data" and op["cin"] % 8)):
             return False
     return True
+
+
+_OVERLAP_WGRAD_DEFAULT = "0"
 
 
 def _conv_taps(op):
@@ -302,9 +308,22 @@ def run_backward(net, dfeat, saved, hook=True):
             if len(readers) == 1 and readers[0]["kind"] == "pool" and readers[0]["pool"] == "max" and op["dst_c0"] == 0:
                 stem_out = op["dst"]
 
+    # SSN_PL_OVERLAP_WGRAD=1: every weight gradient only needs its layer's finished output gradient and writes nothing any other
+    # kernel of the step reads (fp32 dW / db, its own split-K scratch, no amax slot) -- it can run on a side stream next to the
+    # data-gradient chain, the two families filling each other's partly empty last rounds.  One side stream = one workspace.
+    use_side = os.environ.get("SSN_PL_OVERLAP_WGRAD", _OVERLAP_WGRAD_DEFAULT) == "1" and dfeat.is_cuda
+    main = torch.cuda.current_stream(dev) if use_side else None
+    side = None
+    if use_side:
+        side = net._side.get(dev)
+        if side is None:
+            side = net._side[dev] = torch.cuda.Stream(device=dev)
+
     def launch_all(grads, fire_hook):
         masked, inited = {}, set()
         pending_end = total
+        if use_side:
+            side.wait_stream(main)
 
         def gbuf(name):
             if name not in grads:
@@ -406,12 +425,22 @@ def run_backward(net, dfeat, saved, hook=True):
                     def run_wgrad():
                         P.conv_wgrad(gs, xin, dw, db, kh, kw, s, ph, pw, ws, wcfg, cin=cin, g_row_split=op.get("row_split", 0),
                                      g_row_gap=op.get("row_gap", 0))
-                net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad)
-                if raw or "raw_from" in op:
-                    # the (projection's) bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's backward
-                    fin = op["proj_final"] if "raw_from" in op else op["final"]
-                    cp = cout - op.get("raw_from", 0)
-                    P.channel_sum(PSlice(grads[fin[0]], fin[1], cp), db[op.get("raw_from", 0):], cs_ws)
+                def run_wgrad_and_bias(run_wgrad=run_wgrad, op=op, db=db, cout=cout):
+                    run_wgrad()
+                    if raw or "raw_from" in op:
+                        # the (projection's) bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's
+                        # backward (after the weight gradient, which wrote the sum of the pooled gradient there)
+                        fin = op["proj_final"] if "raw_from" in op else op["final"]
+                        cp = cout - op.get("raw_from", 0)
+                        P.channel_sum(PSlice(grads[fin[0]], fin[1], cp), db[op.get("raw_from", 0):], cs_ws)
+                if use_side:
+                    ready = torch.cuda.Event()
+                    ready.record(main)            # the output gradient of this layer is final here
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
+                else:
+                    net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
                 if op["src"] != "data":
                     wt = packed_dg[lids[0]]
                     key = src_key(op)
@@ -431,8 +460,12 @@ def run_backward(net, dfeat, saved, hook=True):
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
                 if fire_hook and net.grad_ready_hook is not None and closes_block:
+                    if use_side:
+                        main.wait_stream(side)    # the block's weight gradients must have landed before the all-reduce
                     net.grad_ready_hook.range_ready(flat, wo, pending_end)
                     pending_end = wo
+        if use_side:
+            main.wait_stream(side)
         if fire_hook and net.grad_ready_hook is not None:
             if pending_end > 0:
                 net.grad_ready_hook.range_ready(flat, 0, pending_end)
