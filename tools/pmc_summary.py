@@ -116,6 +116,9 @@ def main():
             if per(cname) is not None:
                 r[cname.lower() + "_per_launch"] = round(per(cname))
         res[fam] = r
+    res["_note"] = ("effective_clock_ghz = GRBM_GUI_ACTIVE / dispatch duration; NOT what the waves see under matrix load: the cycle "
+                    "counter calibrated against the real-time counter inside the kernels (tools/ablate_conv_pl.py, "
+                    "tools/trace_wgrad_pl.py) reads 1.7-1.9 GHz in the MFMA-dense launches")
     with open(out, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     print(json.dumps(res, indent=1, sort_keys=True)[:4000])
