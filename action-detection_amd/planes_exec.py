@@ -12,7 +12,9 @@ What differs from the fp32-layout executor (bninception._run_forward / _run_back
 * one stream: the launches of a step already fill the GPU (round 2 measured 1.5 % from four-stream overlap), so the planes path
   keeps the whole step on the caller's stream -- one amax / scale slot per tensor suffices and results stay deterministic.
   ``SSN_PL_OVERLAP_WGRAD=1`` (off by default) moves the weight gradients -- which write no planes tensor and no amax slot -- to a
-  side stream: measured 16.88 vs 17.05 ms per step on one box (+1.0 %), not yet run through the full GPU test tier;
+  side stream (bench.py's per-launch event pass switches it off through ``net.overlap_wgrad``): measured 16.88 vs 17.05 ms per
+  step on one box and 16.82 vs 17.06 (two alternating repetitions) on another, +1.0 ... +1.4 %; not yet run through the full GPU
+  test tier, hence not the default;
 * the ReLU / frozen-BN backward of a layer is fused into whichever launch writes its output gradient last and reads only the
   SIGN of the activation's high plane (2 bytes per element instead of the 4 of an fp32 ``y``).
 
@@ -311,7 +313,7 @@ def run_backward(net, dfeat, saved, hook=True):
     # SSN_PL_OVERLAP_WGRAD=1: every weight gradient only needs its layer's finished output gradient and writes nothing any other
     # kernel of the step reads (fp32 dW / db, its own split-K scratch, no amax slot) -- it can run on a side stream next to the
     # data-gradient chain, the two families filling each other's partly empty last rounds.  One side stream = one workspace.
-    use_side = os.environ.get("SSN_PL_OVERLAP_WGRAD", _OVERLAP_WGRAD_DEFAULT) == "1" and dfeat.is_cuda
+    use_side = net.overlap_wgrad and os.environ.get("SSN_PL_OVERLAP_WGRAD", _OVERLAP_WGRAD_DEFAULT) == "1" and dfeat.is_cuda
     main = torch.cuda.current_stream(dev) if use_side else None
     side = None
     if use_side:
