@@ -84,8 +84,8 @@ _SIGS = {
     "ssn_completeness_loss_bwd": "ppppiifp",
     "ssn_cw_smoothl1_fwd": "pppppiip",
     "ssn_cw_smoothl1_bwd": "ppppiip",
-    "ssn_sgd_step": "ppplffffip",
-    "ssn_sgd_step_multi": "ippppppffip",
+    "ssn_sgd_step": "ppplffffipp",
+    "ssn_sgd_step_multi": "ippppppffipp",
     "ssn_bn_fold_multi": "ipppppppppp",
     "ssn_sumsq": "plpipp",
     "ssn_scale": "plpfp",
@@ -96,6 +96,7 @@ _SIGS = {
     "ssn_s2d_weights_bwd": "ppiiip",
     # planes tensors (csrc/planes.h): hi/lo f16 planes, NC8HW8
     "ssn_pl_scales_update": "pppiip",
+    "ssn_pl_range_check": "pppip",
     "ssn_pl_from_f32": "plppiiiilippp",
     "ssn_pl_to_f32": "pplpliiipp",
     "ssn_conv_pl_fwd": "pppppppiiiiliiiliiiiiiipppiiip",

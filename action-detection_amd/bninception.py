@@ -79,6 +79,10 @@ def is_rect(op):
     return kh != kw or kh not in (1, 3, 7)
 
 
+def _recalibrate_after_load(module, _incompatible_keys):
+    module.recalibrate()
+
+
 class _BackboneFn(torch.autograd.Function):
     """The whole backbone as one autograd node.  A batch whose largest activation tensor would exceed what one kernel operand
     can address (32-bit buffer offsets: 2 GiB, 668 frames of 224 x 224) runs as consecutive sub-batches -- forward and backward
@@ -177,7 +181,44 @@ class BNInception(nn.Module):
         self.debug_keep_saved = False
         self._last_saved = None
         self._planes_states = {}
+        self._planes_flags = {}       # device -> int32[2]: the range guard's fault word (+ the calibration loops' move counter)
+        # range guard of the planes path's delayed scales (planes_exec.py): "sync" = every eager pass polls the fault word and
+        # repeats itself with fresh scales before anything reads its result (one 8-byte read per pass); "deferred" = the check is
+        # only launched -- the caller polls scale_fault() / calls recalibrate() (what a hipGraph capture gets in any case); "off"
+        self.scale_guard = os.environ.get("SSN_SCALE_GUARD", "sync")
+        if self.scale_guard not in ("sync", "deferred", "off"):
+            raise ValueError("SSN_SCALE_GUARD must be sync, deferred or off")
+        # weights loaded after the first forward change every activation's magnitude: calibrate again
+        self.register_load_state_dict_post_hook(_recalibrate_after_load)
         self.pl_tiles = {}            # (kind, cin, cout, kh, kw, s, hin) -> tile config of the planes kernels (autotuner)
+
+    # ------------------------------------------------------------------ range guard of the planes path (planes_exec.py)
+    def planes_flag(self, device):
+        """int32[2] on `device`: [0] = fault word of the delayed scales (bit 0: a tensor was clamped, bit 1: one fell far below its
+        scale; sticky until cleared), shared by all executor states of this backbone on the device.  Hand it to
+        ``SSNSGD.step(skip_flag=)`` so that a flagged step's update is skipped on the device."""
+        device = torch.device(device)
+        f = self._planes_flags.get(device)
+        if f is None:
+            f = self._planes_flags[device] = torch.zeros(2, device=device, dtype=torch.int32)
+        return f
+
+    def scale_fault(self):
+        """True if a pass since the last clear left the range of its scales (host sync).  Eager passes under
+        ``scale_guard == "sync"`` repair themselves and never leave this set; a graph replay may."""
+        return any(int(f[0].item()) != 0 for f in self._planes_flags.values())
+
+    def recalibrate(self):
+        """Clear the fault word and make the next forward / backward of every state calibrate from scratch (eagerly)."""
+        for st in self._planes_states.values():
+            st.fwd_calibrated = st.bwd_calibrated = False
+        for f in self._planes_flags.values():
+            f.zero_()
+
+    def guard_stats(self):
+        """{"fwd": passes repeated by the range guard in forwards, "bwd": ... in backwards} over all states."""
+        return {"fwd": sum(st.recalibrations[0] for st in self._planes_states.values()),
+                "bwd": sum(st.recalibrations[1] for st in self._planes_states.values())}
 
     def _timed(self, family, lid, flops, fn):
         """Run one conv launch; with a profiler attached, bracket it with events on the current stream."""

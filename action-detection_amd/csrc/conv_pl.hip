@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
         ch[r] = aff ? p.scale[m + (m >= p.row_split ? p.row_gap : 0)] * inv : inv;
         ch[BM + r] = aff ? p.shift[m] * so : 0.f;
         ch[2 * BM + r] = (ok && p.mask_scale) ? p.mask_scale[m] : __builtin_nanf("");
-        ch[3 * BM + r] = (p.relu && m < p.raw_from) ? 0.f : -PL_F16_MAX;
+        ch[3 * BM + r] = (p.relu && m < p.raw_from) ? 0.f : -__builtin_inff();
     }
     __syncthreads();
 
@@ -384,8 +384,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = pl_clamp_floor(v[e], flo[e]);
-            cmax = fmaxf(cmax, fabsf(v[e]));
+            // the recorded maximum is the value BEFORE the f16 ceiling (after the ReLU floor): an overflowing tensor reports its true
+            // magnitude, so the range guard sees it and one scale update repairs it
+            const float fl = fmaxf(v[e], flo[e]);       // floor: 0 behind a ReLU, -inf otherwise
+            cmax = fmaxf(cmax, fabsf(fl));
+            v[e] = __builtin_amdgcn_fmed3f(fl, -PL_F16_MAX, PL_F16_MAX);
         }
         u32x2 hi, lo;
         pl_split4(v, hi, lo);

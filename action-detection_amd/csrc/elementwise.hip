@@ -15,7 +15,7 @@ void ssn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* ssn_last_error(void) { return g_err; }
-extern "C" int ssn_abi_version(void) { return 5; }
+extern "C" int ssn_abi_version(void) { return 6; }
 
 namespace {
 
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* dy, const
 // per-group lr_mult / decay_mult of ssn_models.py:240-251, over one flat parameter segment:
 //   g = grad * grad_scale + wd * w;  buf = momentum * buf + g (buf = g on the first step);  w -= lr * buf
 __global__ __launch_bounds__(256) void sgd_kernel(float* w, const float* grad, float* buf, long n, float lr,
-                                                  float momentum, float wd, float grad_scale, int first_step) {
+                                                  float momentum, float wd, float grad_scale, int first_step, const int* skip) {
+    if (skip && *skip) return;      // the step's gradients are not trustworthy (range guard of the planes path): leave w, buf alone
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float g = grad[i] * grad_scale + wd * w[i];
         float b = first_step ? g : momentum * buf[i] + g;
@@ -185,7 +186,9 @@ struct SgdTable {
     int count;
 };
 constexpr int MT_CHUNK = 4096;
-__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdTable t, float momentum, float grad_scale, int first_step) {
+__global__ __launch_bounds__(256) void sgd_multi_kernel(SgdTable t, float momentum, float grad_scale, int first_step,
+                                                        const int* skip) {
+    if (skip && *skip) return;      // (see sgd_kernel)
     int ti = 0;
     while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;   // block-uniform linear search
     const long base = (long)((int)blockIdx.x - t.blk0[ti]) * MT_CHUNK;
@@ -392,20 +395,22 @@ extern "C" int ssn_dropout_bwd(const float* dy, const unsigned char* mask, float
 }
 
 extern "C" int ssn_sgd_step(float* w, const float* grad, float* momentum_buf, long n, float lr, float momentum,
-                            float weight_decay, float grad_scale, int first_step, hipStream_t stream) {
+                            float weight_decay, float grad_scale, int first_step, const int* skip_flag, hipStream_t stream) {
     SSN_CHECK_ARG(w && grad && momentum_buf, "sgd_step: null pointer");
     if (n == 0) return SSN_OK;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, stream, w, grad, momentum_buf, n, lr,
-                       momentum, weight_decay, grad_scale, first_step);
+                       momentum, weight_decay, grad_scale, first_step, skip_flag);
     SSN_CHECK_LAUNCH("sgd_step");
     return SSN_OK;
 }
 
 // Multi-tensor SGD: the same update as ssn_sgd_step for `count` tensors with per-tensor lr / weight decay
-// (host arrays of device pointers); ceil(count / 48) launches.
+// (host arrays of device pointers); ceil(count / 48) launches.  skip_flag (device int, may be null): when it reads non-zero at
+// launch time the update is skipped -- the range guard of the planes path (ssn_pl_range_check) flagged the step's gradients, and
+// leaving weights and momentum untouched is what makes the step retryable from a graph replay.
 extern "C" int ssn_sgd_step_multi(int count, float* const* w, const float* const* grad, float* const* momentum_buf,
                                   const long* n, const float* lr, const float* weight_decay, float momentum,
-                                  float grad_scale, int first_step, hipStream_t stream) {
+                                  float grad_scale, int first_step, const int* skip_flag, hipStream_t stream) {
     SSN_CHECK_ARG(count >= 0 && (count == 0 || (w && grad && momentum_buf && n && lr && weight_decay)),
                   "sgd_step_multi: bad arguments");
     for (int base = 0; base < count; base += MT_MAX) {
@@ -425,7 +430,7 @@ extern "C" int ssn_sgd_step_multi(int count, float* const* w, const float* const
         t.blk0[t.count] = blocks;
         if (blocks == 0) continue;
         hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, momentum, grad_scale,
-                           first_step);
+                           first_step, skip_flag);
     }
     SSN_CHECK_LAUNCH("sgd_step_multi");
     return SSN_OK;

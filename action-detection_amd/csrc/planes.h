@@ -31,6 +31,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PL_HEADROOM_BITS = 2;       // a tensor's largest magnitude lands in [2^12, 2^13) when it repeats last step's
 constexpr float PL_F16_MAX = 65504.f;
+// range guard (range_check_kernel): a tensor whose largest scaled magnitude fell below this -- 2^8 under the [2^12, 2^13) target, i.e.
+// it shrank more than 256x since the pass its scale was derived from -- is reported like an overflow (elements below 2^-12 of the
+// tensor's maximum have lost low-plane bits); anything above is absorbed by the format (22 bits down to 2^-16 of the target)
+constexpr float PL_UNDERFLOW_FLOOR = 16.f;
 constexpr uint32_t PL_OOB = 0x80000000u;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t pl_rsrc(const void* base, uint32_t bytes) {

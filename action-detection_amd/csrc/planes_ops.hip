@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void scales_update_kernel(float* amax, float* 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float a = amax[i], s = scale[i];
-    if (a * s >= PL_F16_MAX || a != a) atomicOr(flag, 1);
+    // (exact: the tensor is measured BEFORE it is stored with the scale derived here -- nothing was clamped, whatever the old scale)
+    if (!exact && (a * s >= PL_F16_MAX || a != a)) atomicOr(flag, 1);
     float ns = pl_scale_from_amax(a, s);
     if (exact) ns *= (float)(1 << PL_HEADROOM_BITS);   // a tensor measured before it is stored needs no head-room
     // hysteresis: keep the old scale while the stored maximum stays inside [2^10, 2^14) -- at least 2 bits of head-room, at
@@ -24,6 +25,22 @@ __global__ __launch_bounds__(256) void scales_update_kernel(float* amax, float* 
     if (ns != s) atomicAdd(flag + 1, 1);
     scale[i] = ns;
     amax[i] = 0.f;
+}
+
+// The guard of the delayed scales, one launch at the END of a pass (forward: activation slots, backward: gradient slots; slots
+// nobody wrote hold 0 and are skipped): flag[0] |= 1 when a tensor's recorded (pre-clamp) maximum did not fit the scale it was stored
+// with -- its values were clamped --, |= 2 when it sat more than PL_UNDERFLOW_BITS below the target (the low plane has run out of
+// exponent range: precision is draining).  Reads only: the slots stay as they are for the update at the head of the next pass.
+// The host (planes_exec.py) polls the word -- synchronously after an eager pass, asynchronously behind a graph replay -- and repeats
+// the pass with fresh scales; ssn_sgd_step_multi skips its update while the word is set, so a flagged step is retryable.
+__global__ __launch_bounds__(256) void range_check_kernel(const float* amax, const float* scale, int* flag, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float a = amax[i], s = scale[i];
+    if (a * s >= PL_F16_MAX || a != a)
+        atomicOr(flag, 1);
+    else if (a > 0.f && a * s < PL_UNDERFLOW_FLOOR)
+        atomicOr(flag, 2);
 }
 
 struct CvtArgs {
@@ -183,8 +200,9 @@ __global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
         float out[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            out[e] = pl_clamp(best[e] * r);
-            vmax = fmaxf(vmax, fabsf(out[e]));
+            const float sv = best[e] * r;
+            vmax = fmaxf(vmax, fabsf(sv));      // the TRUE magnitude (before the clamp): what the next scale is derived from
+            out[e] = pl_clamp(sv);
         }
         u32x4 hi, lo;
         pl_split8(out, hi, lo);
@@ -234,8 +252,8 @@ __device__ __forceinline__ float store_grad8(float (&v)[8], const PoolArgs& p, l
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+        vmax = fmaxf(vmax, fabsf(v[e]));        // before the clamp (planes.h: the true magnitude is recorded)
         v[e] = pl_clamp(v[e]);
-        vmax = fmaxf(vmax, fabsf(v[e]));
     }
     u32x4 hi, lo;
     pl_split8(v, hi, lo);
@@ -430,8 +448,8 @@ __global__ __launch_bounds__(256) void pl_avgpool_affine_kernel(PoolArgs p) {
             float v = acc[e] * inv;
             if (p.aff_scale) v = v * p.aff_scale[8 * g + e] + p.aff_shift[8 * g + e];
             if (p.relu) v = fmaxf(v, 0.f);
+            vmax = fmaxf(vmax, fabsf(v * so));
             out[e] = pl_clamp(v * so);
-            vmax = fmaxf(vmax, fabsf(out[e]));
         }
         u32x4 hi, lo;
         pl_split8(out, hi, lo);
@@ -557,6 +575,16 @@ extern "C" int ssn_pl_scales_update(float* amax, float* scale, int* flag, int n,
     if (n == 0) return SSN_OK;
     hipLaunchKernelGGL(scales_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax, scale, flag, n, exact);
     SSN_CHECK_LAUNCH("pl_scales_update");
+    return SSN_OK;
+}
+
+// flag[0] |= 1 (a tensor overflowed the scale it was stored with) / 2 (severe underflow) over `n` consecutive slots; no slot is
+// modified.  One launch at the end of a forward / backward pass: what makes the delayed scales safe on changing data.
+extern "C" int ssn_pl_range_check(const float* amax, const float* scale, int* flag, int n, hipStream_t stream) {
+    SSN_CHECK_ARG(amax && scale && flag && n >= 0, "pl range check: bad arguments");
+    if (n == 0) return SSN_OK;
+    hipLaunchKernelGGL(range_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax, scale, flag, n);
+    SSN_CHECK_LAUNCH("pl_range_check");
     return SSN_OK;
 }
 

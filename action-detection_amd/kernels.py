@@ -746,10 +746,10 @@ def cw_smoothl1_bwd(labels, diff, gout, dpred):
 
 
 # ------------------------------------------------------------------------------------ optimiser
-def sgd_step(w, grad, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False):
+def sgd_step(w, grad, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, skip_flag=None):
     lib = _check(w, grad, buf)
     lib.call("ssn_sgd_step", _p(w), _p(grad), _p(buf), w.numel(), float(lr), float(momentum), float(weight_decay),
-             float(grad_scale), int(first_step), _stream(lib, w))
+             float(grad_scale), int(first_step), _p(skip_flag), _stream(lib, w))
 
 
 def _ptr_array(tensors):
@@ -759,8 +759,9 @@ def _ptr_array(tensors):
     return arr
 
 
-def sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale=1.0, first_step=False):
-    """One fused launch (per 48 tensors) of the SGD update for many parameter tensors."""
+def sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale=1.0, first_step=False, skip_flag=None):
+    """One fused launch (per 48 tensors) of the SGD update for many parameter tensors.  skip_flag: device int32 tensor; the
+    update is skipped while its first word is non-zero (the range guard of the planes path, planes_exec.PlanesState)."""
     if not ws:
         return
     lib = _check(*ws, *grads, *bufs)
@@ -771,7 +772,7 @@ def sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale=1.0, first_st
     pw, pg, pb = _ptr_array(ws), _ptr_array(grads), _ptr_array(bufs)   # keep the arrays alive across the call
     lib.call("ssn_sgd_step_multi", n, ctypes.addressof(pw), ctypes.addressof(pg), ctypes.addressof(pb),
              ctypes.addressof(sizes), ctypes.addressof(lr), ctypes.addressof(wd), float(momentum), float(grad_scale),
-             int(first_step), _stream(lib, ws[0]))
+             int(first_step), _p(skip_flag), _stream(lib, ws[0]))
 
 
 def wgrad_reduce(part, dw, db, splits, taps=1):

@@ -34,8 +34,11 @@ class SSNSGD(torch.optim.Optimizer):
             g["weight_decay"] = self.base_wd * g["decay_mult"]
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
-        """All parameter tensors in ceil(#tensors / 48) fused launches (ssn_sgd_step_multi)."""
+    def step(self, closure=None, grad_scale=1.0, skip_flag=None):
+        """All parameter tensors in ceil(#tensors / 48) fused launches (ssn_sgd_step_multi).  skip_flag: device int32 tensor
+        (``SSN.scale_fault_flag()``); while its first word is non-zero the launches leave weights and momentum untouched -- the
+        range guard of the planes path flagged this step's gradients, the step is to be repeated (needed where the host cannot
+        look before the update runs: inside a hipGraph replay)."""
         batches = {}   # (momentum, first_step) -> lists
         for g in self.param_groups:
             for p in g["params"]:
@@ -53,7 +56,7 @@ class SSNSGD(torch.optim.Optimizer):
                 b[3].append(g["lr"])
                 b[4].append(g["weight_decay"])
         for (momentum, first), (ws, grads, bufs, lrs, wds) in batches.items():
-            K.sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale, first)
+            K.sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale, first, skip_flag)
         return None
 
 

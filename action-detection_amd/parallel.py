@@ -93,6 +93,28 @@ class GradReducer:
             _scale_inplace(self._flat, 1.0 / self.world)
         self._flat = None
 
+    def agree(self, flag):
+        """Logical OR of a per-rank boolean over the ranks (one 4-byte all-reduce; every rank must call it at the same point).
+        The backward executor asks it after a pass whose bucket all-reduces are already in flight: the range guard's decision
+        to repeat that pass -- and issue the collectives again -- has to be the same on every rank."""
+        if self.world == 1 and not self.force:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self._agree_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(t.item())
+
+    def agree_flag_(self, flag_tensor):
+        """In-place MAX of a device fault word over the ranks (no host sync; capturable): what a graph-captured step runs in
+        front of its optimizer launches, so that all ranks skip a flagged step together."""
+        if self.world > 1 or self.force:
+            dist.all_reduce(flag_tensor, op=dist.ReduceOp.MAX, group=self.group)
+        return flag_tensor
+
+    def _agree_device(self):
+        p = next(self.model.parameters())
+        backend = dist.get_backend(self.group)
+        return p.device if (p.is_cuda and backend == "nccl") else torch.device("cpu")
+
     def reduce_all(self, average=False):
         """Deferred mode, after loss.backward(): SUM (average=True: mean) of every gradient over the ranks.  The backbone's
         parameter gradients are views of the executor's flat buffer (autograd adopts them without a copy), so that buffer is

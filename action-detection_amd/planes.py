@@ -13,14 +13,16 @@ from .kernels import _p, _stream
 
 
 class SlotPool:
-    """amax / scale slots of a set of planes tensors, plus the two status words the update kernel maintains:
-    flag[0] = a tensor outgrew its scale (values were clamped), flag[1] = number of scales changed since the last reset."""
+    """amax / scale slots of a set of planes tensors, plus the two status words the update / range-check kernels maintain:
+    flag[0] = range fault of a pass (bit 0: a tensor outgrew its scale and was clamped; bit 1: a tensor fell far below it),
+    flag[1] = number of scales changed since the last reset.  Several pools may share one flag tensor (all executor states of
+    a backbone on a device do: the optimizer's skip word, ``kernels.sgd_step_multi(skip_flag=)``)."""
 
-    def __init__(self, n, device):
+    def __init__(self, n, device, flag=None):
         self.device = device
         self.amax = torch.zeros(n, device=device, dtype=torch.float32)
         self.scale = torch.ones(n, device=device, dtype=torch.float32)
-        self.flag = torch.zeros(2, device=device, dtype=torch.int32)
+        self.flag = torch.zeros(2, device=device, dtype=torch.int32) if flag is None else flag
         self.used = 0
 
     def take(self):
@@ -38,6 +40,13 @@ class SlotPool:
             return
         lib.call("ssn_pl_scales_update", self.amax.data_ptr() + 4 * first, self.scale.data_ptr() + 4 * first,
                  _p(self.flag), int(count), int(bool(exact)), _stream(lib, self.amax))
+
+    def range_check(self):
+        """flag[0] |= fault bits of the used slots (no slot is modified; no host sync: hipGraph-capturable)."""
+        if self.used <= 0:
+            return
+        lib = _lib.get_lib()
+        lib.call("ssn_pl_range_check", _p(self.amax), _p(self.scale), _p(self.flag), int(self.used), _stream(lib, self.amax))
 
 
 class PlaneTensor:

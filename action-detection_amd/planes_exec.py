@@ -8,13 +8,22 @@ What differs from the fp32-layout executor (bninception._run_forward / _run_back
   operands in its inner loop (the round-2 kernels spent 7-13 VALU per MFMA there);
 * scales are delayed (``planes.SlotPool``): a tensor's power-of-two scale for this step comes from the largest magnitude its
   producers recorded in the previous step; the first step of an executor state is CALIBRATED by running the pass until no scale
-  moves any more (2-3 passes), and an overflow flag (a tensor outgrew its head-room; values were clamped) is raised for the host;
+  moves any more (2-3 passes);
+* the RANGE GUARD makes that safe on data that changes from call to call (another batch, an evaluation pass between training
+  steps, a reloaded checkpoint, a loss spike): producers record the magnitude BEFORE their clamp to the f16 range, one
+  ``ssn_pl_range_check`` launch at the end of every pass raises a device word when a tensor left the range of the scale it was
+  stored with, and a flagged pass is REPEATED with fresh scales before anything consumes it -- ``scale_guard = "sync"`` (default for
+  eager calls): the pass polls the word itself (one 8-byte read per pass) and never returns a clamped result; inside a hipGraph
+  capture nothing can be polled, so the check is captured, ``SSNSGD.step(skip_flag=...)`` refuses to apply a flagged step's
+  gradients, and the owner of the graph polls the word behind the replay (``BNInception.scale_fault()`` /
+  ``recalibrate()``; bench.py does).  With an overlapping gradient reducer attached the decision to repeat a backward is taken by
+  ALL ranks (``hook.agree``), so the collectives stay matched;
 * one stream: the launches of a step already fill the GPU (round 2 measured 1.5 % from four-stream overlap), so the planes path
   keeps the whole step on the caller's stream -- one amax / scale slot per tensor suffices and results stay deterministic.
-  ``SSN_PL_OVERLAP_WGRAD=1`` (off by default) moves the weight gradients -- which write no planes tensor and no amax slot -- to a
-  side stream (bench.py's per-launch event pass switches it off through ``net.overlap_wgrad``): measured 16.88 vs 17.05 ms per
-  step on one box and 16.82 vs 17.06 (two alternating repetitions) on another, +1.0 ... +1.4 %; not yet run through the full GPU
-  test tier, hence not the default;
+  The weight gradients -- which write no planes tensor and no amax slot -- run on a side stream (``SSN_PL_OVERLAP_WGRAD=0`` or
+  ``net.overlap_wgrad = False`` keep them on the main one; bench.py's per-launch event pass does): measured 16.88 vs 17.05 ms per
+  step on one box and 16.82 vs 17.06 (two alternating repetitions) on another, +1.0 ... +1.4 %; default since round 4 (full GPU
+  tier run with it);
 * the ReLU / frozen-BN backward of a layer is fused into whichever launch writes its output gradient last and reads only the
   SIGN of the activation's high plane (2 bytes per element instead of the 4 of an fp32 ``y``).
 
@@ -36,13 +45,14 @@ class PlanesState:
 
     MAX_TENSORS = 512
 
-    def __init__(self, device):
-        self.pool = P.SlotPool(2 * self.MAX_TENSORS, device)
+    def __init__(self, device, flag=None):
+        self.pool = P.SlotPool(2 * self.MAX_TENSORS, device, flag)
         self.act_slot = {}      # activation tensor name -> slot
         self.grad_slot = {}     # gradient tensor name -> slot
         self.fwd_calibrated = False
         self.bwd_calibrated = False
         self.calibration_passes = [0, 0]
+        self.recalibrations = [0, 0]     # passes the range guard had repeated (forward, backward)
 
     def slot(self, name, grad):
         table = self.grad_slot if grad else self.act_slot
@@ -57,16 +67,41 @@ class PlanesState:
         """One launch over all slots (slots nobody wrote keep their scale)."""
         self.pool.update(first=0, count=self.pool.used)
 
+    def check(self):
+        """Range guard: one launch over the slots, raises the fault word (no host sync; capturable)."""
+        self.pool.range_check()
+
+    def fault(self):
+        """The fault word (host sync): bit 0 = a tensor was clamped, bit 1 = a tensor fell far below its scale."""
+        return int(self.pool.flag[0].item())
+
     def overflowed(self):
-        return bool(self.pool.flag[0].item())
+        return bool(self.fault() & 1)
+
+    def settle(self, relaunch, what):
+        """Repeat a pass (``relaunch``) until no scale moves and nothing leaves its range; returns the number of repeats.  The
+        pass must already have run once.  (Host syncs: eager only.)"""
+        for it in range(12):
+            self.pool.flag.zero_()
+            self.update()
+            fault, moved = self.pool.flag.tolist()
+            if not moved and not (fault & 1):
+                self.pool.flag.zero_()
+                return it
+            relaunch()
+        raise RuntimeError("planes executor: %s scales did not settle" % what)
 
 
 def _state(net, x):
     key = (x.device, x.shape[1], x.shape[2])
     st = net._planes_states.get(key)
     if st is None:
-        st = net._planes_states[key] = PlanesState(x.device)
+        st = net._planes_states[key] = PlanesState(x.device, net.planes_flag(x.device))
     return st
+
+
+def _capturing(t):
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
 def supported(net, plan):
@@ -82,7 +117,7 @@ def supported(net, plan):
     return True
 
 
-_OVERLAP_WGRAD_DEFAULT = "0"
+_OVERLAP_WGRAD_DEFAULT = "1"
 
 
 def _conv_taps(op):
@@ -232,28 +267,35 @@ def run_forward(net, x, keep):
         return feat
 
     # delayed scales: this pass stores with the scales derived from the previous pass's maxima
-    acts, argmax = {}, {}
+    res = {"acts": {}, "feat": None}
+    argmax = {}
+    capturing = _capturing(x)
+
+    def again():
+        res["acts"] = {}
+        res["feat"] = launch_all(res["acts"], argmax)
+
     if not st.fwd_calibrated:
         # first pass of this state: no history.  Activations start at 1/4 (head-room up to 2.6e5), then the pass is repeated
         # until no scale moves (each pass fixes every tensor whose inputs were already right)
+        if capturing:
+            raise RuntimeError("planes executor: the first pass of a state calibrates its scales with host syncs and cannot be "
+                               "captured into a hipGraph; run one eager step first")
         st.pool.scale[0::2] = 0.25
-        feat = launch_all(acts, argmax)
-        for it in range(12):
-            st.pool.flag.zero_()
-            st.update()
-            moved, over = st.pool.flag[1].item(), st.pool.flag[0].item()
-            st.calibration_passes[0] = it + 1
-            if not moved and not over:
-                break
-            acts = {}
-            feat = launch_all(acts, argmax)
-        else:
-            raise RuntimeError("planes executor: forward scales did not settle")
-        st.pool.flag.zero_()
+        again()
+        st.calibration_passes[0] = 1 + st.settle(again, "forward")
         st.fwd_calibrated = True
     else:
         st.update()
-        feat = launch_all(acts, argmax)
+        again()
+        if net.scale_guard != "off":
+            # range guard: did every tensor fit the scale last pass's maxima gave it?  (another batch, an evaluation pass after
+            # training steps, reloaded weights ...)  Eager: poll and repeat the pass before anyone reads it; capture: the owner of
+            # the graph polls the word (the optimizer kernel skips a flagged step)
+            st.check()
+            if net.scale_guard == "sync" and not capturing and st.fault():
+                st.recalibrations[0] += 1 + st.settle(again, "forward")
+    acts, feat = res["acts"], res["feat"]
     saved = (plan, shapes, acts, argmax, tscale, packed, st) if keep else None
     return feat, saved
 
@@ -406,19 +448,20 @@ def run_backward(net, dfeat, saved, hook=True):
                 flops = 2.0 * n * shapes[op["dst"]][1] * shapes[op["dst"]][2] * cout * cin * kh * kw
                 gs = None if (op.get("s2d") and "__stem_f32__" in grads) else PSlice(grads[op["dst"]], op["dst_c0"], cout)
                 if op.get("s2d") and "__stem_f32__" in grads:
-                    dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
                     g32, xs32 = grads["__stem_f32__"], acts["data_s2d_f32"]
                     from .bninception import tuned_tile
                     ocfg = tuned_tile("wgrad6s2d", n, cin, cout, op["k"], op["s"], shapes[op["src"]][1])
 
                     def run_wgrad():
+                        # (allocated where it is used: under the side stream when the weight gradients overlap)
+                        dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
                         K.conv_wgrad_x6(K.full(g32), K.full(xs32), dw2, db, 4, 2, ws, ocfg)
                         K.s2d_weights_bwd(dw2, dw)
                 elif op.get("s2d"):
                     xs = acts["data_s2d"]
-                    dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
 
                     def run_wgrad():
+                        dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
                         P.conv_wgrad(gs, PSlice(xs, 0, xs.g * 8), dw2, db, 4, 4, 1, 2, 2, ws, wcfg, cin=4 * cin)
                         K.s2d_weights_bwd(dw2, dw)
                 else:
@@ -474,10 +517,23 @@ def run_backward(net, dfeat, saved, hook=True):
             net.grad_ready_hook.finish()
 
     grads = {}
-    fire = hook
+    hook_obj = net.grad_ready_hook if hook else None
+    # a reducer that overlaps its all-reduces with the backward needs the block-by-block ready ranges DURING a pass; a deferred
+    # one (parallel.GradReducer(deferred=True)) and the chunked caller only need to be told once, at the end
+    overlapping = hook_obj is not None and not getattr(hook_obj, "deferred", False)
+    capturing = _capturing(dfeat)
+    polling = net.scale_guard == "sync" and not capturing
+    refire = False
+
+    def silent_pass():
+        launch_all(grads, False)
+
     if not st.bwd_calibrated:
         # no history: every gradient tensor starts from the magnitude of the incoming feature gradient spread over the 7x7 pool
         # (2^11 at that magnitude: f16 then covers 2^-25 .. 2^5 of it), then passes until no scale moves
+        if capturing:
+            raise RuntimeError("planes executor: the first backward of a state calibrates its scales with host syncs and cannot "
+                               "be captured into a hipGraph; run one eager step first")
         amax0 = float(dfeat.abs().max().item())
         hw = 1
         for op in plan:
@@ -485,26 +541,30 @@ def run_backward(net, dfeat, saved, hook=True):
                 hw = shapes[op["src"]][1] * shapes[op["src"]][2]
         s0 = 2.0 ** math.floor(math.log2(2048.0 / max(amax0 / hw, 1e-30))) if amax0 > 0 else 1.0
         st.pool.scale[1::2] = s0
-        for it in range(12):
-            launch_all(grads, False)
-            st.pool.flag.zero_()
-            st.update()
-            moved, over = st.pool.flag[1].item(), st.pool.flag[0].item()
-            st.calibration_passes[1] = it + 1
-            if not moved and not over:
-                break
-        else:
-            raise RuntimeError("planes executor: gradient scales did not settle")
-        st.pool.flag.zero_()
+        silent_pass()
+        st.calibration_passes[1] = 1 + st.settle(silent_pass, "gradient")
         st.bwd_calibrated = True
-        if hook and net.grad_ready_hook is not None:
-            # the last pass stands numerically; with a gradient reducer attached the pass is run once more so that it sees the
-            # block-by-block ready ranges it overlaps its all-reduces with (first step of a state only)
-            grads = {}
-            launch_all(grads, True)
+        refire = overlapping        # the last pass stands numerically; an overlapping reducer gets one more, with its ranges
     else:
         # (the update at the head of this step's forward already derived the gradient scales from the last backward)
-        launch_all(grads, fire)
+        launch_all(grads, overlapping)
+        if net.scale_guard != "off":
+            st.check()              # range guard (see run_forward); captured: the owner of the graph polls the word
+            local = bool(st.fault()) if polling else False
+            fault = local
+            if polling and overlapping and hasattr(hook_obj, "agree"):
+                # this pass has already issued collectives: whether it is repeated must be ONE decision of all ranks
+                fault = hook_obj.agree(local)
+            if fault:
+                repeats = st.settle(silent_pass, "gradient")     # (local: a rank that had no fault of its own repeats nothing here)
+                st.recalibrations[1] += (1 if local else 0) + repeats
+                refire = overlapping                             # ... and every rank issues the pass with its collectives again
+    if hook_obj is not None:
+        if refire:
+            launch_all(grads, True)
+        elif not overlapping:
+            hook_obj.range_ready(flat, 0, total)
+            hook_obj.finish()
     out = []
     for lid in net._conv_ids:
         conv = getattr(net, lid)

@@ -173,6 +173,19 @@ class SSN(torch.nn.Module):
                     m.bias.requires_grad = False
         return self
 
+    # ---- range guard of the backbone's delayed scales (no counterpart in the reference, whose cuDNN path stores fp32): eager
+    # calls repair themselves (planes_exec.py); a training loop that replays a captured step polls these
+    def scale_fault_flag(self, device=None):
+        """Device int32 word for ``SSNSGD.step(skip_flag=)``: non-zero = a pass of the backbone left the range of its scales."""
+        dev = next(self.base_model.parameters()).device if device is None else device
+        return self.base_model.planes_flag(dev)[0:1]
+
+    def scale_fault(self):
+        return self.base_model.scale_fault()
+
+    def recalibrate_scales(self):
+        self.base_model.recalibrate()
+
     # ---- /root/reference/ssn_models.py:176-201
     def prepare_test_fc(self):
         m = self.stpp.feat_multiplier

@@ -326,6 +326,14 @@ def main():
     batch = [t.to(dev) for t in make_batch(v, args.modality, args.num_class, seed=rank, input_size=frame)]
     global_comp_rows = 7 * v * world
     params = [p for g in opt.param_groups for p in g["params"]]
+    # Range guard of the planes path's delayed scales (planes_exec.py): inside a graph replay nothing can be polled, so the step
+    # carries the range check, the optimizer launches take the fault word and skip a flagged step (weights and momentum stay as
+    # they were: the step is retryable), and the host looks at a pinned copy of the word behind every replay.
+    fault_word = model.scale_fault_flag(dev)
+    fault_host = torch.zeros(1, dtype=torch.int32)
+    if not emulator:
+        fault_host = fault_host.pin_memory()
+    guard = {"faults": 0}
 
     def fwd_bwd():
         out = model(*batch)
@@ -340,7 +348,12 @@ def main():
         reducer.reduce_all(average=False)
 
     def update():
-        opt.step(grad_scale=(1.0 / world) if (use_dist and not overlapped) else 1.0)
+        opt.step(grad_scale=(1.0 / world) if (use_dist and not overlapped) else 1.0, skip_flag=fault_word)
+
+    def agree_fault():
+        """N > 1: a step is skipped / repeated by ALL ranks or by none (MAX of the fault word; 4 bytes, capturable)."""
+        if use_dist:
+            reducer.agree_flag_(fault_word)
 
     def step(collectives=True):
         loss = fwd_bwd()
@@ -348,9 +361,23 @@ def main():
             reducer.reduce_heads()
         elif collectives and use_dist:
             allreduce_grads()
+        if collectives:
+            agree_fault()
         update()
         opt.zero_grad(set_to_none=True)
         return loss
+
+    def poll_guard():
+        """Behind every step: queue a copy of the fault word into pinned memory and look at what the previous copies brought
+        (no sync: the value lags by a step or two, during which the optimizer skips on its own).  On a fault: drain, clear,
+        recalibrate and redo the step eagerly -- it calibrates as a first step does."""
+        fault_host.copy_(fault_word, non_blocking=True)
+        if int(fault_host[0]) != 0:
+            torch.cuda.synchronize()
+            guard["faults"] += 1
+            model.recalibrate_scales()
+            fault_host.zero_()
+            step()
 
     def fence():
         if use_dist:
@@ -387,6 +414,7 @@ def main():
                 def run_step():
                     g_fb.replay()
                     allreduce_grads()
+                    agree_fault()
                     g_up.replay()
                     return static["loss"]
                 launch = "hipGraph replay (fwd+bwd graph, eager RCCL all-reduce, optimizer graph)"
@@ -406,13 +434,16 @@ def main():
 
     for _ in range(args.warmup):
         run_step()
+        poll_guard()
 
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run_step()
+        poll_guard()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = 1e3 * elapsed / args.steps
 
     # ---- per-launch HIP events for the roofline: the same K steps once more, launched eagerly (events cannot
     # be recorded inside a graph replay; the kernels and their arguments are identical)
@@ -441,6 +472,40 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- N > 1 (or SSN_FORCE_ALLREDUCE=1): make the run self-validating -- who took part, on which device, with which RCCL,
+    # every rank's own clock, and what the gradient all-reduce costs on its own (same buffers, after the timed region)
+    dist_info = None
+    if use_dist:
+        def _dev_id():
+            if emulator:
+                return "cpu:%d" % os.getpid()
+            pr = torch.cuda.get_device_properties(dev)
+            return str(getattr(pr, "uuid", None) or "%s@%s" % (pr.name, getattr(pr, "pci_bus_id", local_rank)))
+        mine = {"rank": rank, "local_rank": local_rank, "device": _dev_id(), "ms_per_step": round(rank_ms, 3),
+                "guard_faults": guard["faults"]}
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, mine)
+        ar_ms = None
+        if not emulator and reducer is not None:
+            flat = reducer._deferred_flat
+            if flat is None:
+                flat = torch.zeros(sum(p.numel() for p in model.base_model.parameters() if p.requires_grad), device=dev)
+            dist.all_reduce(flat)                      # warm
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fence()
+            e0.record()
+            for _ in range(10):
+                dist.all_reduce(flat)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = round(e0.elapsed_time(e1) / 10, 4)
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:  # noqa: BLE001
+            rccl = None
+        dist_info = {"ranks_seen": seen, "distinct_devices": len({x["device"] for x in seen}), "rccl_version": rccl,
+                     "allreduce_ms_standalone": ar_ms,
+                     "allreduce_bytes": (4 * int(flat.numel()) if (not emulator and reducer is not None) else None)}
 
     proposals = 8 * v * world * args.steps
     value = proposals / elapsed
@@ -482,7 +547,13 @@ def main():
                                          if model.base_model.layout == "planes" else "")
                                       if args.precision == "split" else "exact-f32 MFMA everywhere")},
         "final_loss": float(loss.item()),
+        "scale_guard": {"protocol": "range check of the delayed scales captured in the step; optimizer launches skip a flagged step "
+                                    "(device fault word); host polls a pinned copy behind every step and redoes a flagged step "
+                                    "eagerly after recalibration" + ("; the word is MAX-reduced over the ranks" if use_dist else ""),
+                        "scale_overflows": guard["faults"], "repeated_eager_passes": model.base_model.guard_stats()},
     }
+    if dist_info is not None:
+        result["distributed"] = dist_info
 
     if rank == 0:
         # ---------------- roofline of the dominant kernel family (HIP events, timed region) ----------------

@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define SSN_ERR_WORKSPACE (-3)
 
 const char* ssn_last_error(void);
-int ssn_abi_version(void);   /* 5 */
+int ssn_abi_version(void);   /* 6 */
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
@@ -362,13 +362,16 @@ int ssn_cw_smoothl1_bwd(const long* labels, const float* diff, const float* gout
 /* ------------------------------------------------------------------ optimiser step
  * torch.optim.SGD(momentum, weight_decay) over one flat segment (ssn_train.py:141-144,252);
  * per-group lr_mult / decay_mult of ssn_models.py:240-251 are folded into lr / weight_decay. */
+/* skip_flag (device int, may be NULL): read at launch time; non-zero = leave w and the momentum buffer untouched.  It is the word
+ * ssn_pl_range_check raises when a tensor of the step left the range of its delayed scale: optimizer.step() (ssn_train.py:252) of a
+ * flagged step becomes a no-op, so the host can repeat the step with fresh scales -- also from inside a hipGraph replay. */
 int ssn_sgd_step(float* w, const float* grad, float* momentum_buf, long n, float lr, float momentum,
-                 float weight_decay, float grad_scale, int first_step, hipStream_t stream);
+                 float weight_decay, float grad_scale, int first_step, const int* skip_flag, hipStream_t stream);
 /* The same update for `count` tensors in ceil(count/48) launches; w / grad / momentum_buf / n / lr / weight_decay
  * are HOST arrays (of device pointers resp. scalars), one entry per tensor. */
 int ssn_sgd_step_multi(int count, float* const* w, const float* const* grad, float* const* momentum_buf,
                        const long* n, const float* lr, const float* weight_decay, float momentum, float grad_scale,
-                       int first_step, hipStream_t stream);
+                       int first_step, const int* skip_flag, hipStream_t stream);
 /* clip_grad_norm support (ssn_train.py:245-249): out[0] (+)= sum(x^2); workspace >= 1024 floats. */
 int ssn_sumsq(const float* x, long n, float* out, int accumulate, float* workspace, hipStream_t stream);
 int ssn_scale(float* x, long n, const float* coef_dev, float coef, hipStream_t stream);
@@ -401,6 +404,13 @@ int ssn_embed_planes(const float* g, float* out, int N, int C, int Ho, int Wo, l
  * `*_amax` at its amax slot, raised by every producer (ssn_pl_scales_update turns one into the other between steps and flags
  * tensors that outgrew their head-room).  Packed weights are those of ssn_conv_x6_pack_*. */
 int ssn_pl_scales_update(float* amax, float* scale, int* flag, int n, int exact, hipStream_t stream);
+/* The range guard of the delayed scales: one launch at the END of a forward / backward pass over the `n` slots of the executor.
+ * flag[0] |= 1 if a tensor's recorded (pre-clamp) maximum did not fit the scale it was stored with (its values were clamped to the
+ * f16 range), |= 2 if it fell more than 8 bits below the target range (precision draining).  Modifies no slot.  The reference has no
+ * counterpart (cuDNN computes in fp32 storage); this is what lets loss.backward() / optimizer.step() (ssn_train.py:236,252) and the
+ * alternating train / validate passes (ssn_train.py:191-253, 278-362) run on data whose magnitude changes from call to call: the
+ * host repeats a flagged pass with fresh scales, ssn_sgd_step_multi(skip_flag) refuses to consume a flagged step's gradients. */
+int ssn_pl_range_check(const float* amax, const float* scale, int* flag, int n, hipStream_t stream);
 /* fp32 NCHW <-> planes (the caller's frames, test inputs, the fp32 feature boundary); s2d: the space-to-depth view of the stem. */
 int ssn_pl_from_f32(const float* x, long x_img_stride, void* hi, void* lo, int N, int C, int H, int W, long img_groups, int s2d,
                     const float* scale, float* amax, hipStream_t stream);
