@@ -72,6 +72,7 @@ _SIGS = {
     "ssn_crop_mean": "ppiiip",
     "ssn_detections": "ppppppppuiiiiidip",
     "ssn_frames_crop_normalize": "ppiiiiiiipppiipipip",
+    "ssn_frames_crop_resize_normalize": "ppiiiiiippiipipipup",
     "ssn_reg_denorm": "plffffp",
     "ssn_frame_diff": "ppliiip",
     "ssn_linear_fwd": "ppppiiip",
@@ -118,7 +119,7 @@ EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_w
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_packed_floats_dgrad_rect", "ssn_conv_wgrad_x6_rect_workspace_bytes", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
-                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes"])
+                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes", "ssn_frames_resize_workspace_bytes"])
 
 
 class SsnLibrary:
@@ -153,6 +154,8 @@ class SsnLibrary:
         self.cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
         self.cdll.ssn_pl_channel_sum_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_pl_channel_sum_workspace_bytes.argtypes = [ctypes.c_int]
+        self.cdll.ssn_frames_resize_workspace_bytes.restype = ctypes.c_size_t
+        self.cdll.ssn_frames_resize_workspace_bytes.argtypes = [ctypes.c_int] * 3
         self.cdll.ssn_conv_wgrad_pl_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_conv_wgrad_pl_workspace_bytes.argtypes = [ctypes.c_int] * 8
         self._fn = {}

@@ -176,8 +176,9 @@ class BNInception(nn.Module):
         # "planes": activations and their gradients live as two f16 planes in the channel-blocked layout of the matrix cores,
         # produced by the kernels that compute them (planes_exec.py; frozen BatchNorm only) -- "f32": fp32 NCHW tensors, every
         # consumer converts its operands (the round-1/2 executor below, and the path of training-mode BatchNorm)
-        # Default: planes for BN-Inception (the benchmarked backbone; frozen BatchNorm), fp32 for the Inception-v3 subclass.
-        self.layout = os.environ.get("SSN_LAYOUT", "planes" if type(self).__name__ == "BNInception" else "f32")
+        # Default: planes for both backbones (round 4: Inception-v3 too); a plan with training-mode BatchNorm falls back to the fp32
+        # layout on its own (planes_exec.supported), SSN_LAYOUT=f32 forces it (the cross-check configuration).
+        self.layout = os.environ.get("SSN_LAYOUT", "planes")
         self.debug_keep_saved = False
         self._last_saved = None
         self._planes_states = {}

@@ -58,6 +58,51 @@ class GpuFrameTransform(object):
         return self._run(frames, [(off_w, off_h, flip)]).reshape(-1, self.crop_h, self.crop_w)
 
 
+class GpuTrainAugment(GpuFrameTransform):
+    """``SSN.get_augmentation()`` + the tail of the training chain on the GPU (/root/reference/ssn_models.py:386-395,
+    ssn_train.py:106-111): ``GroupMultiScaleCrop(input_size, scales)`` -> ``GroupRandomHorizontalFlip(is_flow)`` -> ``Stack(roll)`` ->
+    ``ToTorchFormatTensor(div=False)`` -> ``GroupNormalize`` on DECODED uint8 frames -- crop, PIL's bilinear resize (restated
+    bit-exactly, csrc/frames.hip), flip and normalisation in two launches; the loader workers only decode.
+
+    Crop boxes and flips are drawn per GROUP (the reference transforms the frames of one proposal together,
+    ssn_dataset.py:347-380) through Python's ``random`` in the reference's order -- two draws for the box, one for the flip -- so a
+    seeded run picks the reference's crops (tests/golden/ref_transforms.npz)."""
+
+    def __init__(self, input_size, mean, std, scales, roll=True, is_flow=False, device="cuda:0", max_distort=1, fix_crop=True,
+                 more_fix_crop=True):
+        super().__init__(input_size, mean, std, roll=roll, is_flow=is_flow, device=device)
+        self.scales = list(scales)
+        self.max_distort, self.fix_crop, self.more_fix_crop = max_distort, fix_crop, more_fix_crop
+
+    def sample(self, frame_wh, n_groups):
+        """-> (boxes [n_groups][4] = (x0, y0, crop_w, crop_h), flips [n_groups]) with the reference's draws per group."""
+        import random
+        from .transforms import GroupMultiScaleCrop
+        msc = GroupMultiScaleCrop([self.crop_w, self.crop_h], self.scales, self.max_distort, self.fix_crop, self.more_fix_crop)
+        boxes, flips = [], []
+        for _ in range(n_groups):
+            cw, ch, ow, oh = msc.sample_crop(frame_wh)
+            boxes.append((ow, oh, cw, ch))
+            flips.append(random.random() < 0.5)
+        return boxes, flips
+
+    def __call__(self, frames, group_size, boxes=None, flips=None):
+        """frames uint8 [n_img, H, W, C] (n_img = groups x group_size, decoded size) -> fp32 [n_img * C, crop_h, crop_w]."""
+        if frames.dtype != torch.uint8 or frames.dim() != 4:
+            raise ValueError("frames: uint8 [n_img, H, W, C] as decoded")
+        n_img, h, w, c = frames.shape
+        if n_img % group_size:
+            raise ValueError("%d frames do not split into groups of %d" % (n_img, group_size))
+        if boxes is None:
+            boxes, flips = self.sample((w, h), n_img // group_size)
+        per_box = [b for b in boxes for _ in range(group_size)]
+        per_flip = [f for f in flips for _ in range(group_size)]
+        frames = frames.to(self.mean.device).contiguous()
+        out = K.frames_crop_resize_normalize(frames, per_box, per_flip, (self.crop_h, self.crop_w), self.roll, self.is_flow,
+                                             self.mean, self.std)
+        return out.reshape(-1, self.crop_h, self.crop_w)
+
+
 class TrainingBatchPrefetcher(object):
     """Keeps the GPU fed during training.
 
@@ -75,10 +120,15 @@ class TrainingBatchPrefetcher(object):
     non-HIP device (the host emulator of the tests) it degrades to a synchronous loop with the same results.
     """
 
-    def __init__(self, source, transform, depth=2):
+    def __init__(self, source, transform, depth=2, group_size=None):
         import queue
         import threading
         self.transform = transform
+        # with a GpuTrainAugment the frames arrive UN-cropped at their decoded size and the scale-jittered crop + resize + flip run
+        # on the GPU too; group_size = images that share one crop box (the frames of one proposal: segments x new_length)
+        self.group_size = group_size
+        if isinstance(transform, GpuTrainAugment) and not group_size:
+            raise ValueError("GpuTrainAugment needs group_size (images per proposal)")
         self.device = transform.mean.device
         self.cuda = self.device.type == "cuda"
         self.depth = max(2, int(depth))
@@ -125,7 +175,7 @@ class TrainingBatchPrefetcher(object):
         v, n_img, h, w, c = frames.shape
         small = [torch.as_tensor(t) for t in (scaling, target, reg_target, prop_type)]
         if not self.cuda:
-            out = self.transform.crop(frames.reshape(v * n_img, h, w, c), 0, 0, False)
+            out = self._transform(frames.reshape(v * n_img, h, w, c))
             ch, cw = out.shape[-2], out.shape[-1]      # the transform's crop size (the frames may be larger)
             return (out.reshape(v, n_img * c, ch, cw),) + tuple(t.to(self.device) for t in small), None
         if slot["pinned"] is None or slot["pinned"].shape != frames.shape:
@@ -138,12 +188,17 @@ class TrainingBatchPrefetcher(object):
             slot["dev"].copy_(slot["pinned"], non_blocking=True)    # (the device buffer is only touched on this stream)
             slot["uploaded"] = torch.cuda.Event()
             slot["uploaded"].record(self._stream)
-            out = self.transform.crop(slot["dev"].reshape(v * n_img, h, w, c), 0, 0, False)
+            out = self._transform(slot["dev"].reshape(v * n_img, h, w, c))
             out = out.reshape(v, n_img * c, out.shape[-2], out.shape[-1])      # the transform's crop size
             rest = tuple(t.pin_memory().to(self.device, non_blocking=True) for t in small)
             ready = torch.cuda.Event()
             ready.record(self._stream)
         return (out,) + rest, ready
+
+    def _transform(self, frames):
+        if isinstance(self.transform, GpuTrainAugment):
+            return self.transform(frames, self.group_size)
+        return self.transform.crop(frames, 0, 0, False)
 
     # -- consumer ------------------------------------------------------------------------------------------------------
     def __iter__(self):

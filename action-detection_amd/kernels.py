@@ -644,6 +644,35 @@ def frames_crop_normalize(src, dst, crops, roll, invert_even, mean, std):
              int(roll), int(invert_even), _p(mean), mean.numel(), _p(std), std.numel(), _stream(lib, src))
 
 
+def frames_crop_resize_normalize(src, boxes, flips, out_hw, roll, invert_even, mean, std, dst=None):
+    """The training augmentation in two launches (ssn_frames_crop_resize_normalize): src uint8 [n_img, Hs, Ws, C] decoded frames
+    -> fp32 [n_img, C, out_h, out_w] = normalise(roll(flip(PIL-bilinear-resize(crop)))).  boxes: [n_img, 4] ints (x0, y0, crop_w,
+    crop_h) -- host list / array (validated and uploaded here) or a device int32 tensor the caller vouches for; flips likewise."""
+    lib = _check(src, mean, std)
+    assert src.dtype == torch.uint8 and src.dim() == 4 and src.is_contiguous()
+    n_img, hs, ws, c = src.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    if not torch.is_tensor(boxes):
+        import numpy as np
+        b = np.asarray(boxes, dtype=np.int64).reshape(n_img, 4)
+        if (b[:, 0] < 0).any() or (b[:, 1] < 0).any() or (b[:, 2] < 1).any() or (b[:, 3] < 1).any() \
+                or (b[:, 0] + b[:, 2] > ws).any() or (b[:, 1] + b[:, 3] > hs).any():
+            raise ValueError("crop box outside the %dx%d frame" % (ws, hs))
+        if (b[:, 2] > 3 * ow).any() or (b[:, 3] > 3 * oh).any():
+            raise ValueError("crop more than 3x the output size (the resize kernel holds 7 taps per axis)")
+        boxes = torch.from_numpy(b.astype(np.int32)).to(src.device)
+    if not torch.is_tensor(flips):
+        flips = torch.tensor([int(bool(f)) for f in flips], dtype=torch.int32).to(src.device)
+    assert boxes.dtype == torch.int32 and flips.dtype == torch.int32 and boxes.numel() == 4 * n_img and flips.numel() == n_img
+    if dst is None:
+        dst = torch.empty((n_img, c, oh, ow), device=src.device, dtype=torch.float32)
+    ws_bytes = int(lib.cdll.ssn_frames_resize_workspace_bytes(n_img, oh, ow))
+    wsp = torch.empty(max(ws_bytes, 4) // 4, device=src.device, dtype=torch.int32)
+    lib.call("ssn_frames_crop_resize_normalize", _p(src), _p(dst), n_img, hs, ws, c, oh, ow, _p(boxes), _p(flips), int(roll),
+             int(invert_even), _p(mean), mean.numel(), _p(std), std.numel(), _p(wsp), ws_bytes, _stream(lib, src))
+    return dst
+
+
 def frame_diff(x, new_length, channels=3):
     """RGBDiff input (SSN._get_diff): x [..., (new_length + 1) * channels * k, H, W] stacked frames per segment ->
     [n_segments, new_length * channels, H, W] differences of consecutive frames."""

@@ -20,10 +20,8 @@ What differs from the fp32-layout executor (bninception._run_forward / _run_back
   ALL ranks (``hook.agree``), so the collectives stay matched;
 * one stream: the launches of a step already fill the GPU (round 2 measured 1.5 % from four-stream overlap), so the planes path
   keeps the whole step on the caller's stream -- one amax / scale slot per tensor suffices and results stay deterministic.
-  The weight gradients -- which write no planes tensor and no amax slot -- run on a side stream (``SSN_PL_OVERLAP_WGRAD=0`` or
-  ``net.overlap_wgrad = False`` keep them on the main one; bench.py's per-launch event pass does): measured 16.88 vs 17.05 ms per
-  step on one box and 16.82 vs 17.06 (two alternating repetitions) on another, +1.0 ... +1.4 %; default since round 4 (full GPU
-  tier run with it);
+  (Round 3 carried a switch that moved the weight gradients to a side stream: +1.0 ... +1.4 % on two boxes then, -0.3 % on the
+  round-4 box -- 17.03 vs 16.98 ms, profiles/r4_bench_wgrad_side_stream_ab.txt -- i.e. nothing; removed.)
 * the ReLU / frozen-BN backward of a layer is fused into whichever launch writes its output gradient last and reads only the
   SIGN of the activation's high plane (2 bytes per element instead of the 4 of an fp32 ``y``).
 
@@ -31,7 +29,6 @@ Supported: frozen BatchNorm (the reference's default ``bn_mode='frozen'``; /root
 rectangular-tap plans.  Training-mode BatchNorm keeps the fp32-layout executor.
 """
 import math
-import os
 
 import torch
 
@@ -53,6 +50,7 @@ class PlanesState:
         self.bwd_calibrated = False
         self.calibration_passes = [0, 0]
         self.recalibrations = [0, 0]     # passes the range guard had repeated (forward, backward)
+        self.fault_log = []              # diagnostics: the last few faults as (pass, [(tensor, amax * scale), ...])
 
     def slot(self, name, grad):
         table = self.grad_slot if grad else self.act_slot
@@ -77,6 +75,14 @@ class PlanesState:
 
     def overflowed(self):
         return bool(self.fault() & 1)
+
+    def describe_fault(self, which):
+        """Diagnostics (host sync): the tensors whose recorded maximum left the range of their scale in the pass just run."""
+        a = (self.pool.amax[:self.pool.used] * self.pool.scale[:self.pool.used]).tolist()
+        names = {v: ("grad:" if g else "act:") + k for g, tab in ((0, self.act_slot), (1, self.grad_slot)) for k, v in tab.items()}
+        bad = [(names.get(i, "slot%d" % i), v) for i, v in enumerate(a) if v != v or v >= 65504.0 or 0.0 < v < 16.0]
+        self.fault_log = (self.fault_log + [(which, bad)])[-8:]
+        return bad
 
     def settle(self, relaunch, what):
         """Repeat a pass (``relaunch``) until no scale moves and nothing leaves its range; returns the number of repeats.  The
@@ -115,9 +121,6 @@ def supported(net, plan):
         if op["kind"] == "conv" and (op["cout"] % 8 or (op["src"] != "data" and op["cin"] % 8)):
             return False
     return True
-
-
-_OVERLAP_WGRAD_DEFAULT = "1"
 
 
 def _conv_taps(op):
@@ -294,6 +297,7 @@ def run_forward(net, x, keep):
             # the graph polls the word (the optimizer kernel skips a flagged step)
             st.check()
             if net.scale_guard == "sync" and not capturing and st.fault():
+                st.describe_fault("forward")
                 st.recalibrations[0] += 1 + st.settle(again, "forward")
     acts, feat = res["acts"], res["feat"]
     saved = (plan, shapes, acts, argmax, tscale, packed, st) if keep else None
@@ -352,22 +356,9 @@ def run_backward(net, dfeat, saved, hook=True):
             if len(readers) == 1 and readers[0]["kind"] == "pool" and readers[0]["pool"] == "max" and op["dst_c0"] == 0:
                 stem_out = op["dst"]
 
-    # SSN_PL_OVERLAP_WGRAD=1: every weight gradient only needs its layer's finished output gradient and writes nothing any other
-    # kernel of the step reads (fp32 dW / db, its own split-K scratch, no amax slot) -- it can run on a side stream next to the
-    # data-gradient chain, the two families filling each other's partly empty last rounds.  One side stream = one workspace.
-    use_side = net.overlap_wgrad and os.environ.get("SSN_PL_OVERLAP_WGRAD", _OVERLAP_WGRAD_DEFAULT) == "1" and dfeat.is_cuda
-    main = torch.cuda.current_stream(dev) if use_side else None
-    side = None
-    if use_side:
-        side = net._side.get(dev)
-        if side is None:
-            side = net._side[dev] = torch.cuda.Stream(device=dev)
-
     def launch_all(grads, fire_hook):
         masked, inited = {}, set()
         pending_end = total
-        if use_side:
-            side.wait_stream(main)
 
         def gbuf(name):
             if name not in grads:
@@ -453,7 +444,6 @@ def run_backward(net, dfeat, saved, hook=True):
                     ocfg = tuned_tile("wgrad6s2d", n, cin, cout, op["k"], op["s"], shapes[op["src"]][1])
 
                     def run_wgrad():
-                        # (allocated where it is used: under the side stream when the weight gradients overlap)
                         dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
                         K.conv_wgrad_x6(K.full(g32), K.full(xs32), dw2, db, 4, 2, ws, ocfg)
                         K.s2d_weights_bwd(dw2, dw)
@@ -478,14 +468,7 @@ def run_backward(net, dfeat, saved, hook=True):
                         fin = op["proj_final"] if "raw_from" in op else op["final"]
                         cp = cout - op.get("raw_from", 0)
                         P.channel_sum(PSlice(grads[fin[0]], fin[1], cp), db[op.get("raw_from", 0):], cs_ws)
-                if use_side:
-                    ready = torch.cuda.Event()
-                    ready.record(main)            # the output gradient of this layer is final here
-                    side.wait_event(ready)
-                    with torch.cuda.stream(side):
-                        net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
-                else:
-                    net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
+                net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
                 if op["src"] != "data":
                     wt = packed_dg[lids[0]]
                     key = src_key(op)
@@ -505,12 +488,8 @@ def run_backward(net, dfeat, saved, hook=True):
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
                 if fire_hook and net.grad_ready_hook is not None and closes_block:
-                    if use_side:
-                        main.wait_stream(side)    # the block's weight gradients must have landed before the all-reduce
                     net.grad_ready_hook.range_ready(flat, wo, pending_end)
                     pending_end = wo
-        if use_side:
-            main.wait_stream(side)
         if fire_hook and net.grad_ready_hook is not None:
             if pending_end > 0:
                 net.grad_ready_hook.range_ready(flat, 0, pending_end)
@@ -555,6 +534,8 @@ def run_backward(net, dfeat, saved, hook=True):
             if polling and overlapping and hasattr(hook_obj, "agree"):
                 # this pass has already issued collectives: whether it is repeated must be ONE decision of all ranks
                 fault = hook_obj.agree(local)
+            if local:
+                st.describe_fault("backward")
             if fault:
                 repeats = st.settle(silent_pass, "gradient")     # (local: a rank that had no fault of its own repeats nothing here)
                 st.recalibrations[1] += (1 if local else 0) + repeats

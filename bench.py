@@ -550,7 +550,9 @@ def main():
         "scale_guard": {"protocol": "range check of the delayed scales captured in the step; optimizer launches skip a flagged step "
                                     "(device fault word); host polls a pinned copy behind every step and redoes a flagged step "
                                     "eagerly after recalibration" + ("; the word is MAX-reduced over the ranks" if use_dist else ""),
-                        "scale_overflows": guard["faults"], "repeated_eager_passes": model.base_model.guard_stats()},
+                        "scale_overflows": guard["faults"], "repeated_eager_passes": model.base_model.guard_stats(),
+                        "eager_fault_log": [[w, [[n_, round(v_, 3)] for n_, v_ in bad[:6]]]
+                                            for st_ in model.base_model._planes_states.values() for w, bad in st_.fault_log]},
     }
     if dist_info is not None:
         result["distributed"] = dist_info

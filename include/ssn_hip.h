@@ -311,6 +311,16 @@ int ssn_frames_crop_normalize(const unsigned char* src, float* dst, int n_img, i
                               int crop_w, int n_crops, const int* off_x, const int* off_y, const int* flip, int roll,
                               int invert_even, const float* mean, int n_mean, const float* stdv, int n_std,
                               hipStream_t stream);
+/* The TRAINING chain on the GPU: GroupMultiScaleCrop (crop + PIL's bilinear resize to the network input: transforms.py:135-206,
+ * restated bit-exactly from Pillow's 8-bit ImagingResample) -> GroupRandomHorizontalFlip (:49-64) -> Stack(roll) ->
+ * ToTorchFormatTensor(div=False) -> GroupNormalize, i.e. SSN.get_augmentation() + the tail of ssn_train.py:106-111, on decoded
+ * uint8 frames: the loader workers only decode.  src [n_img][Hs][Ws][C] uint8 -> dst [n_img][C][out_h][out_w] fp32; box: DEVICE int
+ * [n_img][4] = (x0, y0, crop_w, crop_h) per image (one box per group in the reference), flip: DEVICE int [n_img]; the caller checks
+ * that boxes lie inside the frame and crop / output <= 3 per axis.  workspace: ssn_frames_resize_workspace_bytes() device bytes. */
+size_t ssn_frames_resize_workspace_bytes(int n_img, int out_h, int out_w);
+int ssn_frames_crop_resize_normalize(const unsigned char* src, float* dst, int n_img, int Hs, int Ws, int C, int out_h, int out_w,
+                                     const int* box, const int* flip, int roll, int invert_even, const float* mean, int n_mean,
+                                     const float* stdv, int n_std, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* Detection post-processing of one video (csrc/detect.hip): score fusion softmax(activity)[1:] * exp(completeness),
  * top-k over all (proposal, class) pairs, temporal NMS per class and location regression

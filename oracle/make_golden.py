@@ -499,6 +499,25 @@ def golden_transforms():
             cw, ch, ow, oh = ref_tf.GroupMultiScaleCrop(224, [1, .875, .75, .66])._sample_crop_size((w, h))
             rec.append([w, h, 1000 + seed, cw, ch, ow, oh, int(random.random() < 0.5)])
     out["crop_params"] = np.array(rec, np.int64)
+    # the training augmentation at the REAL sizes (256 x 340 decoded frame -> 224 network input; every scale of the jitter:
+    # 256 -> 224 shrinks with 5 taps, 192 / 168 -> 224 enlarge with 3, 224 is copied): pins the GPU restatement of PIL's resize
+    full = rs.randint(0, 256, size=(1, 256, 340, 3)).astype(np.uint8)
+    # (smooth content in the right half: noise alone would hide a wrong tap position behind its own variance)
+    yy, xx = np.mgrid[0:256, 0:340]
+    smooth = np.stack([(xx * 3 + yy) % 256, (xx + yy * 2) % 256, (xx * yy // 64) % 256], axis=2).astype(np.uint8)
+    full[0, :, 170:] = smooth[:, 170:]
+    out["aug_full_frames"] = full
+    imgs = [Image.fromarray(f, "RGB") for f in full]
+    boxes = []
+    for seed in (0, 1, 3, 4, 7):        # crop sizes 256x224, 168x168, 168x192, 256x256, 224x224 (w x h)
+        random.seed(100 + seed)
+        msc = ref_tf.GroupMultiScaleCrop(224, [1, .875, .75, .66])
+        st = random.getstate()
+        boxes.append(list(msc._sample_crop_size((340, 256))))
+        random.setstate(st)
+        g = ref_tf.GroupRandomHorizontalFlip(is_flow=False)(msc(imgs))
+        out["aug_full_%d" % seed] = np.stack([np.asarray(im) for im in g])
+    out["aug_full_boxes"] = np.array(boxes, np.int64)        # (crop_w, crop_h, offset_w, offset_h) per seed
     np.savez_compressed(os.path.join(OUT, "ref_transforms.npz"), **out)
 
 

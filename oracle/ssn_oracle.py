@@ -217,15 +217,34 @@ class OracleInceptionV3(nn.Module):
             cin = 2048
         self.top_cls_fc = nn.Linear(2048, num_classes)
 
+    # Mask-forced evaluation (see OracleBNInception.forced): ({layer id: bool mask}, [window-local argmax per max pool, in forward
+    # order]) taken from another implementation's forward; every ReLU multiplies by the mask, every max pool gathers the given element.
+    forced = None
+
     def _cbr(self, name, x):
-        return F.relu(getattr(self, name + "_bn")(getattr(self, name)(x)))
+        z = getattr(self, name + "_bn")(getattr(self, name)(x))
+        if self.forced is not None:
+            return z * self.forced[0][name].to(z.dtype)
+        return F.relu(z)
+
+    def _maxpool(self, x):
+        if self.forced is None:
+            return F.max_pool2d(x, 3, 2)
+        local = self.forced[1][self._pool_i]
+        self._pool_i += 1
+        n, c, h, w = x.shape
+        ho, wo = local.shape[2], local.shape[3]
+        hh = torch.arange(ho).view(1, 1, ho, 1) * 2 + local // 3
+        ww = torch.arange(wo).view(1, 1, 1, wo) * 2 + local % 3
+        return x.flatten(2).gather(2, (hh * w + ww).flatten(2)).view(n, c, ho, wo)
 
     def features(self, x):
         c = self._cbr
+        self._pool_i = 0
         x = c("conv_2b_3x3", c("conv_2a_3x3", c("conv_1a_3x3", x)))
-        x = F.max_pool2d(x, 3, 2)
+        x = self._maxpool(x)
         x = c("conv_4a_3x3", c("conv_3b_1x1", x))
-        x = F.max_pool2d(x, 3, 2)
+        x = self._maxpool(x)
         for nm, _ in self.blocks_a:
             p = nm + "_"
             x = torch.cat([c(p + "1x1", x), c(p + "5x5", c(p + "5x5_reduce", x)),
@@ -233,7 +252,7 @@ class OracleInceptionV3(nn.Module):
                            c(p + "pool_proj", F.avg_pool2d(x, 3, 1, 1, count_include_pad=True))], 1)
         p = "mixed_6a_"
         x = torch.cat([c(p + "3x3", x), c(p + "double_3x3_2", c(p + "double_3x3_1", c(p + "double_3x3_reduce", x))),
-                       F.max_pool2d(x, 3, 2)], 1)
+                       self._maxpool(x)], 1)
         for nm, _ in self.blocks_c:
             p = nm + "_"
             b7 = c(p + "7x1", c(p + "1x7", c(p + "7x7_reduce", x)))
@@ -246,7 +265,7 @@ class OracleInceptionV3(nn.Module):
         b7 = c(p + "7x7x3_reduce", x)
         for s in ("7x7x3_1x7", "7x7x3_7x1", "7x7x3_3x3"):
             b7 = c(p + s, b7)
-        x = torch.cat([c(p + "3x3", c(p + "3x3_reduce", x)), b7, F.max_pool2d(x, 3, 2)], 1)
+        x = torch.cat([c(p + "3x3", c(p + "3x3_reduce", x)), b7, self._maxpool(x)], 1)
         for nm in ("mixed_7b", "mixed_7c"):
             p = nm + "_"
             b3 = c(p + "3x3_reduce", x)

@@ -159,6 +159,52 @@ def test_inceptionv3_backbone_backward_gpu(hip_library):
 
 
 @pytest.mark.gpu
+def test_inceptionv3_gradients_vs_mask_forced_referee_gpu(hip_library):
+    """The tight gradient statement for Inception-v3 (the planes path, round 4), as tests/test_model_gpu.py makes it for BN-Inception:
+    a float64 oracle that is forced to take the HIP forward's ReLU / max-pool decisions (``export_decisions``: the sign its backward
+    kernels read, the argmax its pools stored) is a smooth function of the weights, so EVERY one of the 188 gradient tensors must
+    agree to rounding -- 5e-5 relative -- at 299 x 299, a quarter of the BatchNorm scales negative; the forced forward must reproduce
+    the HIP features to 2e-6.  Also: a second call on data 40 x larger (the range guard repeats the pass) meets the same bar."""
+    from action_detection_amd.inceptionv3 import InceptionV3
+    torch.manual_seed(0)
+    prod = InceptionV3(num_classes=10, input_size=299)
+    init_backbone_synthetic(prod, negative_gamma_frac=0.25)
+    orc = O.OracleInceptionV3(num_classes=10).double()
+    orc.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in prod.state_dict().items()})
+    prod.eval().to("cuda:0")
+    orc.eval()
+    assert prod.layout == "planes"
+    prod.debug_keep_saved = True
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.randint(0, 256, (3, 3, 299, 299), generator=g).float() - 110.0
+    w = torch.randn(3, 2048, generator=g)
+    for k in (1.0, 40.0):
+        x = x0 * k
+        prod.zero_grad(set_to_none=True)
+        orc.zero_grad(set_to_none=True)
+        f = prod.features(x.cuda())
+        (f * w.cuda()).sum().backward()
+        relu, pools = prod.export_decisions()
+        orc.forced = ({n: t.cpu() for n, t in relu.items()}, [t.cpu() for t in pools.values()])
+        fo = orc.features(x.double())
+        assert rel_err(f, fo) < 2e-6, ("forced forward", k, rel_err(f, fo))
+        (fo * w.double()).sum().backward()
+        ref = dict(orc.named_parameters())
+        worst = ("", 0.0)
+        n_t = 0
+        for n, p in prod.named_parameters():
+            if p.grad is None:
+                continue
+            n_t += 1
+            e = rel_err(p.grad, ref[n].grad)
+            worst = (n, e) if e > worst[1] else worst
+        print("Inception-v3 x %g: worst of %d gradient tensors vs the mask-forced float64 referee: %s %.2e   guard %s"
+              % (k, n_t, worst[0], worst[1], prod.guard_stats()))
+        assert n_t == 2 * 94 and worst[1] < 5e-5, worst
+    assert prod.guard_stats()["fwd"] >= 1
+
+
+@pytest.mark.gpu
 def test_inceptionv3_ssn_training_step(hip_library):
     """SSN on Inception-v3 in training mode (ssn_train.py with arch InceptionV3): 2 videos x 8 proposals x 9 segments
     at 139x139 (the topology accepts it; keeps the CPU oracle to seconds), logits / losses 1e-4, gradients vs the oracle."""

@@ -4,10 +4,13 @@
     python tools/pmc_summary.py <dir with pmc*/ sub-directories> <out.json>
 
 Per family: launches, MFMA pipe busy fraction, wait fractions, VALU+SALU per MFMA, LDS bank-conflict fraction
-and HBM bytes per launch.  FETCH_SIZE / WRITE_SIZE are KiB (x1024); on gfx950 FETCH_SIZE reports half of the bytes
-of a wide (16 B/lane) coalesced read stream (/opt/skills/guides/MI355X_MICROARCH.md, section HBM), so families
-whose loads are 16 B/lane (`wide_reads`) get `hbm_bytes_per_launch` = 2*FETCH + WRITE, the others the raw sum
-(upper/lower values are both kept).
+and HBM bytes per launch.  FETCH_SIZE / WRITE_SIZE are KiB (x1024).  On gfx950 FETCH_SIZE reports HALF of the bytes read,
+for EVERY access width: round 4 calibrated it against kernels that touch exactly 1 GiB once (tools/clock/fetch_calib.hip,
+profiles/r4_fetch_size_calibration.txt) -- 16 / 8 / 4 bytes per lane, 8 bytes at a 16-byte pitch and 16-byte LDS-DMA all
+report 524 300 KiB = TCC_EA0_RDREQ (8.39 M requests of 128 B) x 64 B, TCC_BUBBLE (the counter meant to tally the 128-byte
+requests) reads 0; WRITE_SIZE reports the bytes written exactly (1 048 576 KiB), partial 64-byte lines as whole ones.  So
+`hbm_bytes_per_launch` = 2 * FETCH + WRITE for every family (round 3 doubled only the 16-byte streams and left the
+dgrad number "between" two readings).  It counts L2 <-> fabric traffic: Infinity-Cache hits are in it.
 """
 import csv
 import glob
@@ -110,7 +113,7 @@ def main():
         if w is not None:
             r["write_bytes_per_launch"] = round(w * 1024)
         if f is not None and w is not None:
-            r["hbm_bytes_per_launch"] = round(((2 if wide[fam] else 1) * f + w) * 1024)
+            r["hbm_bytes_per_launch"] = round((2 * f + w) * 1024)
         for cname in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
                       "SQ_INSTS_MFMA"):
             if per(cname) is not None:
