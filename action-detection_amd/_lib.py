@@ -96,8 +96,8 @@ _SIGS = {
     "ssn_s2d_weights": "ppiiip",
     "ssn_s2d_weights_bwd": "ppiiip",
     # planes tensors (csrc/planes.h): hi/lo f16 planes, NC8HW8
-    "ssn_pl_scales_update": "pppiip",
-    "ssn_pl_range_check": "pppip",
+    "ssn_pl_scales_update": "pppiiiip",
+    "ssn_pl_range_check": "pppiip",
     "ssn_pl_from_f32": "plppiiiilippp",
     "ssn_pl_to_f32": "pplpliiipp",
     "ssn_conv_pl_fwd": "pppppppiiiiliiiliiiiiiipppiiip",
@@ -105,7 +105,7 @@ _SIGS = {
     "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiip",
     "ssn_conv_pl_dgrad_s2": "pppppiiiiliiiliiplpipppp",
     "ssn_pl_maxpool_fwd": "pplpplpiiiiiiiiipppp",
-    "ssn_pl_maxpool_bwd": "pplpppl" + "i" * 10 + "plppppplp",
+    "ssn_pl_maxpool_bwd": "pplpppl" + "i" * 10 + "plpipppplp",
     "ssn_pl_avgpool_affine": "pplpplppiiiiiiipppp",
     "ssn_pl_relu_bn_bwd": "pplplpiiippp",
     "ssn_pl_gap_fwd": "pplpiiipp",

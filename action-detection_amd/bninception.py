@@ -179,6 +179,7 @@ class BNInception(nn.Module):
         # Default: planes for both backbones (round 4: Inception-v3 too); a plan with training-mode BatchNorm falls back to the fp32
         # layout on its own (planes_exec.supported), SSN_LAYOUT=f32 forces it (the cross-check configuration).
         self.layout = os.environ.get("SSN_LAYOUT", "planes")
+        self.pooled_mask = os.environ.get("SSN_POOLED_MASK", "1") != "0"   # planes_exec: stem pools' backward reads the pooled sign
         self.debug_keep_saved = False
         self._last_saved = None
         self._planes_states = {}

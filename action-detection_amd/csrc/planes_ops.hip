@@ -11,17 +11,23 @@ using namespace pl;
 // scale[i] <- scale for the next step from amax[i] (kept when the tensor was not written), amax[i] <- 0.
 // flag[0] |= 1 when a tensor outgrew the scale it was stored with (values were clamped: the host re-calibrates);
 // flag[1] counts the slots whose scale changed (calibration runs until this stays 0).
-__global__ __launch_bounds__(256) void scales_update_kernel(float* amax, float* scale, int* flag, int n, int exact) {
+// Slots with an ODD global index (slot0 + i: the executor's gradient tensors) take `odd_bits` more bits of head-room: the largest
+// element of a gradient tensor moves far more from step to step than an activation's does (dropout masks, OHEM selections: > 5x
+// between consecutive steps on the same batch was measured, round 4) -- with 2 bits the guard fired every ~10th step.
+__global__ __launch_bounds__(256) void scales_update_kernel(float* amax, float* scale, int* flag, int n, int exact, int slot0,
+                                                            int odd_bits) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float a = amax[i], s = scale[i];
+    const float room = ((slot0 + i) & 1) ? 1.f / (float)(1 << odd_bits) : 1.f;     // extra head-room as a factor on the targets
     // (exact: the tensor is measured BEFORE it is stored with the scale derived here -- nothing was clamped, whatever the old scale)
     if (!exact && (a * s >= PL_F16_MAX || a != a)) atomicOr(flag, 1);
     float ns = pl_scale_from_amax(a, s);
     if (exact) ns *= (float)(1 << PL_HEADROOM_BITS);   // a tensor measured before it is stored needs no head-room
-    // hysteresis: keep the old scale while the stored maximum stays inside [2^10, 2^14) -- at least 2 bits of head-room, at
+    else if (ns != s) ns *= room;                      // (ns == s: amax was 0 / not finite and the old scale stands)
+    // hysteresis: keep the old scale while the stored maximum stays inside [2^10, 2^14) (x room) -- at least 2 bits of head-room, at
     // most 3 bits of the low plane's range given away -- so that scales do not flap between steps
-    if (!exact && a * s < 16384.f && a * s >= 1024.f) ns = s;
+    if (!exact && a * s < 16384.f * room && a * s >= 1024.f * room) ns = s;
     if (ns != s) atomicAdd(flag + 1, 1);
     scale[i] = ns;
     amax[i] = 0.f;
@@ -33,13 +39,14 @@ __global__ __launch_bounds__(256) void scales_update_kernel(float* amax, float* 
 // exponent range: precision is draining).  Reads only: the slots stay as they are for the update at the head of the next pass.
 // The host (planes_exec.py) polls the word -- synchronously after an eager pass, asynchronously behind a graph replay -- and repeats
 // the pass with fresh scales; ssn_sgd_step_multi skips its update while the word is set, so a flagged step is retryable.
-__global__ __launch_bounds__(256) void range_check_kernel(const float* amax, const float* scale, int* flag, int n) {
+__global__ __launch_bounds__(256) void range_check_kernel(const float* amax, const float* scale, int* flag, int n, int odd_bits) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float a = amax[i], s = scale[i];
+    const float room = (i & 1) ? 1.f / (float)(1 << odd_bits) : 1.f;
     if (a * s >= PL_F16_MAX || a != a)
         atomicOr(flag, 1);
-    else if (a > 0.f && a * s < PL_UNDERFLOW_FLOOR)
+    else if (a > 0.f && a * s < PL_UNDERFLOW_FLOOR * room)
         atomicOr(flag, 2);
 }
 
@@ -357,6 +364,10 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
         u32x2 am[4];
         float d[4][8];
         bool wok[4];
+        // p.relu ("pooled mask"): mask_hi is the hi plane of the pool's OUTPUT -- the ReLU decision of the element a window routes its
+        // gradient to is the sign of that window's pooled value (it IS that element), so the backward reads the pooled tensor (1/4 of
+        // the pixels) instead of the full-resolution activation
+        const bool pooled_mask = p.mask_hi && p.relu;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ho = i + base_off + (t >> 1), wo = j + base_off + (t & 1);
@@ -364,6 +375,15 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
             const long oo = wok[t] ? (long)ho * p.Wo + wo : 0;
             am[t] = reinterpret_cast<const u32x2*>(p.argmax)[((long)n * p.G + g) * p.Ho * p.Wo + oo];
             load8(p.x_hi, p.x_lo, ((long)n * p.x_img_groups + g) * p.Ho * p.Wo + oo, d[t]);
+            if (pooled_mask) {
+                const u32x4 pm = reinterpret_cast<const u32x4*>(p.mask_hi)[((long)n * p.mask_img_groups + g) * p.Ho * p.Wo + oo];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sc = p.aff_scale[8 * g + e];
+                    const float m = (e & 1) ? f16_pair_hi(pm[e >> 1]) : f16_pair_lo(pm[e >> 1]);
+                    d[t][e] = (sc != sc) ? d[t][e] : (m > 0.f ? d[t][e] * sc : 0.f);
+                }
+            }
         }
         float v[4][8];
         bool live[4];
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
             for (int e = 0; e < 8; ++e) v[q][e] *= r;
             oq[q] = ((long)n * p.y_img_groups + g) * p.H * p.W + (long)h * p.W + w;
             const long mo = ((long)n * p.mask_img_groups + g) * p.H * p.W + (long)h * p.W + w;
-            prep_grad8(v[q], p, oq[q], mo, 8 * g);
+            if (!pooled_mask) prep_grad8(v[q], p, oq[q], mo, 8 * g);
         }
         if (p.y_f32 && (p.W & 1) == 0) {
             // fp32 NCHW output (the stem's pool: 925 MB per step): the two pixels of a block row are neighbours in every channel
@@ -570,20 +590,25 @@ int grid_for(long total) {
 // ------------------------------------------------------------------------------------------ C ABI
 // amax / scale: `n` consecutive slots.  exact != 0: scales without head-room (tensors measured before they are stored: the
 // caller's frames).  flag: int[2] = {overflow (sticky), slots whose scale changed (cumulative)}.
-extern "C" int ssn_pl_scales_update(float* amax, float* scale, int* flag, int n, int exact, hipStream_t stream) {
-    SSN_CHECK_ARG(amax && scale && flag && n >= 0, "pl scales update: bad arguments");
+// slot0: global index of the first slot (amax / scale point at it); slots with an odd global index take odd_extra_bits more bits
+// of head-room (the executor keeps its gradient tensors there).
+extern "C" int ssn_pl_scales_update(float* amax, float* scale, int* flag, int n, int exact, int slot0, int odd_extra_bits,
+                                    hipStream_t stream) {
+    SSN_CHECK_ARG(amax && scale && flag && n >= 0 && slot0 >= 0 && odd_extra_bits >= 0 && odd_extra_bits <= 8,
+                  "pl scales update: bad arguments");
     if (n == 0) return SSN_OK;
-    hipLaunchKernelGGL(scales_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax, scale, flag, n, exact);
+    hipLaunchKernelGGL(scales_update_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax, scale, flag, n, exact, slot0,
+                       odd_extra_bits);
     SSN_CHECK_LAUNCH("pl_scales_update");
     return SSN_OK;
 }
 
 // flag[0] |= 1 (a tensor overflowed the scale it was stored with) / 2 (severe underflow) over `n` consecutive slots; no slot is
 // modified.  One launch at the end of a forward / backward pass: what makes the delayed scales safe on changing data.
-extern "C" int ssn_pl_range_check(const float* amax, const float* scale, int* flag, int n, hipStream_t stream) {
-    SSN_CHECK_ARG(amax && scale && flag && n >= 0, "pl range check: bad arguments");
+extern "C" int ssn_pl_range_check(const float* amax, const float* scale, int* flag, int n, int odd_extra_bits, hipStream_t stream) {
+    SSN_CHECK_ARG(amax && scale && flag && n >= 0 && odd_extra_bits >= 0 && odd_extra_bits <= 8, "pl range check: bad arguments");
     if (n == 0) return SSN_OK;
-    hipLaunchKernelGGL(range_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax, scale, flag, n);
+    hipLaunchKernelGGL(range_check_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, amax, scale, flag, n, odd_extra_bits);
     SSN_CHECK_LAUNCH("pl_range_check");
     return SSN_OK;
 }
@@ -685,11 +710,14 @@ extern "C" int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img
 // ReLU / frozen-BN backward of the layer that produced the pool's input (mask_hi = hi plane of that activation at dx's slice).
 // dx_f32 != null: dx is written as fp32 NCHW there instead (dx_scale -> 1.0): the gradient of the stem's output, which only the
 // fp32-layout weight-gradient kernel of the 3-channel first layer reads.
+// mask_pooled != 0 (3x3 / stride 2, no accumulation): mask_hi is the hi plane of the pool's OUTPUT activation (Ho x Wo) instead of
+// its input's -- the element a window's gradient goes to is that window's maximum, so its ReLU decision is the sign of the pooled
+// value: the backward of the two stem pools then reads a quarter of the mask bytes.
 extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_img_groups, const unsigned char* argmax,
                                   void* dx_hi, void* dx_lo, long dx_img_groups, int N, int C, int H, int W, int Ho, int Wo, int k,
                                   int s, int pad, int accumulate, const void* mask_hi, long mask_img_groups,
-                                  const float* mask_scale, const float* dy_scale, const float* dx_scale, float* dx_amax,
-                                  float* dx_f32, long dx_f32_img_stride, hipStream_t stream) {
+                                  const float* mask_scale, int mask_pooled, const float* dy_scale, const float* dx_scale,
+                                  float* dx_amax, float* dx_f32, long dx_f32_img_stride, hipStream_t stream) {
     PoolArgs a;
     int rc = fill_pool(a, dy_hi, dy_lo, dy_img_groups, dx_hi, dx_lo, dx_img_groups, N, C, H, W, Ho, Wo, k, s, pad, dy_scale, dx_scale,
                        dx_amax, "pl maxpool bwd");
@@ -708,6 +736,9 @@ extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_
         a.aff_scale = mask_scale;
         a.mask_img_groups = mask_img_groups;
     }
+    SSN_CHECK_ARG(!mask_pooled || (mask_hi && mask_scale && !accumulate && k == 3 && s == 2 && (pad == 0 || pad == 1)),
+                  "pl maxpool bwd: a pooled mask needs a 3x3 / stride-2 pool (pad 0 / 1) that does not accumulate");
+    a.relu = mask_pooled ? 1 : 0;
     const dim3 grid(grid_for((long)N * a.G * H * W));
     if (k == 3 && s == 2 && (pad == 0 || pad == 1))
         hipLaunchKernelGGL(pl_maxpool_bwd_k3s2_kernel, dim3(grid_for((long)N * a.G * ((H + 1) / 2) * ((W + 1) / 2))), dim3(256), 0,

@@ -24,6 +24,7 @@ class SlotPool:
         self.scale = torch.ones(n, device=device, dtype=torch.float32)
         self.flag = torch.zeros(2, device=device, dtype=torch.int32) if flag is None else flag
         self.used = 0
+        self.odd_extra_bits = 0      # extra head-room of the odd slots (planes_exec.PlanesState keeps gradient tensors there)
 
     def take(self):
         i = self.used
@@ -39,14 +40,15 @@ class SlotPool:
         if count <= 0:
             return
         lib.call("ssn_pl_scales_update", self.amax.data_ptr() + 4 * first, self.scale.data_ptr() + 4 * first,
-                 _p(self.flag), int(count), int(bool(exact)), _stream(lib, self.amax))
+                 _p(self.flag), int(count), int(bool(exact)), int(first), int(self.odd_extra_bits), _stream(lib, self.amax))
 
     def range_check(self):
         """flag[0] |= fault bits of the used slots (no slot is modified; no host sync: hipGraph-capturable)."""
         if self.used <= 0:
             return
         lib = _lib.get_lib()
-        lib.call("ssn_pl_range_check", _p(self.amax), _p(self.scale), _p(self.flag), int(self.used), _stream(lib, self.amax))
+        lib.call("ssn_pl_range_check", _p(self.amax), _p(self.scale), _p(self.flag), int(self.used), int(self.odd_extra_bits),
+                 _stream(lib, self.amax))
 
 
 class PlaneTensor:
@@ -231,23 +233,25 @@ def maxpool_fwd(x, y, argmax, k, s, pad):
              x.t.scale_ptr, y.t.scale_ptr, y.t.amax_ptr, _st(lib, x.t))
 
 
-def maxpool_bwd(dy, argmax, dx, k, s, pad, accumulate=False, mask=None, mask_scale=None):
+def maxpool_bwd(dy, argmax, dx, k, s, pad, accumulate=False, mask=None, mask_scale=None, mask_pooled=False):
     """dx: PSlice, or an fp32 NCHW tensor [N, C, H, W] with an amax slot attached (kernels.attach_amax): the gradient is then
-    written in the fp32 layout (for a consumer on the fp32-layout kernels)."""
+    written in the fp32 layout (for a consumer on the fp32-layout kernels).  mask: the forward activation the pool READ (its ReLU /
+    frozen-BN backward is fused) -- or, with mask_pooled, the activation the pool WROTE (3x3 / stride 2, no accumulation: the
+    decision of a window's maximum is the sign of the pooled value; a quarter of the bytes)."""
     lib = _lib_for(dy.t)
     ho, wo = dy.hw
     if isinstance(dx, PSlice):
         h, w = dx.hw
         lib.call("ssn_pl_maxpool_bwd", dy.hi, dy.lo, dy.groups, _p(argmax), dx.hi, dx.lo, dx.groups, dx.n, dx.c, h, w, ho, wo, k,
                  s, pad, int(bool(accumulate)), mask.hi if mask is not None else None, mask.groups if mask is not None else 0,
-                 _p(mask_scale), dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, None, 0, _st(lib, dy.t))
+                 _p(mask_scale), int(bool(mask_pooled)), dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, None, 0, _st(lib, dy.t))
         return
     n, c, h, w = dx.shape
     assert not accumulate and dx.is_contiguous() and dx.dtype == torch.float32
     one = _ones(dx.device)
     lib.call("ssn_pl_maxpool_bwd", dy.hi, dy.lo, dy.groups, _p(argmax), None, None, 0, n, c, h, w, ho, wo, k, s, pad, 0,
-             mask.hi if mask is not None else None, mask.groups if mask is not None else 0, _p(mask_scale), dy.t.scale_ptr,
-             _p(one), _p(getattr(dx, "_ssn_amax", None)), _p(dx), c * h * w, _st(lib, dy.t))
+             mask.hi if mask is not None else None, mask.groups if mask is not None else 0, _p(mask_scale),
+             int(bool(mask_pooled)), dy.t.scale_ptr, _p(one), _p(getattr(dx, "_ssn_amax", None)), _p(dx), c * h * w, _st(lib, dy.t))
 
 
 _ONES = {}

@@ -41,9 +41,13 @@ class PlanesState:
     """Scale / amax slots of one backbone (persistent across steps) and the calibration status."""
 
     MAX_TENSORS = 512
+    GRAD_EXTRA_BITS = 3      # gradients: maximum lands in [2^9, 2^10) (5 - 6 bits to the f16 ceiling), kept while inside [2^7, 2^11)
 
     def __init__(self, device, flag=None):
         self.pool = P.SlotPool(2 * self.MAX_TENSORS, device, flag)
+        # gradient tensors (the odd slots) keep GRAD_EXTRA_BITS more bits of head-room than activations: their largest element
+        # moves > 5x between consecutive steps on the SAME batch (dropout mask, OHEM selection), an activation's barely at all
+        self.pool.odd_extra_bits = self.GRAD_EXTRA_BITS
         self.act_slot = {}      # activation tensor name -> slot
         self.grad_slot = {}     # gradient tensor name -> slot
         self.fwd_calibrated = False
@@ -80,14 +84,22 @@ class PlanesState:
         """Diagnostics (host sync): the tensors whose recorded maximum left the range of their scale in the pass just run."""
         a = (self.pool.amax[:self.pool.used] * self.pool.scale[:self.pool.used]).tolist()
         names = {v: ("grad:" if g else "act:") + k for g, tab in ((0, self.act_slot), (1, self.grad_slot)) for k, v in tab.items()}
-        bad = [(names.get(i, "slot%d" % i), v) for i, v in enumerate(a) if v != v or v >= 65504.0 or 0.0 < v < 16.0]
+        floor = [16.0, 16.0 / (1 << self.pool.odd_extra_bits)]
+        bad = [(names.get(i, "slot%d" % i), v) for i, v in enumerate(a) if v != v or v >= 65504.0 or 0.0 < v < floor[i & 1]]
         self.fault_log = (self.fault_log + [(which, bad)])[-8:]
         return bad
 
     def settle(self, relaunch, what):
         """Repeat a pass (``relaunch``) until no scale moves and nothing leaves its range; returns the number of repeats.  The
         pass must already have run once.  (Host syncs: eager only.)"""
+        trail = []
         for it in range(12):
+            if it >= 9:      # diagnostics for the error below: which tensors are still out of range / moving
+                a = (self.pool.amax[:self.pool.used] * self.pool.scale[:self.pool.used]).tolist()
+                names = {v: ("grad:" if g else "act:") + k for g, tab in ((0, self.act_slot), (1, self.grad_slot))
+                         for k, v in tab.items()}
+                trail.append([(names.get(i, "slot%d" % i), v) for i, v in enumerate(a)
+                              if v != v or v >= 65504.0 or (0.0 < v < 1024.0) or v >= 16384.0][:8])
             self.pool.flag.zero_()
             self.update()
             fault, moved = self.pool.flag.tolist()
@@ -95,7 +107,8 @@ class PlanesState:
                 self.pool.flag.zero_()
                 return it
             relaunch()
-        raise RuntimeError("planes executor: %s scales did not settle" % what)
+        raise RuntimeError("planes executor: %s scales did not settle; tensors outside [2^10, 2^14) x scale in the last passes: %r"
+                           % (what, trail))
 
 
 def _state(net, x):
@@ -394,6 +407,12 @@ def run_backward(net, dfeat, saved, hook=True):
                 c = op["c"]
                 key = (op["src"], 0)
                 my, ms = mask_args(idx, op, c)
+                # a 3x3 / stride-2 pool that is the only writer of its input's gradient: the fused ReLU decision is read from the
+                # POOLED activation (the window's maximum IS the element the gradient goes to) -- a quarter of the mask bytes
+                pooled = (my is not None and key not in inited and (op["k"], op["s"]) == (3, 2) and op["p"] in (0, 1)
+                          and net.pooled_mask)
+                if pooled:
+                    my = PSlice(acts[op["dst"]], op["dst_c0"], c)
                 if op["src"] == stem_out:
                     # the stem's output gradient has ONE consumer, the weight gradient of a 3- (12-) channel layer, which the
                     # planes kernels would pad to 32 input channels: it goes to the fp32-layout split kernel, in its layout
@@ -401,10 +420,10 @@ def run_backward(net, dfeat, saved, hook=True):
                     _, h_, w_ = shapes[op["src"]]
                     grads["__stem_f32__"] = K.attach_amax(K.guarded_empty((n, c, h_, w_), dev))
                     P.maxpool_bwd(PSlice(grads[op["dst"]], op["dst_c0"], c), argmax[op["lid"]], grads["__stem_f32__"], op["k"],
-                                  op["s"], op["p"], mask=my, mask_scale=ms)
+                                  op["s"], op["p"], mask=my, mask_scale=ms, mask_pooled=pooled)
                 else:
                     P.maxpool_bwd(PSlice(grads[op["dst"]], op["dst_c0"], c), argmax[op["lid"]], PSlice(gbuf(op["src"]), 0, c),
-                                  op["k"], op["s"], op["p"], accumulate=key in inited, mask=my, mask_scale=ms)
+                                  op["k"], op["s"], op["p"], accumulate=key in inited, mask=my, mask_scale=ms, mask_pooled=pooled)
                 inited.add(key)
             elif op["kind"] == "pool_aff":
                 c = op["c"]

@@ -413,14 +413,16 @@ int ssn_embed_planes(const float* g, float* out, int N, int C, int Ho, int Wo, l
  * tensor's scale slot, fixed while a step runs and derived from the magnitude recorded in the previous step;
  * `*_amax` at its amax slot, raised by every producer (ssn_pl_scales_update turns one into the other between steps and flags
  * tensors that outgrew their head-room).  Packed weights are those of ssn_conv_x6_pack_*. */
-int ssn_pl_scales_update(float* amax, float* scale, int* flag, int n, int exact, hipStream_t stream);
+int ssn_pl_scales_update(float* amax, float* scale, int* flag, int n, int exact, int slot0, int odd_extra_bits, hipStream_t stream);
+/* (slot0 = global index of the first of the n slots; slots with an ODD global index -- where the executor keeps its gradient tensors,
+ * whose maxima move far more from step to step than an activation's -- get odd_extra_bits more bits of head-room.) */
 /* The range guard of the delayed scales: one launch at the END of a forward / backward pass over the `n` slots of the executor.
  * flag[0] |= 1 if a tensor's recorded (pre-clamp) maximum did not fit the scale it was stored with (its values were clamped to the
  * f16 range), |= 2 if it fell more than 8 bits below the target range (precision draining).  Modifies no slot.  The reference has no
  * counterpart (cuDNN computes in fp32 storage); this is what lets loss.backward() / optimizer.step() (ssn_train.py:236,252) and the
  * alternating train / validate passes (ssn_train.py:191-253, 278-362) run on data whose magnitude changes from call to call: the
  * host repeats a flagged pass with fresh scales, ssn_sgd_step_multi(skip_flag) refuses to consume a flagged step's gradients. */
-int ssn_pl_range_check(const float* amax, const float* scale, int* flag, int n, hipStream_t stream);
+int ssn_pl_range_check(const float* amax, const float* scale, int* flag, int n, int odd_extra_bits, hipStream_t stream);
 /* fp32 NCHW <-> planes (the caller's frames, test inputs, the fp32 feature boundary); s2d: the space-to-depth view of the stem. */
 int ssn_pl_from_f32(const float* x, long x_img_stride, void* hi, void* lo, int N, int C, int H, int W, long img_groups, int s2d,
                     const float* scale, float* amax, hipStream_t stream);
@@ -467,8 +469,9 @@ int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img_groups, vo
                        const float* x_scale, const float* y_scale, float* y_amax, hipStream_t stream);
 int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_img_groups, const unsigned char* argmax, void* dx_hi,
                        void* dx_lo, long dx_img_groups, int N, int C, int H, int W, int Ho, int Wo, int k, int s, int pad,
-                       int accumulate, const void* mask_hi, long mask_img_groups, const float* mask_scale, const float* dy_scale,
-                       const float* dx_scale, float* dx_amax, float* dx_f32, long dx_f32_img_stride, hipStream_t stream);
+                       int accumulate, const void* mask_hi, long mask_img_groups, const float* mask_scale, int mask_pooled,
+                       const float* dy_scale, const float* dx_scale, float* dx_amax, float* dx_f32, long dx_f32_img_stride,
+                       hipStream_t stream);      /* mask_pooled: mask_hi = hi plane of the pool's OUTPUT (3x3 / stride 2, no accumulation) */
 int ssn_pl_avgpool_affine(const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups,
                           const float* scale, const float* shift, int relu, int N, int C, int H, int W, int k, int pad,
                           const float* x_scale, const float* y_scale, float* y_amax, hipStream_t stream);

@@ -61,6 +61,26 @@ def test_scales_update_protocol(backend):
     pool.amax.copy_(torch.tensor([5.0, 0.0, 0.4e-6, 5000.0]))
     pool.update()
     assert torch.equal(pool.scale.cpu(), s) and pool.flag.cpu()[1].item() == 0
+    # odd slots (the executor's gradient tensors) with 3 more bits of head-room: target [2^9, 2^10), kept inside [2^7, 2^11); the
+    # range check flags what left the f16 range (bit 0) or fell 8 bits below the slot's target (bit 1), and modifies nothing
+    pool.odd_extra_bits = 3
+    pool.flag.zero_()
+    pool.amax.copy_(torch.tensor([3.0, 3.0, 3.0, 3.0]))
+    pool.scale.copy_(torch.tensor([1.0, 1.0, 2.0 ** 10, 2.0 ** 10]))
+    pool.update()
+    s = pool.scale.cpu()
+    assert 2 ** 12 <= 3.0 * s[0] < 2 ** 13 and 2 ** 9 <= 3.0 * s[1] < 2 ** 10
+    assert s[2] == 2.0 ** 10 and s[3] != 2.0 ** 10 and 2 ** 9 <= 3.0 * s[3] < 2 ** 10     # 3 * 2^10 = 3072: inside the even band only
+    pool.flag.zero_()
+    pool.amax.copy_(torch.tensor([3.0, 3.0, 0.0, 3.0]))
+    pool.scale.copy_(torch.tensor([4.0, 0.5, 1.0, 2.0 ** 15]))      # 12 (< 16: drained), 1.5 (< 2: fine for an odd slot ... no), -, 98304 (clamped)
+    before = (pool.amax.clone(), pool.scale.clone())
+    pool.range_check()
+    assert pool.flag.cpu()[0].item() == 3 and torch.equal(pool.amax, before[0]) and torch.equal(pool.scale, before[1])
+    pool.flag.zero_()
+    pool.scale.copy_(torch.tensor([8.0, 1.0, 1.0, 2.0 ** 10]))      # 24, 3 (>= 2), -, 3072: all in range
+    pool.range_check()
+    assert pool.flag.cpu()[0].item() == 0
 
 
 CASES_SMALL = [
@@ -291,6 +311,16 @@ def test_planes_pools(backend):
         P.maxpool_bwd(P.pfull(gp), am, dx32, k, s, pad, mask=P.pfull(xp), mask_scale=backend.put(msc))
         assert rel_err(dx32, xd.grad * m.double()) < 2.0 ** -20, ("maxpool bwd fp32", h, k, s, pad)
         assert abs(float(dx32._ssn_amax) - float((xd.grad * m.double()).abs().max())) <= 1e-6 * float(xd.grad.abs().max())
+        if (k, s) == (3, 2):
+            # the same mask read from the POOLED activation (the window's maximum is the element its gradient goes to): planes and
+            # fp32 output, identical to the input-mask result
+            dxp = P.PlaneTensor(n, c, h, h, backend.device)
+            _two_pass(lambda: P.maxpool_bwd(P.pfull(gp), am, P.pfull(dxp), k, s, pad, mask=P.pfull(y), mask_scale=backend.put(msc),
+                                            mask_pooled=True), dxp)
+            assert rel_err(P.to_f32(dxp), xd.grad * m.double()) < 2.0 ** -20, ("maxpool bwd pooled mask", h, k, s, pad)
+            dx32.fill_(7.0)
+            P.maxpool_bwd(P.pfull(gp), am, dx32, k, s, pad, mask=P.pfull(y), mask_scale=backend.put(msc), mask_pooled=True)
+            assert rel_err(dx32, xd.grad * m.double()) < 2.0 ** -20, ("maxpool bwd pooled mask fp32", h, k, s, pad)
     # average pool behind the projection + its backward stencil
     h = 7
     z = torch.randn(n, c, h, h, generator=g)
