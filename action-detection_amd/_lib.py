@@ -102,7 +102,8 @@ _SIGS = {
     "ssn_pl_to_f32": "pplpliiipp",
     "ssn_conv_pl_fwd": "pppppppiiiiliiiliiiiiiipppiiip",
     "ssn_conv_pl_dgrad": "pppppiiiiliiiliiiiiplpipppiiip",
-    "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiip",
+    "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiipp",
+    "ssn_wgrad_reduce_multi": "ipppppppp",
     "ssn_conv_pl_dgrad_s2": "pppppiiiiliiiliiplpipppp",
     "ssn_pl_maxpool_fwd": "pplpplpiiiiiiiiipppp",
     "ssn_pl_maxpool_bwd": "pplpppl" + "i" * 10 + "plpipppplp",

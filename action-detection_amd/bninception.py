@@ -179,6 +179,9 @@ class BNInception(nn.Module):
         # Default: planes for both backbones (round 4: Inception-v3 too); a plan with training-mode BatchNorm falls back to the fp32
         # layout on its own (planes_exec.supported), SSN_LAYOUT=f32 forces it (the cross-check configuration).
         self.layout = os.environ.get("SSN_LAYOUT", "planes")
+        # planes_exec: every weight gradient keeps its split-K slabs in its own workspace region and ONE launch reduces them all at the
+        # end of the pass (at every gradient-ready range with an overlapping reducer) instead of one launch per layer
+        self.defer_wgrad_reduce = os.environ.get("SSN_DEFER_WGRAD_REDUCE", "1") != "0"
         self.pooled_mask = os.environ.get("SSN_POOLED_MASK", "1") != "0"   # planes_exec: stem pools' backward reads the pooled sign
         self.debug_keep_saved = False
         self._last_saved = None

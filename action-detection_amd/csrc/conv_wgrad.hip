@@ -269,6 +269,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     }
 }
 
+// The split-K slabs of MANY layers in one launch (the table travels by value: capturable, nothing staged): block b belongs to tensor
+// t with blk0[t] <= b < blk0[t + 1] and strides over that tensor's M x (K + 1) outputs.  Same arithmetic and summation order as
+// wgrad_reduce_kernel -- the executor defers the reductions of a backward pass and issues them together (44 launches -> 1).
+constexpr int RM_MAX = 48;
+struct ReduceTable {
+    const float* part[RM_MAX];
+    float* dw[RM_MAX];
+    float* db[RM_MAX];
+    int M[RM_MAX], K[RM_MAX], splits[RM_MAX], taps[RM_MAX];
+    int blk0[RM_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceTable t) {
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;
+    const float* part = t.part[ti];
+    float* dw = t.dw[ti];
+    float* db = t.db[ti];
+    const int M = t.M[ti], K = t.K[ti], ldp = K + 1, splits = t.splits[ti], taps = t.taps[ti];
+    const long total = (long)M * ldp;
+    const long nb = t.blk0[ti + 1] - t.blk0[ti];
+    for (long idx = (long)((int)blockIdx.x - t.blk0[ti]) * 256 + threadIdx.x; idx < total; idx += nb * 256) {
+        float s = 0.f;
+        int z = 0;
+        for (; z + 8 <= splits; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = part[(long)(z + q) * total + idx];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; z < splits; ++z) s += part[(long)z * total + idx];
+        const int m = (int)(idx / ldp);
+        const int kk = (int)(idx - (long)m * ldp);
+        if (kk < K) {
+            int col = kk;
+            if (taps > 1) {
+                const int cin = K / taps, tt = kk / cin;
+                col = (kk - tt * cin) * taps + tt;
+            }
+            dw[(long)m * K + col] = s;
+        } else if (db) {
+            db[m] = s;
+        }
+    }
+}
+
 template <int KS, int S, int WM, int WN, int TM, int TN>
 int launch_wgrad(WgradArgs& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
@@ -345,6 +392,36 @@ extern "C" int ssn_wgrad_reduce_taps(const float* part, float* dw, float* db, in
 }
 extern "C" int ssn_wgrad_reduce(const float* part, float* dw, float* db, int M, int K, int splits, hipStream_t stream) {
     return ssn_wgrad_reduce_taps(part, dw, db, M, K, splits, 1, stream);
+}
+// ssn_wgrad_reduce_taps for `count` layers in ceil(count / 48) launches (host arrays, one entry per layer; db entries may be null).
+extern "C" int ssn_wgrad_reduce_multi(int count, const float* const* part, float* const* dw, float* const* db, const int* M,
+                                      const int* K, const int* splits, const int* taps, hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (part && dw && db && M && K && splits && taps)), "wgrad reduce multi: bad arguments");
+    for (int base = 0; base < count; base += RM_MAX) {
+        ReduceTable t;
+        t.count = count - base < RM_MAX ? count - base : RM_MAX;
+        int blocks = 0;
+        for (int i = 0; i < t.count; ++i) {
+            const int j = base + i;
+            SSN_CHECK_ARG(part[j] && dw[j] && M[j] > 0 && K[j] > 0 && splits[j] > 0 && taps[j] >= 1 && K[j] % taps[j] == 0,
+                          "wgrad reduce multi: bad entry %d", j);
+            t.part[i] = part[j];
+            t.dw[i] = dw[j];
+            t.db[i] = db[j];
+            t.M[i] = M[j];
+            t.K[i] = K[j];
+            t.splits[i] = splits[j];
+            t.taps[i] = taps[j];
+            t.blk0[i] = blocks;
+            long nb = ((long)M[j] * (K[j] + 1) + 255) / 256;
+            if (nb > 1024) nb = 1024;
+            blocks += (int)nb;
+        }
+        t.blk0[t.count] = blocks;
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t);
+    }
+    SSN_CHECK_LAUNCH("wgrad_reduce_multi");
+    return SSN_OK;
 }
 
 extern "C" long ssn_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int ksize, int tile_cfg) {

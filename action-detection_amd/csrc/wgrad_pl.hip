@@ -779,7 +779,7 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
                                  int N, int Cin, int H, int W, long x_img_groups, int Cout, int Ho, int Wo, long g_img_groups,
                                  int kh, int kw, int stride, int pad_h, int pad_w, void* workspace, long ws_bytes, int tile_cfg,
                                  const float* g_scale, const float* x_scale, int g_row_split, int g_row_gap,
-                                 hipStream_t stream) {
+                                 int* deferred_reduce, hipStream_t stream) {
     SSN_CHECK_ARG(g_hi && g_lo && x_hi && x_lo && dw && workspace && g_scale && x_scale, "conv wgrad pl: null pointer");
     SSN_CHECK_ARG(Cout > 0 && Cin > 0 && kh >= 1 && kw >= 1 && (stride == 1 || stride == 2), "conv wgrad pl: bad shape");
     SSN_CHECK_ARG(g_row_gap >= 0 && (g_row_gap == 0 || (g_row_split > 0 && g_row_split < Cout && g_row_split % 32 == 0 && g_row_gap % 8 == 0)),
@@ -838,6 +838,11 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
         a.div_w = make_fastdiv((uint32_t)W);
         const int rc1 = launch_wgpl1_tile(a, c1, stream);
         if (rc1 != SSN_OK) return rc1;
+        if (deferred_reduce) {
+            deferred_reduce[0] = a.splits;
+            deferred_reduce[1] = 1;
+            return SSN_OK;
+        }
         return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
     }
     // tile_cfg >= 100: the nine-tap kernel with tile tile_cfg - 100; < 0: it for every layer that qualifies
@@ -855,6 +860,11 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
         a.div_w = make_fastdiv((uint32_t)(W + 1));
         const int rc9 = launch_wgpl9_tile(a, c9, stream);
         if (rc9 != SSN_OK) return rc9;
+        if (deferred_reduce) {
+            deferred_reduce[0] = a.splits * k9KG[c9];
+            deferred_reduce[1] = 9;
+            return SSN_OK;
+        }
         return ssn_wgrad_reduce_taps(a.part, dw, db, Cout, a.K, a.splits * k9KG[c9], 9, stream);
     }
     SSN_CHECK_ARG(tile_cfg < 100, "conv wgrad pl: the nine-tap kernel takes 3x3 / stride 1 / pad 1 layers only");
@@ -867,5 +877,10 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
     }
     const int rc = launch_wgpl_tile(a, cfg, stream);
     if (rc != SSN_OK) return rc;
+    if (deferred_reduce) {
+        deferred_reduce[0] = a.splits;
+        deferred_reduce[1] = 1;
+        return SSN_OK;
+    }
     return ssn_wgrad_reduce(a.part, dw, db, Cout, a.K, a.splits, stream);
 }

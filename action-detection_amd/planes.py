@@ -202,16 +202,38 @@ def wgrad_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile_cfg=-1):
     return int(_lib.get_lib().cdll.ssn_conv_wgrad_pl_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile_cfg))
 
 
-def conv_wgrad(g, x, dw, db, kh, kw, stride, pad_h, pad_w, workspace, tile_cfg=-1, cin=None, g_row_split=0, g_row_gap=0):
+def conv_wgrad(g, x, dw, db, kh, kw, stride, pad_h, pad_w, workspace, tile_cfg=-1, cin=None, g_row_split=0, g_row_gap=0, defer=None):
     """dw [Cout, Cin, kh, kw] (fp32), db [Cout] or None <- weight / bias gradient from the planes slices g (output gradient, final)
-    and x (the layer's input).  cin: real input channels when x's slice is zero-padded (the 12-channel stem)."""
+    and x (the layer's input).  cin: real input channels when x's slice is zero-padded (the 12-channel stem).
+    defer: a list -- the split-K slabs then STAY in `workspace` (which must not be reused before the flush) and an entry for
+    ``wgrad_reduce_multi`` is appended instead of launching this layer's reduction."""
+    import ctypes
     lib = _lib_for(g.t)
     h, w = x.hw
     ho, wo = g.hw
     cin = x.c if cin is None else cin
+    info = (ctypes.c_int * 2)() if defer is not None else None
     lib.call("ssn_conv_wgrad_pl", g.hi, g.lo, x.hi, x.lo, _p(dw), _p(db), x.n, cin, h, w, x.groups, g.c, ho, wo, g.groups, kh, kw,
              stride, pad_h, pad_w, _p(workspace), workspace.numel() * workspace.element_size(), tile_cfg, g.t.scale_ptr,
-             x.t.scale_ptr, int(g_row_split), int(g_row_gap), _st(lib, g.t))
+             x.t.scale_ptr, int(g_row_split), int(g_row_gap), ctypes.addressof(info) if info is not None else None, _st(lib, g.t))
+    if defer is not None:
+        defer.append((workspace, dw, db, g.c, cin * kh * kw, int(info[0]), int(info[1])))
+
+
+def wgrad_reduce_multi(entries):
+    """Reduce the deferred split-K slabs of many layers (entries of ``conv_wgrad(defer=)``) in one launch per 48 layers."""
+    import ctypes
+    if not entries:
+        return
+    lib = _lib.get_lib()
+    n = len(entries)
+    parts = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries])
+    dws = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in entries])
+    dbs = (ctypes.c_void_p * n)(*[(e[2].data_ptr() if e[2] is not None else None) for e in entries])
+    arr = [(ctypes.c_int * n)(*[int(e[k]) for e in entries]) for k in (3, 4, 5, 6)]
+    lib.call("ssn_wgrad_reduce_multi", n, ctypes.addressof(parts), ctypes.addressof(dws), ctypes.addressof(dbs),
+             ctypes.addressof(arr[0]), ctypes.addressof(arr[1]), ctypes.addressof(arr[2]), ctypes.addressof(arr[3]),
+             _stream(lib, entries[0][0]))
 
 
 def conv_dgrad_s2(dy, wt_packed, dx, pad, accumulate=False, tile_cfg=-1, mask=None, mask_scale=None):

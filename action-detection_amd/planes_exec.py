@@ -324,19 +324,31 @@ def run_backward(net, dfeat, saved, hook=True):
     lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
     flat = torch.empty(total, device=dev, dtype=torch.float32)
 
-    # workspace: split-K slabs of the largest weight gradient, channel-sum scratch
-    ws_bytes = 0
+    # workspace: the split-K slabs of EVERY weight gradient of the pass (each layer its own region: the reductions are deferred and
+    # issued together, one launch instead of one per layer; 2.2 GB at the bench batch), channel-sum scratch
+    ws_off, ws_bytes = {}, 0
     for op in plan:
         if op["kind"] != "conv":
             continue
         kh, kw, _, _ = _conv_taps(op)
         _, ho, wo = shapes[op["dst"]]
         if op.get("s2d"):
-            ws_bytes = max(ws_bytes, P.wgrad_workspace_bytes(n, 4 * op["cin"], op["cout"], ho, wo, 4, 4, net._pl_tile("wgrad", op, n, shapes)))
-            ws_bytes = max(ws_bytes, K.wgrad_x6_workspace_bytes(n, 4 * op["cin"], op["cout"], ho, wo, 4))
+            need = max(P.wgrad_workspace_bytes(n, 4 * op["cin"], op["cout"], ho, wo, 4, 4, net._pl_tile("wgrad", op, n, shapes)),
+                       K.wgrad_x6_workspace_bytes(n, 4 * op["cin"], op["cout"], ho, wo, 4))
         else:
-            ws_bytes = max(ws_bytes, P.wgrad_workspace_bytes(n, op["cin"], op["cout"], ho, wo, kh, kw, net._pl_tile("wgrad", op, n, shapes)))
-    ws = net._workspace(ws_bytes, dev)
+            need = P.wgrad_workspace_bytes(n, op["cin"], op["cout"], ho, wo, kh, kw, net._pl_tile("wgrad", op, n, shapes))
+        need = (need + 1023) // 1024 * 1024
+        if not net.defer_wgrad_reduce:
+            ws_off[op["lids"][0]] = (0, need)
+            ws_bytes = max(ws_bytes, need)
+        else:
+            ws_off[op["lids"][0]] = (ws_bytes, need)
+            ws_bytes += need
+    ws_all = net._workspace(ws_bytes, dev)
+
+    def ws_of(op):
+        o, nb = ws_off[op["lids"][0]]
+        return ws_all[o // 4:(o + nb) // 4]
     cs_ws = torch.empty(P.channel_sum_workspace_bytes(max(op["cout"] for op in plan if op["kind"] == "conv")) // 4, device=dev,
                         dtype=torch.float32)
 
@@ -372,6 +384,14 @@ def run_backward(net, dfeat, saved, hook=True):
     def launch_all(grads, fire_hook):
         masked, inited = {}, set()
         pending_end = total
+        pending_reduce, pending_sums = [], []     # deferred split-K reductions / the channel sums that must follow them
+
+        def flush():
+            P.wgrad_reduce_multi(pending_reduce)
+            for fn in pending_sums:
+                fn()
+            del pending_reduce[:], pending_sums[:]
+        defer = pending_reduce if net.defer_wgrad_reduce else None
 
         def gbuf(name):
             if name not in grads:
@@ -462,31 +482,37 @@ def run_backward(net, dfeat, saved, hook=True):
                     from .bninception import tuned_tile
                     ocfg = tuned_tile("wgrad6s2d", n, cin, cout, op["k"], op["s"], shapes[op["src"]][1])
 
-                    def run_wgrad():
+                    def run_wgrad(ws=ws_of(op)):
                         dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
                         K.conv_wgrad_x6(K.full(g32), K.full(xs32), dw2, db, 4, 2, ws, ocfg)
                         K.s2d_weights_bwd(dw2, dw)
                 elif op.get("s2d"):
                     xs = acts["data_s2d"]
 
-                    def run_wgrad():
+                    def run_wgrad(ws=ws_of(op)):
                         dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
                         P.conv_wgrad(gs, PSlice(xs, 0, xs.g * 8), dw2, db, 4, 4, 1, 2, 2, ws, wcfg, cin=4 * cin)
                         K.s2d_weights_bwd(dw2, dw)
                 else:
                     xin = PSlice(acts[op["src"]], op["src_c0"], cin) if op["src"] != "data" else PSlice(acts["data"], 0, acts["data"].g * 8)
 
-                    def run_wgrad():
+                    def run_wgrad(ws=ws_of(op)):
                         P.conv_wgrad(gs, xin, dw, db, kh, kw, s, ph, pw, ws, wcfg, cin=cin, g_row_split=op.get("row_split", 0),
-                                     g_row_gap=op.get("row_gap", 0))
+                                     g_row_gap=op.get("row_gap", 0), defer=defer)
                 def run_wgrad_and_bias(run_wgrad=run_wgrad, op=op, db=db, cout=cout):
                     run_wgrad()
                     if raw or "raw_from" in op:
                         # the (projection's) bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's
-                        # backward (after the weight gradient, which wrote the sum of the pooled gradient there)
+                        # backward (after the weight gradient's reduction, which wrote the sum of the pooled gradient there)
                         fin = op["proj_final"] if "raw_from" in op else op["final"]
                         cp = cout - op.get("raw_from", 0)
-                        P.channel_sum(PSlice(grads[fin[0]], fin[1], cp), db[op.get("raw_from", 0):], cs_ws)
+
+                        def bias_sum(fin=fin, cp=cp, db=db, r0=op.get("raw_from", 0)):
+                            P.channel_sum(PSlice(grads[fin[0]], fin[1], cp), db[r0:], cs_ws)
+                        if defer is not None:
+                            pending_sums.append(bias_sum)
+                        else:
+                            bias_sum()
                 net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
                 if op["src"] != "data":
                     wt = packed_dg[lids[0]]
@@ -507,8 +533,10 @@ def run_backward(net, dfeat, saved, hook=True):
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
                 if fire_hook and net.grad_ready_hook is not None and closes_block:
+                    flush()                                   # the block's gradients must be final before their all-reduce
                     net.grad_ready_hook.range_ready(flat, wo, pending_end)
                     pending_end = wo
+        flush()
         if fire_hook and net.grad_ready_hook is not None:
             if pending_end > 0:
                 net.grad_ready_hook.range_ready(flat, 0, pending_end)

@@ -451,7 +451,12 @@ int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const float* wt_p
 int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void* x_hi, const void* x_lo, float* dw, float* db, int N, int Cin,
                       int H, int W, long x_img_groups, int Cout, int Ho, int Wo, long g_img_groups, int kh, int kw, int stride,
                       int pad_h, int pad_w, void* workspace, long ws_bytes, int tile_cfg, const float* g_scale,
-                      const float* x_scale, int g_row_split, int g_row_gap, hipStream_t stream);
+                      const float* x_scale, int g_row_split, int g_row_gap, int* deferred_reduce, hipStream_t stream);
+/* deferred_reduce (HOST int[2], may be NULL): when given, the split-K slabs are left in `workspace` -- which then must stay untouched
+ * until the caller has reduced them -- and {slabs, taps} for ssn_wgrad_reduce_multi are written there instead of launching the
+ * reduction: a backward pass reduces the slabs of all its layers in one launch. */
+int ssn_wgrad_reduce_multi(int count, const float* const* part, float* const* dw, float* const* db, const int* M, const int* K,
+                           const int* splits, const int* taps, hipStream_t stream);
 long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int tile_cfg);
 int ssn_conv_wgrad_pl_tiles(void);
 int ssn_conv_pl_tiles(void);

@@ -68,3 +68,34 @@ def test_training_batch_prefetcher(backend):
     import pytest
     with pytest.raises(RuntimeError):
         next(it)
+
+
+def test_training_batch_prefetcher_with_gpu_augmentation(backend):
+    """Un-cropped decoded frames in, network input out: the prefetcher runs SSN.get_augmentation() (scale-jittered crop, PIL's
+    bilinear resize, flip) + the normalisation tail on the device, one box / flip per proposal group drawn through `random` in the
+    reference's order -- equal to the host chain of action_detection_amd.transforms (itself pinned to the reference's classes,
+    tests/test_transforms.py) with the same seed."""
+    import random
+    from PIL import Image
+    from action_detection_amd import transforms as T
+    from action_detection_amd.input_pipeline import GpuTrainAugment, TrainingBatchPrefetcher
+    rs = np.random.RandomState(12)
+    dev = backend.device
+    aug = GpuTrainAugment(32, [104, 117, 128], [1], [1, .875, .75, .66], roll=True, device=dev)
+    items = []
+    for _ in range(3):
+        frames = rs.randint(0, 256, size=(2, 6, 40, 52, 3)).astype(np.uint8)        # 2 videos x (2 proposals x 3 frames)
+        items.append((frames, rs.rand(2, 2, 2).astype(np.float32), rs.randint(0, 5, (2, 2)), rs.randn(2, 2, 2).astype(np.float32),
+                      np.tile(np.array([0, 2]), (2, 1))))
+    random.seed(77)
+    got = [b[0].cpu() for b in TrainingBatchPrefetcher(iter(items), aug, depth=2, group_size=3)]
+    random.seed(77)
+    host = T.Compose([T.GroupMultiScaleCrop(32, [1, .875, .75, .66]), T.GroupRandomHorizontalFlip(is_flow=False)])
+    tail = T.Compose([T.Stack(roll=True), T.ToTorchFormatTensor(div=False), T.GroupNormalize([104, 117, 128], [1])])
+    for g, item in zip(got, items):
+        frames = item[0].reshape(4, 3, 40, 52, 3)                                   # 4 proposal groups per batch, in order
+        want = torch.cat([tail(host([Image.fromarray(f, "RGB") for f in grp])) for grp in frames])
+        assert g.shape == (2, 18, 32, 32) and torch.equal(g.reshape(-1, 32, 32), want)
+    import pytest
+    with pytest.raises(ValueError):
+        TrainingBatchPrefetcher(iter(items), aug)                                  # group_size is required

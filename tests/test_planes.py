@@ -233,6 +233,36 @@ def test_conv_pl_wgrad(backend):
             assert rel_err(db, b.grad) < 5e-6, ("bias", n, cin, h, cout, kh, kw, s, tile)
 
 
+def test_wgrad_deferred_reduce_multi(backend):
+    """The split-K slabs of several layers (one-tap, nine-tap, chunked 1x1) left in their own workspace regions and reduced by ONE
+    launch (ssn_wgrad_reduce_multi) give bit-identical dW / db to the per-layer reductions."""
+    g = torch.Generator().manual_seed(14)
+    layers = [(2, 16, 9, 40, 3, 1, 1, -1), (1, 24, 6, 64, 1, 1, 0, -1), (2, 8, 10, 32, 3, 2, 1, -1), (1, 16, 7, 96, 1, 1, 0, 200),
+              (2, 16, 9, 40, 3, 1, 1, 0)]
+    if backend.is_gpu:
+        layers = [(9, 64, 56, 192, 3, 1, 1, -1), (18, 576, 14, 512, 1, 1, 0, -1), (18, 128, 28, 160, 3, 2, 1, -1),
+                  (18, 192, 28, 224, 1, 1, 0, 201), (18, 160, 14, 192, 3, 1, 1, -1)]
+    want, entries, keep = [], [], []
+    for (n, cin, h, cout, k, s, pad, tile) in layers:
+        x = torch.randn(n, cin, h, h, generator=g)
+        ho = (h + 2 * pad - k) // s + 1
+        gy = torch.randn(n, cout, ho, ho, generator=g) * 1e-3
+        gp, xp = P.from_f32(backend.put(gy)), P.from_f32(backend.put(x))
+        nbytes = P.wgrad_workspace_bytes(n, cin, cout, ho, ho, k, k, tile)
+        dw0, db0 = backend.put(torch.empty(cout, cin, k, k)), backend.put(torch.empty(cout))
+        P.conv_wgrad(P.pfull(gp), P.pfull(xp), dw0, db0, k, k, s, pad, pad, backend.put(torch.empty(nbytes // 4)), tile)
+        want.append((dw0, db0))
+        dw1, db1 = backend.put(torch.full((cout, cin, k, k), 7.0)), backend.put(torch.full((cout,), 7.0))
+        ws = backend.put(torch.empty(nbytes // 4))
+        P.conv_wgrad(P.pfull(gp), P.pfull(xp), dw1, db1 if len(entries) != 1 else None, k, k, s, pad, pad, ws, tile, defer=entries)
+        keep.append((dw1, db1, gp, xp, ws))
+    assert len(entries) == len(layers) and all(float(k_[0].flatten()[0]) == 7.0 for k_ in keep)      # nothing reduced yet
+    P.wgrad_reduce_multi(entries)
+    for i, ((dw0, db0), (dw1, db1, _, _, _)) in enumerate(zip(want, keep)):
+        assert torch.equal(dw0.cpu(), dw1.cpu()), i
+        assert torch.equal(db0.cpu(), db1.cpu()) if i != 1 else bool((db1 == 7.0).all()), i      # (entry 1 asked for no bias gradient)
+
+
 def test_wgrad_reduce_tap_major(backend):
     """Split-K slabs in the nine-tap kernel's tap-major column order are summed and permuted back to dW[m][ci][tap]."""
     g = torch.Generator().manual_seed(9)

@@ -1,8 +1,10 @@
 """Does the input side keep up with the training step?  (the reference's `Data` meter,
 /root/reference/ssn_train.py:194,262 -- the time the loop waits for its next batch.)
 
-Drives `input_pipeline.TrainingBatchPrefetcher` from host-resident uint8 frames of decoded-JPEG size (what the loader workers
-hand over after the PIL part: 4 videos x 72 frames x 224 x 224 x 3 per step) into the real training step (SSN forward, losses,
+Drives `input_pipeline.TrainingBatchPrefetcher` from host-resident uint8 frames into the real training step -- by default
+UN-CROPPED decoded frames (256 x 340 x 3, what a loader worker holds right after JPEG decoding): the scale-jittered crop, PIL's
+bilinear resize, the flip and the normalisation all run on the GPU (`GpuTrainAugment`, round 4); `--precropped` = the round-3
+measurement (frames already cropped / resized to 224 x 224 by PIL on the host) -- (SSN forward, losses,
 backward, SGD on the MI355X, replayed as one hipGraph on a static batch the prefetched one is copied into) and reports, per step:
 
   * host_wait_ms   -- time `next(prefetcher)` blocks the training loop's thread (staging / upload not ready yet),
@@ -23,7 +25,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import action_detection_amd as pkg  # noqa: E402
-from action_detection_amd.input_pipeline import GpuFrameTransform, TrainingBatchPrefetcher  # noqa: E402
+from action_detection_amd.input_pipeline import GpuFrameTransform, GpuTrainAugment, TrainingBatchPrefetcher  # noqa: E402
 from action_detection_amd.ops.ssn_ops import ActivityLoss, ClassWiseRegressionLoss, CompletenessLoss  # noqa: E402
 from action_detection_amd.optim import SSNSGD  # noqa: E402
 from action_detection_amd.ssn_models import SSN  # noqa: E402
@@ -34,6 +36,8 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--videos", type=int, default=4)
 ap.add_argument("--depth", type=int, default=3)
+ap.add_argument("--precropped", action="store_true", help="host frames already at 224 x 224 (crop / resize done by PIL on the host)")
+ap.add_argument("--decoded-size", type=int, nargs=2, default=[256, 340], help="H W of the decoded frames")
 args = ap.parse_args()
 pkg.build()
 dev = torch.device("cuda:0")
@@ -48,7 +52,8 @@ crit = (ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss())
 _, scaling, target, reg_target, prop_type = make_batch(v, "RGB", num_class, seed=0)
 rs = np.random.RandomState(0)
 # a few distinct host batches (uint8, as decoded), cycled: the content does not change the work, the copies are real
-host = [rs.randint(0, 256, size=(v, 72, 224, 224, 3), dtype=np.uint8) for _ in range(3)]
+fh, fw = (224, 224) if args.precropped else args.decoded_size
+host = [rs.randint(0, 256, size=(v, 72, fh, fw, 3), dtype=np.uint8) for _ in range(3)]
 
 
 def source(n):
@@ -65,7 +70,10 @@ def train_step(batch):
     return loss
 
 
-tf = GpuFrameTransform(224, model.input_mean, model.input_std, roll=True, device=dev)
+if args.precropped:
+    tf, group = GpuFrameTransform(224, model.input_mean, model.input_std, roll=True, device=dev), None
+else:       # SSN.get_augmentation() for RGB: GroupMultiScaleCrop(224, [1, .875, .75, .66]) + flip; one box per proposal = 9 frames
+    tf, group = GpuTrainAugment(224, model.input_mean, model.input_std, [1, .875, .75, .66], roll=True, device=dev), 9
 # ---- the step as one hipGraph on a STATIC batch (how bench.py runs it): a prefetched batch is copied into the static input
 # (173 MB device-to-device, ~0.06 ms) and the graph replayed -- the training thread then issues two calls per step, so the
 # staging thread's Python work does not compete with ~400 eager launches for the interpreter lock
@@ -100,7 +108,7 @@ torch.cuda.synchronize()
 resident_ms = 1e3 * (time.perf_counter() - t0) / args.steps
 
 # ---- through the prefetcher
-pf = TrainingBatchPrefetcher(source(args.warmup + args.steps), tf, depth=args.depth)
+pf = TrainingBatchPrefetcher(source(args.warmup + args.steps), tf, depth=args.depth, group_size=group)
 host_wait, ev = [], []
 stream = torch.cuda.current_stream(dev)
 t_start = None
@@ -131,7 +139,9 @@ res = {
     "wait_frac_of_step": round(float(np.mean(stream_wait)) / pipe_ms, 5),
     "frames_per_s_sustained": round(frames_per_step / (pipe_ms * 1e-3), 1),
     "frames_per_s_needed_by_resident_step": round(frames_per_step / (resident_ms * 1e-3), 1),
-    "bytes_per_step_over_pcie": int(frames_per_step * 224 * 224 * 3),
+    "bytes_per_step_over_pcie": int(frames_per_step * fh * fw * 3),
+    "host_frames": "%d x %d x 3 uint8 (%s)" % (fh, fw, "cropped + resized by PIL on the host" if args.precropped else
+                                               "as decoded: crop + PIL-exact bilinear resize + flip + normalise on the GPU"),
     "config": {"videos": v, "frames_per_step": frames_per_step, "depth": args.depth, "steps": args.steps, "launch": launch,
                "layout": model.base_model.layout,
                "note": "uint8 frames staged in pinned memory by a background thread, uploaded and normalised on a side stream "
