@@ -68,6 +68,8 @@ _SIGS = {
     "ssn_dropout_bwd": "ppplfp",
     "ssn_stpp_fwd": "ppppiipp",
     "ssn_stpp_bwd": "ppppiipp",
+    "ssn_heads_fwd": "pppppppppppiipp",
+    "ssn_heads_bwd": "pppppppppppiippppp",
     "ssn_stpp_reorg": "piippppiiiiipppp",
     "ssn_crop_mean": "ppiiip",
     "ssn_detections": "ppppppppuiiiiidip",

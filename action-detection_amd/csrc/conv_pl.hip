@@ -77,12 +77,13 @@ struct PlConvArgs {
 #define PL_DMA_B128(rsrc_, dst_, voff_, soff_) ((void)(dst_), (void)(voff_), (void)(soff_))
 #endif
 
-// OCC (0: default): workgroups per CU the kernel is compiled for.  3 / 4 = the same tile with a 3-slot ring and the register budget of
-// three (four) co-resident workgroups -- the compiler meets it without spills (128 x 128: 149 VGPRs instead of 186) -- for the layers
-// whose K loop is short (1x1 block-input launches: 12 - 66 slabs): with two workgroups per CU one of them is in its prologue /
-// epilogue for a third of the time and the other, alone on the matrix pipe, keeps it only ~64 % busy (profiles/r3_ablate_conv_pl.txt).
-template <int MODE, int WM, int WN, int TM, int TN, int OCC = 0>
-__global__ __launch_bounds__(256, OCC ? OCC : ((TM * TN >= 8) ? 1 : 2)) void conv_pl_kernel(PlConvArgs p) {
+// (Round 4 measured variants of the 128 x 128 / 96 x 128 / 192 x 64 / 64 x 128 tiles compiled for THREE / FOUR workgroups per CU --
+// __launch_bounds__(256, 3 | 4) with a 3-slot ring; no spills: 149 / 129 / 129 / 110 VGPRs -- to cover one workgroup's prologue /
+// epilogue with the loops of two others: the autotuner picked them for 39 of ~100 entries, end to end they changed nothing (17.55 vs
+// 17.55 ms, profiles/r4_occupancy_tiles_and_deferred_reduce_ab.txt) -- under load the matrix pipe is clock-limited, not occupancy-
+// limited (r4_clock_control.txt) -- and they were removed.)
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(PlConvArgs p) {
     constexpr int NW = 4;
     constexpr int NT = 256;
     constexpr int BM = WM * TM * 32;
@@ -100,8 +101,7 @@ __global__ __launch_bounds__(256, OCC ? OCC : ((TM * TN >= 8) ? 1 : 2)) void con
     // one slab of MFMAs (0.4-1.2k cycles) covers less of a loaded L2 / HBM round trip than two did for the fp32-layout kernels,
     // whose slabs carried twice the VALU work -- else 3
     constexpr bool ONE_WAVE = (TM * TN >= 8);
-    constexpr int NSTAGE = OCC >= 3 ? 3 : ((STAGE * 4 * 4 * (ONE_WAVE ? 1 : 2) <= 163840) ? 4 : 3);
-    static_assert(NSTAGE * STAGE * 4 * (OCC ? OCC : 1) <= 163840, "the ring of OCC workgroups must fit the 160 KiB of LDS");
+    constexpr int NSTAGE = (STAGE * 4 * 4 * (ONE_WAVE ? 1 : 2) <= 163840) ? 4 : 3;
     constexpr int NB = 4 * SEGS / NW;          // B pieces per wave and slab
     constexpr int NLOAD = NA + NB;
 
@@ -463,7 +463,7 @@ int g_pl_default_tile = -1;
 int g_pl_dbg = 0;
 unsigned long long* g_pl_trace = nullptr;
 
-template <int MODE, int WM, int WN, int TM, int TN, int OCC = 0>
+template <int MODE, int WM, int WN, int TM, int TN>
 int launch_cfg(PlConvArgs& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
@@ -471,7 +471,7 @@ int launch_cfg(PlConvArgs& a, hipStream_t stream) {
     a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
     a.n_ptiles = (a.P + BN - 1) / BN;
     const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
-    hipLaunchKernelGGL((conv_pl_kernel<MODE, WM, WN, TM, TN, OCC>), dim3(nblk), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_pl_kernel<MODE, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("conv_pl");
     return SSN_OK;
 }
@@ -479,10 +479,9 @@ int launch_cfg(PlConvArgs& a, hipStream_t stream) {
 // Tile ids (rows x pixels), 4 waves each:
 //   0 128x128 (2x2 waves of 64x64)   1 64x128   2 128x64   3 64x64   4 192x128   5 256x128   6 128x256
 //   7 96x128 (1x4 waves of 96x32)    8 160x128 (1x4)    9 32x128 (1x4)   10 64x256 (2x2 of 32x128)   11 192x64
-//   12 128x128, 13 96x128, 14 192x64 compiled for THREE workgroups per CU, 15 64x128 for FOUR (3-slot ring; see OCC above)
-constexpr int PL_NCFG = 16;
-const int kPlBM[PL_NCFG] = {128, 64, 128, 64, 192, 256, 128, 96, 160, 32, 64, 192, 128, 96, 192, 64};
-const int kPlBN[PL_NCFG] = {128, 128, 64, 64, 128, 128, 256, 128, 128, 128, 256, 64, 128, 128, 64, 128};
+constexpr int PL_NCFG = 12;
+const int kPlBM[PL_NCFG] = {128, 64, 128, 64, 192, 256, 128, 96, 160, 32, 64, 192};
+const int kPlBN[PL_NCFG] = {128, 128, 64, 64, 128, 128, 256, 128, 128, 128, 256, 64};
 
 template <int MODE>
 int launch_tile(PlConvArgs& a, int cfg, hipStream_t stream) {
@@ -499,10 +498,6 @@ int launch_tile(PlConvArgs& a, int cfg, hipStream_t stream) {
         case 9: return launch_cfg<MODE, 1, 4, 1, 1>(a, stream);
         case 10: return launch_cfg<MODE, 2, 2, 1, 4>(a, stream);
         case 11: return launch_cfg<MODE, 2, 2, 3, 1>(a, stream);
-        case 12: return launch_cfg<MODE, 2, 2, 2, 2, 3>(a, stream);
-        case 13: return launch_cfg<MODE, 1, 4, 3, 1, 3>(a, stream);
-        case 14: return launch_cfg<MODE, 2, 2, 3, 1, 3>(a, stream);
-        case 15: return launch_cfg<MODE, 2, 2, 1, 2, 4>(a, stream);
     }
     ssn_set_error("conv_pl: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
@@ -513,7 +508,7 @@ int default_tile(int M, long P) {
     double best = 1e300;
     int bc = 0;
     for (int c = 0; c < PL_NCFG; ++c) {
-        if (c == 5 || c == 6 || c == 10 || c >= 12) continue;      // the register-heavy and the high-occupancy tiles: autotuner only
+        if (c == 5 || c == 6 || c == 10) continue;      // the register-heavy tiles: autotuner only
         const long mt = (M + kPlBM[c] - 1) / kPlBM[c], pt = (P + kPlBN[c] - 1) / kPlBN[c];
         const double padded = (double)(mt * kPlBM[c]) * (double)(pt * kPlBN[c]);
         const double small = (kPlBM[c] * kPlBN[c] >= 128 * 128) ? 1.0 : (kPlBM[c] * kPlBN[c] >= 64 * 128 ? 1.1 : 1.3);

@@ -333,3 +333,224 @@ extern "C" int ssn_cw_smoothl1_bwd(const long* labels, const float* diff, const 
     SSN_CHECK_LAUNCH("cw_smoothl1_bwd");
     return SSN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fused head: StructuredTemporalPyramidPooling + the three Linear heads + the prop_type row selection of
+// SSN.train_forward (/root/reference/ssn_models.py:268-289, ops/ssn_ops.py:39-70) as ONE launch forward and ONE backward, instead
+// of 7 and 16 (stpp, 3 x linear, 3 x row gather | 3 x (fill + row scatter), 3 x (dx, dW, db), stpp backward).  Same arithmetic in
+// the same order as the separate kernels above and in stpp.hip (the tests compare the two paths).
+#define SSN_STPP_MAX_PARTS 24
+struct SsnStppTable {      // (stpp.hip holds the same definition: the table the host builds from the reference's torch.arange + int())
+    int n_parts;
+    int n_seg;
+    int act_lo, act_hi;
+    int lo[SSN_STPP_MAX_PARTS];
+    int hi[SSN_STPP_MAX_PARTS];
+    int norm[SSN_STPP_MAX_PARTS];
+    int col[SSN_STPP_MAX_PARTS];
+};
+
+namespace {
+
+struct HeadsArgs {
+    const float* ft;         // [P * n_seg][D] backbone features (behind the dropout)
+    const float* scaling;    // [P][2]
+    const float* w[3];       // activity [O0][D], completeness [O1][m D], regression [O2][m D] (null: no regression head)
+    const float* b[3];
+    const int* pos[3];       // [P]: row of proposal p in head h's gathered output, -1 = not selected by its prop_type
+    const long* idx[3];      // [n_h]: proposal of gathered row r (backward)
+    float* out[3];           // forward: gathered outputs [n_h][O_h];   backward: their gradients (read)
+    float* act_ft;           // [P][D]    forward: written (kept for the backward);  backward: read
+    float* stpp_ft;          // [P][m D]
+    float* d_ft;             // backward: [P * n_seg][D]
+    float* dw[3];            // backward: weight / bias gradients
+    float* db[3];
+    int O[3], n[3];
+    int D, P;
+    int wblk0[4];            // backward: first dW block of head h (prefix sums over O_h * chunks_h), [3] = total
+    SsnStppTable t;
+};
+
+// grid P; LDS: the (1 + m) * D pooled features of the proposal (<= 64 KiB, checked by the host)
+__global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs a) {
+    __shared__ __attribute__((aligned(16))) float sh[16384];
+    const int prop = blockIdx.x, D = a.D, m = a.t.n_parts;
+    const float* src = a.ft + ((long)prop * a.t.n_seg) * D;
+    for (int part = 0; part <= m; ++part) {          // part == m: the activity (course mean) feature
+        const bool is_act = part == m;
+        const int lo = is_act ? a.t.act_lo : a.t.lo[part], hi = is_act ? a.t.act_hi : a.t.hi[part];
+        const float len = (float)(hi - lo);
+        const float norm = is_act ? 1.f : (float)a.t.norm[part];
+        const int col = is_act ? -1 : a.t.col[part];
+        const float s = col >= 0 ? a.scaling[prop * 2 + col] : 1.f;
+        float* dst = is_act ? a.act_ft + (long)prop * D : a.stpp_ft + ((long)prop * m + part) * D;
+        float* lds = is_act ? sh : sh + (long)(1 + part) * D;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float acc = 0.f;
+            for (int seg = lo; seg < hi; ++seg) acc += src[(long)seg * D + d];
+            float v = acc / len;
+            if (!is_act) {
+                v = v / norm;
+                if (col >= 0) v = v * s;
+            }
+            dst[d] = v;
+            lds[d] = v;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int h = 0; h < 3; ++h) {
+        if (!a.w[h]) continue;
+        const int row = a.pos[h][prop];
+        if (row < 0) continue;
+        const int Dh = h == 0 ? D : m * D;
+        const float* xp = h == 0 ? sh : sh + D;
+        for (int o = wave; o < a.O[h]; o += 4) {
+            const float* wp = a.w[h] + (long)o * Dh;
+            float acc = 0.f;
+            if ((Dh & 3) == 0) {
+                for (int d = lane * 4; d < Dh; d += 256) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + d);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + d);
+                    acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+                }
+            } else {
+                for (int d = lane; d < Dh; d += 64) acc += xp[d] * wp[d];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) a.out[h][(long)row * a.O[h] + o] = acc + (a.b[h] ? a.b[h][o] : 0.f);
+        }
+    }
+}
+
+// blocks [0, P): gradient of the features of one proposal (heads' dx -> STPP backward);  blocks [P, P + wblk0[3]): one (head, output
+// row, 256-column chunk) of a weight gradient;  the last 3 blocks: the bias gradients
+__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsArgs a) {
+    const int D = a.D, m = a.t.n_parts, b = blockIdx.x;
+    if (b < a.P) {
+        const int prop = b;
+        int row[3];
+        for (int h = 0; h < 3; ++h) row[h] = a.w[h] ? a.pos[h][prop] : -1;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float da = 0.f;
+            if (row[0] >= 0)
+                for (int o = 0; o < a.O[0]; ++o) da += a.out[0][(long)row[0] * a.O[0] + o] * a.w[0][(long)o * D + d];
+            float ds[SSN_STPP_MAX_PARTS];
+            for (int part = 0; part < m; ++part) {
+                float acc = 0.f;
+                if (row[1] >= 0)
+                    for (int o = 0; o < a.O[1]; ++o) acc += a.out[1][(long)row[1] * a.O[1] + o] * a.w[1][(long)o * m * D + (long)part * D + d];
+                if (row[2] >= 0) {
+                    float acc2 = 0.f;
+                    for (int o = 0; o < a.O[2]; ++o) acc2 += a.out[2][(long)row[2] * a.O[2] + o] * a.w[2][(long)o * m * D + (long)part * D + d];
+                    acc = acc + acc2;
+                }
+                ds[part] = acc;
+            }
+            for (int seg = 0; seg < a.t.n_seg; ++seg) {
+                float g = 0.f;
+                for (int part = 0; part < m; ++part) {
+                    if (seg < a.t.lo[part] || seg >= a.t.hi[part]) continue;
+                    float v = ds[part];
+                    if (a.t.col[part] >= 0) v = v * a.scaling[prop * 2 + a.t.col[part]];
+                    v = v / (float)a.t.norm[part];
+                    g += v / (float)(a.t.hi[part] - a.t.lo[part]);
+                }
+                if (seg >= a.t.act_lo && seg < a.t.act_hi) g += da / (float)(a.t.act_hi - a.t.act_lo);
+                a.d_ft[((long)prop * a.t.n_seg + seg) * D + d] = g;
+            }
+        }
+        return;
+    }
+    int wb = b - a.P;
+    if (wb < a.wblk0[3]) {
+        int h = 0;
+        while (h < 2 && wb >= a.wblk0[h + 1]) ++h;
+        wb -= a.wblk0[h];
+        const int Dh = h == 0 ? D : m * D;
+        const int chunks = (Dh + 255) / 256;
+        const int o = wb / chunks, d = (wb - o * chunks) * 256 + threadIdx.x;
+        if (d >= Dh) return;
+        const float* x = h == 0 ? a.act_ft : a.stpp_ft;
+        float acc = 0.f;
+        for (int r = 0; r < a.n[h]; ++r) acc += a.out[h][(long)r * a.O[h] + o] * x[a.idx[h][r] * Dh + d];
+        a.dw[h][(long)o * Dh + d] = acc;
+        return;
+    }
+    const int h = wb - a.wblk0[3];
+    if (h < 3 && a.w[h] && a.db[h])
+        for (int o = threadIdx.x; o < a.O[h]; o += 256) {
+            float acc = 0.f;
+            for (int r = 0; r < a.n[h]; ++r) acc += a.out[h][(long)r * a.O[h] + o];
+            a.db[h][o] = acc;
+        }
+}
+
+int fill_heads(HeadsArgs& a, const float* ft, const float* scaling, const float* const* w, const float* const* b,
+               const int* const* pos, const long* const* idx, float* const* out, const int* O, const int* n, float* act_ft,
+               float* stpp_ft, int P, int D, const SsnStppTable* table, const char* what) {
+    SSN_CHECK_ARG(ft && scaling && w && b && pos && idx && out && O && n && act_ft && stpp_ft && table, "%s: null pointer", what);
+    SSN_CHECK_ARG(P > 0 && D > 0 && table->n_parts >= 1 && table->n_parts <= SSN_STPP_MAX_PARTS, "%s: bad shape", what);
+    SSN_CHECK_ARG(w[0] && w[1] && pos[0] && pos[1] && out[0] && out[1], "%s: the activity and completeness heads are required", what);
+    a.ft = ft;
+    a.scaling = scaling;
+    for (int h = 0; h < 3; ++h) {
+        a.w[h] = w[h];
+        a.b[h] = b[h];
+        a.pos[h] = pos[h];
+        a.idx[h] = idx[h];
+        a.out[h] = out[h];
+        a.O[h] = O[h];
+        a.n[h] = n[h];
+        a.dw[h] = a.db[h] = nullptr;
+    }
+    a.act_ft = act_ft;
+    a.stpp_ft = stpp_ft;
+    a.d_ft = nullptr;
+    a.D = D;
+    a.P = P;
+    a.t = *table;
+    return SSN_OK;
+}
+
+}  // namespace
+
+// w / b / pos / idx / out / O / n: HOST arrays of 3 (activity, completeness, regression; entry 2 of w null = no regression head).
+// pos[h]: DEVICE int [P], idx[h]: DEVICE long [n_h].  Forward: out[h] [n_h][O_h] <- the gathered head outputs, act_ft / stpp_ft <-
+// the pooled features (kept for the backward).
+extern "C" int ssn_heads_fwd(const float* ft, const float* scaling, const float* const* w, const float* const* b,
+                             const int* const* pos, const long* const* idx, float* const* out, const int* O, const int* n,
+                             float* act_ft, float* stpp_ft, int P, int D, const SsnStppTable* table, hipStream_t stream) {
+    HeadsArgs a;
+    int rc = fill_heads(a, ft, scaling, w, b, pos, idx, out, O, n, act_ft, stpp_ft, P, D, table, "heads fwd");
+    if (rc != SSN_OK) return rc;
+    const size_t lds = (size_t)(1 + table->n_parts) * D * sizeof(float);
+    SSN_CHECK_ARG(lds <= 65536, "heads fwd: %d parts x %d features do not fit the 64 KiB of LDS this kernel uses", table->n_parts, D);
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3(P), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("heads_fwd");
+    return SSN_OK;
+}
+// Backward: dout[h] = gradients of the gathered outputs (read); d_ft [P * n_seg][D], dw[h], db[h] (HOST arrays of 3 device
+// pointers; db entries may be null) <- gradients.
+extern "C" int ssn_heads_bwd(const float* ft_unused, const float* scaling, const float* const* w, const float* const* b,
+                             const int* const* pos, const long* const* idx, float* const* dout, const int* O, const int* n,
+                             float* act_ft, float* stpp_ft, int P, int D, const SsnStppTable* table, float* d_ft,
+                             float* const* dw, float* const* db, hipStream_t stream) {
+    HeadsArgs a;
+    int rc = fill_heads(a, ft_unused ? ft_unused : act_ft, scaling, w, b, pos, idx, dout, O, n, act_ft, stpp_ft, P, D, table,
+                        "heads bwd");
+    if (rc != SSN_OK) return rc;
+    SSN_CHECK_ARG(d_ft && dw && db && dw[0] && dw[1] && (!w[2] || dw[2]), "heads bwd: null gradient pointer");
+    a.d_ft = d_ft;
+    int blocks = 0;
+    for (int h = 0; h < 3; ++h) {
+        a.dw[h] = dw[h];
+        a.db[h] = db[h];
+        a.wblk0[h] = blocks;
+        if (w[h]) blocks += O[h] * (((h == 0 ? D : table->n_parts * D) + 255) / 256);
+    }
+    a.wblk0[3] = blocks;
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3(P + blocks + 3), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("heads_bwd");
+    return SSN_OK;
+}

@@ -87,6 +87,48 @@ class StppFn(torch.autograd.Function):
         return d_ft, None, None, None
 
 
+class HeadsFn(torch.autograd.Function):
+    """STPP + activity / completeness / regression heads + the prop_type row selection of ``SSN.train_forward``
+    (/root/reference/ssn_models.py:268-289) as one launch forward and one backward (csrc/heads_losses.hip: ssn_heads_*) -- the same
+    arithmetic as ``StppFn`` + ``LinearFn`` x 3 + ``RowGatherFn`` x 3, which remain the path of every other caller."""
+
+    @staticmethod
+    def forward(ctx, ft, scaling, table, n_seg, idx, pos, w0, b0, w1, b1, w2, b2):
+        ft = ft.contiguous()
+        scaling = scaling.reshape(-1, 2).contiguous().float()
+        d = ft.shape[1]
+        if ft.shape[0] % n_seg:
+            raise ValueError("feature rows (%d) are not a multiple of %d segments" % (ft.shape[0], n_seg))
+        p = ft.shape[0] // n_seg
+        if scaling.shape[0] != p:
+            raise ValueError("scaling has %d rows, expected %d proposals" % (scaling.shape[0], p))
+        ws = [w.detach().contiguous() if w is not None else None for w in (w0, w1, w2)]
+        bs = [b.detach().contiguous() if b is not None else None for b in (b0, b1, b2)]
+        act = _new(ft, (p, d))
+        stpp = _new(ft, (p, table.n_parts * d))
+        outs = [None if w is None else _new(ft, (i.numel(), w.shape[0])) for w, i in zip(ws, idx)]
+        K.heads_fwd(ft, scaling, ws, bs, pos, idx, outs, act, stpp, table)
+        ctx.save_for_backward(scaling, act, stpp, *[t for t in ws + bs if t is not None])
+        ctx.layout = ([w is not None for w in ws], [b is not None for b in bs])
+        ctx.table, ctx.idx, ctx.pos, ctx.ft_shape = table, idx, pos, ft.shape
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        saved = list(ctx.saved_tensors)
+        scaling, act, stpp = saved[:3]
+        rest = saved[3:]
+        ws = [rest.pop(0) if has else None for has in ctx.layout[0]]
+        bs = [rest.pop(0) if has else None for has in ctx.layout[1]]
+        douts = [None if w is None else (torch.zeros((i.numel(), w.shape[0]), device=act.device) if g is None else g.contiguous())
+                 for w, i, g in zip(ws, ctx.idx, douts)]
+        d_ft = _new(act, ctx.ft_shape)
+        dws = [None if w is None else _new(w, w.shape) for w in ws]
+        dbs = [None if b is None else _new(b, b.shape) for b in bs]
+        K.heads_bwd(scaling, ws, bs, ctx.pos, ctx.idx, douts, act, stpp, ctx.table, d_ft, dws, dbs)
+        return (d_ft, None, None, None, None, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2])
+
+
 class RowGatherFn(torch.autograd.Function):
     """prop_type row selection (/root/reference/ssn_models.py:275-289)."""
 

@@ -137,7 +137,8 @@ def _hbm_timed(fn):
         prof = HBM_PROFILER
         if prof is None:
             return fn(*args, **kw)
-        tens = [a for a in args if torch.is_tensor(a)]
+        flat = [b for a in args for b in (a if isinstance(a, (list, tuple)) else (a,))]
+        tens = [a for a in flat if torch.is_tensor(a)]
         slices = [a for a in args if isinstance(a, ChanSlice)]
         first = tens[0] if tens else (slices[0].t if slices else None)
         if first is None or not first.is_cuda:
@@ -602,6 +603,36 @@ def stpp_bwd(d_act, d_stpp, scaling, d_ft, table):
     lib = _check(d_act, d_stpp, scaling, d_ft)
     lib.call("ssn_stpp_bwd", _p(d_act), _p(d_stpp), _p(scaling), _p(d_ft), d_stpp.shape[0], d_ft.shape[1],
              ctypes.addressof(table), _stream(lib, d_ft))
+
+
+def _heads_tables(ws, bs, pos, idx, outs):
+    arr3 = ctypes.c_void_p * 3
+    ci3 = ctypes.c_int * 3
+    return (arr3(*[None if t is None else t.data_ptr() for t in ws]), arr3(*[None if t is None else t.data_ptr() for t in bs]),
+            arr3(*[None if t is None else t.data_ptr() for t in pos]), arr3(*[None if t is None else t.data_ptr() for t in idx]),
+            arr3(*[None if t is None else t.data_ptr() for t in outs]),
+            ci3(*[0 if w is None else int(w.shape[0]) for w in ws]), ci3(*[0 if t is None else int(t.numel()) for t in idx]))
+
+
+@_hbm_timed
+def heads_fwd(ft, scaling, ws, bs, pos, idx, outs, act_ft, stpp_ft, table):
+    """STPP + the three Linear heads + the prop_type row selection in one launch (ssn_heads_fwd).  ws / bs / pos / idx / outs:
+    lists of 3 (activity, completeness, regression; entries of an absent regression head None)."""
+    lib = _check(ft, scaling, act_ft, stpp_ft, *[t for t in list(ws) + list(bs) + list(outs) if t is not None])
+    tabs = _heads_tables(ws, bs, pos, idx, outs)
+    lib.call("ssn_heads_fwd", _p(ft), _p(scaling), *[ctypes.addressof(t) for t in tabs], _p(act_ft), _p(stpp_ft),
+             act_ft.shape[0], ft.shape[1], ctypes.addressof(table), _stream(lib, ft))
+
+
+@_hbm_timed
+def heads_bwd(scaling, ws, bs, pos, idx, douts, act_ft, stpp_ft, table, d_ft, dws, dbs):
+    lib = _check(scaling, act_ft, stpp_ft, d_ft, *[t for t in list(ws) + list(douts) + list(dws) + list(dbs) if t is not None])
+    tabs = _heads_tables(ws, bs, pos, idx, douts)
+    arr3 = ctypes.c_void_p * 3
+    pdw = arr3(*[None if t is None else t.data_ptr() for t in dws])
+    pdb = arr3(*[None if t is None else t.data_ptr() for t in dbs])
+    lib.call("ssn_heads_bwd", None, _p(scaling), *[ctypes.addressof(t) for t in tabs], _p(act_ft), _p(stpp_ft), act_ft.shape[0],
+             d_ft.shape[1], ctypes.addressof(table), _p(d_ft), ctypes.addressof(pdw), ctypes.addressof(pdb), _stream(lib, d_ft))
 
 
 def stpp_reorg(scores, ranges, act_range, scaling, part_scale_col, act_len, comp_len, reg_len, out_act, out_comp,

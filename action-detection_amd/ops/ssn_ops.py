@@ -65,11 +65,15 @@ class StructuredTemporalPyramidPooling(torch.nn.Module):
                     rows.append((lo + ticks[i], lo + ticks[i + 1], norm, col))
         return rows
 
-    def forward(self, ft, scaling, seg_split):
+    def table_for(self, seg_split):
         key = tuple(int(v) for v in seg_split)
         if key not in self._tables:
             self._tables[key] = K.make_stpp_table(self.part_table(key), key[2], key[0], key[1])
-        act_ft, stpp_ft = FN.StppFn.apply(ft, scaling, self._tables[key], key[2])
+        return self._tables[key]
+
+    def forward(self, ft, scaling, seg_split):
+        key = tuple(int(v) for v in seg_split)
+        act_ft, stpp_ft = FN.StppFn.apply(ft, scaling, self.table_for(key), key[2])
         if not self.sc:
             return stpp_ft, stpp_ft
         return act_ft, stpp_ft

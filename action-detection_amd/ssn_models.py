@@ -12,6 +12,8 @@ deliberate and documented in DESIGN.md:
   * one host sync per forward (prop_type -> row indices) instead of the reference's three
     ``nonzero()`` syncs.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -253,8 +255,35 @@ class SSN(torch.nn.Module):
         feat = self.base_model.features(x)
         return getattr(self.base_model, self.base_model.last_layer_name)(feat)
 
+    # STPP + the three heads + the row selection as one launch each way (functional.HeadsFn); False: the separate kernels
+    fused_heads = os.environ.get("SSN_FUSED_HEADS", "1") != "0"
+
+    def _fused_train_heads(self, base_out, aug_scaling, target, reg_target, prop_type):
+        seg_split = (self.starting_segment, self.starting_segment + self.course_segment, self.num_segments)
+        table = self.stpp.table_for(seg_split)
+        dev = base_out.device
+        idx = self._row_indexers(prop_type, dev)
+        pos = self._indexer_cache[4]
+        target = target.reshape(-1).to(dev)
+        reg = self.regressor_fc if self.with_regression else None
+        outs = FN.HeadsFn.apply(base_out, aug_scaling, table, seg_split[2], idx if reg is not None else idx[:2] + (None,),
+                                pos if reg is not None else pos[:2] + (None,),
+                                self.activity_fc.weight, self.activity_fc.bias, self.completeness_fc.weight, self.completeness_fc.bias,
+                                None if reg is None else reg.weight, None if reg is None else reg.bias)
+
+        def sel(t, i):
+            return t.index_select(0, i)
+        if reg is not None:
+            reg_target = reg_target.reshape(-1, 2).to(dev)
+            return (outs[0], sel(target, idx[0]), outs[1], sel(target, idx[1]),
+                    outs[2].reshape(-1, self.completeness_fc.out_features, 2), sel(target, idx[2]), sel(reg_target, idx[2]))
+        return (outs[0], sel(target, idx[0]), outs[1], sel(target, idx[1]))
+
     def train_forward(self, input, aug_scaling, target, reg_target, prop_type):
         base_out = self._backbone(input)
+        if (self.fused_heads and self.stpp.sc and (1 + self.stpp.feat_multiplier) * self.stpp.feat_dim * 4 <= 65536
+                and type(self.activity_fc) is HipLinear and type(self.completeness_fc) is HipLinear):
+            return self._fused_train_heads(base_out, aug_scaling, target, reg_target, prop_type)
         activity_ft, completeness_ft = self.stpp(base_out, aug_scaling,
                                                  [self.starting_segment,
                                                   self.starting_segment + self.course_segment,
@@ -300,12 +329,15 @@ class SSN(torch.nn.Module):
             return cache[2]
         type_host = prop_type.detach().reshape(-1).cpu()
         if cache is not None and cache[0][2] == str(dev) and torch.equal(cache[1], type_host):
-            self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), cache[1], cache[2], prop_type._version)
+            self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), cache[1], cache[2], prop_type._version,
+                                   cache[4])
             return cache[2]
-        idx = (torch.nonzero((type_host == 0) | (type_host == 2)).reshape(-1).to(dev),
-               torch.nonzero((type_host == 0) | (type_host == 1)).reshape(-1).to(dev),
-               torch.nonzero(type_host == 0).reshape(-1).to(dev))
-        self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), type_host.clone(), idx, prop_type._version)
+        sets = ((type_host == 0) | (type_host == 2), (type_host == 0) | (type_host == 1), type_host == 0)
+        idx = tuple(torch.nonzero(m_).reshape(-1).to(dev) for m_ in sets)
+        # the inverse maps the fused head kernels use: row of proposal p in each gathered output, -1 = not selected
+        pos = tuple((torch.cumsum(m_.to(torch.int32), 0, dtype=torch.int32) - 1).masked_fill(~m_, -1).to(dev) for m_ in sets)
+        self._indexer_cache = ((prop_type.data_ptr(), tuple(prop_type.shape), str(dev)), type_host.clone(), idx, prop_type._version,
+                               pos)
         return idx
 
     def test_forward(self, input):

@@ -284,6 +284,18 @@ int ssn_stpp_fwd(const float* ft, const float* scaling, float* act_ft, float* st
                  const SsnStppTable* table, hipStream_t stream);
 int ssn_stpp_bwd(const float* d_act, const float* d_stpp, const float* scaling, float* d_ft, int P, int D,
                  const SsnStppTable* table, hipStream_t stream);
+/* The fused head of SSN.train_forward (ssn_models.py:268-289): STPP + activity / completeness / regression Linear + the prop_type
+ * row selection as ONE launch each way (instead of 7 forward, 16 backward), same arithmetic and summation order as ssn_stpp_* /
+ * ssn_linear_* / ssn_row_gather|scatter.  w / b / pos / idx / out / O / n: HOST arrays of 3 (activity, completeness, regression;
+ * w[2] == NULL: no regression head); pos[h]: DEVICE int [P] = row of proposal p in head h's gathered output or -1; idx[h]: DEVICE
+ * long [n_h] = proposal of gathered row r.  Forward: out[h] [n_h][O_h], act_ft [P][D], stpp_ft [P][m D] (kept for the backward).
+ * Backward: dout[h] gradients of the gathered outputs -> d_ft [P n_seg][D], dw[h], db[h]. */
+int ssn_heads_fwd(const float* ft, const float* scaling, const float* const* w, const float* const* b, const int* const* pos,
+                  const long* const* idx, float* const* out, const int* O, const int* n, float* act_ft, float* stpp_ft, int P, int D,
+                  const SsnStppTable* table, hipStream_t stream);
+int ssn_heads_bwd(const float* ft_unused, const float* scaling, const float* const* w, const float* const* b, const int* const* pos,
+                  const long* const* idx, float* const* dout, const int* O, const int* n, float* act_ft, float* stpp_ft, int P, int D,
+                  const SsnStppTable* table, float* d_ft, float* const* dw, float* const* db, hipStream_t stream);
 /* STPPReorgainzed.forward (ops/ssn_ops.py:109-170), stand-alone activity classifier form.
  * ranges: int32 [P][n_parts][2] row ranges (pr<=pl: skipped); act_range: int32 [P][2]. */
 int ssn_stpp_reorg(const float* scores, int T, int D, const int* ranges, const int* act_range,

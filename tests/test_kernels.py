@@ -949,3 +949,69 @@ def test_stem_space_to_depth(backend):
         dw = backend.put(torch.empty(cout, c, 7, 7))
         K.s2d_weights_bwd(dw2, dw)
         assert rel_err(dw, w.grad) < 5e-5 and rel_err(db, b.grad) < 5e-5, (n, c, h)
+
+
+def test_fused_heads_match_the_separate_kernels(backend):
+    """functional.HeadsFn (STPP + three Linear heads + prop_type row selection, one launch each way) against the chain of
+    StppFn / LinearFn / RowGatherFn it replaces in SSN.train_forward: outputs and every gradient (features, 3 weights, 3 biases),
+    for both STPP configurations of the reference, with and without the regression head, and against float64 torch."""
+    from action_detection_amd import functional as FN
+    from action_detection_amd.ops.ssn_ops import StructuredTemporalPyramidPooling
+    g = torch.Generator().manual_seed(31)
+    for cfg, with_reg in (((1, 1, 1), True), ((1, (1, 2), 1), True), ((1, 1, 1), False)):
+        p, s, d, c = 16, 9, 64, 5
+        stpp = StructuredTemporalPyramidPooling(d, True, configs=cfg)
+        m = stpp.feat_multiplier
+        table = stpp.table_for((2, 7, 9))
+        ft = torch.randn(p * s, d, generator=g)
+        sc = torch.rand(p, 2, generator=g)
+        ws = [torch.randn(c + 1, d, generator=g) * 0.1, torch.randn(c, m * d, generator=g) * 0.1,
+              torch.randn(2 * c, m * d, generator=g) * 0.1 if with_reg else None]
+        bs = [torch.randn(c + 1, generator=g), torch.randn(c, generator=g), torch.randn(2 * c, generator=g) if with_reg else None]
+        ptype = torch.tensor(([0, 1, 1, 1, 1, 1, 1, 2] * 2))
+        sets = ((ptype == 0) | (ptype == 2), (ptype == 0) | (ptype == 1), ptype == 0)
+        idx = [torch.nonzero(q).reshape(-1) for q in sets]
+        pos = [(torch.cumsum(q.to(torch.int32), 0, dtype=torch.int32) - 1).masked_fill(~q, -1) for q in sets]
+        gouts = [torch.randn(i.numel(), w.shape[0], generator=g) if w is not None else None for i, w in zip(idx, ws)]
+
+        def leaf(t):
+            return None if t is None else backend.put(t).clone().requires_grad_()
+
+        def run(fused):
+            f, w_, b_ = leaf(ft), [leaf(t) for t in ws], [leaf(t) for t in bs]
+            di = [backend.put(t) for t in idx]
+            if fused:
+                dp = [backend.put(t) for t in pos]
+                outs = FN.HeadsFn.apply(f, backend.put(sc), table, 9, tuple(di) if with_reg else (di[0], di[1], None),
+                                        tuple(dp) if with_reg else (dp[0], dp[1], None), w_[0], b_[0], w_[1], b_[1], w_[2], b_[2])
+            else:
+                a, st = FN.StppFn.apply(f, backend.put(sc), table, 9)
+                full = [FN.LinearFn.apply(a, w_[0], b_[0]), FN.LinearFn.apply(st, w_[1], b_[1]),
+                        FN.LinearFn.apply(st, w_[2], b_[2]) if with_reg else None]
+                outs = [None if o is None else FN.RowGatherFn.apply(o, i) for o, i in zip(full, di)]
+            loss = sum((o * backend.put(go)).sum() for o, go in zip(outs, gouts) if o is not None)
+            loss.backward()
+            return [o for o in outs if o is not None], [t.grad for t in [f] + w_ + b_ if t is not None]
+
+        o1, g1 = run(True)
+        o0, g0 = run(False)
+        for a, b in zip(o1 + g1, o0 + g0):
+            assert rel_err(a, b) < 1e-6, (cfg, with_reg, rel_err(a, b))
+        # and against float64 torch
+        f64 = ft.double().requires_grad_()
+        w64 = [None if t is None else t.double().requires_grad_() for t in ws]
+        b64 = [None if t is None else t.double().requires_grad_() for t in bs]
+        src = f64.view(p, s, d)
+        parts = []
+        for lo, hi, norm, col in stpp.part_table((2, 7, 9)):
+            v = src[:, lo:hi].mean(1) / norm
+            if col >= 0:
+                v = v * sc[:, col:col + 1].double()
+            parts.append(v)
+        act64, st64 = src[:, 2:7].mean(1), torch.cat(parts, 1)
+        outs64 = [(act64 @ w64[0].t() + b64[0])[idx[0]], (st64 @ w64[1].t() + b64[1])[idx[1]],
+                  (st64 @ w64[2].t() + b64[2])[idx[2]] if with_reg else None]
+        sum((o * go.double()).sum() for o, go in zip(outs64, gouts) if o is not None).backward()
+        ref = [o for o in outs64 if o is not None] + [t.grad for t in [f64] + w64 + b64 if t is not None]
+        for a, b in zip(o1 + g1, ref):
+            assert rel_err(a, b) < 2e-6, (cfg, with_reg, "float64", rel_err(a, b))
