@@ -371,10 +371,13 @@ struct HeadsArgs {
     SsnStppTable t;
 };
 
-// grid P; LDS: the (1 + m) * D pooled features of the proposal (<= 64 KiB, checked by the host)
+// grid (P, chunks of HEADS_CHUNK outputs): every block pools the features of its proposal into LDS ((1 + m) * D floats <= 64 KiB,
+// checked by the host; 36 KB of reads -- cheaper than a second launch) and computes its share of the 81 (C = 20) head outputs;
+// chunk 0 also writes the pooled features out for the backward.  (One block per proposal -- 32 blocks -- took 144 us.)
+constexpr int HEADS_CHUNK = 8;
 __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs a) {
     __shared__ __attribute__((aligned(16))) float sh[16384];
-    const int prop = blockIdx.x, D = a.D, m = a.t.n_parts;
+    const int prop = blockIdx.x, chunk = blockIdx.y, D = a.D, m = a.t.n_parts;
     const float* src = a.ft + ((long)prop * a.t.n_seg) * D;
     for (int part = 0; part <= m; ++part) {          // part == m: the activity (course mean) feature
         const bool is_act = part == m;
@@ -393,19 +396,25 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs a) {
                 v = v / norm;
                 if (col >= 0) v = v * s;
             }
-            dst[d] = v;
+            if (chunk == 0) dst[d] = v;
             lds[d] = v;
         }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int h = 0; h < 3; ++h) {
-        if (!a.w[h]) continue;
+    for (int j = chunk * HEADS_CHUNK + wave; j < (chunk + 1) * HEADS_CHUNK; j += 4) {
+        // output j of the concatenated heads -> (head h, row o of its weight)
+        int h = 0, o = j;
+        while (h < 3 && o >= (a.w[h] ? a.O[h] : 0)) {
+            o -= a.w[h] ? a.O[h] : 0;
+            ++h;
+        }
+        if (h >= 3) break;
         const int row = a.pos[h][prop];
         if (row < 0) continue;
         const int Dh = h == 0 ? D : m * D;
         const float* xp = h == 0 ? sh : sh + D;
-        for (int o = wave; o < a.O[h]; o += 4) {
+        {
             const float* wp = a.w[h] + (long)o * Dh;
             float acc = 0.f;
             if ((Dh & 3) == 0) {
@@ -423,15 +432,17 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs a) {
     }
 }
 
-// blocks [0, P): gradient of the features of one proposal (heads' dx -> STPP backward);  blocks [P, P + wblk0[3]): one (head, output
-// row, 256-column chunk) of a weight gradient;  the last 3 blocks: the bias gradients
+// blocks [0, P * dchunks): gradient of 256 features of one proposal (heads' dx -> STPP backward);  then wblk0[3] blocks: one (head,
+// output row, 256-column chunk) of a weight gradient;  the last 3 blocks: the bias gradients
 __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsArgs a) {
-    const int D = a.D, m = a.t.n_parts, b = blockIdx.x;
-    if (b < a.P) {
-        const int prop = b;
+    const int D = a.D, m = a.t.n_parts;
+    const int dchunks = (D + 255) / 256;
+    int b = blockIdx.x;
+    if (b < a.P * dchunks) {
+        const int prop = b / dchunks;
         int row[3];
         for (int h = 0; h < 3; ++h) row[h] = a.w[h] ? a.pos[h][prop] : -1;
-        for (int d = threadIdx.x; d < D; d += 256) {
+        for (int d = (b - prop * dchunks) * 256 + threadIdx.x; d < D; d += D) {      // (one feature per thread)
             float da = 0.f;
             if (row[0] >= 0)
                 for (int o = 0; o < a.O[0]; ++o) da += a.out[0][(long)row[0] * a.O[0] + o] * a.w[0][(long)o * D + d];
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsArgs a) {
         }
         return;
     }
-    int wb = b - a.P;
+    int wb = b - a.P * dchunks;
     if (wb < a.wblk0[3]) {
         int h = 0;
         while (h < 2 && wb >= a.wblk0[h + 1]) ++h;
@@ -526,7 +537,9 @@ extern "C" int ssn_heads_fwd(const float* ft, const float* scaling, const float*
     if (rc != SSN_OK) return rc;
     const size_t lds = (size_t)(1 + table->n_parts) * D * sizeof(float);
     SSN_CHECK_ARG(lds <= 65536, "heads fwd: %d parts x %d features do not fit the 64 KiB of LDS this kernel uses", table->n_parts, D);
-    hipLaunchKernelGGL(heads_fwd_kernel, dim3(P), dim3(256), 0, stream, a);
+    int J = 0;
+    for (int h = 0; h < 3; ++h) J += w[h] ? O[h] : 0;
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3(P, (J + HEADS_CHUNK - 1) / HEADS_CHUNK), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("heads_fwd");
     return SSN_OK;
 }
@@ -550,7 +563,7 @@ extern "C" int ssn_heads_bwd(const float* ft_unused, const float* scaling, const
         if (w[h]) blocks += O[h] * (((h == 0 ? D : table->n_parts * D) + 255) / 256);
     }
     a.wblk0[3] = blocks;
-    hipLaunchKernelGGL(heads_bwd_kernel, dim3(P + blocks + 3), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3(P * ((D + 255) / 256) + blocks + 3), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("heads_bwd");
     return SSN_OK;
 }
