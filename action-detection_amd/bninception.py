@@ -90,8 +90,11 @@ class _BackboneFn(torch.autograd.Function):
     BatchNorm: the images are independent)."""
 
     @staticmethod
-    def forward(ctx, x, net, *params):
-        need_grad = any(ctx.needs_input_grad)
+    def forward(ctx, x, net, grad_mode, *params):
+        # (needs_input_grad is set from requires_grad alone, and grad mode is always off in here -- the caller passes it: inside
+        # torch.no_grad() -- validation, dense testing -- nothing will ever call backward, so nothing is kept: no argmax tensors, no
+        # fp32 copy of the stem input, and the inference cache applies)
+        need_grad = (grad_mode and any(ctx.needs_input_grad)) or net.debug_keep_saved
         bounds = net._chunk_bounds(x)
         if len(bounds) > 2 and net._train_bn_ids():
             raise NotImplementedError("a batch of %d frames needs chunked execution (2 GiB per kernel operand), which would change "
@@ -118,7 +121,7 @@ class _BackboneFn(torch.autograd.Function):
         dfeat = dfeat.contiguous()
         if len(saved) == 1:
             grads, _ = net._run_backward(dfeat, saved[0])
-            return (None, None) + tuple(grads)
+            return (None, None, None) + tuple(grads)
         # sub-batches: per-chunk backward without the gradient-ready hook, one summed flat buffer, then the hook once
         total = None
         for k, (i0, i1) in enumerate(zip(bounds[:-1], bounds[1:])):
@@ -131,7 +134,7 @@ class _BackboneFn(torch.autograd.Function):
         if net.grad_ready_hook is not None:
             net.grad_ready_hook.range_ready(total, 0, total.numel())
             net.grad_ready_hook.finish()
-        return (None, None) + tuple(out)
+        return (None, None, None) + tuple(out)
 
 
 class BNInception(nn.Module):
@@ -182,6 +185,7 @@ class BNInception(nn.Module):
         # planes_exec: every weight gradient keeps its split-K slabs in its own workspace region and ONE launch reduces them all at the
         # end of the pass (at every gradient-ready range with an overlapping reducer) instead of one launch per layer
         self.defer_wgrad_reduce = os.environ.get("SSN_DEFER_WGRAD_REDUCE", "1") != "0"
+        self.infer_cache = os.environ.get("SSN_INFER_CACHE", "1") != "0"   # planes_exec: packed weights / folded BN reused across no-grad forwards
         self.pooled_mask = os.environ.get("SSN_POOLED_MASK", "1") != "0"   # planes_exec: stem pools' backward reads the pooled sign
         self.debug_keep_saved = False
         self._last_saved = None
@@ -215,6 +219,7 @@ class BNInception(nn.Module):
 
     def recalibrate(self):
         """Clear the fault word and make the next forward / backward of every state calibrate from scratch (eagerly)."""
+        self.__dict__.pop("_infer_cache", None)
         for st in self._planes_states.values():
             st.fwd_calibrated = st.bwd_calibrated = False
         for f in self._planes_flags.values():
@@ -294,7 +299,7 @@ class BNInception(nn.Module):
     def features(self, x):
         if x.dim() != 4:
             raise ValueError("expected NCHW input")
-        return _BackboneFn.apply(x.contiguous(), self, *self._param_list())
+        return _BackboneFn.apply(x.contiguous(), self, torch.is_grad_enabled(), *self._param_list())
 
     def forward(self, x):
         return self.fc(self.features(x))
@@ -309,6 +314,17 @@ class BNInception(nn.Module):
         return build_manifest(cin, x.shape[2])
 
     def _plan(self, x):
+        """The launch plan for inputs of x's shape, memoised: building it costs 1 - 2 ms of Python per call, which an eager
+        forward that ends in the range guard's poll (planes_exec) exposes on every call -- 10 % of a dense-test video."""
+        key = (tuple(x.shape[1:]), tuple(self._train_bn_ids()), self.pool_after_projection, self.merge_projection,
+               self.conv_precision, getattr(self, "fuse_block_inputs", None), getattr(self, self._conv_ids[0]).in_channels)
+        cache = self.__dict__.setdefault("_plan_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            hit = cache[key] = self._build_plan(x)
+        return hit
+
+    def _build_plan(self, x):
         """Manifest -> launch plan.
 
         Plan ops are dicts.  The two 1x1 reduce convolutions of an Inception block read the same input;

@@ -379,25 +379,30 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(HeadsArgs a) {
     __shared__ __attribute__((aligned(16))) float sh[16384];
     const int prop = blockIdx.x, chunk = blockIdx.y, D = a.D, m = a.t.n_parts;
     const float* src = a.ft + ((long)prop * a.t.n_seg) * D;
-    for (int part = 0; part <= m; ++part) {          // part == m: the activity (course mean) feature
-        const bool is_act = part == m;
-        const int lo = is_act ? a.t.act_lo : a.t.lo[part], hi = is_act ? a.t.act_hi : a.t.hi[part];
-        const float len = (float)(hi - lo);
-        const float norm = is_act ? 1.f : (float)a.t.norm[part];
-        const int col = is_act ? -1 : a.t.col[part];
-        const float s = col >= 0 ? a.scaling[prop * 2 + col] : 1.f;
-        float* dst = is_act ? a.act_ft + (long)prop * D : a.stpp_ft + ((long)prop * m + part) * D;
-        float* lds = is_act ? sh : sh + (long)(1 + part) * D;
-        for (int d = threadIdx.x; d < D; d += 256) {
+    constexpr int MAXSEG = 16;      // (the host refuses more segments per proposal)
+    for (int d = threadIdx.x; d < D; d += 256) {
+        // all segment values of this feature first (independent loads: one memory round trip, not one per segment and part)
+        float sv[MAXSEG];
+#pragma unroll
+        for (int q = 0; q < MAXSEG; ++q) sv[q] = q < a.t.n_seg ? src[(long)q * D + d] : 0.f;
+        for (int part = 0; part <= m; ++part) {          // part == m: the activity (course mean) feature
+            const bool is_act = part == m;
+            const int lo = is_act ? a.t.act_lo : a.t.lo[part], hi = is_act ? a.t.act_hi : a.t.hi[part];
             float acc = 0.f;
-            for (int seg = lo; seg < hi; ++seg) acc += src[(long)seg * D + d];
-            float v = acc / len;
+#pragma unroll
+            for (int q = 0; q < MAXSEG; ++q) acc += (q >= lo && q < hi) ? sv[q] : 0.f;      // (ascending segments, as stpp_fwd_kernel)
+            float v = acc / (float)(hi - lo);
             if (!is_act) {
-                v = v / norm;
-                if (col >= 0) v = v * s;
+                v = v / (float)a.t.norm[part];
+                if (a.t.col[part] >= 0) v = v * a.scaling[prop * 2 + a.t.col[part]];
             }
-            if (chunk == 0) dst[d] = v;
-            lds[d] = v;
+            if (is_act) {
+                if (chunk == 0) a.act_ft[(long)prop * D + d] = v;
+                sh[d] = v;
+            } else {
+                if (chunk == 0) a.stpp_ft[((long)prop * m + part) * D + d] = v;
+                sh[(long)(1 + part) * D + d] = v;
+            }
         }
     }
     __syncthreads();
@@ -484,7 +489,21 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadsArgs a) {
         if (d >= Dh) return;
         const float* x = h == 0 ? a.act_ft : a.stpp_ft;
         float acc = 0.f;
-        for (int r = 0; r < a.n[h]; ++r) acc += a.out[h][(long)r * a.O[h] + o] * x[a.idx[h][r] * Dh + d];
+        int r = 0;
+        for (; r + 4 <= a.n[h]; r += 4) {      // four independent (index -> row) chains in flight; summation order unchanged
+            long i4[4];
+            float g4[4], x4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                i4[q] = a.idx[h][r + q];
+                g4[q] = a.out[h][(long)(r + q) * a.O[h] + o];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x4[q] = x[i4[q] * Dh + d];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += g4[q] * x4[q];
+        }
+        for (; r < a.n[h]; ++r) acc += a.out[h][(long)r * a.O[h] + o] * x[a.idx[h][r] * Dh + d];
         a.dw[h][(long)o * Dh + d] = acc;
         return;
     }
@@ -501,7 +520,8 @@ int fill_heads(HeadsArgs& a, const float* ft, const float* scaling, const float*
                const int* const* pos, const long* const* idx, float* const* out, const int* O, const int* n, float* act_ft,
                float* stpp_ft, int P, int D, const SsnStppTable* table, const char* what) {
     SSN_CHECK_ARG(ft && scaling && w && b && pos && idx && out && O && n && act_ft && stpp_ft && table, "%s: null pointer", what);
-    SSN_CHECK_ARG(P > 0 && D > 0 && table->n_parts >= 1 && table->n_parts <= SSN_STPP_MAX_PARTS, "%s: bad shape", what);
+    SSN_CHECK_ARG(P > 0 && D > 0 && table->n_parts >= 1 && table->n_parts <= SSN_STPP_MAX_PARTS && table->n_seg <= 16,
+                  "%s: bad shape (at most 24 parts, 16 segments per proposal)", what);
     SSN_CHECK_ARG(w[0] && w[1] && pos[0] && pos[1] && out[0] && out[1], "%s: the activity and completeness heads are required", what);
     a.ft = ft;
     a.scaling = scaling;

@@ -53,7 +53,7 @@ class InceptionV3(BNInception):
             raise ValueError("square inputs only")
         return build_manifest(cin, x.shape[2])
 
-    def _plan(self, x):
+    def _build_plan(self, x):
         ops, shapes = self._manifest(x)
         shapes = dict(shapes)
         plan = []

@@ -806,7 +806,14 @@ def cw_smoothl1_bwd(labels, diff, gout, dpred):
 
 
 # ------------------------------------------------------------------------------------ optimiser
+# Counts the in-place parameter updates issued through this module (they go through raw pointers: torch's version counters do not
+# see them).  planes_exec keys its inference cache of packed weights on it.
+PARAM_EPOCH = 0
+
+
 def sgd_step(w, grad, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, skip_flag=None):
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
     lib = _check(w, grad, buf)
     lib.call("ssn_sgd_step", _p(w), _p(grad), _p(buf), w.numel(), float(lr), float(momentum), float(weight_decay),
              float(grad_scale), int(first_step), _p(skip_flag), _stream(lib, w))
@@ -824,6 +831,8 @@ def sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale=1.0, first_st
     update is skipped while its first word is non-zero (the range guard of the planes path, planes_exec.PlanesState)."""
     if not ws:
         return
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
     lib = _check(*ws, *grads, *bufs)
     n = len(ws)
     sizes = (ctypes.c_long * n)(*[w.numel() for w in ws])

@@ -282,6 +282,7 @@ class SSN(torch.nn.Module):
     def train_forward(self, input, aug_scaling, target, reg_target, prop_type):
         base_out = self._backbone(input)
         if (self.fused_heads and self.stpp.sc and (1 + self.stpp.feat_multiplier) * self.stpp.feat_dim * 4 <= 65536
+                and self.num_segments <= 16
                 and type(self.activity_fc) is HipLinear and type(self.completeness_fc) is HipLinear):
             return self._fused_train_heads(base_out, aug_scaling, target, reg_target, prop_type)
         activity_ft, completeness_ft = self.stpp(base_out, aug_scaling,

@@ -330,3 +330,37 @@ def test_dense_tester_on_dark_and_bright_tick_batches_gpu(hip_library):
         assert rel_err(f, rf) < 1e-4 and rel_err(s, rs) < 1e-4, (k, rel_err(f, rf), rel_err(s, rs))
         assert not net.scale_fault()
     assert net.base_model.guard_stats()["fwd"] >= 2
+
+
+def test_inference_cache_follows_parameter_updates(emu):
+    """No-grad forwards reuse the packed weights / folded BatchNorm vectors of the previous one (dense testing: ten calls per
+    video) -- and must notice every way the parameters change in the reference's loop: this package's optimizer kernels (raw
+    pointers, invisible to torch's version counters), torch in-place updates, load_state_dict, BatchNorm buffers."""
+    dev = torch.device("cpu")
+    net, ref = _pair(dev)
+    net.debug_keep_saved = False
+    x, w = _data(seed=9)
+
+    def check():
+        ref.forced = None
+        ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        with torch.no_grad():
+            f = net.features(x)
+        assert rel_err(f, ref(x)) < 1e-5
+    check()
+    key0 = net.__dict__["_infer_cache"][0]
+    check()
+    assert net.__dict__["_infer_cache"][0] == key0                     # second call: cache hit
+    opt = SSNSGD([{"params": [p for p in net.parameters() if p.requires_grad], "lr_mult": 1, "decay_mult": 1, "name": "w"}],
+                 lr=0.05, momentum=0.9, weight_decay=5e-4)
+    net.zero_grad(set_to_none=True)
+    (net.features(x) * w).sum().backward()
+    opt.step()
+    check()                                                            # after the package's own SGD kernel
+    with torch.no_grad():
+        net.conv1_3x3.weight.mul_(1.5)
+    check()                                                            # after a torch in-place update
+    net.branch_3x3_bn.running_var.mul_(2.0)
+    check()                                                            # BatchNorm buffers are part of the key
+    net.load_state_dict({k: v * 0.5 if k.endswith("branch_3x3.bias") else v for k, v in net.state_dict().items()})
+    check()
