@@ -289,8 +289,8 @@ class BNInception(nn.Module):
     def _chunk_bounds(self, x):
         """[0, n1, ..., N]: sub-batches whose largest activation tensor stays below max_operand_bytes (one chunk = all of
         it for the batches of the reference's configurations)."""
-        _, shapes = self._manifest(x)
-        per_image = 4 * max(c * h * w for c, h, w in dict(shapes).values())
+        _, shapes = self._plan(x)       # (memoised; its shapes are a superset of the manifest's)
+        per_image = 4 * max(v[0] * v[1] * v[2] for v in dict(shapes).values() if isinstance(v, tuple))
         per_image = max(per_image, 4 * x.shape[1] * x.shape[2] * x.shape[3])
         n, cap = x.shape[0], max(1, self.max_operand_bytes // per_image)
         parts = (n + cap - 1) // cap

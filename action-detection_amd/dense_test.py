@@ -13,7 +13,11 @@ outputs are de-normalised with the training-set statistics.  Same inputs, same o
   as ``fc(mean over crops of x)``: one ``ssn_crop_mean`` launch on the 1024-d features, then the
   folded FC on 10x fewer rows;
 * ``STPPReorgainzed`` is one launch per video (ops/ssn_ops.py:109-170 runs Python loops over
-  proposals, stages and parts); the de-normalisation is ``ssn_reg_denorm``.
+  proposals, stages and parts); the de-normalisation is ``ssn_reg_denorm``;
+* the range guard of the backbone's delayed scales (planes_exec.py) is polled ONCE per video instead of once per backbone call:
+  every call leaves its fault word in a per-call slot, the inputs of the video's calls stay referenced, and after the last call
+  one host read says which calls (if any) have to be repeated -- with the per-call poll the host-side preparation of every call
+  sat exposed behind a drained queue (8 % of a video: 19.7 -> 21.4 k frames/s on Inception-v3).
 """
 import torch
 
@@ -37,6 +41,8 @@ class DenseTester(object):
         self.stats = stats
         self.tick_batch = int(tick_batch)
         self.length = (3 if net.modality == "RGB" else 2) * net.new_length
+        self.max_keep_bytes = 24 << 30      # inputs kept referenced for a possible repeat; beyond it the calls poll one by one
+        self.repeated_calls = 0             # backbone calls the once-per-video poll had to repeat
 
     @torch.no_grad()
     def frame_scores(self, frames_gen, frame_cnt, num_crop):
@@ -46,6 +52,16 @@ class DenseTester(object):
         output = torch.empty((frame_cnt, self.output_dim), device=dev, dtype=torch.float32)
         cnt = 0
         pending, pending_ticks = [], 0
+        bm = self.net.base_model
+        lag = {"on": (getattr(bm, "scale_guard", "") == "sync" and dev.type == "cuda" and getattr(bm, "layout", "") == "planes"),
+               "kept": [], "marks": [], "bytes": 0}
+        word = bm.planes_flag(dev)[0:1] if lag["on"] else None
+
+        def score(x, row0, ticks):
+            base = self.net._backbone(x)                                    # [num_crop * b, feat]
+            feat = torch.empty((ticks, base.shape[1]), device=dev, dtype=torch.float32)
+            K.crop_mean(base.contiguous(), num_crop, feat)
+            output[row0:row0 + ticks] = self.net.test_fc(feat)
 
         def flush():
             nonlocal cnt, pending, pending_ticks
@@ -57,11 +73,21 @@ class DenseTester(object):
             else:
                 x = torch.cat([p.reshape((num_crop, -1) + tuple(p.shape[1:])) for p in pending], dim=1)
                 x = x.reshape((-1,) + tuple(pending[0].shape[1:]))
-            base = self.net._backbone(x.contiguous())                       # [num_crop * b, feat]
-            feat = torch.empty((pending_ticks, base.shape[1]), device=dev, dtype=torch.float32)
-            K.crop_mean(base.contiguous(), num_crop, feat)
-            sc = self.net.test_fc(feat)
-            output[cnt:cnt + pending_ticks] = sc
+            x = x.contiguous()
+            if lag["on"] and lag["bytes"] + x.numel() * x.element_size() > self.max_keep_bytes:
+                lag["on"] = False                                           # (a very long video: poll call by call from here on)
+            if lag["on"]:
+                bm.scale_guard = "deferred"                                 # the call launches its range check, polls nothing
+                try:
+                    score(x, cnt, pending_ticks)
+                finally:
+                    bm.scale_guard = "sync"
+                lag["marks"].append(word.clone())                           # this call's fault word (device-side copy, no sync)
+                word.zero_()
+                lag["kept"].append((x, cnt, pending_ticks))
+                lag["bytes"] += x.numel() * x.element_size()
+            else:
+                score(x, cnt, pending_ticks)
             cnt += pending_ticks
             pending, pending_ticks = [], 0
 
@@ -74,6 +100,11 @@ class DenseTester(object):
             if pending_ticks >= self.tick_batch:
                 flush()
         flush()
+        if lag["marks"]:
+            bad = [i for i, v in enumerate(torch.cat(lag["marks"]).tolist()) if v]      # the one host read of the video
+            for i in bad:                                                   # repeat exactly the calls that left their range
+                self.repeated_calls += 1
+                score(*lag["kept"][i])                                      # (sync guard: repairs itself)
         if cnt != frame_cnt:
             raise ValueError("the frame source gave %d ticks, expected %d" % (cnt, frame_cnt))
         return output

@@ -28,6 +28,7 @@ What differs from the fp32-layout executor (bninception._run_forward / _run_back
 Supported: frozen BatchNorm (the reference's default ``bn_mode='frozen'``; /root/reference/ssn_models.py:95-105) on the square /
 rectangular-tap plans.  Training-mode BatchNorm keeps the fp32-layout executor.
 """
+import itertools
 import math
 
 import torch
@@ -209,8 +210,8 @@ def run_forward(net, x, keep):
     ckey = None
     hit = None
     if not keep and net.infer_cache:
-        ckey = (dev, tuple(x.shape[1:]), K.PARAM_EPOCH, tuple(t._version for t in net.state_dict(keep_vars=True).values()),
-                tuple(t.data_ptr() for t in net.parameters()))
+        ckey = (dev, tuple(x.shape[1:]), K.PARAM_EPOCH,
+                tuple((t._version, t.data_ptr()) for t in itertools.chain(net.parameters(), net.buffers())))
         hit = net.__dict__.get("_infer_cache")
         if hit is not None and hit[0] == ckey:
             tscale, shift_of, scale_slice, packed = hit[1]

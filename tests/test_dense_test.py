@@ -89,3 +89,36 @@ def test_empty_inputs(backend):
         backend.put(torch.zeros(0, 20, 2)), device=dev)
     assert dets == {} and comb.shape == (0, 20)
     K.reg_denorm(backend.put(torch.empty(0, 20, 2)), 0.0, 1.0, 0.0, 1.0)
+
+
+@pytest.mark.gpu
+def test_dense_tester_repeats_the_calls_that_left_their_range(hip_library):
+    """ssn_test.py:78-92 on a video whose tick batches alternate dark (x 1/40) and bright (x 8) frames: every activation of the
+    backbone moves 320x up and down between consecutive calls.  The tester polls the range guard once per video and repeats
+    exactly the calls that left the range of their delayed scales; the scores of every tick must match the oracle's."""
+    from action_detection_amd.dense_test import DenseTester
+    from action_detection_amd.ssn_models import SSN
+    from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic
+    num_class, n_ticks, num_crop = 20, 12, 2
+    torch.manual_seed(0)
+    net = SSN(num_class, 2, 5, 2, "RGB", test_mode=True, stpp_cfg=(1, 1, 1))
+    init_backbone_synthetic(net.base_model)
+    init_heads_synthetic(net, std=0.05)
+    oracle = O.OracleSSN(num_class, 2, 5, 2, "RGB", test_mode=True, stpp_cfg=(1, 1, 1))
+    oracle.load_state_dict(net.state_dict())
+    net.prepare_test_fc()
+    oracle.prepare_test_fc()
+    net.to("cuda:0").eval()
+    oracle.eval()
+    batches = synthetic_video(n_ticks, num_crop, 3, 3, seed=8)
+    batches = [b * k for b, k in zip(batches, (1.0, 1.0 / 40.0, 8.0, 1.0 / 40.0))]
+    ticks = np.array([[1, 3, 7, 9], [0, 0, 12, 12]], dtype=np.int64)
+    scaling = np.array([[1.0, 1.0], [0.3, 0.6]])
+    tester = DenseTester(net, num_class, stpp_cfg=(1, 1, 1), stats=None, tick_batch=3)
+    act, comp, reg, output = tester.score_video(iter(batches), n_ticks, torch.from_numpy(ticks), torch.from_numpy(scaling),
+                                                num_crop=num_crop)
+    r_act, r_comp, r_reg, r_out = O.dense_test_video(oracle, iter(batches), n_ticks, ticks, scaling, num_class, num_crop=num_crop)
+    assert tester.repeated_calls >= 1 and not net.scale_fault()
+    for t0 in range(0, n_ticks, 3):         # per call: a clamped batch would be off by far more than this
+        assert rel_err(output[t0:t0 + 3], torch.from_numpy(r_out[t0:t0 + 3])) < 1e-4, t0
+    assert rel_err(act, torch.from_numpy(r_act)) < 1e-4 and rel_err(comp, torch.from_numpy(r_comp)) < 1e-4
