@@ -350,11 +350,12 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_kernel(PoolArgs p) {
 // 3x3 / stride-2 max pool backward with one thread per 2 x 2 block of INPUT pixels: the four pixels of a block can only belong to
 // the same 2 x 2 windows, so those are fetched once (argmax + both planes) instead of once per pixel -- 2.25x fewer loads than the
 // gather form above, which matters for the two stem pools (a third of the step's pooling traffic)
+template <int PAD>
 __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
     const int Hb = (p.H + 1) / 2, Wb = (p.W + 1) / 2;
     const long total = (long)p.N * p.G * Hb * Wb;
     const float r = *p.y_scale / *p.x_scale;
-    const int base_off = (p.pad + 1) / 2 - 1;      // first candidate window of block i is i + base_off (pad 0: i - 1, pad 1: i)
+    constexpr int base_off = (PAD + 1) / 2 - 1;      // first candidate window of block i is i + base_off (pad 0: i - 1, pad 1: i)
     float vmax = 0.f;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int j = (int)(idx % Wb);
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
             const long oo = wok[t] ? (long)ho * p.Wo + wo : 0;
             am[t] = reinterpret_cast<const u32x2*>(p.argmax)[((long)n * p.G + g) * p.Ho * p.Wo + oo];
             load8(p.x_hi, p.x_lo, ((long)n * p.x_img_groups + g) * p.Ho * p.Wo + oo, d[t]);
+            if (!wok[t]) am[t] = u32x2{0xFFFFFFFFu, 0xFFFFFFFFu};          // (a window that does not exist matches no local index)
             if (pooled_mask) {
                 const u32x4 pm = reinterpret_cast<const u32x4*>(p.mask_hi)[((long)n * p.mask_img_groups + g) * p.Ho * p.Wo + oo];
 #pragma unroll
@@ -395,14 +397,17 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[q][e] = 0.f;
             if (!live[q]) continue;
+            // window t = (a, b) of the block's 2 x 2 candidates covers pixel q = (qr, qc) at the window-local position
+            // rr = qr + 2 (1 - a) - (1 - PAD) ... a COMPILE-TIME table: of the 16 (pixel, window) pairs only 9 can match
+            // (an odd row / column lies in one window only), the others are never compared
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int ho = i + base_off + (t >> 1), wo = j + base_off + (t & 1);
-                const int rr = h - (2 * ho - p.pad), ss = w - (2 * wo - p.pad);
-                const int local = (wok[t] && (unsigned)rr < 3u && (unsigned)ss < 3u) ? rr * 3 + ss : 255;
+                const int rr = (q >> 1) - 2 * (base_off + (t >> 1)) + PAD, ss = (q & 1) - 2 * (base_off + (t & 1)) + PAD;   // constants after unrolling
+                if (rr < 0 || rr > 2 || ss < 0 || ss > 2) continue;
+                const unsigned local = (unsigned)(rr * 3 + ss);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int a = (int)((am[t][e >> 2] >> (8 * (e & 3))) & 0xFFu);
+                    const unsigned a = (am[t][e >> 2] >> (8 * (e & 3))) & 0xFFu;
                     v[q][e] += (a == local) ? d[t][e] : 0.f;
                 }
             }
@@ -741,8 +746,12 @@ extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_
     a.relu = mask_pooled ? 1 : 0;
     const dim3 grid(grid_for((long)N * a.G * H * W));
     if (k == 3 && s == 2 && (pad == 0 || pad == 1))
-        hipLaunchKernelGGL(pl_maxpool_bwd_k3s2_kernel, dim3(grid_for((long)N * a.G * ((H + 1) / 2) * ((W + 1) / 2))), dim3(256), 0,
-                           stream, a);
+        if (pad == 0)
+            hipLaunchKernelGGL(pl_maxpool_bwd_k3s2_kernel<0>, dim3(grid_for((long)N * a.G * ((H + 1) / 2) * ((W + 1) / 2))), dim3(256), 0,
+                               stream, a);
+        else
+            hipLaunchKernelGGL(pl_maxpool_bwd_k3s2_kernel<1>, dim3(grid_for((long)N * a.G * ((H + 1) / 2) * ((W + 1) / 2))), dim3(256), 0,
+                               stream, a);
     else if (k == 3 && s == 2)
         hipLaunchKernelGGL((pl_maxpool_bwd_kernel<3, 2>), grid, dim3(256), 0, stream, a);
     else if (k == 3 && s == 1)
