@@ -364,3 +364,65 @@ def test_inference_cache_follows_parameter_updates(emu):
     check()                                                            # BatchNorm buffers are part of the key
     net.load_state_dict({k: v * 0.5 if k.endswith("branch_3x3.bias") else v for k, v in net.state_dict().items()})
     check()
+
+
+@pytest.mark.gpu
+def test_graph_replay_protocol_on_changing_data_gpu(hip_library):
+    """The protocol of a training loop that REPLAYS a captured step (what bench.py runs): the range check and the optimizer's skip
+    word are part of the hipGraph; the static input buffer is overwritten between replays with batches of very different
+    magnitude.  A replay whose tensors left the range of their delayed scales must leave weights and momentum untouched and raise
+    the device word; after ``recalibrate()`` + an eager redo the weights must equal those of a twin model that ran the same
+    sequence of batches eagerly (sync guard) -- step for step, to rounding."""
+    import copy
+    dev = torch.device("cuda:0")
+    net = init_tiny(TinyBackbone()).to(dev).train()
+    twin = copy.deepcopy(net)
+    assert twin.planes_flag(dev) is not net.planes_flag(dev)
+
+    def opt_for(m):
+        return SSNSGD([{"params": [p for p in m.parameters() if p.requires_grad], "lr_mult": 1, "decay_mult": 1, "name": "w"}],
+                      lr=1e-3, momentum=0.9, weight_decay=5e-4)
+    opt, opt2 = opt_for(net), opt_for(twin)
+    x0, w0 = _data(n=4, seed=40)
+    xs, ws = x0.to(dev), w0.to(dev)                       # static buffers of the captured step
+    flag = net.planes_flag(dev)
+
+    def step(m, o, x, w, skip=None):
+        o.zero_grad(set_to_none=True)
+        (m.features(x) * w).sum().backward()
+        o.step(skip_flag=skip)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):                                 # eager warm-up: calibrates the scales
+            step(net, opt, xs, ws, flag)
+            step(twin, opt2, xs, ws)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(net, opt, xs, ws, flag)
+    step(twin, opt2, xs, ws)                               # the twin's third step; the capture itself executed nothing ...
+
+    def same(tol=2e-6):
+        for (n1, p1), (n2, p2) in zip(net.named_parameters(), twin.named_parameters()):
+            assert rel_err(p1, p2) < tol, (n1, rel_err(p1, p2))
+    graph.replay()                                         # ... so the first replay is the net's third step
+
+    torch.cuda.synchronize()
+    same()
+    for k in (1.0, 0.5, 1.0 / 64.0, 600.0, 1.0, 2000.0):   # the static batch changes magnitude between replays
+        xs.copy_((x0 * k).to(dev))
+        before = [p.detach().clone() for p in net.parameters()]
+        graph.replay()
+        torch.cuda.synchronize()
+        if net.scale_fault():                              # the replay flagged itself: nothing may have moved ...
+            assert all(torch.equal(p, q) for p, q in zip(net.parameters(), before)), k
+            net.recalibrate()                              # ... host side: clear, recalibrate, redo the step eagerly
+            step(net, opt, xs, ws, flag)
+            assert not net.scale_fault()
+        step(twin, opt2, xs, ws)
+        torch.cuda.synchronize()
+        same()
+    assert twin.guard_stats()["fwd"] >= 1                 # the eager twin repaired the same jumps by itself
