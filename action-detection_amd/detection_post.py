@@ -43,7 +43,9 @@ class DetectionPostProcessor(object):
             combined, dets, counts = K.detections(act, comp, reg, rp, 0, mode, self.nms_threshold, not self.no_regression)
             vs = np.asarray(video_cls_score.detach().cpu() if torch.is_tensor(video_cls_score) else video_cls_score).reshape(-1)
             assert vs.shape[0] == self.num_class
-            classes = sorted(int(c) for c in np.argsort(vs, kind="stable")[-self.cls_top_k:])
+            # the reference's own expression (eval_detection_results.py:137: default-kind np.argsort): with exact ties in the
+            # classifier's scores the same numpy picks the same classes
+            classes = sorted(int(c) for c in np.argsort(vs,)[-self.cls_top_k:])
         else:
             combined, dets, counts = K.detections(act, comp, reg, rp, self.top_k, self.top_k <= 0, self.nms_threshold,
                                                   not self.no_regression)
