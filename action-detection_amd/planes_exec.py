@@ -408,7 +408,9 @@ def run_backward(net, dfeat, saved, hook=True):
         pending_reduce, pending_sums = [], []     # deferred split-K reductions / the channel sums that must follow them
 
         def flush():
-            P.wgrad_reduce_multi(pending_reduce)
+            if pending_reduce:       # (timed with the weight-gradient family it belongs to: bench.py's roofline_detail)
+                entries = list(pending_reduce)
+                net._timed("conv_wgrad_pl", "reduce_multi", 0.0, lambda: P.wgrad_reduce_multi(entries))
             for fn in pending_sums:
                 fn()
             del pending_reduce[:], pending_sums[:]
