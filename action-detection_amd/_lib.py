@@ -122,7 +122,7 @@ EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_w
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_packed_floats_dgrad_rect", "ssn_conv_wgrad_x6_rect_workspace_bytes", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
-                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes", "ssn_frames_resize_workspace_bytes"])
+                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_halo_taken", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes", "ssn_frames_resize_workspace_bytes"])
 
 
 class SsnLibrary:
@@ -201,7 +201,7 @@ def build(force=False, verbose=False):
     a multi-GPU launch all call this)."""
     import fcntl
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("ssn_common.h", "conv_epilogue.h", "conv_x6_kernel.h", "planes.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("ssn_common.h", "conv_epilogue.h", "conv_x6_kernel.h", "planes.h", "conv_pl_epilogue.inc")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     stamp_path = LIB_PATH + ".stamp"
     want = _source_stamp(deps, flags)

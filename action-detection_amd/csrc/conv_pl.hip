@@ -58,6 +58,10 @@ struct PlConvArgs {
     // sub-sampled output (stride-2 dgrad as four stride-1 problems, one per parity class of the input pixel): the
     // enumerated pixel (u, v) is stored at (2u + sub_a, 2v + sub_b) of planes sub_W wide.  sub_W == 0: dense output.
     int sub_a, sub_b, sub_W;
+    // haloed 3x3 kernel (conv_pl9_kernel): ceil(2^32 / (W + 2)) for the row / column split of a padded slot, FastDiv of the padded
+    // image (H + 2)(W + 2)
+    uint32_t magic_wp;
+    FastDiv div_sp;
     unsigned long long* trace;   // tooling only: per-block phase timestamps (tools/ablate_conv_pl.py), normally null
     int dbg;                     // tooling only: ablation switches (1: no B fetch, 2: no A fetch, 4: no fragment reads, 8: no stores)
     FastDiv div_hw, div_w, div_mt;
@@ -323,128 +327,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     SSN_WAIT_VMCNT(0);   // the out-of-range tail pieces still write (zeros) into the ring the epilogue is about to reuse
     if (p.trace) tr2 = __builtin_readcyclecounter();
 
-    // ---- epilogue ----
-    __syncthreads();
-    float* ch = reinterpret_cast<float*>(lds);
-    // ch[0,BM) = multiplier, ch[BM,2BM) = shift (scaled), ch[2BM,3BM) = mask scale (NaN: pass through), ch[3BM,4BM) = floor
-    for (int r = tid; r < BM; r += NT) {
-        const int m = m0 + r;
-        const bool ok = m < p.M;
-        const bool aff = ok && p.scale && m < p.raw_from;
-        ch[r] = aff ? p.scale[m + (m >= p.row_split ? p.row_gap : 0)] * inv : inv;
-        ch[BM + r] = aff ? p.shift[m] * so : 0.f;
-        ch[2 * BM + r] = (ok && p.mask_scale) ? p.mask_scale[m] : __builtin_nanf("");
-        ch[3 * BM + r] = (p.relu && m < p.raw_from) ? 0.f : -__builtin_inff();
-    }
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t yrsrc[2] = {pl_rsrc(p.y_hi, p.y_bytes), pl_rsrc(p.y_lo, p.y_bytes)};
-    const __amdgpu_buffer_rsrc_t orsrc[2] = {pl_rsrc(p.y_hi, p.accumulate ? p.y_bytes : 0u),
-                                             pl_rsrc(p.y_lo, p.accumulate ? p.y_bytes : 0u)};
-    const __amdgpu_buffer_rsrc_t mrsrc = pl_rsrc(p.mask_hi ? p.mask_hi : p.y_hi, p.mask_hi ? p.mask_bytes : 0u);
-    uint32_t yoff[TN], moff[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int pp = p0 + (wn * TN + j) * 32 + li;
-        uint32_t n, hw;
-        fd_divmod((uint32_t)(pp < p.P ? pp : 0), p.div_hw, n, hw);
-        if (p.sub_W) {
-            uint32_t u, v;
-            fd_divmod(hw, p.div_w, u, v);
-            hw = (2u * u + (uint32_t)p.sub_a) * (uint32_t)p.sub_W + 2u * v + (uint32_t)p.sub_b;
-        }
-        yoff[j] = pp < p.P ? n * p.y_img_bytes + hw * 16u + 8u * (uint32_t)lh : PL_OOB;
-        moff[j] = pp < p.P ? n * p.mask_img_bytes + hw * 16u + 8u * (uint32_t)lh : PL_OOB;
-    }
-    const int row0 = wm * TM * 32;
-    const bool rmw = p.accumulate || p.mask_hi;
-    float vmax = 0.f;
-    // per accumulator tile (i, j) and 8-row group q: output channel group offset, row validity
-    auto goff_of = [&](int i, int q) {
-        const int mrow = m0 + row0 + i * 32;
-        const int gap = (mrow >= p.row_split) ? p.row_gap : 0;     // wave-uniform channel displacement
-        return (uint32_t)((mrow + gap) / 8 + q) * p.y_grp_bytes;
-    };
-    auto finish = [&](int i, int j, int q, const u32x2& ohi, const u32x2& olo, const u32x2& mk, float& cmax) {
-        const int mrow = m0 + row0 + i * 32;
-        const int sr = row0 + i * 32 + 8 * q + 4 * lh;          // this lane's first of 4 consecutive tile rows
-        const f32x4 mul = *reinterpret_cast<const f32x4*>(ch + sr);
-        const f32x4 add = *reinterpret_cast<const f32x4*>(ch + BM + sr);
-        const f32x4 flo = *reinterpret_cast<const f32x4*>(ch + 3 * BM + sr);
-        const bool rows_ok = mrow + 8 * q < p.M;
-        const uint32_t vo = (rows_ok && !PL_DBG(8)) ? yoff[j] : PL_OOB;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * mul[e] + add[e];
-        if (rmw) {
-            const f32x4 msc = *reinterpret_cast<const f32x4*>(ch + 2 * BM + sr);
-            float old[4];
-            pl_join4(ohi, olo, old);
-            const float mv[4] = {f16_pair_lo(mk[0]), f16_pair_hi(mk[0]), f16_pair_lo(mk[1]), f16_pair_hi(mk[1])};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] += old[e];
-                v[e] = (msc[e] != msc[e]) ? v[e] : (mv[e] > 0.f ? v[e] * msc[e] : 0.f);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // the recorded maximum is the value BEFORE the f16 ceiling (after the ReLU floor): an overflowing tensor reports its true
-            // magnitude, so the range guard sees it and one scale update repairs it
-            const float fl = fmaxf(v[e], flo[e]);       // floor: 0 behind a ReLU, -inf otherwise
-            cmax = fmaxf(cmax, fabsf(fl));
-            v[e] = __builtin_amdgcn_fmed3f(fl, -PL_F16_MAX, PL_F16_MAX);
-        }
-        u32x2 hi, lo;
-        pl_split4(v, hi, lo);
-        const uint32_t goff = goff_of(i, q);
-        pl_store_b64(hi, yrsrc[0], vo, goff);
-        pl_store_b64(lo, yrsrc[1], vo, goff);
-    };
-    if (!rmw) {
-        const u32x2 z2 = u32x2{0u, 0u};
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float cmax = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) finish(i, j, q, z2, z2, z2, cmax);
-            vmax = fmaxf(vmax, yoff[j] != PL_OOB ? cmax : 0.f);
-        }
-    } else {
-        // read-modify-write / masked: the operands of tile g + 1 are requested before tile g is stored (the stores alias the
-        // loads as far as the compiler knows, so without this every group would wait out a full memory round trip)
-        constexpr int NG = TM * TN;
-        u32x2 ohi[2][4], olo[2][4], mk[2][4];
-        auto fetch = [&](int g, int b) {
-            const int j = g / TM, i = g % TM;
-            const int mrow = m0 + row0 + i * 32;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool rows_ok = mrow + 8 * q < p.M;
-                const uint32_t goff = goff_of(i, q);
-                ohi[b][q] = __builtin_amdgcn_raw_buffer_load_b64(orsrc[0], rows_ok ? yoff[j] : PL_OOB, goff, 0);
-                olo[b][q] = __builtin_amdgcn_raw_buffer_load_b64(orsrc[1], rows_ok ? yoff[j] : PL_OOB, goff, 0);
-                mk[b][q] = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, rows_ok ? moff[j] : PL_OOB,
-                                                               (uint32_t)(mrow / 8 + q) * p.y_grp_bytes, 0);
-            }
-        };
-        fetch(0, 0);
-        float cmax = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
-            const int j = g / TM, i = g % TM;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) finish(i, j, q, ohi[g & 1][q], olo[g & 1][q], mk[g & 1][q], cmax);
-            if (i == TM - 1) {
-                vmax = fmaxf(vmax, yoff[j] != PL_OOB ? cmax : 0.f);
-                cmax = 0.f;
-            }
-        }
-    }
-    amax_emit(p.y_amax, vmax / so);
+#include "conv_pl_epilogue.inc"
     if (p.trace && tid == 0) {
         unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
         t[0] = tr0;
@@ -456,6 +339,260 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
         t[6] = trr;
         t[7] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 layers (69 % of the backbone's MACs), forward and dgrad: ONE haloed copy of a 16-channel input slab in LDS
+// serves all nine taps.
+//
+// conv_pl_kernel above fetches the B tile of every (tap, channel group) slab separately: the same input pixels travel L2 -> LDS nine
+// times (8 KiB per slab for a 128-pixel tile, as much as the weights).  Here the tile's input pixels are enumerated in PADDED slots
+//        U = n SP + (h + 1) Wp + (w + 1),   Wp = W + 2,  SP = (H + 2) Wp
+// so that the input pixel of tap (r, s) of an output pixel is a CONSTANT slot displacement (r - 1) Wp + (s - 1) from the pixel's own
+// slot, and the border slots hold zeros (their DMA offsets are out of range): per channel group ONE copy of the slots
+// [U(first pixel) - Wp - 1, U(last pixel) + Wp + 1] of the tile (HS slots x 4 (plane, k-half) rows, <= 20 KiB) is fetched, the nine
+// taps read their B fragments from it at displaced addresses (one ds_read_b128 per fragment and plane, as before).  B-operand DMA per
+// group: HS / 64 x 4 instructions instead of 9 x BN / 64 x 4 (128-pixel tile: 20 instead of 72).
+//   * slab order: channel groups OUTERMOST, taps innermost (= the packed weight order g * 9 + tap: A advances by one slab per slab);
+//   * the halo of group g + 1 is fetched during the first HS / 64 slabs of group g into the other of two halo buffers: wave w owns row
+//     (plane w >> 1, k-half w & 1) and issues one 64-slot piece per slab between its MFMAs (a dummy piece in the remaining slabs keeps the
+//     per-slab vmcnt constant); the halo of a group that does not exist is fetched as zeros (the dead slab of an odd slab count);
+//   * everything else -- A ring, two fragment register sets, one barrier per slab, epilogue -- is conv_pl_kernel's.
+// dgrad of such a layer is the same kernel with the tap displacement mirrored (MODE_DGRAD) on the transposed packed operand.
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(PlConvArgs p) {
+    constexpr int NW = 4;
+    constexpr int NT = 256;
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(BN == 64 || BN == 128, "tile width 64 / 128 pixels");
+    constexpr int HS = BN == 128 ? 320 : 192;          // halo slots per (plane, k-half) row (the host checks every tile's span)
+    constexpr int NSEG = HS / 64;                       // 64-slot DMA pieces per row
+    constexpr int A_PIECES = BM / 16;
+    constexpr int NA = (A_PIECES + NW - 1) / NW;
+    constexpr int A_STAGE = NA * NW * 256;              // dwords
+    constexpr int HROW = HS * 4;                        // dwords of one halo row
+    constexpr int HBUF = 4 * HROW;                      // one halo buffer: rows (plane, k-half)
+    constexpr int NSTAGE = ((4 * A_STAGE + 2 * HBUF + 256) * 4 * 2 <= 163840) ? 4 : 3;      // A ring: 4 slots where two workgroups fit
+    constexpr int NLOAD = NA + 1;                       // per wave and slab: its A pieces + one halo (or dummy) piece
+    constexpr int HALO0 = NSTAGE * A_STAGE;             // dword offset of the two halo buffers
+    constexpr int DUMMY = HALO0 + 2 * HBUF;             // 1 KiB nobody reads
+    static_assert(NSEG <= 9 - (NSTAGE - 1), "the halo of the next group must have landed before its first read");
+    static_assert((DUMMY + 256) * 4 * 2 <= 163840, "two workgroups per CU");
+
+    __shared__ __attribute__((aligned(1024))) uint32_t lds[DUMMY + 256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const uint32_t nblk = (uint32_t)p.n_ptiles * (uint32_t)p.n_mtiles;
+    const uint32_t logical = xcd_remap(blockIdx.x, nblk);
+    uint32_t ptile, mtile;
+    fd_divmod(logical, p.div_mt, ptile, mtile);
+    const int m0 = (int)mtile * BM;
+    const int p0 = (int)ptile * BN;
+    const int Wp = p.W + 2;
+    const int SPs = (p.H + 2) * Wp;
+
+    // padded slot of an output pixel
+    auto slot_of = [&](int pp) -> int {
+        uint32_t n, hw, h, w;
+        fd_divmod((uint32_t)pp, p.div_hw, n, hw);
+        fd_divmod(hw, p.div_w, h, w);
+        return (int)n * SPs + ((int)h + 1) * Wp + (int)w + 1;
+    };
+    const int ubase = slot_of(p0) - (Wp + 1);          // first slot of the halo (wave-uniform; >= 0)
+
+    // ---- halo fetch state: this wave's row, this lane's source offset of every piece ----
+    const int hplane = wave >> 1, hkhalf = wave & 1;
+    uint32_t hoff[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const uint32_t U = (uint32_t)(ubase + sg * 64 + lane);
+        uint32_t n, u;
+        fd_divmod(U, p.div_sp, n, u);
+        const uint32_t hp = __umulhi(u, p.magic_wp), wp = u - hp * (uint32_t)Wp;
+        const bool ok = n < (uint32_t)p.N && hp >= 1u && hp <= (uint32_t)p.H && wp >= 1u && wp <= (uint32_t)p.W && !PL_DBG(1);
+        hoff[sg] = ok ? n * p.x_img_bytes + ((hp - 1u) * (uint32_t)p.W + (wp - 1u)) * 16u : PL_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t hrsrc = pl_rsrc(hplane ? p.x_lo : p.x_hi, p.x_bytes);
+    const bool c_half = (p.C & 8) != 0;                // the last group holds 8 channels only: its second k-half is zeros
+
+    // ---- A copy: wave w moves 1 KiB pieces (q * NW + w) of the tile ----
+    uint32_t aoff[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        const int f = (q * NW + wave) * 64 + lane;
+        aoff[q] = (f < BM * 4 && m0 + f / 4 < p.M && !PL_DBG(2)) ? (uint32_t)(m0 * APITCH) * 4u + (uint32_t)f * 16u : PL_OOB;
+    }
+    const __amdgpu_buffer_rsrc_t arsrc = pl_rsrc(p.ap, p.a_bytes);
+    const uint32_t a_step = (uint32_t)(p.M * APITCH) * 4u;
+    const int nslab = p.ngroups * 9;
+
+    // A producer: slab index of the next fetch
+    int pf_slab = 0;
+    uint32_t pf_a = 0;
+    uint32_t d_aso, d_dead;
+    uint32_t* d_a;
+    auto issue_a_begin = [&](uint32_t st_off) {
+        d_dead = pf_slab < nslab ? 0u : PL_OOB;
+        d_aso = pf_a;
+        d_a = lds + st_off + wave * 256;
+        pf_a += a_step;
+        ++pf_slab;
+    };
+    // halo producer: piece `sg` of channel group `g` into buffer g & 1 (sg >= NSEG: the dummy piece)
+    auto issue_halo = [&](int g, int sg) {
+        const bool real = sg < NSEG;
+        const bool live = real && g < p.ngroups && !(hkhalf && c_half && g == p.ngroups - 1);
+        uint32_t v = PL_OOB;
+#pragma unroll
+        for (int q = 0; q < NSEG; ++q)
+            if (q == sg) v = hoff[q];
+        if (!live) v = PL_OOB;
+        uint32_t* dst = real ? lds + HALO0 + (g & 1) * HBUF + (2 * hplane + hkhalf) * HROW + sg * 256 : lds + DUMMY;
+        PL_DMA_B128(hrsrc, dst, v, (uint32_t)g * 2u * p.x_grp_bytes + (hkhalf ? p.x_grp_bytes : 0u));
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: the whole halo of group 0, then the first NSTAGE weight slabs (each with its dummy piece: constant count per slab)
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) issue_halo(0, sg);
+#pragma unroll
+    for (int st = 0; st < NSTAGE; ++st) {
+        issue_a_begin(st * A_STAGE);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) PL_DMA_B128(arsrc, d_a + q * NW * 256, aoff[q] | d_dead, d_aso);
+        issue_halo(0, NSEG);
+    }
+
+    const float sa = f16_scale_of(__builtin_bit_cast(float, p.ap[p.a_bytes >> 2]));
+    const float sb = *p.x_scale;
+    const float so = *p.y_scale;
+    const float inv = so / (sa * sb);
+
+    // fragment addressing.  A as in conv_pl_kernel; B: the lane's pixel -> its centre slot inside the halo
+    const int swz = (li >> 2) & 3;
+    int achunk[2];
+#pragma unroll
+    for (int pn = 0; pn < 2; ++pn) achunk[pn] = ((2 * pn + lh) ^ swz) * 4;
+    const int arow = (wm * TM * 32 + li) * APITCH;
+    int bcen[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pp = p0 + (wn * TN + j) * 32 + li;
+        bcen[j] = HALO0 + lh * HROW + ((pp < p.P ? slot_of(pp) - ubase : Wp + 1)) * 4;      // (dwords; lh = the k-half row)
+    }
+
+    struct Frags {
+        f16x8 af[2][TM];
+        f16x8 bf[2][TN];
+    };
+    Frags fr0, fr1;
+    constexpr int NREAD = 2 * TN + 2 * TM;
+    // consumer state of the slab whose fragments are read next: ring slot of its weights, halo buffer + tap displacement of its B
+    const uint32_t* rd_a;
+    int rd_boff;                          // dword offset added to bcen[j]: buffer, plane row pair and tap displacement
+    int rd_g = 0, rd_r = 0, rd_s = 0;     // (group, tap row, tap column) of the slab read_begin() was last called for
+    auto read_begin = [&](uint32_t st_off) {
+        rd_a = lds + st_off;
+        const int disp = (MODE == MODE_FWD) ? (rd_r - 1) * Wp + (rd_s - 1) : (1 - rd_r) * Wp + (1 - rd_s);
+        rd_boff = (rd_g & 1) * HBUF + disp * 4;
+        if (++rd_s == 3) {
+            rd_s = 0;
+            if (++rd_r == 3) {
+                rd_r = 0;
+                ++rd_g;
+            }
+        }
+    };
+    auto read_step = [&](Frags& f, int k) {
+        if (k < 2 * TN) {
+            const int pn = k / TN, j = k % TN;
+            f.bf[pn][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds + bcen[j] + rd_boff + pn * 2 * HROW));
+        } else {
+            const int q = k - 2 * TN, pn = q / TM, i = q % TM;
+            f.af[pn][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(rd_a + arow + i * 32 * APITCH + achunk[pn]));
+        }
+    };
+    // compute-side slab counters: the halo piece issued during slab (cg, ctap) is piece ctap of group cg + 1
+    int cg = 0, ctap = 0;
+    auto mfma = [&](const Frags& f, uint32_t dma_stage, Frags& nxt) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 0, 1};
+        constexpr int NM = 3 * TM * TN;
+        constexpr int EVERY = NM / NLOAD > 0 ? NM / NLOAD : 1;
+        issue_a_begin(dma_stage);
+        __builtin_amdgcn_sched_barrier(0);
+        auto piece = [&](int k) {          // k compile-time: 0 = the halo / dummy piece, 1.. = the A pieces
+            if (k == 0)
+                issue_halo(cg + 1, ctap);
+            else
+                PL_DMA_B128(arsrc, d_a + (k - 1) * NW * 256, aoff[k - 1] | d_dead, d_aso);
+        };
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.af[PA[c]][i], f.bf[PB[c]][j], acc[i][j], 0, 0, 0);
+                    const int idx = (c * TM + i) * TN + j;
+#pragma unroll
+                    for (int k = idx * NREAD / NM; k < (idx + 1) * NREAD / NM; ++k)
+                        if (!PL_DBG(4)) read_step(nxt, k);
+                    if ((idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) piece((idx + 1) / EVERY - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+        for (int k = NM / EVERY; k < NLOAD; ++k) piece(k);
+        if (++ctap == 9) {
+            ctap = 0;
+            ++cg;
+        }
+    };
+
+    SSN_WAIT_VMCNT((NSTAGE - 1) * NLOAD);
+    __builtin_amdgcn_s_barrier();
+    read_begin(0);
+#pragma unroll
+    for (int k = 0; k < NREAD; ++k) read_step(fr0, k);
+    uint32_t s_cur = 0, s_n1 = A_STAGE, s_n2 = 2 * A_STAGE, s_n3 = 3 * A_STAGE;
+    auto half = [&](Frags& cur, Frags& nxt) {
+        SSN_WAIT_VMCNT((NSTAGE - 2) * NLOAD);
+        SSN_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_begin(s_n1);
+        mfma(cur, s_cur, nxt);
+        const uint32_t o = s_cur;
+        s_cur = s_n1;
+        s_n1 = s_n2;
+        if (NSTAGE == 4) {
+            s_n2 = s_n3;
+            s_n3 = o;
+        } else {
+            s_n2 = o;
+        }
+    };
+    for (int t = 0; t < nslab; t += 2) {
+        half(fr0, fr1);
+        half(fr1, fr0);
+    }
+    SSN_WAIT_LGKM0();
+    SSN_WAIT_VMCNT(0);
+
+#include "conv_pl_epilogue.inc"
 }
 #undef PL_DMA_B128
 
@@ -501,6 +638,65 @@ int launch_tile(PlConvArgs& a, int cfg, hipStream_t stream) {
     }
     ssn_set_error("conv_pl: unknown tile config %d", cfg);
     return SSN_ERR_ARG;
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+int launch_cfg9(PlConvArgs& a, hipStream_t stream) {
+    constexpr int BM = WM * TM * 32;
+    constexpr int BN = WN * TN * 32;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
+    a.n_ptiles = (a.P + BN - 1) / BN;
+    const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
+    hipLaunchKernelGGL((conv_pl9_kernel<MODE, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("conv_pl9");
+    return SSN_OK;
+}
+// haloed variants exist for the tiles of 64 / 128 pixels that run two workgroups per CU
+bool halo_tile(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 11; }
+template <int MODE>
+int launch_tile9(PlConvArgs& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_cfg9<MODE, 2, 2, 2, 2>(a, stream);
+        case 1: return launch_cfg9<MODE, 2, 2, 1, 2>(a, stream);
+        case 2: return launch_cfg9<MODE, 2, 2, 2, 1>(a, stream);
+        case 3: return launch_cfg9<MODE, 2, 2, 1, 1>(a, stream);
+        case 4: return launch_cfg9<MODE, 2, 2, 3, 2>(a, stream);
+        case 7: return launch_cfg9<MODE, 1, 4, 3, 1>(a, stream);
+        case 8: return launch_cfg9<MODE, 1, 4, 5, 1>(a, stream);
+        case 9: return launch_cfg9<MODE, 1, 4, 1, 1>(a, stream);
+        case 11: return launch_cfg9<MODE, 2, 2, 3, 1>(a, stream);
+    }
+    ssn_set_error("conv_pl9: tile config %d has no haloed variant", cfg);
+    return SSN_ERR_ARG;
+}
+// does every BN-pixel tile of an N x H x W grid span at most `hs` padded slots (incl. the halo of Wp + 1 slots on either side)?
+bool halo_fits(int N, int H, int W, int bn, int hs) {
+    const long P = (long)N * H * W;
+    const int Wp = W + 2, SP = (H + 2) * Wp;
+    auto slot = [&](long pp) { return (pp / (H * W)) * SP + ((pp % (H * W)) / W + 1) * Wp + (pp % W) + 1; };
+    for (long t = 0; t * bn < P; ++t) {
+        const long p0 = t * bn, p1 = (p0 + bn - 1 < P - 1) ? p0 + bn - 1 : P - 1;
+        if (slot(p1) - slot(p0) + 2 * (Wp + 1) + 1 > hs) return false;
+        if (t > 4096) break;      // (tiles repeat with period lcm(bn, H W) / bn; the worst case shows up long before)
+    }
+    return true;
+}
+
+// tile_cfg >= 32 asks for the haloed kernel with tile tile_cfg - 32; layers it does not take (not 3x3 / stride 1 / pad 1 / same size,
+// a tile without a haloed variant, a tile whose slot span exceeds the LDS budget) run the plain kernel with that tile
+constexpr int PL_HALO_BASE = 32;
+template <int MODE>
+int launch_any(PlConvArgs& a, int cfg, bool halo_layer, hipStream_t stream) {
+    if (cfg >= PL_HALO_BASE) {
+        cfg -= PL_HALO_BASE;
+        if (halo_layer && cfg < PL_NCFG && halo_tile(cfg) && halo_fits(a.N, a.H, a.W, kPlBN[cfg], kPlBN[cfg] == 128 ? 320 : 192)) {
+            a.magic_wp = (uint32_t)((0x100000000ull + (unsigned)(a.W + 2) - 1) / (unsigned)(a.W + 2));
+            a.div_sp = make_fastdiv((uint32_t)((a.H + 2) * (a.W + 2)));
+            return launch_tile9<MODE>(a, cfg, stream);
+        }
+    }
+    return launch_tile<MODE>(a, cfg, stream);
 }
 
 // fewest padded rows x columns, then the larger tile (slots = 512 workgroup slots: prefer a grid that fills them)
@@ -585,6 +781,11 @@ int fill_common(PlConvArgs& a, const void* x_hi, const void* x_lo, const uint32_
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int ssn_conv_pl_tiles(void) { return PL_NCFG; }
+// 1 when tile_cfg (>= 32) runs the haloed kernel on a 3x3 / stride 1 / pad 1 layer of N x H x W pixels, 0 when it falls back
+extern "C" int ssn_conv_pl_halo_taken(int N, int H, int W, int tile_cfg) {
+    const int cfg = tile_cfg - PL_HALO_BASE;
+    return cfg >= 0 && cfg < PL_NCFG && halo_tile(cfg) && halo_fits(N, H, W, kPlBN[cfg], kPlBN[cfg] == 128 ? 320 : 192);
+}
 extern "C" void ssn_conv_pl_debug_flags(int flags) { g_pl_dbg = flags; }
 extern "C" void ssn_conv_pl_debug_trace(unsigned long long* buf) { g_pl_trace = buf; }
 extern "C" int ssn_conv_pl_tile_shape(int cfg, int* bm, int* bn) {
@@ -621,7 +822,8 @@ extern "C" int ssn_conv_pl_fwd(const void* x_hi, const void* x_lo, const float* 
         a.row_gap = row_gap;
     }
     const int cfg = tile_cfg >= 0 ? tile_cfg : (g_pl_default_tile >= 0 ? g_pl_default_tile : default_tile(Cout, a.P));
-    return launch_tile<MODE_FWD>(a, cfg, stream);
+    const bool halo_layer = kh == 3 && kw == 3 && stride == 1 && pad_h == 1 && pad_w == 1 && Ho == H && Wo == W && !row_gap;
+    return launch_any<MODE_FWD>(a, cfg, halo_layer, stream);
 }
 
 // Data gradient of a stride-1 convolution (any kh x kw taps): dx = sum over taps of w^T dy, as a gather over dy with
@@ -662,9 +864,10 @@ extern "C" int ssn_conv_pl_dgrad(const void* dy_hi, const void* dy_lo, const flo
         // gradient is then the forward correlation of dy with it, padding k - 1 - pad
         a.pad_h = kh - 1 - pad_h;
         a.pad_w = kw - 1 - pad_w;
-        return launch_tile<MODE_FWD>(a, cfg, stream);
+        return launch_tile<MODE_FWD>(a, cfg >= PL_HALO_BASE ? cfg - PL_HALO_BASE : cfg, stream);
     }
-    return launch_tile<MODE_DGRAD>(a, cfg, stream);
+    const bool halo_layer = kh == 3 && kw == 3 && pad_h == 1 && pad_w == 1 && Ho == H && Wo == W && !k_gap;
+    return launch_any<MODE_DGRAD>(a, cfg, halo_layer, stream);
 }
 
 // Data gradient of a 3x3 / stride-2 convolution (pad 1 on an even input, or pad 0) on planes slices: four stride-1 launches,
@@ -707,7 +910,8 @@ extern "C" int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const 
             a.mask_img_bytes = (uint32_t)(mask_img_groups * yg);
             a.mask_bytes = (uint32_t)((long)(N - 1) * a.mask_img_bytes + (long)(Cin / 8) * yg);
         }
-        const int cfg = tile_cfg >= 0 ? tile_cfg : (g_pl_default_tile >= 0 ? g_pl_default_tile : default_tile(Cin, a.P));
+        int cfg = tile_cfg >= 0 ? tile_cfg : (g_pl_default_tile >= 0 ? g_pl_default_tile : default_tile(Cin, a.P));
+        if (cfg >= PL_HALO_BASE) cfg -= PL_HALO_BASE;
         rc = launch_tile<MODE_FWD>(a, cfg, stream);
         if (rc != SSN_OK) return rc;
         off += (long)a.ngroups * kh * kw * Cin * APITCH + 4;

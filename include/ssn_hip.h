@@ -441,7 +441,10 @@ int ssn_pl_from_f32(const float* x, long x_img_stride, void* hi, void* lo, int N
 int ssn_pl_to_f32(const void* hi, const void* lo, long img_groups, float* y, long y_img_stride, int N, int C, int HW,
                   const float* scale, hipStream_t stream);
 /* conv + frozen-BN affine + ReLU (cuDNN conv / BN(eval) / ReLU behind ssn_models.py:266) on planes slices: any kh x kw taps,
- * stride 1 / 2; raw_from / row_split / row_gap as ssn_conv_x6_fwd (fused launch on an Inception block input). */
+ * stride 1 / 2; raw_from / row_split / row_gap as ssn_conv_x6_fwd (fused launch on an Inception block input).  tile_cfg < 0: the
+ * heuristic; 0 .. ssn_conv_pl_tiles() - 1: that tile; 32 + c: the haloed kernel with tile c on 3x3 / stride 1 / pad 1 layers (each
+ * input pixel is staged once per channel group instead of once per tap; ssn_conv_pl_halo_taken says whether the launch takes it,
+ * a layer or tile it does not fit runs the plain kernel with tile c). */
 int ssn_conv_pl_fwd(const void* x_hi, const void* x_lo, const float* w_packed, const float* scale, const float* shift, void* y_hi,
                     void* y_lo, int N, int Cin, int H, int W, long x_img_groups, int Cout, int Ho, int Wo, long y_img_groups, int kh,
                     int kw, int stride, int pad_h, int pad_w, int relu, int tile_cfg, const float* x_scale, const float* y_scale,
@@ -472,6 +475,7 @@ int ssn_wgrad_reduce_multi(int count, const float* const* part, float* const* dw
 long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int tile_cfg);
 int ssn_conv_wgrad_pl_tiles(void);
 int ssn_conv_pl_tiles(void);
+int ssn_conv_pl_halo_taken(int N, int H, int W, int tile_cfg);
 int ssn_conv_pl_tile_shape(int cfg, int* bm, int* bn);
 void ssn_conv_pl_debug_flags(int flags);                    /* tooling (tools/ablate_conv_pl.py) */
 void ssn_conv_pl_debug_trace(unsigned long long* buf);

@@ -88,13 +88,18 @@ CASES_SMALL = [
     (2, 16, 9, 9, 40, 3, 3, 1, 1, 1), (1, 16, 7, 7, 96, 1, 1, 1, 0, 0), (2, 8, 10, 10, 32, 3, 3, 2, 1, 1),
     (1, 24, 6, 8, 64, 1, 1, 1, 0, 0), (2, 16, 5, 5, 72, 5, 5, 1, 2, 2), (1, 32, 8, 8, 48, 1, 7, 1, 0, 3),
     (1, 16, 9, 9, 32, 3, 3, 1, 0, 0), (1, 16, 12, 12, 64, 4, 4, 1, 2, 2), (2, 16, 9, 9, 32, 3, 3, 2, 0, 0),
+    (5, 24, 7, 7, 48, 3, 3, 1, 1, 1), (3, 40, 6, 11, 72, 3, 3, 1, 1, 1),      # 3x3 / pad 1: tiles that cross images, an 8-channel tail group
 ]
 CASES_GPU = [
     (9, 64, 56, 56, 192, 3, 3, 1, 1, 1), (18, 192, 28, 28, 224, 1, 1, 1, 0, 0), (18, 128, 28, 28, 160, 3, 3, 2, 1, 1),
     (18, 576, 14, 14, 512, 1, 1, 1, 0, 0), (18, 160, 14, 14, 192, 3, 3, 1, 1, 1), (36, 1056, 7, 7, 832, 1, 1, 1, 0, 0),
     (36, 224, 7, 7, 224, 3, 3, 1, 1, 1), (4, 16, 112, 112, 64, 4, 4, 1, 2, 2), (4, 48, 35, 35, 64, 5, 5, 1, 2, 2),
     (4, 128, 17, 17, 128, 1, 7, 1, 0, 3), (4, 128, 17, 17, 128, 7, 1, 1, 3, 0), (4, 32, 37, 37, 64, 3, 3, 1, 0, 0),
+    (18, 96, 28, 28, 96, 3, 3, 1, 1, 1), (5, 64, 35, 35, 96, 3, 3, 1, 1, 1),
 ]
+
+
+HALO_TILES = [32 + c for c in (0, 1, 2, 3, 4, 7, 8, 9, 11)]
 
 
 def _pack_fwd(w, backend):
@@ -120,7 +125,13 @@ def test_conv_pl_forward(backend):
         xp = P.from_f32(backend.put(x))
         wp = _pack_fwd(w, backend)
         c0, ctot = 16, cout + 48
-        for tile in (range(ntiles) if ci == 0 else [-1]):
+        tiles = list(range(ntiles)) if ci == 0 else [-1]
+        if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1):
+            tiles += HALO_TILES if (ci == 0 or backend.is_gpu) else [32, 36]      # the haloed 3x3 kernel (tile 32 + c)
+        for tile in tiles:
+            if tile >= 32:      # (on the GPU cases some tiles span more slots than the halo buffer, e.g. 128 pixels across two 56 x 56 images: plain kernel)
+                taken = action_detection_amd._lib.get_lib().cdll.ssn_conv_pl_halo_taken(n, h, wd, tile)
+                assert taken == 1 or backend.is_gpu, (n, h, wd, tile)
             y = P.PlaneTensor(n, ctot, ho, wo, backend.device)
             y.data.fill_(7.0)
             # the delayed protocol: first pass with a guessed scale records the maximum, the update derives the scale,
@@ -183,10 +194,12 @@ def test_conv_pl_dgrad(backend):
             wt = K.pack_dgrad_rect(backend.put(w))
         gp = P.from_f32(backend.put(gy))
         dx = P.PlaneTensor(n, cin, h, wd, backend.device)
-        for _ in range(2):
-            P.conv_dgrad(P.pfull(gp), wt, P.pfull(dx), kh, kw, ph, pw, taps_reversed=rev)
-            dx.pool.update()
-        assert rel_err(P.to_f32(dx), dref) < 3e-6, ("dgrad", n, cin, h, cout, kh, kw)
+        for tile in ([-1] + (HALO_TILES if (kh, kw, ph, pw) == (3, 3, 1, 1) else [])):
+            dx.data.fill_(3.0)
+            for _ in range(2):
+                P.conv_dgrad(P.pfull(gp), wt, P.pfull(dx), kh, kw, ph, pw, tile_cfg=tile, taps_reversed=rev)
+                dx.pool.update()
+            assert rel_err(P.to_f32(dx), dref) < 3e-6, ("dgrad", n, cin, h, cout, kh, kw, tile)
         # accumulate on top of itself, then the mask: dx <- (dx + dgrad) * (act > 0) * mscale
         act = torch.randn(n, cin, h, wd, generator=g).clamp(min=0)
         msc = torch.randn(cin, generator=g)

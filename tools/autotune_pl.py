@@ -79,6 +79,10 @@ def main():
             else:
                 xc, xh, k_, s_, p_ = cin, hin, kh, s, ph
             rect = (kh != kw) or kh not in (1, 3, 7)
+            halo = [32 + c for c in range(nfwd) if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1)
+                    and lib.cdll.ssn_conv_pl_halo_taken(n, hin, hin, 32 + c) == 1]      # the haloed 3x3 kernel
+            if os.environ.get("HALO_ONLY") and not halo:
+                continue
             x = torch.randn(n, xc, xh, xh, generator=g).clamp(min=0).to(dev)
             w = (torch.randn(cout, xc, k_, k_ if not rect else kw, generator=g) * 0.05).to(dev)
             sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
@@ -93,7 +97,7 @@ def main():
             pw_ = p_ if not rect else pw
             # ---- forward
             res = {}
-            for t in (range(nfwd) if "fwd" in kinds else []):
+            for t in ((list(range(nfwd)) + halo) if "fwd" in kinds else []):
                 fn = lambda: P.conv_fwd(xs, wp, sc, sh, P.pfull(yp), k_, kw_, s_, p_, pw_, True, t)  # noqa: E731
                 fn()
                 yp.pool.update()
@@ -103,6 +107,8 @@ def main():
                 best = min(res, key=res.get)
                 tiles["fwd|" + key], ms["fwd|" + key] = best, round(res[best], 4)
                 line += " fwd tile %2d %.4f ms" % (best, res[best])
+                if halo:
+                    line += " (plain %.4f)" % min(v for t, v in res.items() if t < 32)
             # ---- dgrad (not for the first layer)
             gy = (torch.randn(n, cout, ho, wo, generator=g) * 1e-3).to(dev)
             gp = P.from_f32(gy)
@@ -121,7 +127,7 @@ def main():
                     wt = K.pack_weights_multi([([w], 1)], x6=True)[0]
                     mk = lambda t: (lambda: P.conv_dgrad(P.pfull(gp), wt, P.pfull(dxp), kh, kw, ph, pw, False, t, mask=P.pfull(xp),  # noqa: E731
                                                          mask_scale=msc))
-                for t in range(nfwd):
+                for t in list(range(nfwd)) + halo:
                     fn = mk(t)
                     fn()
                     dxp.pool.update()
@@ -129,6 +135,8 @@ def main():
                 best = min(res, key=res.get)
                 tiles["dgrad|" + key], ms["dgrad|" + key] = best, round(res[best], 4)
                 line += " | dgrad tile %2d %.4f ms" % (best, res[best])
+                if halo:
+                    line += " (plain %.4f)" % min(v for t, v in res.items() if t < 32)
             # ---- wgrad
             if "wgrad" not in kinds:
                 print(line, flush=True)
