@@ -19,7 +19,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libssn_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "bn_train.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip", "conv_pl.hip", "planes_ops.hip", "wgrad_pl.hip"]
+SOURCES = ["conv_igemm.hip", "conv_x6.hip", "conv_x6_rect.hip", "conv_wgrad.hip", "conv_wgrad_x6.hip", "elementwise.hip", "bn_train.hip", "frames.hip", "detect.hip", "pool.hip", "stpp.hip", "heads_losses.hip", "conv_pl.hip", "planes_ops.hip", "planes_bn.hip", "wgrad_pl.hip"]
 
 STPP_MAX_PARTS = 24
 
@@ -114,6 +114,11 @@ _SIGS = {
     "ssn_pl_gap_fwd": "pplpiiipp",
     "ssn_pl_gap_bwd": "pppliiiplpppp",
     "ssn_pl_channel_sum": "pplpiiipplp",
+    "ssn_conv_x6_pack_batch_begin": "",
+    "ssn_conv_x6_pack_batch_end": "plip",
+    "ssn_pl_bn_train_stats": "pplpppppp" + "iiiffplp",
+    "ssn_pl_bn_train_apply": "pplppplpp" + "ppppiiiip",
+    "ssn_pl_bn_train_bwd": "pplpplpplp" + "ppppp" + "pplpp" + "pliiiplp",
 }
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double,
        "u": ctypes.c_ulonglong}
@@ -122,7 +127,7 @@ EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_w
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_packed_floats_dgrad_rect", "ssn_conv_wgrad_x6_rect_workspace_bytes", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
-                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_halo_taken", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes", "ssn_frames_resize_workspace_bytes"])
+                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_halo_taken", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes", "ssn_pl_bn_train_workspace_bytes", "ssn_conv_x6_pack_batch_entries", "ssn_conv_x6_pack_entry_bytes", "ssn_conv_x6_pack_batch_abort", "ssn_frames_resize_workspace_bytes"])
 
 
 class SsnLibrary:
@@ -157,6 +162,10 @@ class SsnLibrary:
         self.cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
         self.cdll.ssn_pl_channel_sum_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_pl_channel_sum_workspace_bytes.argtypes = [ctypes.c_int]
+        self.cdll.ssn_conv_x6_pack_entry_bytes.restype = ctypes.c_long
+        self.cdll.ssn_conv_x6_pack_batch_abort.restype = None
+        self.cdll.ssn_pl_bn_train_workspace_bytes.restype = ctypes.c_long
+        self.cdll.ssn_pl_bn_train_workspace_bytes.argtypes = [ctypes.c_int]
         self.cdll.ssn_frames_resize_workspace_bytes.restype = ctypes.c_size_t
         self.cdll.ssn_frames_resize_workspace_bytes.argtypes = [ctypes.c_int] * 3
         self.cdll.ssn_conv_wgrad_pl_workspace_bytes.restype = ctypes.c_long

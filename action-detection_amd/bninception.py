@@ -187,6 +187,11 @@ class BNInception(nn.Module):
         self.defer_wgrad_reduce = os.environ.get("SSN_DEFER_WGRAD_REDUCE", "1") != "0"
         self.infer_cache = os.environ.get("SSN_INFER_CACHE", "1") != "0"   # planes_exec: packed weights / folded BN reused across no-grad forwards
         self.pooled_mask = os.environ.get("SSN_POOLED_MASK", "1") != "0"   # planes_exec: stem pools' backward reads the pooled sign
+        # planes_exec: all weight operands of a pass packed in three launches through a device-resident plan (kernels.PackBatch)
+        self.batch_packing = os.environ.get("SSN_BATCH_PACKING", "1") != "0"
+        # planes_exec: training-mode BatchNorm layers (bn_mode 'partial' / 'full') on the planes kernels of csrc/planes_bn.hip;
+        # 0: plans with such layers run on the fp32-layout executor below (csrc/bn_train.hip)
+        self.planes_train_bn = os.environ.get("SSN_PLANES_TRAIN_BN", "1") != "0"
         self.debug_keep_saved = False
         self._last_saved = None
         self._planes_states = {}
@@ -372,7 +377,8 @@ class BNInception(nn.Module):
                 _, lid, src, dst = op
                 plan.append(dict(kind="gap", lid=lid, src=src, dst=dst, c=shapes[src][0]))
         train_bn = set(self._train_bn_ids())
-        if self.pool_after_projection and not train_bn:
+        # (bn_mode 'partial': only the stem's BatchNorm takes batch statistics -- the block rewrites below never touch that layer)
+        if self.pool_after_projection and not (train_bn - {self._conv_ids[0]}):
             merge = self.conv_precision == "split" and self.merge_projection
             plan = self._move_avg_pools(plan, shapes, merge=merge)
             if merge:

@@ -32,6 +32,8 @@
 //  * Epilogue: per-channel vectors via LDS, branch-free buffer addressing (out-of-range rows/pixels fall off the
 //    buffer), read-modify-write operands fetched one accumulator tile ahead.
 #include "conv_x6_kernel.h"
+#include <unordered_map>
+#include <vector>
 
 namespace {
 
@@ -64,37 +66,64 @@ struct X6PackTable {
     int ablk0[XP_MAX + 1];      // block ranges of the amax launch
     int count;
 };
-__global__ __launch_bounds__(64) void pack_x6_clear_tail_kernel(X6PackTable t) {
-    for (int i = threadIdx.x; i < t.count * ATAIL; i += 64) t.out[i / ATAIL][t.rows_dw[i / ATAIL] + i % ATAIL] = 0u;
+// One entry of a packing launch, as the kernels see it (the by-value table above, or a row of a device-resident plan)
+struct X6PackEntry {
+    const float* w[4];
+    uint32_t* out;
+    long rows_dw;
+    int cout, cin, kk, mode, split, split2, split3, srckk;
+    unsigned tapmap;
+    int blk0, ablk0;    // first block of the entry in the packing / amax launch
+    int pad_;
+};
+__device__ __forceinline__ X6PackEntry pack_entry_of(const X6PackTable& t, int ti) {
+    X6PackEntry e;
+    e.w[0] = t.w0[ti];
+    e.w[1] = t.w1[ti];
+    e.w[2] = t.w2[ti];
+    e.w[3] = t.w3[ti];
+    e.out = t.out[ti];
+    e.rows_dw = t.rows_dw[ti];
+    e.cout = t.cout[ti];
+    e.cin = t.cin[ti];
+    e.kk = t.kk[ti];
+    e.mode = t.mode[ti];
+    e.split = t.split[ti];
+    e.split2 = t.split2[ti];
+    e.split3 = t.split3[ti];
+    e.srckk = t.srckk[ti];
+    e.tapmap = t.tapmap[ti];
+    e.blk0 = t.blk0[ti];
+    e.ablk0 = t.ablk0[ti];
+    e.pad_ = 0;
+    return e;
 }
-__global__ __launch_bounds__(256) void pack_x6_amax_kernel(X6PackTable t) {
-    int ti = 0;
-    while (ti + 1 < t.count && (int)blockIdx.x >= t.ablk0[ti + 1]) ++ti;
-    const long per = (long)t.cin[ti] * t.srckk[ti];
-    const long n0 = (long)t.split[ti] * per;                          // elements of w0
-    const long n1 = (long)(t.split2[ti] - t.split[ti]) * per;         // ... of w1 (fused pair)
-    const long n2 = (long)(t.split3[ti] - t.split2[ti]) * per;        // ... of w2
-    const long n3 = (long)(t.cout[ti] - t.split3[ti]) * per;          // ... of w3
-    const long base = (long)((int)blockIdx.x - t.ablk0[ti]) * XP_ACHUNK;
+// block `lb` (entry-local) of the amax launch: max |w| over XP_ACHUNK source elements into the entry's tail
+__device__ __forceinline__ void pack_entry_amax(const X6PackEntry& e, int lb) {
+    const long per = (long)e.cin * e.srckk;
+    const long n0 = (long)e.split * per;                        // elements of w0
+    const long n1 = (long)(e.split2 - e.split) * per;           // ... of w1 (fused pair)
+    const long n2 = (long)(e.split3 - e.split2) * per;          // ... of w2
+    const long n3 = (long)(e.cout - e.split3) * per;            // ... of w3
+    const long base = (long)lb * XP_ACHUNK;
     long end = base + XP_ACHUNK;
     if (end > n0 + n1 + n2 + n3) end = n0 + n1 + n2 + n3;
     float m = 0.f;
     for (long i = base + threadIdx.x; i < end; i += 256)
-        m = fmaxf(m, fabsf(i < n0 ? t.w0[ti][i] : (i < n0 + n1 ? t.w1[ti][i - n0] : (i < n0 + n1 + n2 ? t.w2[ti][i - n0 - n1]
-                                                                                     : t.w3[ti][i - n0 - n1 - n2]))));
-    amax_emit(reinterpret_cast<float*>(t.out[ti] + t.rows_dw[ti]), m);
+        m = fmaxf(m, fabsf(i < n0 ? e.w[0][i] : (i < n0 + n1 ? e.w[1][i - n0] : (i < n0 + n1 + n2 ? e.w[2][i - n0 - n1]
+                                                                               : e.w[3][i - n0 - n1 - n2]))));
+    amax_emit(reinterpret_cast<float*>(e.out + e.rows_dw), m);
 }
-__global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
-    int ti = 0;
-    while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;
-    const int mode = t.mode[ti], Cout = t.cout[ti], Cin = t.cin[ti], KK = t.kk[ti];
+// block `lb` (entry-local) of the packing launch: XP_CHUNK (slab, m, kpair) triples
+__device__ __forceinline__ void pack_entry_rows(const X6PackEntry& e, int lb) {
+    const int mode = e.mode, Cout = e.cout, Cin = e.cin, KK = e.kk;
     const int M = mode ? Cin : Cout, C = mode ? Cout : Cin;
     const int ngroups = (C + 15) / 16;
     const long total = (long)ngroups * KK * M * 8;     // kpairs
-    const long base = (long)((int)blockIdx.x - t.blk0[ti]) * XP_CHUNK;
+    const long base = (long)lb * XP_CHUNK;
     long end = base + XP_CHUNK;
     if (end > total) end = total;
-    const float sa = f16_scale_of(__builtin_bit_cast(float, t.out[ti][t.rows_dw[ti]]));
+    const float sa = f16_scale_of(__builtin_bit_cast(float, e.out[e.rows_dw]));
     for (long idx = base + threadIdx.x; idx < end; idx += 256) {
         const int kp = (int)(idx & 7);
         const long sm = idx >> 3;
@@ -103,29 +132,83 @@ __global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
         const int g = slab / KK, tap = slab - g * KK;
         float v[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = 16 * g + 2 * kp + e;
+        for (int q = 0; q < 2; ++q) {
+            const int c = 16 * g + 2 * kp + q;
             float x = 0.f;
             if (c < C) {
                 const int co = mode ? c : m, ci = mode ? m : c;
-                const float* src = co < t.split[ti] ? t.w0[ti] : (co < t.split2[ti] ? t.w1[ti] : (co < t.split3[ti] ? t.w2[ti] : t.w3[ti]));
-                const int cor = co < t.split[ti] ? co : (co < t.split2[ti] ? co - t.split[ti]
-                                                         : (co < t.split3[ti] ? co - t.split2[ti] : co - t.split3[ti]));
-                const int stap = t.srckk[ti] == KK ? (mode == 2 ? KK - 1 - tap : tap) : (int)((t.tapmap[ti] >> (4 * tap)) & 15u);
-                x = src[((long)cor * Cin + ci) * t.srckk[ti] + stap];
+                const float* src = co < e.split ? e.w[0] : (co < e.split2 ? e.w[1] : (co < e.split3 ? e.w[2] : e.w[3]));
+                const int cor = co < e.split ? co : (co < e.split2 ? co - e.split : (co < e.split3 ? co - e.split2 : co - e.split3));
+                const int stap = e.srckk == KK ? (mode == 2 ? KK - 1 - tap : tap) : (int)((e.tapmap >> (4 * tap)) & 15u);
+                x = src[((long)cor * Cin + ci) * e.srckk + stap];
             }
-            v[e] = x;
+            v[q] = x;
         }
         uint32_t hi, lo;
         f16_split2_pair(v[0], v[1], sa, hi, lo);
-        uint32_t* row = t.out[ti] + ((long)slab * M + m) * APITCH;
+        uint32_t* row = e.out + ((long)slab * M + m) * APITCH;
         const int swz = (m >> 2) & 3;
         const int khalf = kp >> 2, w = kp & 3;
         row[((0 + khalf) ^ swz) * 4 + w] = hi;
         row[((2 + khalf) ^ swz) * 4 + w] = lo;
     }
 }
-// the three launches of a filled table (blk0[count] = blocks of the packing launch)
+
+__global__ __launch_bounds__(64) void pack_x6_clear_tail_kernel(X6PackTable t) {
+    for (int i = threadIdx.x; i < t.count * ATAIL; i += 64) t.out[i / ATAIL][t.rows_dw[i / ATAIL] + i % ATAIL] = 0u;
+}
+__global__ __launch_bounds__(256) void pack_x6_amax_kernel(X6PackTable t) {
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.ablk0[ti + 1]) ++ti;
+    pack_entry_amax(pack_entry_of(t, ti), (int)blockIdx.x - t.ablk0[ti]);
+}
+__global__ __launch_bounds__(256) void pack_x6_kernel(X6PackTable t) {
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.blk0[ti + 1]) ++ti;
+    pack_entry_rows(pack_entry_of(t, ti), (int)blockIdx.x - t.blk0[ti]);
+}
+
+// ---- a device-resident PLAN: every weight operand of a step (forward, dgrad, stride-2 dgrad, rectangular, stem) in three
+// launches.  The entries are the ones the ssn_conv_x6_pack_* calls between ssn_conv_x6_pack_batch_begin / _end would have
+// launched table by table (<= XP_MAX entries per kernel argument); _end writes them into the caller's device buffer -- only when
+// they differ from what that buffer already holds: parameters and operand buffers keep their addresses from step to step --
+// and launches clear / amax / pack ONCE over all of them.
+__global__ __launch_bounds__(64) void pack_x6_plan_write_kernel(X6PackTable t, X6PackEntry* plan, int first, int blk_base,
+                                                                int ablk_base) {
+    for (int i = threadIdx.x; i < t.count; i += 64) {
+        X6PackEntry e = pack_entry_of(t, i);
+        e.blk0 += blk_base;
+        e.ablk0 += ablk_base;
+        plan[first + i] = e;
+    }
+}
+// entry of block b: the last one whose first block is <= b (entries without blocks share their successor's first block)
+__device__ __forceinline__ int plan_entry_of_block(const X6PackEntry* plan, int count, int b, bool amax) {
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((amax ? plan[mid].ablk0 : plan[mid].blk0) <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void pack_x6_plan_clear_kernel(const X6PackEntry* plan, int count) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count * ATAIL; i += gridDim.x * 256)
+        plan[i / ATAIL].out[plan[i / ATAIL].rows_dw + i % ATAIL] = 0u;
+}
+__global__ __launch_bounds__(256) void pack_x6_plan_amax_kernel(const X6PackEntry* plan, int count) {
+    const X6PackEntry e = plan[plan_entry_of_block(plan, count, (int)blockIdx.x, true)];
+    pack_entry_amax(e, (int)blockIdx.x - e.ablk0);
+}
+__global__ __launch_bounds__(256) void pack_x6_plan_kernel(const X6PackEntry* plan, int count) {
+    const X6PackEntry e = plan[plan_entry_of_block(plan, count, (int)blockIdx.x, false)];
+    pack_entry_rows(e, (int)blockIdx.x - e.blk0);
+}
+
+bool g_pack_batching = false;
+std::vector<X6PackTable> g_pack_batch;                 // the tables collected since ssn_conv_x6_pack_batch_begin
+std::unordered_map<const void*, uint64_t> g_plan_hash; // device plan buffer -> hash of the entries it holds
+
+// the three launches of a filled table (blk0[count] = blocks of the packing launch) -- or, inside a batch, its collection
 int launch_pack(X6PackTable& t, hipStream_t stream) {
     if (t.count == 0 || t.blk0[t.count] == 0) return SSN_OK;
     int ablocks = 0;
@@ -134,6 +217,19 @@ int launch_pack(X6PackTable& t, hipStream_t stream) {
         ablocks += (int)(((long)t.cout[i] * t.cin[i] * t.srckk[i] + XP_ACHUNK - 1) / XP_ACHUNK);
     }
     t.ablk0[t.count] = ablocks;
+    if (g_pack_batching) {
+        // (unused columns zeroed: the table is hashed)
+        for (int i = t.count; i < XP_MAX; ++i) {
+            t.w0[i] = t.w1[i] = t.w2[i] = t.w3[i] = nullptr;
+            t.out[i] = nullptr;
+            t.rows_dw[i] = 0;
+            t.cout[i] = t.cin[i] = t.kk[i] = t.mode[i] = t.split[i] = t.split2[i] = t.split3[i] = t.srckk[i] = 0;
+            t.tapmap[i] = 0;
+        }
+        for (int i = t.count + 1; i <= XP_MAX; ++i) t.blk0[i] = t.ablk0[i] = 0;
+        g_pack_batch.push_back(t);
+        return SSN_OK;
+    }
     hipLaunchKernelGGL(pack_x6_clear_tail_kernel, dim3(1), dim3(64), 0, stream, t);
     hipLaunchKernelGGL(pack_x6_amax_kernel, dim3((unsigned)ablocks), dim3(256), 0, stream, t);
     hipLaunchKernelGGL(pack_x6_kernel, dim3((unsigned)t.blk0[t.count]), dim3(256), 0, stream, t);
@@ -295,6 +391,76 @@ extern "C" void ssn_conv_x6_debug_trace(unsigned long long* buf) { g_x6_trace = 
 
 extern "C" long ssn_conv_x6_packed_floats(int Cout, int Cin, int ksize, int transposed) {
     return x6_packed_dwords(Cout, Cin, ksize, transposed);
+}
+
+// ---- batched packing: every ssn_conv_x6_pack_* call between _begin and _end only records its entries; _end issues them all in three
+// launches through a device-resident plan (plan: >= ssn_conv_x6_pack_batch_entries() * ssn_conv_x6_pack_entry_bytes() bytes of
+// device memory that the caller keeps from step to step -- it is rewritten, by ceil(entries / 40) small launches, only when the
+// recorded entries differ from the ones last written there, or with force_write: a buffer the caller has just allocated).  Replaces the ~24 launches per training step that packing layer group by layer
+// group costs (cuDNN reads the caller's weights as they are: /root/reference/ssn_models.py:266, ssn_train.py:236 have no such step).
+extern "C" int ssn_conv_x6_pack_batch_begin(void) {
+    SSN_CHECK_ARG(!g_pack_batching, "conv x6 pack batch: already open");
+    g_pack_batch.clear();
+    g_pack_batching = true;
+    return SSN_OK;
+}
+extern "C" int ssn_conv_x6_pack_batch_entries(void) {
+    int n = 0;
+    for (const X6PackTable& t : g_pack_batch) n += t.count;
+    return n;
+}
+extern "C" long ssn_conv_x6_pack_entry_bytes(void) { return (long)sizeof(X6PackEntry); }
+extern "C" void ssn_conv_x6_pack_batch_abort(void) {
+    g_pack_batching = false;
+    g_pack_batch.clear();
+}
+extern "C" int ssn_conv_x6_pack_batch_end(void* plan, long plan_bytes, int force_write, hipStream_t stream) {
+    SSN_CHECK_ARG(g_pack_batching, "conv x6 pack batch: not open");
+    g_pack_batching = false;
+    const int count = ssn_conv_x6_pack_batch_entries();
+    if (count == 0) return SSN_OK;
+    if (!plan || plan_bytes < (long)count * (long)sizeof(X6PackEntry)) {
+        g_pack_batch.clear();
+        ssn_set_error("conv x6 pack batch: plan buffer %ld < %ld bytes", plan_bytes, (long)count * (long)sizeof(X6PackEntry));
+        return SSN_ERR_WORKSPACE;
+    }
+    uint64_t h = 1469598103934665603ull;      // FNV-1a over the recorded tables
+    for (const X6PackTable& t : g_pack_batch) {
+        // (field by field: the struct's padding bytes are indeterminate)
+        auto mix = [&](const void* p, size_t n) {
+            const unsigned char* q = static_cast<const unsigned char*>(p);
+            for (size_t i = 0; i < n; ++i) h = (h ^ q[i]) * 1099511628211ull;
+        };
+        mix(t.w0, sizeof(t.w0)); mix(t.w1, sizeof(t.w1)); mix(t.w2, sizeof(t.w2)); mix(t.w3, sizeof(t.w3));
+        mix(t.out, sizeof(t.out)); mix(t.rows_dw, sizeof(t.rows_dw)); mix(t.cout, sizeof(t.cout)); mix(t.cin, sizeof(t.cin));
+        mix(t.kk, sizeof(t.kk)); mix(t.mode, sizeof(t.mode)); mix(t.split, sizeof(t.split)); mix(t.split2, sizeof(t.split2));
+        mix(t.split3, sizeof(t.split3)); mix(t.srckk, sizeof(t.srckk)); mix(t.tapmap, sizeof(t.tapmap));
+        mix(t.blk0, sizeof(t.blk0)); mix(t.ablk0, sizeof(t.ablk0)); mix(&t.count, sizeof(t.count));
+    }
+    int blocks = 0, ablocks = 0;
+    for (const X6PackTable& t : g_pack_batch) {
+        blocks += t.blk0[t.count];
+        ablocks += t.ablk0[t.count];
+    }
+    X6PackEntry* dev = static_cast<X6PackEntry*>(plan);
+    auto it = g_plan_hash.find(plan);
+    if (force_write || it == g_plan_hash.end() || it->second != h) {
+        int first = 0, bb = 0, ab = 0;
+        for (const X6PackTable& t : g_pack_batch) {
+            hipLaunchKernelGGL(pack_x6_plan_write_kernel, dim3(1), dim3(64), 0, stream, t, dev, first, bb, ab);
+            first += t.count;
+            bb += t.blk0[t.count];
+            ab += t.ablk0[t.count];
+        }
+        g_plan_hash[plan] = h;
+    }
+    g_pack_batch.clear();
+    hipLaunchKernelGGL(pack_x6_plan_clear_kernel, dim3((unsigned)((count * ATAIL + 255) / 256)), dim3(256), 0, stream,
+                       (const X6PackEntry*)dev, count);
+    hipLaunchKernelGGL(pack_x6_plan_amax_kernel, dim3((unsigned)ablocks), dim3(256), 0, stream, (const X6PackEntry*)dev, count);
+    hipLaunchKernelGGL(pack_x6_plan_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const X6PackEntry*)dev, count);
+    SSN_CHECK_LAUNCH("conv_x6_pack_batch_end");
+    return SSN_OK;
 }
 
 // Scale + split + pack `count` weights (HOST arrays, one entry per layer; see ssn_conv_pack_weights_multi for w1/split).

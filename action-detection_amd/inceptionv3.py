@@ -58,7 +58,8 @@ class InceptionV3(BNInception):
         shapes = dict(shapes)
         plan = []
         train_bn = set(self._train_bn_ids())
-        fuse = self.fuse_block_inputs and self.conv_precision == "split" and not train_bn
+        blocks_frozen = not (train_bn - {self._conv_ids[0]})      # bn_mode 'partial': only the stem's BatchNorm is in training mode
+        fuse = self.fuse_block_inputs and self.conv_precision == "split" and blocks_frozen
         # The two 1x1 "reduce" convolutions of a block (5x5 + double 3x3, 7x7 + double 7x7, 3x3 + 7x7x3 / double 3x3) read the
         # same input and write private tensors: planned as ONE convolution with concatenated output channels into a shared
         # "<block>_reduce" tensor, as in BNInception._plan -- the precondition for its block-input merges below.
@@ -94,7 +95,7 @@ class InceptionV3(BNInception):
             else:
                 _, lid, src, dst = op
                 plan.append(dict(kind="gap", lid=lid, src=src, dst=dst, c=shapes[src][0]))
-        if self.pool_after_projection and not train_bn:
+        if self.pool_after_projection and blocks_frozen:
             merge = fuse and self.merge_projection
             plan = self._move_avg_pools(plan, shapes, merge=merge)
             if merge:        # 1x1 branch + reduce pair + projection: one launch on the block input

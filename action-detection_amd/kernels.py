@@ -127,6 +127,7 @@ def _amax_in(x):
 # heads, row selection, losses) bracket their launch with HIP events on the launch stream and append
 # (kernel name, algorithmic bytes = operands read + results written, start event, end event).
 HBM_PROFILER = None
+HBM_PROFILER_REPEATS = 16
 
 
 def _hbm_timed(fn):
@@ -145,11 +146,20 @@ def _hbm_timed(fn):
             return fn(*args, **kw)
         nbytes = sum(t.numel() * t.element_size() for t in tens)
         nbytes += sum(c.n * c.c * c.hw[0] * c.hw[1] * c.t.element_size() for c in slices)
+        # an event pair around ONE launch of a 2-5 us kernel reads 15-25 us (the pair's own granularity): the launch is
+        # repeated back to back -- these kernels are pure functions of their operands (no atomics, nothing accumulated unless
+        # asked) -- and the pair divided by the count
+        reps = HBM_PROFILER_REPEATS
+        if kw.get("accumulate") or kw.get("accumulate_dx") or (fn.__name__ == "gap_bwd" and len(args) > 2 and args[2]) or \
+                (fn.__name__ == "linear_bwd" and len(args) > 6 and args[6]):
+            reps = 1
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         out = fn(*args, **kw)
+        for _ in range(reps - 1):
+            fn(*args, **kw)
         e.record()
-        prof.append((fn.__name__, nbytes, s, e))
+        prof.append((fn.__name__, nbytes, s, e, reps))
         return out
     return wrapper
 
@@ -187,6 +197,62 @@ def pack_weights(w, transposed, out=None):
     return out
 
 
+_PACK_BATCH = None      # the open PackBatch, if any
+
+
+def _pack_alloc(nfloats, device):
+    """Operand buffer of a packing call: fresh, or -- inside a PackBatch -- the persistent one of this position in the batch."""
+    if _PACK_BATCH is not None:
+        return _PACK_BATCH.take(int(nfloats), device)
+    return torch.empty(int(nfloats), device=device, dtype=torch.float32)
+
+
+class PackBatch:
+    """``with PackBatch(state, device):`` -- the x6 / planes weight-packing calls inside (pack_weights_multi(x6=True), pack_rect_multi,
+    pack_weights_rect, pack_dgrad_s2, pack_dgrad_rect, s2d_weights' output) are only RECORDED; leaving the block issues all of them
+    in three launches through a device-resident plan (ssn_conv_x6_pack_batch_end).  `state` is a dict the caller keeps (one per
+    backbone and kind of pass): it holds the operand buffers -- the k-th allocation of a batch gets the same buffer every time, so
+    the recorded entries repeat from step to step and the plan is written once -- and the plan buffer.  The returned operands are
+    valid after the block; they are overwritten by the next batch on the same state (same weights -> same contents)."""
+
+    def __init__(self, state, device):
+        self.state, self.device, self.k = state, device, 0
+
+    def take(self, nfloats, device):
+        bufs = self.state.setdefault("bufs", [])
+        if self.k < len(bufs) and bufs[self.k].numel() == nfloats and bufs[self.k].device == device:
+            t = bufs[self.k]
+        else:
+            t = torch.empty(nfloats, device=device, dtype=torch.float32)
+            del bufs[self.k:]
+            bufs.append(t)
+        self.k += 1
+        return t
+
+    def __enter__(self):
+        global _PACK_BATCH
+        assert _PACK_BATCH is None, "PackBatch blocks do not nest"
+        self.lib = _lib.get_lib()
+        self.lib.call("ssn_conv_x6_pack_batch_begin")
+        _PACK_BATCH = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _PACK_BATCH
+        _PACK_BATCH = None
+        if et is not None:
+            self.lib.cdll.ssn_conv_x6_pack_batch_abort()
+            return False
+        need = int(self.lib.cdll.ssn_conv_x6_pack_batch_entries()) * int(self.lib.cdll.ssn_conv_x6_pack_entry_bytes())
+        plan, fresh = self.state.get("plan"), 0
+        if need and (plan is None or plan.numel() < need or plan.device != self.device):
+            plan = self.state["plan"] = torch.empty(max(need, 1 << 16), device=self.device, dtype=torch.uint8)
+            fresh = 1
+        self.lib.call("ssn_conv_x6_pack_batch_end", _p(plan), plan.numel() if plan is not None else 0, fresh,
+                      _stream(self.lib, plan) if plan is not None else None)
+        return False
+
+
 def pack_weights_multi(entries, x6=False):
     """entries: list of (weights, mode) with weights = [w], [wA, wB] (fused pair) or -- x6 only -- [wA, wB, wC]
     ... [wA, wB, wC, wD] (concatenated output channels).
@@ -203,7 +269,7 @@ def pack_weights_multi(entries, x6=False):
     cins = [ws[0].shape[1] for ws, _ in entries]
     kss = [ws[0].shape[2] for ws, _ in entries]
     sizes = [packed_floats(co, ci, k, m, x6) for co, ci, k, (_, m) in zip(couts, cins, kss, entries)]
-    flat = torch.empty(sum(sizes), device=first.device, dtype=torch.float32)
+    flat = _pack_alloc(sum(sizes), first.device) if x6 else torch.empty(sum(sizes), device=first.device, dtype=torch.float32)
     outs, off = [], 0
     for sz in sizes:
         outs.append(flat[off:off + sz])
@@ -279,8 +345,7 @@ def pack_weights_rect(w):
     """Split + pack one [cout, cin, kh, kw] forward weight for conv_x6_fwd_rect."""
     lib = _check(w)
     cout, cin, kh, kw = w.shape
-    out = torch.empty(int(lib.cdll.ssn_conv_x6_packed_floats_rect(cout, cin, kh, kw)), device=w.device,
-                      dtype=torch.float32)
+    out = _pack_alloc(int(lib.cdll.ssn_conv_x6_packed_floats_rect(cout, cin, kh, kw)), w.device)
     lib.call("ssn_conv_x6_pack_weights_rect", _p(w.contiguous()), _p(out), cout, cin, kh, kw, _stream(lib, w))
     return out
 
@@ -315,7 +380,7 @@ def pack_dgrad_s2(w):
     lib = _check(w)
     cout, cin = w.shape[0], w.shape[1]
     assert tuple(w.shape[2:]) == (3, 3)
-    out = torch.empty(int(lib.cdll.ssn_conv_x6_dgrad_s2_packed_floats(cout, cin)), device=w.device, dtype=torch.float32)
+    out = _pack_alloc(int(lib.cdll.ssn_conv_x6_dgrad_s2_packed_floats(cout, cin)), w.device)
     lib.call("ssn_conv_x6_pack_dgrad_s2", _p(w.contiguous()), _p(out), cout, cin, _stream(lib, w))
     return out
 
@@ -324,8 +389,7 @@ def pack_dgrad_rect(w):
     """dgrad operand of a stride-1 layer with rectangular taps for conv_x6_dgrad_rect (transposed, taps reversed)."""
     lib = _check(w)
     cout, cin, kh, kw = w.shape
-    out = torch.empty(int(lib.cdll.ssn_conv_x6_packed_floats_dgrad_rect(cout, cin, kh, kw)), device=w.device,
-                      dtype=torch.float32)
+    out = _pack_alloc(int(lib.cdll.ssn_conv_x6_packed_floats_dgrad_rect(cout, cin, kh, kw)), w.device)
     lib.call("ssn_conv_x6_pack_dgrad_rect", _p(w.contiguous()), _p(out), cout, cin, kh, kw, _stream(lib, w))
     return out
 
@@ -339,7 +403,7 @@ def pack_rect_multi(ws, dgrad=False):
     n = len(ws)
     size_fn = lib.cdll.ssn_conv_x6_packed_floats_dgrad_rect if dgrad else lib.cdll.ssn_conv_x6_packed_floats_rect
     sizes = [int(size_fn(*w.shape)) for w in ws]
-    flat = torch.empty(sum(sizes), device=ws[0].device, dtype=torch.float32)
+    flat = _pack_alloc(sum(sizes), ws[0].device)
     outs, off = [], 0
     for sz in sizes:
         outs.append(flat[off:off + sz])
@@ -432,7 +496,8 @@ def s2d_weights(w):
     """[Cout, C, k, k] (k odd, stride-2 layer) -> [Cout, 4C, (k+1)/2, (k+1)/2] for the space-to-depth input."""
     lib = _check(w)
     cout, c, k, _ = w.shape
-    w2 = torch.empty((cout, 4 * c, (k + 1) // 2, (k + 1) // 2), device=w.device, dtype=torch.float32)
+    # (inside a PackBatch the result is an operand of a recorded packing call: it gets a persistent buffer like the packed ones)
+    w2 = _pack_alloc(cout * 4 * c * ((k + 1) // 2) ** 2, w.device).view(cout, 4 * c, (k + 1) // 2, (k + 1) // 2)
     lib.call("ssn_s2d_weights", _p(w.contiguous()), _p(w2), cout, c, k, _stream(lib, w))
     return w2
 

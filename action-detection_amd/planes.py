@@ -318,6 +318,47 @@ def gap_bwd(dy, dx, mask=None, mask_scale=None):
              mask.groups if mask is not None else 0, _p(mask_scale), dx.t.scale_ptr, dx.t.amax_ptr, _st(lib, dx.t))
 
 
+def bn_train_workspace_bytes(c):
+    return int(_lib.get_lib().cdll.ssn_pl_bn_train_workspace_bytes(int(c)))
+
+
+def bn_train_stats(z, conv_bias, mean, invstd, running_mean, running_var, eps, momentum, workspace):
+    """Batch statistics of the planes slice z (the convolution WITHOUT its bias): mean / invstd (real units) and the running
+    statistics update of torch.nn.BatchNorm2d (running_mean / running_var None: not tracked)."""
+    lib = _lib_for(z.t)
+    h, w = z.hw
+    lib.call("ssn_pl_bn_train_stats", z.hi, z.lo, z.groups, z.t.scale_ptr, _p(conv_bias), _p(mean), _p(invstd), _p(running_mean),
+             _p(running_var), z.n, z.c, h * w, float(eps), float(momentum), _p(workspace),
+             workspace.numel() * workspace.element_size(), _st(lib, z.t))
+
+
+def bn_train_apply(z, y, mean, invstd, gamma, beta, relu=True):
+    """y = relu?(gamma * (z - mean) * invstd + beta), planes slice -> planes slice."""
+    lib = _lib_for(z.t)
+    h, w = z.hw
+    lib.call("ssn_pl_bn_train_apply", z.hi, z.lo, z.groups, z.t.scale_ptr, y.hi, y.lo, y.groups, y.t.scale_ptr, y.t.amax_ptr,
+             _p(mean), _p(invstd), _p(gamma), _p(beta), int(bool(relu)), z.n, z.c, h * w, _st(lib, z.t))
+
+
+def bn_train_bwd(dy, y, z, mean, invstd, gamma, dgamma, dbeta, dz, workspace, relu=True):
+    """Backward of bn_train_apply (+ the statistics): dgamma, dbeta, and dz -- a PSlice, or an fp32 NCHW tensor with an amax slot
+    attached (kernels.attach_amax: the stem, whose weight gradient runs on the fp32-layout kernel).  y: the layer's output slice
+    (only the sign of its high plane is read)."""
+    lib = _lib_for(dy.t)
+    h, w = z.hw
+    ws_bytes = workspace.numel() * workspace.element_size()
+    if isinstance(dz, PSlice):
+        lib.call("ssn_pl_bn_train_bwd", dy.hi, dy.lo, dy.groups, dy.t.scale_ptr, y.hi if relu else None, y.groups, z.hi, z.lo,
+                 z.groups, z.t.scale_ptr, _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), dz.hi, dz.lo, dz.groups,
+                 dz.t.scale_ptr, dz.t.amax_ptr, None, 0, z.n, z.c, h * w, _p(workspace), ws_bytes, _st(lib, dy.t))
+        return
+    n, c, hh, ww = dz.shape
+    assert (n, c, hh * ww) == (z.n, z.c, h * w) and dz.is_contiguous() and dz.dtype == torch.float32
+    lib.call("ssn_pl_bn_train_bwd", dy.hi, dy.lo, dy.groups, dy.t.scale_ptr, y.hi if relu else None, y.groups, z.hi, z.lo,
+             z.groups, z.t.scale_ptr, _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), None, None, 0, None,
+             _p(getattr(dz, "_ssn_amax", None)), _p(dz), c * hh * ww, z.n, z.c, h * w, _p(workspace), ws_bytes, _st(lib, dy.t))
+
+
 def channel_sum_workspace_bytes(c):
     return int(_lib.get_lib().cdll.ssn_pl_channel_sum_workspace_bytes(int(c)))
 

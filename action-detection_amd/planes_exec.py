@@ -28,6 +28,7 @@ What differs from the fp32-layout executor (bninception._run_forward / _run_back
 Supported: frozen BatchNorm (the reference's default ``bn_mode='frozen'``; /root/reference/ssn_models.py:95-105) on the square /
 rectangular-tap plans.  Training-mode BatchNorm keeps the fp32-layout executor.
 """
+import contextlib
 import itertools
 import math
 
@@ -125,12 +126,15 @@ def _capturing(t):
 
 
 def supported(net, plan):
-    if net._train_bn_ids():
+    if net._train_bn_ids() and not net.planes_train_bn:
         return False
-    for op in plan:
+    for idx, op in enumerate(plan):
         if op["kind"] == "pool" and op["pool"] != "max":
-            return False
-        if op["kind"] == "bn_train":
+            # a plain average pool (plans with training-mode BatchNorm keep it in front of its projection): stride 1, and the LAST
+            # reader of its input, so that its backward is the first writer of that gradient (the stencil kernel does not accumulate)
+            if op["pool"] != "avg" or op["s"] != 1 or any(q.get("src") == op["src"] for q in plan[idx + 1:]):
+                return False
+        if op["kind"] == "bn_train" and any(c % 8 for c in op["couts"]):
             return False
         if op["kind"] == "conv" and (op["cout"] % 8 or (op["src"] != "data" and op["cin"] % 8)):
             return False
@@ -174,6 +178,12 @@ def _fold_bn(net, plan, shapes, dev):
             shift_of.setdefault(lid_, shift_flat[soff + o_:soff + o_ + getattr(net, lid_).out_channels])
         off = 0
         aff_dst, aff_c0 = op.get("final", (op["dst"], op["dst_c0"]))
+        if op.get("bn_train"):
+            # batch-statistics layer: nothing to fold; the NaN scales of its slice say "not a frozen ReLU / BN output", so the fused
+            # backward epilogues of the consumers leave that gradient alone (the bn_train op owns its backward)
+            scale_slice(aff_dst, aff_c0, op["cout"])
+            soff += op["cout"]
+            continue
         for lid, c in zip(op["lids"], op["couts"]):
             conv, bn = getattr(net, lid), getattr(net, lid + "_bn")
             if "raw_from" in op and off >= op["raw_from"]:
@@ -185,7 +195,8 @@ def _fold_bn(net, plan, shapes, dev):
                 lst.append(v)
             off += c
         soff += op["cout"]
-    K.bn_fold_multi(*fold)
+    if fold[0]:
+        K.bn_fold_multi(*fold)
     return tscale, shift_of, scale_slice
 
 
@@ -195,6 +206,28 @@ def _pool_out(h, k, s, p):
     if (o - 1) * s >= h + p:
         o -= 1
     return o
+
+
+def _dgrad_is_s2(op):
+    return len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3 and op["s"] == 2
+
+
+def _pack_dgrad(net, plan):
+    """The data-gradient operands of every convolution that has one (not the layers on the caller's frames)."""
+    dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
+    packed_dg = {}
+    for op in dg_ops:
+        if _dgrad_is_s2(op):
+            packed_dg[op["lids"][0]] = K.pack_dgrad_s2(getattr(net, op["lids"][0]).weight.detach())
+        elif op["s"] != 1:
+            raise NotImplementedError("planes layout: data gradient of a %dx%d / stride-%d convolution" % (op["k"], op["k"], op["s"]))
+    rect_ops = [op for op in dg_ops if op["rect"]]
+    packed_dg.update(zip((op["lids"][0] for op in rect_ops),
+                         K.pack_rect_multi([getattr(net, op["lids"][0]).weight.detach() for op in rect_ops], dgrad=True)))
+    sq_ops = [op for op in dg_ops if not op["rect"] and not _dgrad_is_s2(op)]
+    packed_dg.update(zip((op["lids"][0] for op in sq_ops), K.pack_weights_multi(
+        [([getattr(net, lid).weight.detach() for lid in op["lids"]], 1) for op in sq_ops], x6=True)))
+    return packed_dg
 
 
 def run_forward(net, x, keep):
@@ -224,22 +257,33 @@ def run_forward(net, x, keep):
     for op in conv_ops:
         op["rect"] = _is_rect(op)
         op["s2d"] = (op["src"] == "data" and len(op["lids"]) == 1 and (op["k"], op["s"], op["p"]) == (7, 2, 3)
-                     and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and not op.get("raw"))
+                     and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
         if op["src"] == "data" and not op["s2d"] and not op["rect"] and op["k"] not in (1, 3):
             raise NotImplementedError("planes layout: first convolution %dx%d / stride %d" % (op["k"], op["k"], op["s"]))
+    packed_dg = None
     if keep or hit is None:
-        packed = {}
-        for op in conv_ops:
-            if op["s2d"]:
-                packed[op["lids"][0]] = K.pack_weights_rect(K.s2d_weights(getattr(net, op["lids"][0]).weight.detach()))
-        rect_ops = [op for op in conv_ops if op["rect"] and not op["s2d"]]
-        packed.update(zip((op["lids"][0] for op in rect_ops),
-                          K.pack_rect_multi([getattr(net, op["lids"][0]).weight.detach() for op in rect_ops])))
-        sq_ops = [op for op in conv_ops if not op["rect"] and not op["s2d"]]
-        packed.update(zip((op["lids"][0] for op in sq_ops), K.pack_weights_multi(
-            [([getattr(net, lid).weight.detach() for lid in op["lids"]], 0) for op in sq_ops], x6=True)))
+        # every weight operand of the step -- forward, and with a backward to come the data-gradient ones too (the weights autograd
+        # would have saved) -- recorded and issued in three launches (kernels.PackBatch; one state per kind of pass so that the
+        # operand buffers, and with them the device-resident plan, repeat from step to step)
+        pstate = net.__dict__.setdefault("_pack_states", {}).setdefault((dev, bool(keep), tuple(x.shape[1:])), {})
+        batch = K.PackBatch(pstate, dev) if net.batch_packing else contextlib.nullcontext()
+        with batch:
+            packed = {}
+            for op in conv_ops:
+                if op["s2d"]:
+                    packed[op["lids"][0]] = K.pack_weights_rect(K.s2d_weights(getattr(net, op["lids"][0]).weight.detach()))
+            rect_ops = [op for op in conv_ops if op["rect"] and not op["s2d"]]
+            packed.update(zip((op["lids"][0] for op in rect_ops),
+                              K.pack_rect_multi([getattr(net, op["lids"][0]).weight.detach() for op in rect_ops])))
+            sq_ops = [op for op in conv_ops if not op["rect"] and not op["s2d"]]
+            packed.update(zip((op["lids"][0] for op in sq_ops), K.pack_weights_multi(
+                [([getattr(net, lid).weight.detach() for lid in op["lids"]], 0) for op in sq_ops], x6=True)))
+            if keep:
+                packed_dg = _pack_dgrad(net, plan)
         if ckey is not None:
             net.__dict__["_infer_cache"] = (ckey, (tscale, shift_of, scale_slice, packed))
+
+    bnstat, bn_before = {}, {}      # training-mode BatchNorm layers: layer id -> (batch mean of z, 1 / sqrt(var + eps))
 
     def launch_all(acts, argmax):
         # the scales this pass stores with, frozen: the pool's entries move on with the next pass (another sub-batch, an
@@ -272,7 +316,7 @@ def run_forward(net, x, keep):
                             acts["data_s2d_f32"] = K.space_to_depth2(x)
                     src = P.pfull(acts["data_s2d"])
                     net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
-                        PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, True, net._pl_tile("fwd", op, n, shapes)))
+                        PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, not raw, net._pl_tile("fwd", op, n, shapes)))
                 else:
                     if op["src"] == "data":
                         if "data" not in acts:
@@ -284,6 +328,39 @@ def run_forward(net, x, keep):
                     net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
                         src, wp, scale, shift, dst, kh, kw, op["s"], ph, pw, not raw, net._pl_tile("fwd", op, n, shapes),
                         raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0)))
+            elif op["kind"] == "pool" and op["pool"] == "avg":
+                c = op["c"]
+                P.avgpool_affine(PSlice(acts[op["src"]], 0, c), PSlice(get(op["dst"]), op["dst_c0"], c), None, None, False,
+                                 op["k"], op["p"])
+            elif op["kind"] == "bn_train":
+                # training-mode BatchNorm2d of the layer(s) whose bare convolution wrote z = acts[op["src"]] (planes_bn.hip)
+                off = 0
+                bws = torch.empty(P.bn_train_workspace_bytes(op["c"]) // 4, device=dev, dtype=torch.float32)
+                for lid, c in zip(op["lids"], op["couts"]):
+                    conv, bn = getattr(net, lid), getattr(net, lid + "_bn")
+                    mean = torch.empty(c, device=dev, dtype=torch.float32)
+                    invstd = torch.empty(c, device=dev, dtype=torch.float32)
+                    zs = PSlice(acts[op["src"]], off, c)
+                    track = bn.track_running_stats and bn.running_mean is not None
+                    if bn.momentum is None and track:
+                        raise NotImplementedError("BatchNorm2d(momentum=None) in training mode (cumulative moving average) is "
+                                                  "not supported; the reference's models use the default momentum 0.1")
+                    rm, rv = (None, None)
+                    if track:
+                        if lid not in bn_before:
+                            bn_before[lid] = (bn.running_mean.clone(), bn.running_var.clone())
+                            if bn.num_batches_tracked is not None:
+                                bn.num_batches_tracked.add_(1)      # torch increments BEFORE it updates the running statistics
+                        else:      # a pass repeated by the calibration / the range guard restarts from the statistics it found
+                            bn.running_mean.copy_(bn_before[lid][0])
+                            bn.running_var.copy_(bn_before[lid][1])
+                        rm, rv = bn.running_mean, bn.running_var
+                    P.bn_train_stats(zs, conv.bias.detach(), mean, invstd, rm, rv, bn.eps,
+                                     0.1 if bn.momentum is None else bn.momentum, bws)
+                    P.bn_train_apply(zs, PSlice(get(op["dst"]), op["dst_c0"] + off, c), mean, invstd, bn.weight.detach(),
+                                     bn.bias.detach(), True)
+                    bnstat[lid] = (mean, invstd)
+                    off += c
             elif op["kind"] == "pool":
                 c = op["c"]
                 out = PSlice(get(op["dst"]), op["dst_c0"], c)
@@ -334,12 +411,13 @@ def run_forward(net, x, keep):
                 st.describe_fault("forward")
                 st.recalibrations[0] += 1 + st.settle(again, "forward")
     acts, feat = res["acts"], res["feat"]
-    saved = (plan, shapes, acts, argmax, tscale, packed, st) if keep else None
+    saved = (plan, shapes, acts, argmax, tscale, {"packed": packed, "packed_dg": packed_dg, "bnstat": bnstat}, st) if keep else None
     return feat, saved
 
 
 def run_backward(net, dfeat, saved, hook=True):
-    plan, shapes, acts, argmax, tscale, packed_fwd, st = saved
+    plan, shapes, acts, argmax, tscale, extras, st = saved
+    bnstat, bn_grads = extras["bnstat"], {}
     n, dev = dfeat.shape[0], dfeat.device
     layout, total = net.flat_grad_layout(plan)
     lay = {lid: (wo, wn, bo, bn) for lid, wo, wn, bo, bn in layout}
@@ -373,20 +451,8 @@ def run_backward(net, dfeat, saved, hook=True):
     cs_ws = torch.empty(P.channel_sum_workspace_bytes(max(op["cout"] for op in plan if op["kind"] == "conv")) // 4, device=dev,
                         dtype=torch.float32)
 
-    dg_ops = [op for op in plan if op["kind"] == "conv" and op["src"] != "data"]
-    dg_s2 = {op["lids"][0]: (len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3 and op["s"] == 2) for op in dg_ops}
-    packed_dg = {}
-    for op in dg_ops:
-        if dg_s2[op["lids"][0]]:
-            packed_dg[op["lids"][0]] = K.pack_dgrad_s2(getattr(net, op["lids"][0]).weight.detach())
-        elif op["s"] != 1:
-            raise NotImplementedError("planes layout: data gradient of a %dx%d / stride-%d convolution" % (op["k"], op["k"], op["s"]))
-    rect_ops = [op for op in dg_ops if op["rect"]]
-    packed_dg.update(zip((op["lids"][0] for op in rect_ops),
-                         K.pack_rect_multi([getattr(net, op["lids"][0]).weight.detach() for op in rect_ops], dgrad=True)))
-    sq_ops = [op for op in dg_ops if not op["rect"] and not dg_s2[op["lids"][0]]]
-    packed_dg.update(zip((op["lids"][0] for op in sq_ops), K.pack_weights_multi(
-        [([getattr(net, lid).weight.detach() for lid in op["lids"]], 1) for op in sq_ops], x6=True)))
+    dg_s2 = {op["lids"][0]: _dgrad_is_s2(op) for op in plan if op["kind"] == "conv" and op["src"] != "data"}
+    packed_dg = extras["packed_dg"]      # (packed with the forward operands: the weights the forward saw)
 
     def src_key(op):
         return (op["src"], op.get("src_c0", 0))
@@ -401,6 +467,8 @@ def run_backward(net, dfeat, saved, hook=True):
             readers = [q for q in plan if q.get("src") == op["dst"]]
             if len(readers) == 1 and readers[0]["kind"] == "pool" and readers[0]["pool"] == "max" and op["dst_c0"] == 0:
                 stem_out = op["dst"]
+
+    conv_of = {op["dst"]: op for op in plan if op["kind"] == "conv" and op.get("bn_train")}      # z tensor -> its convolution
 
     def launch_all(grads, fire_hook):
         masked, inited = {}, set()
@@ -446,6 +514,35 @@ def run_backward(net, dfeat, saved, hook=True):
                 if fuse:
                     masked.setdefault(op["src"], []).append((0, c))
                 inited.add(key)
+            elif op["kind"] == "pool" and op["pool"] == "avg":
+                # plain average pool (stride 1, zero padding counted): its adjoint is the same stencil on the gradient
+                c = op["c"]
+                key = (op["src"], 0)
+                assert key not in inited, "average pool %s is not the first writer of its input's gradient" % op["lid"]
+                P.avgpool_affine(PSlice(grads[op["dst"]], op["dst_c0"], c), PSlice(gbuf(op["src"]), 0, c), None, None, False,
+                                 op["k"], op["p"])
+                inited.add(key)
+            elif op["kind"] == "bn_train":
+                # batch-norm backward of the layer(s): the slice's gradient arrives untouched (NaN scales, see _fold_bn)
+                off = 0
+                bws = torch.empty(P.bn_train_workspace_bytes(op["c"]) // 4, device=dev, dtype=torch.float32)
+                cop = conv_of[op["src"]]
+                stem32 = bool(cop.get("s2d")) and "data_s2d_f32" in acts      # (its weight gradient runs on the fp32-layout kernel)
+                for lid, c in zip(op["lids"], op["couts"]):
+                    bn = getattr(net, lid + "_bn")
+                    mean, invstd = bnstat[lid]
+                    dgamma = torch.empty(c, device=dev, dtype=torch.float32)
+                    dbeta = torch.empty(c, device=dev, dtype=torch.float32)
+                    if stem32:
+                        _, h_, w_ = shapes[op["src"]]
+                        dz = grads["__stem_f32__"] = K.attach_amax(K.guarded_empty((n, c, h_, w_), dev))
+                    else:
+                        dz = PSlice(gbuf(op["src"]), off, c)
+                    P.bn_train_bwd(PSlice(grads[op["dst"]], op["dst_c0"] + off, c), PSlice(acts[op["dst"]], op["dst_c0"] + off, c),
+                                   PSlice(acts[op["src"]], off, c), mean, invstd, bn.weight.detach(), dgamma, dbeta, dz, bws, True)
+                    bn_grads[lid] = (dgamma, dbeta)
+                    off += c
+                inited.add((op["src"], 0))
             elif op["kind"] == "pool":
                 c = op["c"]
                 key = (op["src"], 0)
@@ -524,7 +621,7 @@ def run_backward(net, dfeat, saved, hook=True):
                                      g_row_gap=op.get("row_gap", 0), defer=defer)
                 def run_wgrad_and_bias(run_wgrad=run_wgrad, op=op, db=db, cout=cout):
                     run_wgrad()
-                    if raw or "raw_from" in op:
+                    if (raw and not op.get("bn_train")) or "raw_from" in op:
                         # the (projection's) bias sits behind the pool: its gradient is the sum of the gradient BEFORE the pool's
                         # backward (after the weight gradient's reduction, which wrote the sum of the pooled gradient there)
                         fin = op["proj_final"] if "raw_from" in op else op["final"]
@@ -622,6 +719,11 @@ def run_backward(net, dfeat, saved, hook=True):
         wo, wn, bo, bn = lay[lid]
         out.append(flat[wo:wo + wn].view_as(conv.weight) if conv.weight.requires_grad else None)
         out.append(flat[bo:bo + bn] if conv.bias.requires_grad else None)
+    for lid in net._train_bn_ids():
+        bnm = getattr(net, lid + "_bn")
+        dgamma, dbeta = bn_grads[lid]
+        out.append(dgamma if bnm.weight.requires_grad else None)
+        out.append(dbeta if bnm.bias.requires_grad else None)
     return out, flat
 
 

@@ -61,6 +61,8 @@ def parse():
                     help="videos in the CPU-oracle sample (default: the full config-2 batch, 4 videos = 32 proposals; "
                          "0 disables the cpu_baseline leg)")
     ap.add_argument("--cpu-baseline-reps", type=int, default=3, help="timed repetitions of the CPU sample (median)")
+    ap.add_argument("--bn-mode", default="frozen", choices=["frozen", "partial", "full"],
+                    help="ssn_opts.py --bn_mode; 'frozen' is the reference's default and the configuration of the headline metric")
     ap.add_argument("--precision", default="split", choices=["split", "f32"],
                     help="matrix path of the 1x1/3x3 convolutions: per-tensor scaled 2-way f16 split, 3 products on the "
                          "f16 MFMA (fp32-class error, default) or the exact-f32 MFMA for every layer")
@@ -305,7 +307,7 @@ def main():
         pkg.build()
     v = args.videos_per_gpu
     torch.manual_seed(1234 + rank)
-    model = SSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1), base_model=args.arch)
+    model = SSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1), base_model=args.arch, bn_mode=args.bn_mode)
     frame = args.frame_size or model.input_size
     init_backbone_synthetic(model.base_model)  # same weights on every rank (same seed)
     init_heads_synthetic(model, std=0.001)
@@ -541,7 +543,7 @@ def main():
                    "collectives": (args.collectives if use_dist else "none"),
                    "ranks": (dist.get_world_size() if use_dist else 1),
                    "backend": ({"nccl": "nccl (RCCL over xGMI)"}.get(backend, backend) if use_dist else None),
-                   "layout": model.base_model.layout,
+                   "layout": model.base_model.layout, "bn_mode": args.bn_mode,
                    "conv_precision": ("fp32 parameters / features / gradients; every convolution multiply = 3 f16-MFMA products of "
                                       "per-tensor power-of-two-scaled 2-way f16 operand splits (22 of 24 significand bits per "
                                       "operand, fp32 accumulation: fp32-class error, tests/test_kernels.py K-sweep), the 7x7 "
@@ -647,10 +649,10 @@ def main():
         # ---------------- HBM-bound kernels of the path (STPP, heads, row selection, losses): achieved GB/s ----------
         if prof is not None and hbm_prof:
             hk = {}
-            for name, nbytes, s_, e_ in hbm_prof:
+            for name, nbytes, s_, e_, reps in hbm_prof:
                 h = hk.setdefault(name, [0, 0.0, 0])
                 h[0] += nbytes
-                h[1] += s_.elapsed_time(e_)
+                h[1] += s_.elapsed_time(e_) / reps
                 h[2] += 1
             out_h = {}
             for name, (nbytes, ms, n) in sorted(hk.items()):
@@ -661,7 +663,9 @@ def main():
             tot_b = sum(h[0] for h in hk.values())
             tot_ms = sum(h[1] for h in hk.values())
             result["hbm_kernels"] = {"peak_gbps": HBM_PEAK_GBPS, "note": "algorithmic bytes (operands + results) / HIP-event "
-                                     "duration per launch; these launches move <= 5 MB each and are latency-bound",
+                                     "duration per launch (each launch repeated %d x back to back inside its event pair: a pair around "
+                                     "one 2-5 us launch reads its own 15-25 us granularity); these launches move <= 5 MB each and are "
+                                     "latency-bound" % K_.HBM_PROFILER_REPEATS,
                                      "total_ms_per_step": round(tot_ms / args.steps, 4),
                                      "total_gbps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1) if tot_ms else None,
                                      "kernels": out_h}
@@ -671,7 +675,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import ssn_oracle as O
             cv = args.cpu_baseline_videos
-            oracle = O.OracleSSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1), base_model=args.arch)
+            oracle = O.OracleSSN(args.num_class, 2, 5, 2, args.modality, dropout=0.8, stpp_cfg=(1, 1, 1), base_model=args.arch,
+                                 bn_mode=args.bn_mode)
             sd = {k: t.detach().cpu() for k, t in model.state_dict().items()}
             oracle.load_state_dict(sd)
             oracle.train()

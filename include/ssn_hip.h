@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define SSN_ERR_WORKSPACE (-3)
 
 const char* ssn_last_error(void);
-int ssn_abi_version(void);   /* 6 */
+int ssn_abi_version(void);   /* 7 */
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
@@ -135,6 +135,16 @@ int ssn_conv_x6_pack_weights_multi(int count, const float* const* w0, const floa
                                    const float* const* w3, float* const* out, const int* cout, const int* cin,
                                    const int* ksize, const int* mode, const int* split, const int* split2,
                                    const int* split3, hipStream_t stream);
+/* Batched packing: every ssn_conv_x6_pack_* call between _begin and _end only RECORDS its entries; _end issues all of them in three
+ * launches (clear the amax tails, max |w| per entry, pack) through a device-resident plan.  plan: >= ssn_conv_x6_pack_batch_entries()
+ * * ssn_conv_x6_pack_entry_bytes() bytes of device memory the caller keeps from step to step; it is rewritten (ceil(entries / 40)
+ * small launches) only when the recorded entries differ from the ones last written there, or with force_write (a buffer the caller
+ * has just allocated).  _abort drops an open batch.  One batch at a time per process (one process per GPU). */
+int ssn_conv_x6_pack_batch_begin(void);
+int ssn_conv_x6_pack_batch_entries(void);
+long ssn_conv_x6_pack_entry_bytes(void);
+void ssn_conv_x6_pack_batch_abort(void);
+int ssn_conv_x6_pack_batch_end(void* plan, long plan_bytes, int force_write, hipStream_t stream);
 int ssn_conv_x6_fwd(const float* x, const float* w_packed, const float* scale, const float* shift, float* y, int N,
                     int Cin, int H, int W, long x_img_stride, int Cout, int Ho, int Wo, long y_img_stride,
                     int ksize, int stride, int pad, int relu, int x_guard_bytes, int tile_cfg, const float* x_amax,
@@ -505,6 +515,22 @@ int ssn_pl_gap_bwd(const float* dy, void* dx_hi, void* dx_lo, long dx_img_groups
 long ssn_pl_channel_sum_workspace_bytes(int C);
 int ssn_pl_channel_sum(const void* g_hi, const void* g_lo, long g_img_groups, float* out, int N, int C, int HW,
                        const float* g_scale, void* workspace, long ws_bytes, hipStream_t stream);
+/* training-mode BatchNorm2d (+ ReLU) on planes slices (csrc/planes_bn.hip): bn_mode 'partial' / 'full' of ssn_models.py:95-105,
+ * 156-174 on the planes executor; the mathematics of ssn_bn_train_* above.  C a multiple of 8; z is the convolution output WITHOUT
+ * its bias; mean / invstd / running statistics / dgamma / dbeta in real units.  bwd: y_hi = HIGH plane of the layer's output (the
+ * ReLU decision; NULL: no ReLU); dz goes to the planes slice (dz_hi, dz_lo) or, with dz_f32, to an fp32 NCHW tensor. */
+long ssn_pl_bn_train_workspace_bytes(int C);
+int ssn_pl_bn_train_stats(const void* z_hi, const void* z_lo, long z_img_groups, const float* z_scale, const float* conv_bias,
+                          float* mean, float* invstd, float* running_mean, float* running_var, int N, int C, int HW, float eps,
+                          float momentum, void* workspace, long ws_bytes, hipStream_t stream);
+int ssn_pl_bn_train_apply(const void* z_hi, const void* z_lo, long z_img_groups, const float* z_scale, void* y_hi, void* y_lo,
+                          long y_img_groups, const float* y_scale, float* y_amax, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, int relu, int N, int C, int HW, hipStream_t stream);
+int ssn_pl_bn_train_bwd(const void* dy_hi, const void* dy_lo, long dy_img_groups, const float* dy_scale, const void* y_hi,
+                        long y_img_groups, const void* z_hi, const void* z_lo, long z_img_groups, const float* z_scale,
+                        const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dz_hi,
+                        void* dz_lo, long dz_img_groups, const float* dz_scale, float* dz_amax, float* dz_f32,
+                        long dz_f32_img_stride, int N, int C, int HW, void* workspace, long ws_bytes, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,43 @@ def test_inceptionv3_backward_emulated(emu):
     assert total == sum(p.numel() for n, p in prod.named_parameters() if "_bn" not in n and "top_cls" not in n)
 
 
+@pytest.mark.slow_emu
+@pytest.mark.skipif(os.environ.get("SSN_SLOW") != "1", reason="~10 min through the host emulator; set SSN_SLOW=1")
+@pytest.mark.parametrize("which", ["six_layers", "partial"])
+def test_inceptionv3_training_bn_on_planes_emulated(which, emu):
+    """Training-mode BatchNorm2d layers of Inception-v3 on the planes executor (planes_bn.hip; the plain plan with its average
+    pools in front of their projections for a mixed set, the fused plan for bn_mode 'partial'): three 75x75 images against the
+    oracle in float64 with the same modules in training mode."""
+    from action_detection_amd.inceptionv3 import InceptionV3
+    torch.manual_seed(0)
+    prod = InceptionV3(num_classes=10, input_size=75)
+    init_backbone_synthetic(prod, negative_gamma_frac=0.25)
+    orc = O.OracleInceptionV3(num_classes=10)
+    orc.load_state_dict(prod.state_dict())
+    prod.eval()
+    prod.debug_keep_saved = True
+    train = {"six_layers": ("conv_1a_3x3", "mixed_5b_5x5", "mixed_6b_1x7", "mixed_6a_3x3", "mixed_7b_3x3_3x1", "mixed_5c_pool_proj"),
+             "partial": ("conv_1a_3x3",)}[which]
+    for lid in train:
+        getattr(prod, lid + "_bn").train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (3, 3, 75, 75), generator=g).float() - 110.0
+    w = torch.randn(3, 2048, generator=g)
+    ferr, errs, cpu = _backbone_grads(prod, orc, x, w, with_cpu=True)
+    saved = prod._last_saved[0]
+    assert len(saved) == 7 and set(saved[5]["bnstat"]) == set(train), "the planes executor must have taken the plan"
+    # (batch statistics over 3 images x 1 pixel at the last stage are ill-conditioned: the yardstick is torch's own fp32 path against
+    # the same float64 referee, as in the 299 x 299 GPU test below)
+    keys = [k for k in errs if k not in [lid + ".bias" for lid in train]]
+    e, ec = torch.tensor([errs[k] for k in keys]), torch.tensor([cpu[k] for k in keys])
+    worst = max(keys, key=lambda k: errs[k])
+    print("  %s: feature error %.2e, gradients median %.2e max %.2e (%s) | torch fp32 CPU median %.2e max %.2e"
+          % (which, ferr, e.median(), e.max(), worst, ec.median(), ec.max()))
+    assert ferr < 1e-4
+    assert len(errs) == 2 * 94 + 2 * len(train)
+    assert e.median() <= 3.0 * ec.median() + 1e-5 and e.max() <= max(2.0 * ec.max(), 2e-2)
+
+
 @pytest.mark.gpu
 def test_inceptionv3_backbone_backward_gpu(hip_library):
     """299x299, 4 images: features and every conv gradient against the oracle in float64 (distribution criterion of

@@ -396,3 +396,113 @@ def test_planes_pools(backend):
     _two_pass(lambda: P.gap_bwd(backend.put(dfeat), P.pfull(dxp), mask=P.pfull(actp), mask_scale=backend.put(msc)), dxp)
     refg = (dfeat.double() / (h * h)).view(n, c, 1, 1) * (act > 0).double() * msc.double().view(1, -1, 1, 1)
     assert rel_err(P.to_f32(dxp), refg) < 1e-6
+
+
+def test_planes_bn_train(backend):
+    """Training-mode BatchNorm2d + ReLU on planes slices (csrc/planes_bn.hip) against float64 autograd of F.batch_norm: statistics,
+    running statistics, output, dgamma / dbeta, dz as planes and as fp32 NCHW; slices inside wider tensors."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(6, 64, 28), (3, 24, 9)] if backend.is_gpu else [(3, 16, 6), (2, 24, 5)]
+    for (n, c, h) in shapes:
+        for relu in (True, False):
+            # |mean| several sigma on some channels (the pivoted variance), a conv bias that only the running mean sees.  (A planes
+            # tensor carries 22 bits below ITS maximum: the bounds below are relative to that, as for every kernel of this layout)
+            z = torch.randn(n, c, h, h, generator=g) * (torch.rand(c, generator=g) * 3 + 0.5).view(1, -1, 1, 1) \
+                + (torch.randn(c, generator=g) * 4).view(1, -1, 1, 1)
+            bias = torch.randn(c, generator=g)
+            gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+            gamma[1] = -gamma[1]
+            rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+            eps, mom = 1e-5, 0.1
+            zd = z.double().requires_grad_()
+            gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+            rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+            pre = F.batch_norm(zd + bias.double().view(1, -1, 1, 1), rm_ref, rv_ref, gd, bd, True, mom, eps)
+            ref = F.relu(pre) if relu else pre
+            # the slice sits at channel 8 of a wider planes tensor (image stride != slice size)
+            zt = P.PlaneTensor(n, c + 16, h, h, backend.device).zero_()
+            zs = P.PSlice(zt, 8, c)
+            zfull = torch.zeros(n, c + 16, h, h)
+            zfull[:, 8:8 + c] = z
+            P.from_f32(backend.put(zfull), zt)
+            mean, invstd = backend.put(torch.empty(c)), backend.put(torch.empty(c))
+            rmd, rvd = backend.put(rm.clone()), backend.put(rv.clone())
+            ws = backend.put(torch.empty(P.bn_train_workspace_bytes(c) // 4))
+            P.bn_train_stats(zs, backend.put(bias), mean, invstd, rmd, rvd, eps, mom, ws)
+            bm = z.double().mean(dim=(0, 2, 3))
+            bv = z.double().var(dim=(0, 2, 3), unbiased=False)
+            assert (mean.cpu().double() - bm).abs().max() < z.abs().max() * 2.0 ** -21
+            assert rel_err(invstd, 1.0 / (bv + eps).sqrt()) < 5e-6
+            assert rel_err(rmd, rm_ref) < 1e-6 and rel_err(rvd, rv_ref) < 2e-6
+            yt = P.PlaneTensor(n, c + 8, h, h, backend.device).zero_()
+            ys = P.PSlice(yt, 0, c)
+            _two_pass(lambda: P.bn_train_apply(zs, ys, mean, invstd, backend.put(gamma), backend.put(beta), relu), yt)
+            assert rel_err(P.to_f32(ys), ref) < 1e-5, ("bn apply", n, c, h, relu)
+            # backward
+            gy = torch.randn(ref.shape, generator=g) * 1e-2
+            ref.backward(gy.double())
+            gp = P.from_f32(backend.put(gy))
+            dgm, dbt = backend.put(torch.empty(c)), backend.put(torch.empty(c))
+            dzt = P.PlaneTensor(n, c + 8, h, h, backend.device).zero_()
+            dzs = P.PSlice(dzt, 8, c)
+            _two_pass(lambda: P.bn_train_bwd(P.pfull(gp), ys, zs, mean, invstd, backend.put(gamma), dgm, dbt, dzs, ws, relu), dzt)
+            assert rel_err(dgm, gd.grad) < 1e-5 and rel_err(dbt, bd.grad) < 1e-5, ("bn bwd params", n, c, h, relu)
+            assert rel_err(P.to_f32(dzs), zd.grad) < 2e-5, ("bn bwd dz", n, c, h, relu)
+            dz32 = K.attach_amax(backend.put(torch.full((n, c, h, h), 7.0)))
+            P.bn_train_bwd(P.pfull(gp), ys, zs, mean, invstd, backend.put(gamma), dgm, dbt, dz32, ws, relu)
+            assert rel_err(dz32, zd.grad) < 2e-5, ("bn bwd dz fp32", n, c, h, relu)
+            assert abs(float(dz32._ssn_amax) - float(zd.grad.abs().max())) <= 1e-4 * float(zd.grad.abs().max())
+
+
+def test_batched_weight_packing_is_bit_identical(backend):
+    """kernels.PackBatch: the packing calls of a pass recorded and issued in three launches through a device-resident plan give the
+    very bytes the separate calls give -- fused pairs, dgrad operands, stride-2 parity sections, rectangular taps, the stem's
+    space-to-depth operand, more entries than one kernel-argument table holds (40) -- and keep doing so when the batch repeats with
+    the same buffers (plan not rewritten) and after the weights changed in place."""
+    g = torch.Generator().manual_seed(21)
+
+    def rnd(*shape):
+        return backend.put(torch.randn(*shape, generator=g) * 0.1)
+    sq = [([rnd(24, 16, 3, 3)], 0), ([rnd(16, 8, 1, 1), rnd(8, 8, 1, 1)], 0), ([rnd(32, 16, 1, 1), rnd(16, 16, 1, 1), rnd(8, 16, 1, 1)], 0)]
+    sq += [([rnd(8 + 8 * (i % 3), 16, 1, 1)], i % 2) for i in range(45)]
+    dg = [([rnd(24, 16, 3, 3)], 1), ([rnd(16, 24, 1, 1), rnd(8, 24, 1, 1)], 1)]
+    rect = [rnd(16, 8, 1, 7), rnd(8, 16, 5, 5), rnd(24, 8, 3, 1)]
+    s2 = rnd(16, 24, 3, 3)
+    stem = rnd(16, 3, 7, 7)
+
+    def run_all():
+        outs = list(K.pack_weights_multi(sq, x6=True)) + list(K.pack_weights_multi(dg, x6=True))
+        outs += list(K.pack_rect_multi(rect)) + list(K.pack_rect_multi(rect, dgrad=True))
+        outs += [K.pack_dgrad_s2(s2), K.pack_dgrad_rect(rect[0]), K.pack_weights_rect(K.s2d_weights(stem))]
+        return outs
+    ref = [t.clone() for t in run_all()]
+    state = {}
+    for rep in range(3):
+        with K.PackBatch(state, backend.device):
+            got = run_all()
+        assert len(got) == len(ref)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), ("entry", i, "repeat", rep)
+        if rep == 0:
+            ptrs = [t.data_ptr() for t in got]
+        else:
+            assert ptrs == [t.data_ptr() for t in got], "operand buffers must repeat (the plan is keyed on them)"
+        for t in got:
+            t.fill_(7.0)      # (a repeat must rewrite everything)
+    # weights updated in place (an optimizer step): same plan, new contents
+    for ws, _ in sq + dg:
+        for w in ws:
+            w.mul_(-1.5)
+    s2.add_(0.01)
+    ref2 = [t.clone() for t in run_all()]
+    with K.PackBatch(state, backend.device):
+        got = run_all()
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(got, ref2))
+    # an exception inside the block drops the batch, the next one works
+    with pytest.raises(ZeroDivisionError):
+        with K.PackBatch(state, backend.device):
+            K.pack_dgrad_s2(s2)
+            1 / 0
+    with K.PackBatch({}, backend.device):
+        one = K.pack_dgrad_s2(s2)
+    assert torch.equal(one.view(torch.int32), K.pack_dgrad_s2(s2).view(torch.int32))
