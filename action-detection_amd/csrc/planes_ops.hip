@@ -585,6 +585,62 @@ __global__ __launch_bounds__(256) void pl_channel_sum_final_kernel(const float* 
     out[c] = s / *scale;
 }
 
+// several slices in one pair of launches (the bias gradients of all pool projections of a backward pass)
+constexpr int CSM_MAX = 24;
+struct ChannelSumTable {
+    const void* hi[CSM_MAX];
+    const void* lo[CSM_MAX];
+    const float* scale[CSM_MAX];
+    float* out[CSM_MAX];
+    long img_groups[CSM_MAX];
+    int HW[CSM_MAX];
+    int g0[CSM_MAX + 1];       // first channel group of the entry in the launch (prefix sums of G)
+    int N, count;
+};
+__global__ __launch_bounds__(256) void pl_channel_sum_multi_kernel(ChannelSumTable t, float* part) {
+    __shared__ float red[256][9];
+    int ti = 0;
+    while (ti + 1 < t.count && (int)blockIdx.x >= t.g0[ti + 1]) ++ti;
+    const int g = (int)blockIdx.x - t.g0[ti], share = blockIdx.y;
+    const int HW = t.HW[ti];
+    const long total = (long)t.N * HW;
+    const long per = (total + CS_SHARES - 1) / CS_SHARES;
+    const long begin = (long)share * per;
+    long end = begin + per;
+    if (end > total) end = total;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (long i = begin + threadIdx.x; i < end; i += 256) {
+        const long n = i / HW, q = i - n * HW;
+        float v[8];
+        load8(t.hi[ti], t.lo[ti], (n * t.img_groups[ti] + g) * HW + q, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + st][e];
+        __syncthreads();
+    }
+    const int GT = t.g0[t.count];
+    if (threadIdx.x < 8) part[((long)share * GT + blockIdx.x) * 8 + threadIdx.x] = red[0][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void pl_channel_sum_multi_final_kernel(ChannelSumTable t, const float* part) {
+    const int GT = t.g0[t.count];
+    const int c = blockIdx.x * 256 + threadIdx.x;       // channel of the launch (8 per group)
+    if (c >= GT * 8) return;
+    int ti = 0;
+    while (ti + 1 < t.count && (c >> 3) >= t.g0[ti + 1]) ++ti;
+    float s = 0.f;
+    for (int sh = 0; sh < CS_SHARES; ++sh) s += part[(long)sh * GT * 8 + c];
+    t.out[ti][c - 8 * t.g0[ti]] = s / *t.scale[ti];
+}
+
 int grid_for(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -830,6 +886,44 @@ extern "C" int ssn_pl_gap_bwd(const float* dy, void* dx_hi, void* dx_lo, long dx
 extern "C" long ssn_pl_channel_sum_workspace_bytes(int C) { return (long)CS_SHARES * ((C + 7) / 8) * 8 * (long)sizeof(float); }
 
 // out[c] = sum over images and pixels of a planes slice (fixed order: deterministic)
+// `count` slices (HOST arrays, one entry per slice; the same N) in ONE pair of launches; workspace:
+// ssn_pl_channel_sum_workspace_bytes(sum of C) bytes.  Same summation order per slice as ssn_pl_channel_sum: bit-identical results.
+extern "C" int ssn_pl_channel_sum_multi(int count, const void* const* g_hi, const void* const* g_lo, const long* g_img_groups,
+                                        float* const* out, int N, const int* C, const int* HW, const float* const* g_scale,
+                                        void* workspace, long ws_bytes, hipStream_t stream) {
+    SSN_CHECK_ARG(count >= 0 && (count == 0 || (g_hi && g_lo && g_img_groups && out && C && HW && g_scale && workspace)),
+                  "pl channel sum multi: bad arguments");
+    for (int base = 0; base < count; base += CSM_MAX) {
+        ChannelSumTable t;
+        t.count = count - base < CSM_MAX ? count - base : CSM_MAX;
+        t.N = N;
+        int groups = 0;
+        for (int i = 0; i < t.count; ++i) {
+            const int j = base + i;
+            SSN_CHECK_ARG(g_hi[j] && g_lo[j] && out[j] && g_scale[j] && C[j] > 0 && C[j] % 8 == 0 && HW[j] > 0,
+                          "pl channel sum multi: bad entry %d", j);
+            t.hi[i] = g_hi[j];
+            t.lo[i] = g_lo[j];
+            t.scale[i] = g_scale[j];
+            t.out[i] = out[j];
+            t.img_groups[i] = g_img_groups[j];
+            t.HW[i] = HW[j];
+            t.g0[i] = groups;
+            groups += C[j] / 8;
+        }
+        t.g0[t.count] = groups;
+        if (ws_bytes < ssn_pl_channel_sum_workspace_bytes(groups * 8)) {
+            ssn_set_error("pl channel sum multi: workspace too small");
+            return SSN_ERR_WORKSPACE;
+        }
+        hipLaunchKernelGGL(pl_channel_sum_multi_kernel, dim3(groups, CS_SHARES), dim3(256), 0, stream, t, (float*)workspace);
+        hipLaunchKernelGGL(pl_channel_sum_multi_final_kernel, dim3((groups * 8 + 255) / 256), dim3(256), 0, stream, t,
+                           (const float*)workspace);
+    }
+    SSN_CHECK_LAUNCH("pl_channel_sum_multi");
+    return SSN_OK;
+}
+
 extern "C" int ssn_pl_channel_sum(const void* g_hi, const void* g_lo, long g_img_groups, float* out, int N, int C, int HW,
                                   const float* g_scale, void* workspace, long ws_bytes, hipStream_t stream) {
     SSN_CHECK_ARG(g_hi && g_lo && out && g_scale && workspace && C % 8 == 0, "pl channel sum: bad arguments");

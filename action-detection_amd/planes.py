@@ -139,10 +139,11 @@ def _st(lib, t):
     return _stream(lib, t.data)
 
 
-def from_f32(x, dst=None, pool=None, s2d=False, exact=True):
+def from_f32(x, dst=None, pool=None, s2d=False, exact=True, amax=None):
     """fp32 NCHW tensor (or ChanSlice-like [N, C, H, W] contiguous tensor) -> planes.  exact: measure max |x| first and
     derive the scale from it (two passes: what the caller's frames and test inputs get); otherwise the destination's
-    current scale is used and its amax slot raised (the delayed protocol)."""
+    current scale is used and its amax slot raised (the delayed protocol).  amax (with exact): a one-element tensor that already
+    holds max |x| -- another kernel that read x left it there -- instead of the measuring pass."""
     from . import kernels as K
     n, c, h, w = x.shape
     if dst is None:
@@ -151,8 +152,11 @@ def from_f32(x, dst=None, pool=None, s2d=False, exact=True):
     sl = dst if isinstance(dst, PSlice) else pfull(dst)
     lib = _lib_for(t)
     if exact:
-        t.amax.zero_()
-        K.tensor_amax(x, t.amax)
+        if amax is not None:
+            t.amax.copy_(amax.reshape(t.amax.shape))
+        else:
+            t.amax.zero_()
+            K.tensor_amax(x, t.amax)
         t.pool.update(exact=True, first=t.slot, count=1)
         if t.scale_store is not t.pool.scale:
             t.scale_store[t.slot:t.slot + 1].copy_(t.pool.scale[t.slot:t.slot + 1])
@@ -316,6 +320,26 @@ def gap_bwd(dy, dx, mask=None, mask_scale=None):
     h, w = dx.hw
     lib.call("ssn_pl_gap_bwd", _p(dy), dx.hi, dx.lo, dx.groups, dx.n, dx.c, h * w, mask.hi if mask is not None else None,
              mask.groups if mask is not None else 0, _p(mask_scale), dx.t.scale_ptr, dx.t.amax_ptr, _st(lib, dx.t))
+
+
+def channel_sum_multi(entries, workspace):
+    """entries: [(g: PSlice, out: fp32 [C])] of one pass -> every out = per-channel sums of its slice, in one pair of launches."""
+    import ctypes
+    if not entries:
+        return
+    first = entries[0][0]
+    lib = _lib_for(first.t)
+    n = len(entries)
+    vp = ctypes.c_void_p * n
+    hi, lo = vp(*[g.hi for g, _ in entries]), vp(*[g.lo for g, _ in entries])
+    outs, scales = vp(*[_p(o) for _, o in entries]), vp(*[g.t.scale_ptr for g, _ in entries])
+    groups = (ctypes.c_long * n)(*[g.groups for g, _ in entries])
+    cs = (ctypes.c_int * n)(*[g.c for g, _ in entries])
+    hws = (ctypes.c_int * n)(*[g.hw[0] * g.hw[1] for g, _ in entries])
+    assert all(g.n == first.n for g, _ in entries)
+    lib.call("ssn_pl_channel_sum_multi", n, ctypes.addressof(hi), ctypes.addressof(lo), ctypes.addressof(groups),
+             ctypes.addressof(outs), first.n, ctypes.addressof(cs), ctypes.addressof(hws), ctypes.addressof(scales), _p(workspace),
+             workspace.numel() * workspace.element_size(), _st(lib, first.t))
 
 
 def bn_train_workspace_bytes(c):

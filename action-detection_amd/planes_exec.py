@@ -311,9 +311,11 @@ def run_forward(net, x, keep):
                     if "data_s2d" not in acts:
                         acts["data_s2d"] = PlaneTensor(n, 4 * cin, x.shape[2] // 2, x.shape[3] // 2, dev, st.pool,
                                                        st.slot("data_s2d", False), snap)
-                        P.from_f32(x, acts["data_s2d"], s2d=True, exact=True)
+                        measured = None
                         if keep:     # the stem's weight gradient runs on the fp32-layout kernel (3 real channels: see run_backward)
                             acts["data_s2d_f32"] = K.space_to_depth2(x)
+                            measured = acts["data_s2d_f32"]._ssn_amax      # (that pass over the frames also took their maximum)
+                        P.from_f32(x, acts["data_s2d"], s2d=True, exact=True, amax=measured)
                     src = P.pfull(acts["data_s2d"])
                     net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
                         PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, not raw, net._pl_tile("fwd", op, n, shapes)))
@@ -448,8 +450,11 @@ def run_backward(net, dfeat, saved, hook=True):
     def ws_of(op):
         o, nb = ws_off[op["lids"][0]]
         return ws_all[o // 4:(o + nb) // 4]
-    cs_ws = torch.empty(P.channel_sum_workspace_bytes(max(op["cout"] for op in plan if op["kind"] == "conv")) // 4, device=dev,
-                        dtype=torch.float32)
+    # (the bias sums of the projections in front of their pools are deferred with the reductions and issued together: the scratch
+    # holds all of them)
+    cs_ws = torch.empty(P.channel_sum_workspace_bytes(sum(op["cout"] for op in plan if op["kind"] == "conv" and
+                                                           (op.get("raw") or "raw_from" in op)) + 8) // 4,
+                        device=dev, dtype=torch.float32)
 
     dg_s2 = {op["lids"][0]: _dgrad_is_s2(op) for op in plan if op["kind"] == "conv" and op["src"] != "data"}
     packed_dg = extras["packed_dg"]      # (packed with the forward operands: the weights the forward saw)
@@ -479,8 +484,8 @@ def run_backward(net, dfeat, saved, hook=True):
             if pending_reduce:       # (timed with the weight-gradient family it belongs to: bench.py's roofline_detail)
                 entries = list(pending_reduce)
                 net._timed("conv_wgrad_pl", "reduce_multi", 0.0, lambda: P.wgrad_reduce_multi(entries))
-            for fn in pending_sums:
-                fn()
+            if pending_sums:
+                P.channel_sum_multi(list(pending_sums), cs_ws)
             del pending_reduce[:], pending_sums[:]
         defer = pending_reduce if net.defer_wgrad_reduce else None
 
@@ -627,12 +632,11 @@ def run_backward(net, dfeat, saved, hook=True):
                         fin = op["proj_final"] if "raw_from" in op else op["final"]
                         cp = cout - op.get("raw_from", 0)
 
-                        def bias_sum(fin=fin, cp=cp, db=db, r0=op.get("raw_from", 0)):
-                            P.channel_sum(PSlice(grads[fin[0]], fin[1], cp), db[r0:], cs_ws)
+                        entry = (PSlice(grads[fin[0]], fin[1], cp), db[op.get("raw_from", 0):])
                         if defer is not None:
-                            pending_sums.append(bias_sum)
+                            pending_sums.append(entry)
                         else:
-                            bias_sum()
+                            P.channel_sum_multi([entry], cs_ws)
                 net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
                 if op["src"] != "data":
                     wt = packed_dg[lids[0]]

@@ -515,6 +515,11 @@ int ssn_pl_gap_bwd(const float* dy, void* dx_hi, void* dx_lo, long dx_img_groups
 long ssn_pl_channel_sum_workspace_bytes(int C);
 int ssn_pl_channel_sum(const void* g_hi, const void* g_lo, long g_img_groups, float* out, int N, int C, int HW,
                        const float* g_scale, void* workspace, long ws_bytes, hipStream_t stream);
+/* count slices of one pass in ONE pair of launches (host arrays; the same N; workspace: ssn_pl_channel_sum_workspace_bytes(sum C));
+ * per slice bit-identical to ssn_pl_channel_sum. */
+int ssn_pl_channel_sum_multi(int count, const void* const* g_hi, const void* const* g_lo, const long* g_img_groups, float* const* out,
+                             int N, const int* C, const int* HW, const float* const* g_scale, void* workspace, long ws_bytes,
+                             hipStream_t stream);
 /* training-mode BatchNorm2d (+ ReLU) on planes slices (csrc/planes_bn.hip): bn_mode 'partial' / 'full' of ssn_models.py:95-105,
  * 156-174 on the planes executor; the mathematics of ssn_bn_train_* above.  C a multiple of 8; z is the convolution output WITHOUT
  * its bias; mean / invstd / running statistics / dgamma / dbeta in real units.  bwd: y_hi = HIGH plane of the layer's output (the

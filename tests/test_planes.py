@@ -387,6 +387,16 @@ def test_planes_pools(backend):
     ws = backend.put(torch.empty(P.channel_sum_workspace_bytes(c) // 4))
     P.channel_sum(P.pfull(gz), out, ws)
     assert rel_err(out, refm.sum(dim=(0, 2, 3))) < 2e-6
+    # several slices in one pair of launches: bit-identical to the single-slice calls
+    wide = P.from_f32(backend.put(torch.randn(n, c + 24, 5, 5, generator=g)))
+    ent = [(P.pfull(gz), backend.put(torch.empty(c))), (P.PSlice(wide, 8, 16), backend.put(torch.empty(16))),
+           (P.PSlice(wide, 24, c), backend.put(torch.empty(c)))]
+    wsm = backend.put(torch.empty(P.channel_sum_workspace_bytes(2 * c + 16) // 4))
+    P.channel_sum_multi(ent, wsm)
+    for sl, got in ent:
+        one = backend.put(torch.empty(sl.c))
+        P.channel_sum(sl, one, ws)
+        assert torch.equal(got, one)
     feat = backend.put(torch.empty(n, c))
     P.gap_fwd(P.pfull(zp), feat)
     assert rel_err(feat, z.double().mean(dim=(2, 3))) < 1e-6
