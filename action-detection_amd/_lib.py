@@ -114,7 +114,7 @@ _SIGS = {
     "ssn_pl_gap_fwd": "pplpiiipp",
     "ssn_pl_gap_bwd": "pppliiiplpppp",
     "ssn_pl_channel_sum": "pplpiiipplp",
-    "ssn_pl_channel_sum_multi": "ippppippplp",
+    "ssn_pl_channel_sum_multi": "ippppipppplp",
     "ssn_conv_x6_pack_batch_begin": "",
     "ssn_conv_x6_pack_batch_end": "plip",
     "ssn_pl_bn_train_stats": "pplpppppp" + "iiiffplp",

@@ -288,3 +288,26 @@ def test_proposal_sampler_matches_reference_dataset():
             assert np.array_equal(rel, np.array(t["rel"])) and np.array_equal(pticks, np.array(t["ticks"]))
             assert np.array_equal(scaling, np.array(t["scaling"]))
         assert s.all_gt() == e["all_gt"]
+
+
+def test_ctypes_signatures_agree_with_the_header():
+    """Every entry of _lib._SIGS (the argument types ctypes converts with) against the prototype of that function in
+    include/ssn_hip.h: same count, pointers / ints / longs / floats in the same places.  (A missing trailing 'p' once passed the
+    emulator -- its stream argument is NULL -- and truncated the stream handle on the GPU.)"""
+    import re
+    from action_detection_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ssn_hip.h")).read(), flags=re.S)
+    protos = dict(re.findall(r"\b(?:int|long|void|size_t)\s+(ssn_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S))
+    kinds = {"int": "i", "long": "l", "float": "f", "double": "d", "size_t": "l", "unsigned long long": "l", "unsigned": "i"}
+
+    def code(arg):
+        arg = arg.strip()
+        if arg in ("void", ""):
+            return ""
+        if "*" in arg or "hipStream_t" in arg:
+            return "p"
+        return kinds[arg.rsplit(" ", 1)[0].replace("const ", "").strip()]
+    for name, sig in _lib._SIGS.items():
+        assert name in protos, "no prototype for %s in include/ssn_hip.h" % name
+        want = "".join(code(a) for a in protos[name].split(","))
+        assert sig.replace("u", "l") == want, (name, sig, want)
