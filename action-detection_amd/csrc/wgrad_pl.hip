@@ -818,9 +818,11 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
     a.x_grp_bytes = (uint32_t)xg;
     a.g_img_bytes = (uint32_t)(g_img_groups * gg);
     a.x_img_bytes = (uint32_t)(x_img_groups * xg);
-    // the descriptors end with the TENSORS (a fragment may reach past the slice: rows / columns that are never stored)
-    a.g_bytes = (uint32_t)gb;
-    a.x_bytes = (uint32_t)xb;
+    // the descriptors end with the SLICES in the last image (a fragment may reach past the slice -- rows / columns that are never
+    // stored: in earlier images it reads the neighbouring channels, behind the last image it must read nothing: a slice at the end
+    // of its tensor would otherwise be over-read past the allocation)
+    a.g_bytes = (uint32_t)((long)(N - 1) * a.g_img_bytes + (long)((Cout + g_row_gap + 7) / 8) * gg);
+    a.x_bytes = (uint32_t)((long)(N - 1) * a.x_img_bytes + (long)((Cin + 7) / 8) * xg);
     a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
     a.div_w = make_fastdiv((uint32_t)Wo);
     // tile_cfg >= 200: the chunked 1x1 kernel with tile tile_cfg - 200

@@ -242,6 +242,7 @@ def test_conv_pl_wgrad(backend):
         if (kh, kw, s, ph, pw) == (1, 1, 1, 0, 0):
             tiles += [200, 201, 202, 203]     # the chunked 1x1 kernel's tiles
         for tile in tiles:
+            print("  wgrad case", (n, cin, h, wd, cout, kh, kw, s, ph, pw), "tile", tile, flush=True)
             ws = backend.put(torch.empty(P.wgrad_workspace_bytes(n, cin, cout, ho, wo, kh, kw, tile) // 4))
             dw, db = backend.put(torch.full(w.shape, 9.0)), backend.put(torch.full((cout,), 9.0))
             P.conv_wgrad(P.PSlice(gt, 8, cout), P.PSlice(xt, 8, cin), dw, db, kh, kw, s, ph, pw, ws, tile)
