@@ -147,15 +147,21 @@ class GradReducer:
 
     # --- heads
     def head_parameters(self):
+        """The parameters whose gradients do not live in the backbone's flat buffer: the three heads, and -- bn_mode 'partial' /
+        'full' -- gamma / beta of the BatchNorm2d layers SSN.train() leaves in training mode (ssn_models.py:156-174)."""
         ps = []
         for name in ("activity_fc", "completeness_fc", "regressor_fc"):
             fc = getattr(self.model, name, None)
             if fc is not None:
                 ps.extend(p for p in fc.parameters() if p.grad is not None)
+        base = getattr(self.model, "base_model", None)
+        for lid in (base._train_bn_ids() if hasattr(base, "_train_bn_ids") else ()):
+            bn = getattr(base, lid + "_bn")
+            ps.extend(p for p in (bn.weight, bn.bias) if p.grad is not None)
         return ps
 
     def reduce_heads(self):
-        """Average the head gradients (call after loss.backward())."""
+        """Average the gradients outside the flat buffer -- heads, training-mode BatchNorm parameters (call after loss.backward())."""
         if self.world == 1 and not self.force:
             return
         ps = self.head_parameters()

@@ -29,6 +29,14 @@ def _worker(rank, world, port, ret):
     class FakeBackbone(torch.nn.Module):
         grad_ready_hook = None
 
+        def __init__(self):
+            super().__init__()
+            self.conv1_bn = torch.nn.BatchNorm2d(4)      # bn_mode 'partial': its gamma / beta have gradients of their own
+            self.conv2_bn = torch.nn.BatchNorm2d(4)      # frozen: never touched
+
+        def _train_bn_ids(self):
+            return ["conv1"]
+
     class FakeModel(torch.nn.Module):
         def __init__(self):
             super().__init__()
@@ -53,7 +61,9 @@ def _worker(rank, world, port, ret):
     for p in model.parameters():
         p.grad = torch.full_like(p, float(rank + 1))
     red.reduce_heads()
-    ok2 = all(torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2.0)) for p in model.parameters())
+    frozen = [model.base_model.conv2_bn.weight, model.base_model.conv2_bn.bias]
+    ok2 = all(torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2.0 if not any(p is q for q in frozen) else float(rank + 1)))
+              for p in model.parameters())      # heads + the training-mode BatchNorm's gamma / beta averaged, nothing else touched
 
     # (2) loss semantics: shard 4 videos over 2 ranks vs the gathered batch
     rng = np.random.RandomState(3)
