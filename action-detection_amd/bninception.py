@@ -496,6 +496,17 @@ class BNInception(nn.Module):
             return -1
         return tab.get(key, -1)
 
+    def _pl_split(self, kind, op, n, shapes):
+        """Optional split of a forward / dgrad launch by images (tuned table, "splits": key -> [n1, tile of the tail]): images [0, n1)
+        run with the launch's tuned tile and fill whole rounds of workgroup slots, images [n1, n) run as a second launch on a smaller
+        tile instead of leaving most slots of a last round empty.  None: one launch (no table entry, another batch size)."""
+        kh, kw = op.get("kh", op["k"]), op.get("kw", op["k"])
+        key = "%s|%d|%d|%d|%d|%d|%d" % (kind, op["cin"], op["cout"], kh, kw, op["s"], shapes[op["src"]][1])
+        ent = _TUNED_PL.get("splits", {}).get(key)
+        if not ent or n != _TUNED_PL.get("n_images", 0) or not 0 < ent[0] < n:
+            return None
+        return int(ent[0]), int(ent[1])
+
     def export_decisions(self):
         """The discrete decisions of the last forward (debug_keep_saved = True; one chunk): ({layer id: bool [N, C, H, W] = "the
         ReLU behind this layer passed the element" as the BACKWARD of this executor sees it}, {pool id: int64 [N, C, Ho, Wo] =

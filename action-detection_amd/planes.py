@@ -124,6 +124,35 @@ class PSlice:
         return self.t.g
 
 
+    def images(self, n0, n1):
+        """The same channels of images [n0, n1) only (a launch on a sub-range of the batch)."""
+        return PImages(self, n0, n1)
+
+
+class PImages(PSlice):
+    """Images [n0, n1) of a PSlice: same tensor / scale / amax slots, plane pointers moved to image n0, n = n1 - n0."""
+
+    def __init__(self, base, n0, n1):
+        assert 0 <= n0 < n1 <= base.t.n
+        self.t, self.c0, self.c = base.t, base.c0, base.c
+        self.n0, self.n1 = int(n0), int(n1)
+
+    def _off(self):
+        return self.n0 * self.t.g * self.t.h * self.t.w * 16
+
+    @property
+    def hi(self):
+        return self.t.plane_ptr(0, self.c0) + self._off()
+
+    @property
+    def lo(self):
+        return self.t.plane_ptr(1, self.c0) + self._off()
+
+    @property
+    def n(self):
+        return self.n1 - self.n0
+
+
 def pfull(t):
     return PSlice(t, 0, t.c)
 

@@ -208,6 +208,15 @@ def _pool_out(h, k, s, p):
     return o
 
 
+def _image_parts(net, kind, op, n, shapes):
+    """[(first image, end image, tile)] of a forward / dgrad launch: one part, or bulk + tail (BNInception._pl_split)."""
+    tile = net._pl_tile(kind, op, n, shapes)
+    split = net._pl_split(kind, op, n, shapes)
+    if split is None:
+        return [(0, n, tile)]
+    return [(0, split[0], tile), (split[0], n, split[1])]
+
+
 def _dgrad_is_s2(op):
     return len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3 and op["s"] == 2
 
@@ -327,9 +336,13 @@ def run_forward(net, x, keep):
                         src = PSlice(acts["data"], 0, acts["data"].g * 8)
                     else:
                         src = PSlice(acts[op["src"]], op["src_c0"], cin)
-                    net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
-                        src, wp, scale, shift, dst, kh, kw, op["s"], ph, pw, not raw, net._pl_tile("fwd", op, n, shapes),
-                        raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0)))
+                    parts = _image_parts(net, "fwd", op, n, shapes)
+
+                    def run_fwd():
+                        for n0, n1, tcfg in parts:
+                            P.conv_fwd(src.images(n0, n1), wp, scale, shift, dst.images(n0, n1), kh, kw, op["s"], ph, pw, not raw, tcfg,
+                                       raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0))
+                    net._timed("conv_fwd_pl", op["lids"][0], flops, run_fwd)
             elif op["kind"] == "pool" and op["pool"] == "avg":
                 c = op["c"]
                 P.avgpool_affine(PSlice(acts[op["src"]], 0, c), PSlice(get(op["dst"]), op["dst_c0"], c), None, None, False,
@@ -650,9 +663,14 @@ def run_backward(net, dfeat, saved, hook=True):
                                    lambda: P.conv_dgrad_s2(gs, wt, dx, op["p"], acc_flag, tcfg, mask=my, mask_scale=ms))
                     else:
                         # (a fused block-input launch reads its rows behind the split k_gap channels further up dy's tensor)
-                        net._timed("conv_dgrad_pl", lids[0], flops, lambda: P.conv_dgrad(
-                            gs, wt, dx, kh, kw, ph, pw, acc_flag, tcfg, mask=my, mask_scale=ms, k_split=op.get("row_split", 0),
-                            k_gap=op.get("row_gap", 0), taps_reversed=op["rect"]))
+                        parts = _image_parts(net, "dgrad", op, n, shapes)
+
+                        def run_dgrad():
+                            for n0, n1, tc in parts:
+                                P.conv_dgrad(gs.images(n0, n1), wt, dx.images(n0, n1), kh, kw, ph, pw, acc_flag, tc,
+                                             mask=my.images(n0, n1) if my is not None else None, mask_scale=ms,
+                                             k_split=op.get("row_split", 0), k_gap=op.get("row_gap", 0), taps_reversed=op["rect"])
+                        net._timed("conv_dgrad_pl", lids[0], flops, run_dgrad)
                     inited.add(key)
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
