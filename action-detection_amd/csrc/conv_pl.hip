@@ -65,6 +65,8 @@ struct PlConvArgs {
     unsigned long long* trace;   // tooling only: per-block phase timestamps (tools/ablate_conv_pl.py), normally null
     int dbg;                     // tooling only: ablation switches (1: no B fetch, 2: no A fetch, 4: no fragment reads, 8: no stores)
     FastDiv div_hw, div_w, div_mt;
+    // conv_pl9_kernel with per-image tiles (the last member: the offsets of everything above are those of the verified kernels)
+    FastDiv div_tpi;             // tiles per image = ceil(H W / BN)
 };
 
 // tooling build only (tools/build_trace_lib.sh: -DPL_ABLATE): runtime ablation switches; compiled out of the product
@@ -327,7 +329,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     SSN_WAIT_VMCNT(0);   // the out-of-range tail pieces still write (zeros) into the ring the epilogue is about to reuse
     if (p.trace) tr2 = __builtin_readcyclecounter();
 
+#define PL_PEND p.P
 #include "conv_pl_epilogue.inc"
+#undef PL_PEND
     if (p.trace && tid == 0) {
         unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
         t[0] = tr0;
@@ -359,7 +363,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
 //     per-slab vmcnt constant); the halo of a group that does not exist is fetched as zeros (the dead slab of an odd slab count);
 //   * everything else -- A ring, two fragment register sets, one barrier per slab, epilogue -- is conv_pl_kernel's.
 // dgrad of such a layer is the same kernel with the tap displacement mirrored (MODE_DGRAD) on the transposed packed operand.
-template <int MODE, int WM, int WN, int TM, int TN>
+// PI ("per image"): pixel tiles do not cross images -- tile t of image n covers pixels [n H W + t BN, min(+ BN, (n + 1) H W)) -- so that a
+// tile's slot span stays BN + a few rows whatever the image size (a 128-pixel tile across two 56 x 56 images spans 371 slots; inside
+// one image 253): the last tile of an image is partly empty (56 x 56: 2 % of the pixels enumerated).
+template <int MODE, int WM, int WN, int TM, int TN, bool PI = false>
 __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(PlConvArgs p) {
     constexpr int NW = 4;
     constexpr int NT = 256;
@@ -393,7 +400,15 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
     uint32_t ptile, mtile;
     fd_divmod(logical, p.div_mt, ptile, mtile);
     const int m0 = (int)mtile * BM;
-    const int p0 = (int)ptile * BN;
+    int p0 = (int)ptile * BN;
+    [[maybe_unused]] int pl_pend = 0;      // PI: first pixel this tile must not touch (otherwise p.P is read where it is needed, as before)
+    if constexpr (PI) {
+        uint32_t img, t;
+        fd_divmod(ptile, p.div_tpi, img, t);
+        const int hw = p.H * p.W;
+        p0 = (int)img * hw + (int)t * BN;
+        pl_pend = ((int)img + 1) * hw < p.P ? ((int)img + 1) * hw : p.P;
+    }
     const int Wp = p.W + 2;
     const int SPs = (p.H + 2) * Wp;
 
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pp = p0 + (wn * TN + j) * 32 + li;
-        bcen[j] = HALO0 + lh * HROW + ((pp < p.P ? slot_of(pp) - ubase : Wp + 1)) * 4;      // (dwords; lh = the k-half row)
+        bcen[j] = HALO0 + lh * HROW + ((pp < (PI ? pl_pend : p.P) ? slot_of(pp) - ubase : Wp + 1)) * 4;      // (dwords; lh = the k-half row)
     }
 
     struct Frags {
@@ -592,7 +607,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
     SSN_WAIT_LGKM0();
     SSN_WAIT_VMCNT(0);
 
+#define PL_PEND (PI ? pl_pend : p.P)
 #include "conv_pl_epilogue.inc"
+#undef PL_PEND
 }
 #undef PL_DMA_B128
 
@@ -640,17 +657,49 @@ int launch_tile(PlConvArgs& a, int cfg, hipStream_t stream) {
     return SSN_ERR_ARG;
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool PI = false>
 int launch_cfg9(PlConvArgs& a, hipStream_t stream) {
     constexpr int BM = WM * TM * 32;
     constexpr int BN = WN * TN * 32;
     a.n_mtiles = (a.M + BM - 1) / BM;
     a.div_mt = make_fastdiv((uint32_t)a.n_mtiles);
-    a.n_ptiles = (a.P + BN - 1) / BN;
+    if (PI) {
+        const int tpi = (a.H * a.W + BN - 1) / BN;
+        a.div_tpi = make_fastdiv((uint32_t)tpi);
+        a.n_ptiles = a.N * tpi;
+    } else {
+        a.div_tpi = make_fastdiv(1u);
+        a.n_ptiles = (a.P + BN - 1) / BN;
+    }
     const unsigned nblk = (unsigned)a.n_ptiles * (unsigned)a.n_mtiles;
-    hipLaunchKernelGGL((conv_pl9_kernel<MODE, WM, WN, TM, TN>), dim3(nblk), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_pl9_kernel<MODE, WM, WN, TM, TN, PI>), dim3(nblk), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("conv_pl9");
     return SSN_OK;
+}
+// per-image tiles: the 128-pixel tiles that run two workgroups per CU
+bool halo_tile_pi(int cfg) { return cfg == 0 || cfg == 1 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9; }
+template <int MODE>
+int launch_tile9_pi(PlConvArgs& a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_cfg9<MODE, 2, 2, 2, 2, true>(a, stream);
+        case 1: return launch_cfg9<MODE, 2, 2, 1, 2, true>(a, stream);
+        case 4: return launch_cfg9<MODE, 2, 2, 3, 2, true>(a, stream);
+        case 7: return launch_cfg9<MODE, 1, 4, 3, 1, true>(a, stream);
+        case 8: return launch_cfg9<MODE, 1, 4, 5, 1, true>(a, stream);
+        case 9: return launch_cfg9<MODE, 1, 4, 1, 1, true>(a, stream);
+    }
+    ssn_set_error("conv_pl9: tile config %d has no per-image haloed variant", cfg);
+    return SSN_ERR_ARG;
+}
+// does every BN-pixel tile INSIDE an H x W image span at most `hs` padded slots?
+bool halo_fits_pi(int H, int W, int bn, int hs) {
+    const int Wp = W + 2;
+    auto slot = [&](int q) { return (q / W + 1) * Wp + (q % W) + 1; };
+    for (int p0 = 0; p0 < H * W; p0 += bn) {
+        const int p1 = p0 + bn - 1 < H * W - 1 ? p0 + bn - 1 : H * W - 1;
+        if (slot(p1) - slot(p0) + 2 * (Wp + 1) + 1 > hs) return false;
+    }
+    return true;
 }
 // haloed variants exist for the tiles of 64 / 128 pixels that run two workgroups per CU
 bool halo_tile(int cfg) { return cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 7 || cfg == 8 || cfg == 9 || cfg == 11; }
@@ -686,8 +735,19 @@ bool halo_fits(int N, int H, int W, int bn, int hs) {
 // tile_cfg >= 32 asks for the haloed kernel with tile tile_cfg - 32; layers it does not take (not 3x3 / stride 1 / pad 1 / same size,
 // a tile without a haloed variant, a tile whose slot span exceeds the LDS budget) run the plain kernel with that tile
 constexpr int PL_HALO_BASE = 32;
+constexpr int PL_HALO_PI_BASE = 48;      // tile_cfg 48 + c: the haloed kernel with per-image tiles of shape c
+inline int plain_tile(int cfg) { return cfg >= PL_HALO_PI_BASE ? cfg - PL_HALO_PI_BASE : (cfg >= PL_HALO_BASE ? cfg - PL_HALO_BASE : cfg); }
 template <int MODE>
 int launch_any(PlConvArgs& a, int cfg, bool halo_layer, hipStream_t stream) {
+    if (cfg >= PL_HALO_PI_BASE) {
+        cfg -= PL_HALO_PI_BASE;
+        if (halo_layer && cfg < PL_NCFG && halo_tile_pi(cfg) && halo_fits_pi(a.H, a.W, 128, 320)) {
+            a.magic_wp = (uint32_t)((0x100000000ull + (unsigned)(a.W + 2) - 1) / (unsigned)(a.W + 2));
+            a.div_sp = make_fastdiv((uint32_t)((a.H + 2) * (a.W + 2)));
+            return launch_tile9_pi<MODE>(a, cfg, stream);
+        }
+        return launch_tile<MODE>(a, cfg < PL_NCFG ? cfg : 0, stream);
+    }
     if (cfg >= PL_HALO_BASE) {
         cfg -= PL_HALO_BASE;
         if (halo_layer && cfg < PL_NCFG && halo_tile(cfg) && halo_fits(a.N, a.H, a.W, kPlBN[cfg], kPlBN[cfg] == 128 ? 320 : 192)) {
@@ -783,6 +843,10 @@ int fill_common(PlConvArgs& a, const void* x_hi, const void* x_lo, const uint32_
 extern "C" int ssn_conv_pl_tiles(void) { return PL_NCFG; }
 // 1 when tile_cfg (>= 32) runs the haloed kernel on a 3x3 / stride 1 / pad 1 layer of N x H x W pixels, 0 when it falls back
 extern "C" int ssn_conv_pl_halo_taken(int N, int H, int W, int tile_cfg) {
+    if (tile_cfg >= PL_HALO_PI_BASE) {
+        const int c = tile_cfg - PL_HALO_PI_BASE;
+        return c < PL_NCFG && halo_tile_pi(c) && halo_fits_pi(H, W, 128, 320);
+    }
     const int cfg = tile_cfg - PL_HALO_BASE;
     return cfg >= 0 && cfg < PL_NCFG && halo_tile(cfg) && halo_fits(N, H, W, kPlBN[cfg], kPlBN[cfg] == 128 ? 320 : 192);
 }
@@ -864,7 +928,7 @@ extern "C" int ssn_conv_pl_dgrad(const void* dy_hi, const void* dy_lo, const flo
         // gradient is then the forward correlation of dy with it, padding k - 1 - pad
         a.pad_h = kh - 1 - pad_h;
         a.pad_w = kw - 1 - pad_w;
-        return launch_tile<MODE_FWD>(a, cfg >= PL_HALO_BASE ? cfg - PL_HALO_BASE : cfg, stream);
+        return launch_tile<MODE_FWD>(a, plain_tile(cfg), stream);
     }
     const bool halo_layer = kh == 3 && kw == 3 && pad_h == 1 && pad_w == 1 && Ho == H && Wo == W && !k_gap;
     return launch_any<MODE_DGRAD>(a, cfg, halo_layer, stream);
@@ -911,7 +975,7 @@ extern "C" int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const 
             a.mask_bytes = (uint32_t)((long)(N - 1) * a.mask_img_bytes + (long)(Cin / 8) * yg);
         }
         int cfg = tile_cfg >= 0 ? tile_cfg : (g_pl_default_tile >= 0 ? g_pl_default_tile : default_tile(Cin, a.P));
-        if (cfg >= PL_HALO_BASE) cfg -= PL_HALO_BASE;
+        cfg = plain_tile(cfg);
         rc = launch_tile<MODE_FWD>(a, cfg, stream);
         if (rc != SSN_OK) return rc;
         off += (long)a.ngroups * kh * kw * Cin * APITCH + 4;

@@ -454,7 +454,8 @@ int ssn_pl_to_f32(const void* hi, const void* lo, long img_groups, float* y, lon
  * stride 1 / 2; raw_from / row_split / row_gap as ssn_conv_x6_fwd (fused launch on an Inception block input).  tile_cfg < 0: the
  * heuristic; 0 .. ssn_conv_pl_tiles() - 1: that tile; 32 + c: the haloed kernel with tile c on 3x3 / stride 1 / pad 1 layers (each
  * input pixel is staged once per channel group instead of once per tap; ssn_conv_pl_halo_taken says whether the launch takes it,
- * a layer or tile it does not fit runs the plain kernel with tile c). */
+ * a layer or tile it does not fit runs the plain kernel with tile c); 48 + c: the same with pixel tiles that do not cross images (the
+ * 56 x 56 layer: a 128-pixel tile across two images does not fit the halo buffer; prepared in round 4, not yet measured). */
 int ssn_conv_pl_fwd(const void* x_hi, const void* x_lo, const float* w_packed, const float* scale, const float* shift, void* y_hi,
                     void* y_lo, int N, int Cin, int H, int W, long x_img_groups, int Cout, int Ho, int Wo, long y_img_groups, int kh,
                     int kw, int stride, int pad_h, int pad_w, int relu, int tile_cfg, const float* x_scale, const float* y_scale,

@@ -100,6 +100,14 @@ CASES_GPU = [
 
 
 HALO_TILES = [32 + c for c in (0, 1, 2, 3, 4, 7, 8, 9, 11)]
+# the haloed kernel with per-image tiles (tile_cfg 48 + c): prepared for the 56 x 56 layer, not selected by any committed table and not
+# yet run on a GPU -- the emulator tier covers it, the GPU tier only with SSN_TEST_EXPERIMENTAL=1
+HALO_PI_TILES = [48 + c for c in (0, 1, 4, 7, 8, 9)]
+
+
+def _experimental(backend):
+    import os
+    return (not backend.is_gpu) or os.environ.get("SSN_TEST_EXPERIMENTAL") == "1"
 
 
 def _pack_fwd(w, backend):
@@ -128,6 +136,8 @@ def test_conv_pl_forward(backend):
         tiles = list(range(ntiles)) if ci == 0 else [-1]
         if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1):
             tiles += HALO_TILES if (ci == 0 or backend.is_gpu) else [32, 36]      # the haloed 3x3 kernel (tile 32 + c)
+            if _experimental(backend):
+                tiles += HALO_PI_TILES if (ci == 0 or backend.is_gpu) else [48, 55]
         for tile in tiles:
             if tile >= 32:      # (on the GPU cases some tiles span more slots than the halo buffer, e.g. 128 pixels across two 56 x 56 images: plain kernel)
                 taken = action_detection_amd._lib.get_lib().cdll.ssn_conv_pl_halo_taken(n, h, wd, tile)
@@ -196,6 +206,8 @@ def test_conv_pl_dgrad(backend):
         gp = P.from_f32(backend.put(gy))
         dx = P.PlaneTensor(n, cin, h, wd, backend.device)
         halo = (HALO_TILES if (backend.is_gpu or not halo_done) else [32, 36]) if (kh, kw, ph, pw) == (3, 3, 1, 1) else []
+        if halo and _experimental(backend):
+            halo = halo + (HALO_PI_TILES if (backend.is_gpu or not halo_done) else [48, 52])
         halo_done = halo_done or bool(halo)      # (emulator: every haloed tile on the first 3x3 case, two of them on the others)
         for tile in [-1] + halo:
             dx.data.fill_(3.0)
@@ -520,3 +532,30 @@ def test_batched_weight_packing_is_bit_identical(backend):
     with K.PackBatch({}, backend.device):
         one = K.pack_dgrad_s2(s2)
     assert torch.equal(one.view(torch.int32), K.pack_dgrad_s2(s2).view(torch.int32))
+
+
+def test_conv_pl_halo_per_image_tiles_at_56(emu):
+    """The layer the per-image tiling of the haloed kernel is for: 3x3 / pad 1 at 56 x 56 (conv2), where a 128-pixel tile that crosses an
+    image does not fit the halo buffer (tile_cfg 32 + c falls back to the plain kernel) and a tile inside one image does (48 + c)."""
+    lib = action_detection_amd._lib.get_lib()
+    assert lib.cdll.ssn_conv_pl_halo_taken(2, 56, 56, 32) == 0 and lib.cdll.ssn_conv_pl_halo_taken(2, 56, 56, 48) == 1      # (N = 2: a crossing exists)
+    g = torch.Generator().manual_seed(31)
+    n, cin, cout, h = 1, 16, 40, 56
+    x = torch.randn(n, cin, h, h, generator=g, dtype=torch.float64).requires_grad_()
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    y = F.conv2d(x, w.double(), None, 1, 1)
+    gy = torch.randn(y.shape, generator=g) * 1e-3
+    y.backward(gy.double())
+    dev = torch.device("cpu")
+    xp = P.from_f32(x.detach().float())
+    wp = _pack_fwd(w, type("B", (), {"put": staticmethod(lambda t: t)}))
+    wt = K.pack_weights_multi([([w], 1)], x6=True)[0]
+    gp = P.from_f32(gy)
+    one, zero = torch.ones(cout), torch.zeros(cout)
+    for tile in (48, 55):
+        yt = P.PlaneTensor(n, cout, h, h, dev)
+        _two_pass(lambda: P.conv_fwd(P.pfull(xp), wp, one, zero, P.pfull(yt), 3, 3, 1, 1, 1, False, tile), yt)
+        assert rel_err(P.to_f32(yt), y) < 3e-6, ("fwd", tile)
+        dx = P.PlaneTensor(n, cin, h, h, dev)
+        _two_pass(lambda: P.conv_dgrad(P.pfull(gp), wt, P.pfull(dx), 3, 3, 1, 1, tile_cfg=tile), dx)
+        assert rel_err(P.to_f32(dx), x.grad) < 3e-6, ("dgrad", tile)

@@ -103,8 +103,8 @@ def main():
             else:
                 xc, xh, k_, s_, p_ = cin, hin, kh, s, ph
             rect = (kh != kw) or kh not in (1, 3, 7)
-            halo = [32 + c for c in range(nfwd) if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1)
-                    and lib.cdll.ssn_conv_pl_halo_taken(n, hin, hin, 32 + c) == 1]      # the haloed 3x3 kernel
+            halo = [b + c for b in (32, 48) for c in range(nfwd) if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1)
+                    and lib.cdll.ssn_conv_pl_halo_taken(n, hin, hin, b + c) == 1]      # the haloed 3x3 kernel (48 + c: per-image tiles)
             if os.environ.get("HALO_ONLY") and not halo:
                 continue
             x = torch.randn(n, xc, xh, xh, generator=g).clamp(min=0).to(dev)
