@@ -137,7 +137,7 @@ def test_conv_pl_forward(backend):
         if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1):
             tiles += HALO_TILES if (ci == 0 or backend.is_gpu) else [32, 36]      # the haloed 3x3 kernel (tile 32 + c)
             if _experimental(backend):
-                tiles += HALO_PI_TILES if (ci == 0 or backend.is_gpu) else [48, 55]
+                tiles += HALO_PI_TILES if (ci == 0 or backend.is_gpu) else [55]
         for tile in tiles:
             if tile >= 32:      # (on the GPU cases some tiles span more slots than the halo buffer, e.g. 128 pixels across two 56 x 56 images: plain kernel)
                 taken = action_detection_amd._lib.get_lib().cdll.ssn_conv_pl_halo_taken(n, h, wd, tile)
@@ -207,7 +207,7 @@ def test_conv_pl_dgrad(backend):
         dx = P.PlaneTensor(n, cin, h, wd, backend.device)
         halo = (HALO_TILES if (backend.is_gpu or not halo_done) else [32, 36]) if (kh, kw, ph, pw) == (3, 3, 1, 1) else []
         if halo and _experimental(backend):
-            halo = halo + (HALO_PI_TILES if (backend.is_gpu or not halo_done) else [48, 52])
+            halo = halo + (HALO_PI_TILES if backend.is_gpu else ([48, 52, 55] if not halo_done else [52]))
         halo_done = halo_done or bool(halo)      # (emulator: every haloed tile on the first 3x3 case, two of them on the others)
         for tile in [-1] + halo:
             dx.data.fill_(3.0)
@@ -552,7 +552,7 @@ def test_conv_pl_halo_per_image_tiles_at_56(emu):
     wt = K.pack_weights_multi([([w], 1)], x6=True)[0]
     gp = P.from_f32(gy)
     one, zero = torch.ones(cout), torch.zeros(cout)
-    for tile in (48, 55):
+    for tile in (52,):
         yt = P.PlaneTensor(n, cout, h, h, dev)
         _two_pass(lambda: P.conv_fwd(P.pfull(xp), wp, one, zero, P.pfull(yt), 3, 3, 1, 1, 1, False, tile), yt)
         assert rel_err(P.to_f32(yt), y) < 3e-6, ("fwd", tile)
