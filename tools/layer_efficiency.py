@@ -8,7 +8,7 @@ CEILING_TF (the algorithmic rate of conv_pl's loop body at the clock the chip su
   last round    workgroup slots left empty in the last round of the launch (512 slots = 2 workgroups x 256 CUs; 1 for the big tiles)
   residual      everything else: per-workgroup prologue / epilogue, waits, clock below the control's
 
-    python tools/layer_efficiency.py [fwd|dgrad] [--top N]
+    python tools/layer_efficiency.py [fwd|dgrad|wgrad] [--top N]      (wgrad: measured time against the ceiling only)
 """
 import json
 import math
@@ -46,6 +46,12 @@ def main():
         if key not in table["tiles"] or (kind == "dgrad" and s == 2):      # (stride-2 dgrads: four parity-class launches)
             continue
         tile, ms = table["tiles"][key], table["ms"][key]
+        if kind == "wgrad":              # (split-K kernels: no tile-padding / round model here, time against the ceiling only)
+            flop = 2.0 * n * ho * ho * cin * cout * kh * kw
+            t_ideal = flop / (CEILING_TF * 1e12) * 1e3
+            rows.append(dict(key=key, tile=tile, ms=ms, tf=flop / ms / 1e9, ideal=t_ideal, pad=0.0, last=0.0, resid=ms - t_ideal, wgs=0,
+                             rounds=0))
+            continue
         if kind == "fwd":
             m, c, pix = cout, cin, n * ho * ho
         else:                            # dgrad: rows = input channels, reduction over output channels, pixels of the INPUT
