@@ -39,24 +39,28 @@ class SSNSGD(torch.optim.Optimizer):
         (``SSN.scale_fault_flag()``); while its first word is non-zero the launches leave weights and momentum untouched -- the
         range guard of the planes path flagged this step's gradients, the step is to be repeated (needed where the host cannot
         look before the update runs: inside a hipGraph replay)."""
-        batches = {}   # (momentum, first_step) -> lists
+        batches = {}   # momentum -> lists
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
                     continue
                 st = self.state[p]
-                first = "momentum_buffer" not in st
-                if first:
-                    st["momentum_buffer"] = torch.empty_like(p)
+                if "momentum_buffer" not in st:
+                    # ZERO-initialised, and every step takes the kernel's general branch: momentum * 0 + g is exactly the `buf = g`
+                    # torch.optim.SGD starts with (dampening 0), and -- unlike an uninitialised buffer with a host-side "first step"
+                    # marker -- it stays right when the device SKIPS this launch (skip_flag set by an earlier pass, by another rank
+                    # through the MAX-reduced word, or for a parameter whose first gradient arrives in a flagged step): the next
+                    # step then starts from zeros again instead of from whatever the allocation held
+                    st["momentum_buffer"] = torch.zeros_like(p)
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                b = batches.setdefault((g["momentum"], first), ([], [], [], [], []))
+                b = batches.setdefault(g["momentum"], ([], [], [], [], []))
                 b[0].append(p.data)
                 b[1].append(grad)
                 b[2].append(st["momentum_buffer"])
                 b[3].append(g["lr"])
                 b[4].append(g["weight_decay"])
-        for (momentum, first), (ws, grads, bufs, lrs, wds) in batches.items():
-            K.sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale, first, skip_flag)
+        for momentum, (ws, grads, bufs, lrs, wds) in batches.items():
+            K.sgd_step_multi(ws, grads, bufs, lrs, wds, momentum, grad_scale, False, skip_flag)
         return None
 
 

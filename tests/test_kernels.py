@@ -288,6 +288,42 @@ def test_sgd_and_norm(backend):
     assert rel_err(x, gr * 0.5) < 1e-7
 
 
+def test_sgd_first_step_skipped_by_the_fault_word(backend):
+    """SSNSGD when the FIRST step of a parameter is the one the device skips (skip_flag set: a flagged pass, another rank's fault
+    through the MAX-reduced word, a parameter whose first gradient arrives late): the momentum buffer must not hold garbage that the
+    next step multiplies by the momentum (it was torch.empty_like + a host-side first-step marker)."""
+    from action_detection_amd.optim import SSNSGD
+    g = torch.Generator().manual_seed(21)
+    w0 = [torch.randn(700, generator=g), torch.randn(33, 5, generator=g)]
+    grads = [[torch.randn(w.shape, generator=g) for w in w0] for _ in range(3)]
+    ref = [torch.nn.Parameter(w.clone()) for w in w0]
+    ropt = torch.optim.SGD(ref, lr=0.01, momentum=0.9, weight_decay=5e-4)
+    got = [torch.nn.Parameter(backend.put(w.clone())) for w in w0]
+    opt = SSNSGD([{"params": got, "lr_mult": 1, "decay_mult": 1, "name": "w"}], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    flag = backend.put(torch.ones(2, dtype=torch.int32))
+    # poison what a fresh allocation of the buffers' size would hand out (best effort: same-size blocks are recycled by the caching
+    # allocator on the GPU); with the fix the buffers are zero-filled whatever the allocation held
+    junk = [backend.put(torch.full(w.shape, float("nan"))) for w in w0]
+    del junk
+    for p_, gr in zip(got, grads[0]):
+        p_.grad = backend.put(gr.clone())
+    opt.step(skip_flag=flag)                                  # flagged: nothing may move
+    for p_, w in zip(got, w0):
+        assert torch.equal(p_.detach().cpu(), w)
+        assert torch.equal(opt.state[p_]["momentum_buffer"].cpu(), torch.zeros(w.shape))
+    flag.zero_()
+    for it in (1, 2):                                        # the two steps that are applied == torch's first two steps
+        for r, p_, gr in zip(ref, got, grads[it]):
+            r.grad = gr.clone()
+            p_.grad = backend.put(gr.clone())
+        ropt.step()
+        opt.step(skip_flag=flag)
+    for r, p_ in zip(ref, got):
+        assert torch.isfinite(p_.detach().cpu()).all()
+        assert rel_err(p_.detach(), r.detach()) < 1e-6
+        assert rel_err(opt.state[p_]["momentum_buffer"], ropt.state[r]["momentum_buffer"]) < 1e-6
+
+
 def test_clip_grad_norm(backend):
     """optim.clip_grad_norm (ssn_train.py:245-248) against torch.nn.utils.clip_grad_norm_, clipping and not clipping."""
     from action_detection_amd.optim import clip_grad_norm
