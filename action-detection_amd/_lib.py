@@ -106,6 +106,7 @@ _SIGS = {
     "ssn_conv_pl_dgrad": "pppppiiiiliiiliiiiiplpipppiiip",
     "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiipp",
     "ssn_wgrad_reduce_multi": "ipppppppp",
+    "ssn_conv_wgrad_pl_group": "ippppppppppplplp",
     "ssn_conv_pl_dgrad_s2": "pppppiiiiliiiliiplpipppp",
     "ssn_pl_maxpool_fwd": "pplpplpiiiiiiiiipppp",
     "ssn_pl_maxpool_bwd": "pplpppl" + "i" * 10 + "plpipppplp",
@@ -128,7 +129,7 @@ EXPORTS = sorted(list(_SIGS) + ["ssn_last_error", "ssn_abi_version", "ssn_conv_w
                                 "ssn_conv_pick_tile", "ssn_conv_packed_floats", "ssn_conv_x6_packed_floats", "ssn_conv_x6_packed_floats_rect", "ssn_conv_x6_packed_floats_dgrad_rect", "ssn_conv_wgrad_x6_rect_workspace_bytes", "ssn_conv_x6_dgrad_s2_packed_floats", "ssn_conv_x6_debug_flags", "ssn_conv_x6_debug_trace",
                                 "ssn_conv_wgrad_x6_workspace_bytes", "ssn_detections_workspace_bytes",
                                 "ssn_conv_debug_flags", "ssn_channel_sum_shares", "ssn_bn_train_workspace_floats",
-                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_halo_taken", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_pl_channel_sum_workspace_bytes", "ssn_pl_bn_train_workspace_bytes", "ssn_conv_x6_pack_batch_entries", "ssn_conv_x6_pack_entry_bytes", "ssn_conv_x6_pack_batch_abort", "ssn_frames_resize_workspace_bytes"])
+                                "ssn_conv_dgrad_layout", "ssn_conv_pl_tiles", "ssn_conv_pl_halo_taken", "ssn_conv_pl_debug_flags", "ssn_conv_pl_debug_trace", "ssn_conv_wgrad_pl_debug_trace", "ssn_conv_wgrad_pl_debug_flags", "ssn_conv_pl_tile_shape", "ssn_conv_wgrad_pl_tiles", "ssn_conv_wgrad_pl_workspace_bytes", "ssn_conv_wgrad_pl_group_workspace_bytes", "ssn_conv_wgrad_pl_group_table_bytes", "ssn_conv_wgrad_pl_group_tuning", "ssn_pl_channel_sum_workspace_bytes", "ssn_pl_bn_train_workspace_bytes", "ssn_conv_x6_pack_batch_entries", "ssn_conv_x6_pack_entry_bytes", "ssn_conv_x6_pack_batch_abort", "ssn_frames_resize_workspace_bytes"])
 
 
 class SsnLibrary:
@@ -171,6 +172,12 @@ class SsnLibrary:
         self.cdll.ssn_frames_resize_workspace_bytes.argtypes = [ctypes.c_int] * 3
         self.cdll.ssn_conv_wgrad_pl_workspace_bytes.restype = ctypes.c_long
         self.cdll.ssn_conv_wgrad_pl_workspace_bytes.argtypes = [ctypes.c_int] * 8
+        self.cdll.ssn_conv_wgrad_pl_group_workspace_bytes.restype = ctypes.c_long
+        self.cdll.ssn_conv_wgrad_pl_group_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.cdll.ssn_conv_wgrad_pl_group_table_bytes.restype = ctypes.c_long
+        self.cdll.ssn_conv_wgrad_pl_group_table_bytes.argtypes = [ctypes.c_int]
+        self.cdll.ssn_conv_wgrad_pl_group_tuning.restype = None
+        self.cdll.ssn_conv_wgrad_pl_group_tuning.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int]
         self._fn = {}
         for name, sig in _SIGS.items():
             fn = getattr(self.cdll, name)

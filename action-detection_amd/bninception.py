@@ -185,6 +185,14 @@ class BNInception(nn.Module):
         # planes_exec: every weight gradient keeps its split-K slabs in its own workspace region and ONE launch reduces them all at the
         # end of the pass (at every gradient-ready range with an overlapping reducer) instead of one launch per layer
         self.defer_wgrad_reduce = os.environ.get("SSN_DEFER_WGRAD_REDUCE", "1") != "0"
+        # planes_exec: ALL weight gradients of a backward pass as one grouped call (<= 4 launches over a device-resident problem table
+        # + one reduction, csrc/wgrad_pl.hip: ssn_conv_wgrad_pl_group) at the end of the pass -- or, with an overlapping gradient
+        # reducer, at every gradient-ready range -- instead of one launch (+ reduction) per layer; 0: per-layer launches
+        self.group_wgrad = os.environ.get("SSN_GROUP_WGRAD", "1") != "0"
+        if os.environ.get("SSN_GROUP_TUNING"):      # tooling: planner constants "fixed9,fixed1,min9,min1" (ssn_conv_wgrad_pl_group_tuning)
+            from . import _lib
+            f9, f1, m9, m1 = (os.environ["SSN_GROUP_TUNING"].split(",") + ["0"] * 4)[:4]
+            _lib.get_lib().cdll.ssn_conv_wgrad_pl_group_tuning(float(f9), float(f1), int(m9), int(m1))
         self.infer_cache = os.environ.get("SSN_INFER_CACHE", "1") != "0"   # planes_exec: packed weights / folded BN reused across no-grad forwards
         self.pooled_mask = os.environ.get("SSN_POOLED_MASK", "1") != "0"   # planes_exec: stem pools' backward reads the pooled sign
         # planes_exec: all weight operands of a pass packed in three launches through a device-resident plan (kernels.PackBatch)
@@ -496,17 +504,6 @@ class BNInception(nn.Module):
             return -1
         return tab.get(key, -1)
 
-    def _pl_split(self, kind, op, n, shapes):
-        """Optional split of a forward / dgrad launch by images (tuned table, "splits": key -> [n1, tile of the tail]): images [0, n1)
-        run with the launch's tuned tile and fill whole rounds of workgroup slots, images [n1, n) run as a second launch on a smaller
-        tile instead of leaving most slots of a last round empty.  None: one launch (no table entry, another batch size)."""
-        kh, kw = op.get("kh", op["k"]), op.get("kw", op["k"])
-        key = "%s|%d|%d|%d|%d|%d|%d" % (kind, op["cin"], op["cout"], kh, kw, op["s"], shapes[op["src"]][1])
-        ent = _TUNED_PL.get("splits", {}).get(key)
-        if not ent or n != _TUNED_PL.get("n_images", 0) or not 0 < ent[0] < n:
-            return None
-        return int(ent[0]), int(ent[1])
-
     def export_decisions(self):
         """The discrete decisions of the last forward (debug_keep_saved = True; one chunk): ({layer id: bool [N, C, H, W] = "the
         ReLU behind this layer passed the element" as the BACKWARD of this executor sees it}, {pool id: int64 [N, C, Ho, Wo] =
@@ -791,6 +788,19 @@ class BNInception(nn.Module):
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
             self._ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
         return self._ws
+
+    def _wgrad_group_buffers(self, jobs, dev):
+        """(workspace, table) of a grouped weight-gradient call: persistent buffers, grown on demand (planes_exec.run_backward)."""
+        from . import planes as P
+        ws_bytes, tb_bytes, _ = P.wgrad_group_plan(jobs)
+        bufs = self.__dict__.setdefault("_wg_group_bufs", {})
+        ws, tb = bufs.get(dev, (None, None))
+        if ws is None or ws.numel() * 4 < ws_bytes + 16:
+            ws = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
+        if tb is None or tb.numel() < tb_bytes:
+            tb = torch.empty(max(tb_bytes, 1 << 15), device=dev, dtype=torch.uint8)
+        bufs[dev] = (ws, tb)
+        return ws, tb
 
     def _run_backward(self, dfeat, saved, hook=True):
         if len(saved) == 7:      # a forward of the planes executor

@@ -114,6 +114,16 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 #ifndef SSN_LDS_PTR
 #define SSN_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #endif
+// A pointer to device memory that (a) holds the same bytes for the whole kernel and (b) is read at wave-uniform addresses, as a
+// CONSTANT-address-space pointer: the compiler then fetches through the scalar unit (s_load into SGPRs, like kernel arguments) instead
+// of copying the structure through VGPRs into scratch.  For device-resident problem tables that a previous launch wrote.
+#ifndef SSN_CONST_PTR
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SSN_CONST_PTR(T, p) ((const __attribute__((address_space(4))) T*)(p))
+#else
+#define SSN_CONST_PTR(T, p) ((const T*)(p))      /* (hipcc's host pass only parses the kernels) */
+#endif
+#endif
 #ifndef SSN_WAIT_VMCNT
 #define SSN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #endif

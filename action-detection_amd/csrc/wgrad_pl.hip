@@ -21,6 +21,10 @@
 // column is the product of the dY fragments with a fragment of ones (workgroups of the first input tile and tap only).
 #include "planes.h"
 
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 namespace {
 
 using namespace pl;
@@ -88,8 +92,17 @@ struct WgTrace {
 #define WG_DMA_B128(rsrc_, dst_, voff_, soff_) ((void)(dst_), (void)(voff_), (void)(soff_))
 #endif
 
+// LDS dwords of the one-tap body: a 3-slot ring of k-steps ([dY: frag][plane] then [X: frag][plane], 256 dwords per fragment-plane)
+// + the dummy piece the surplus DMA instructions of the narrower operand land in
 template <int WM, int WC, int TM, int TC>
-__global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(WgPlArgs p) {
+constexpr int wgpl_lds_dwords() {
+    return 3 * 2 * (WM * TM + WC * TC) * 256 + 256;
+}
+
+// The body of the one-tap kernel as a device function: `bid` = block id INSIDE the problem (the grid of a single-problem launch, or
+// the block's offset from its problem's first block in a grouped launch), `lds` = wgpl_lds_dwords() dwords, 1 KiB aligned.
+template <int WM, int WC, int TM, int TC>
+__device__ __forceinline__ void wgrad_pl_body(const WgPlArgs& p, const uint32_t bid, uint32_t* lds) {
     constexpr int BM = WM * TM * 32;
     constexpr int BC = WC * TC * 32;
     constexpr int FA = BM / 32, FB = BC / 32;     // fragments per k-step of dY / X
@@ -101,8 +114,7 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
     // this loop is not latency (tools/trace_wgrad_pl.py)
     constexpr int NSTAGE = 3;
     static_assert(WM * WC == 4, "4 waves");
-
-    __shared__ __attribute__((aligned(1024))) uint32_t lds[NSTAGE * STAGE + PIECE];   // + the dummy piece
+    static_assert(NSTAGE * STAGE + PIECE == wgpl_lds_dwords<WM, WC, TM, TC>(), "LDS size");
 
     const int tid = threadIdx.x;
     WgTrace trc;
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
     const int li = lane & 31, lh = lane >> 5;
 
     const uint32_t tiles = (uint32_t)p.n_mtiles * (uint32_t)p.n_ctiles * (uint32_t)(p.kh * p.kw);
-    const uint32_t logical = xcd_remap(blockIdx.x, tiles * (uint32_t)p.splits);
+    const uint32_t logical = xcd_remap(bid, tiles * (uint32_t)p.splits);
     uint32_t z, tile, mct, tap, mt, ct;
     fd_divmod(logical, p.div_tiles, z, tile);
     fd_divmod(tile, p.div_kk, mct, tap);
@@ -123,9 +135,13 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
     // ---- DMA role of this wave: operand (0 = dY, 1 = X) and plane ----
     const int op = wave >> 1, plane = wave & 1;
     const int myF = op ? FB : FA;
-    const __amdgpu_buffer_rsrc_t rsrc = op ? pl_rsrc(plane ? p.x_lo : p.x_hi, p.x_bytes) : pl_rsrc(plane ? p.g_lo : p.g_hi, p.g_bytes);
-    const uint32_t grp_bytes = op ? p.x_grp_bytes : p.g_grp_bytes;
-    const uint32_t img_bytes = op ? p.x_img_bytes : p.g_img_bytes;
+    // (fields read into values BEFORE the selects: `c ? p.a : p.b` on two fields is a select of ADDRESSES, which pins a problem that
+    // was loaded from a table -- the grouped kernels -- to scratch memory instead of registers)
+    const void *xh = p.x_hi, *xl = p.x_lo, *gh = p.g_hi, *gl = p.g_lo;
+    const uint32_t xbytes = p.x_bytes, gbytes = p.g_bytes, xgrp = p.x_grp_bytes, ggrp = p.g_grp_bytes, ximg = p.x_img_bytes, gimg = p.g_img_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = op ? pl_rsrc(plane ? xl : xh, xbytes) : pl_rsrc(plane ? gl : gh, gbytes);
+    const uint32_t grp_bytes = op ? xgrp : ggrp;
+    const uint32_t img_bytes = op ? ximg : gimg;
     const int dsl = lane >> 2;                                       // slot of the k-step this lane fetches
     const uint32_t lane_grp = (uint32_t)(lane & 3) * grp_bytes;      // its channel group inside a fragment
     // scalar byte offset of fragment f of this wave's operand (dY: rows behind the split sit g_row_gap channels further up)
@@ -303,6 +319,12 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
     trc.end(p);
 }
 
+template <int WM, int WC, int TM, int TC>
+__global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(WgPlArgs p) {
+    __shared__ __attribute__((aligned(1024))) uint32_t lds[wgpl_lds_dwords<WM, WC, TM, TC>()];
+    wgrad_pl_body<WM, WC, TM, TC>(p, blockIdx.x, lds);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 layers (two thirds of the weight-gradient work): ALL NINE TAPS in one workgroup.
 //
@@ -322,8 +344,15 @@ __global__ __launch_bounds__(256, (TM * TC >= 6) ? 1 : 2) void wgrad_pl_kernel(W
 // k-steps of every chunk between them (partial slabs z * 2 + group).  For the layers whose LDS footprint leaves room for one
 // workgroup per CU only: a lone wave per SIMD keeps the matrix pipe 45 % busy in this loop (nobody covers its LDS round
 // trips and DMA address arithmetic), two waves per SIMD 80 % (tools/trace_wgrad_pl.py).
+// LDS bytes of the chunked body: two buffers of [dY: frag][plane][64 slots][32 ch] + [X: frag][plane][XP * 16 slots][32 ch]
+template <int TM, int TC, int XP>
+constexpr int wgpl9_lds_bytes() {
+    return 2 * ((2 * TM) * 2 * 4 * 1024 + (2 * TC) * 2 * XP * 1024);
+}
+
+// (`bid`, `lds`: see wgrad_pl_body; wgpl9_lds_bytes() bytes, 1 KiB aligned)
 template <int KK, int TM, int TC, int XP, int KG = 1>
-__global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) void wgrad_pl9_kernel(WgPlArgs p) {
+__device__ __forceinline__ void wgrad_pl9_body(const WgPlArgs& p, const uint32_t bid, unsigned char* lds) {
     constexpr int NS = 64, KSC = NS / 16;
     constexpr int KSG = KSC / KG;                      // k-steps of a chunk per wave group
     static_assert(KK == 1 || KK == 9, "1x1 or 3x3");
@@ -334,7 +363,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
     constexpr int A_BYTES = FA * 2 * KSC * 1024;     // [frag][plane][64 slots][32 ch]
     constexpr int X_BYTES = FB * 2 * XP * 1024;      // [frag][plane][XP * 16 slots][32 ch]
     constexpr int STAGE = A_BYTES + X_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    static_assert(2 * STAGE == wgpl9_lds_bytes<TM, TC, XP>(), "LDS size");
 
     const int tid = threadIdx.x;
     WgTrace trc;
@@ -345,7 +374,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
     const int li = lane & 31, lh = lane >> 5;
 
     const uint32_t tiles = (uint32_t)p.n_mtiles * (uint32_t)p.n_ctiles;
-    const uint32_t logical = xcd_remap(blockIdx.x, tiles * (uint32_t)p.splits);
+    const uint32_t logical = xcd_remap(bid, tiles * (uint32_t)p.splits);
     uint32_t z, tile, mt, ct;
     fd_divmod(logical, p.div_tiles, z, tile);
     fd_divmod(tile, p.div_ct, mt, ct);
@@ -357,9 +386,13 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
 
     // ---- DMA role: operand (0 = dY, 1 = X) and plane ----
     const int op = wave >> 1, plane = wave & 1;
-    const __amdgpu_buffer_rsrc_t rsrc = op ? pl_rsrc(plane ? p.x_lo : p.x_hi, p.x_bytes) : pl_rsrc(plane ? p.g_lo : p.g_hi, p.g_bytes);
-    const uint32_t grp_bytes = op ? p.x_grp_bytes : p.g_grp_bytes;
-    const uint32_t img_bytes = op ? p.x_img_bytes : p.g_img_bytes;
+    // (fields read into values BEFORE the selects: `c ? p.a : p.b` on two fields is a select of ADDRESSES, which pins a problem that
+    // was loaded from a table -- the grouped kernels -- to scratch memory instead of registers)
+    const void *xh = p.x_hi, *xl = p.x_lo, *gh = p.g_hi, *gl = p.g_lo;
+    const uint32_t xbytes = p.x_bytes, gbytes = p.g_bytes, xgrp = p.x_grp_bytes, ggrp = p.g_grp_bytes, ximg = p.x_img_bytes, gimg = p.g_img_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = op ? pl_rsrc(plane ? xl : xh, xbytes) : pl_rsrc(plane ? gl : gh, gbytes);
+    const uint32_t grp_bytes = op ? xgrp : ggrp;
+    const uint32_t img_bytes = op ? ximg : gimg;
     const int dsl = lane >> 2;
     const uint32_t lane_grp = (uint32_t)(lane & 3) * grp_bytes;
     constexpr int NF = FA > FB ? FA : FB;
@@ -569,6 +602,88 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
     trc.end(p);
 }
 
+template <int KK, int TM, int TC, int XP, int KG = 1>
+__global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC >= 4) ? 1 : 2) void wgrad_pl9_kernel(WgPlArgs p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[wgpl9_lds_bytes<TM, TC, XP>()];
+    wgrad_pl9_body<KK, TM, TC, XP, KG>(p, blockIdx.x, lds);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// GROUPED launches: every weight gradient of a backward pass in <= 4 launches (+ one reduction).
+//
+// The weight gradients of a pass are mutually independent, and launched one by one each of them has to fill 256 CUs on its own:
+// split-K factors of 20 - 130, i.e. workgroups that run 8 - 12 chunks and then store a 150 KB partial slab (2.2 GB of slabs per
+// step at the bench batch, half of the family's time in ramps, prologues, epilogues and the reduction: profiles/r4_layer_efficiency.txt).
+// Here the problems of a pass are gathered in a DEVICE-RESIDENT TABLE and each kernel family runs ONE grid over all of its problems:
+//   * an item = (problem, output tile, share of the reduction range); the items of a problem are consecutive blocks, the problems
+//     are ordered longest item first, so the hardware's in-order block dispatch is a longest-first list schedule: slots freed by
+//     short items are refilled by the next problem's -- no ramp, no partly empty last round per layer;
+//   * the reduction range of a problem is split only as far as the WHOLE group needs to fill the slots a few times over
+//     (plan_group: item length ~ sqrt(2 x fixed cost x work per slot)): 3 - 5 x fewer partial slabs, the prologue / epilogue of a
+//     workgroup amortised over 3 - 5 x more chunks;
+//   * the bodies are the single-launch kernels' (wgrad_pl9_body / wgrad_pl_body), selected per problem by a wave-uniform switch;
+//     the partial slabs are reduced in the fixed order of ssn_wgrad_reduce_multi: deterministic, bit-identical from call to call.
+// Families (one launch each, only if it has problems): nine-tap 64 x 64 tiles with XP = 6 / 8 / 12 (rows <= 14 / <= 30 / <= 56
+// pixels; 80 / 96 / 128 KiB of LDS), and everything else (1x1, stride-2, rectangular taps) on the one-tap / chunked 1x1 bodies.
+constexpr int WGG_MAX = 96;             // problems per grouped launch (block -> problem search table travels by value)
+constexpr int WGG_WRITE = 12;           // table entries written per plan-write launch (by-value kernel arguments: < 4 KiB)
+struct WgGroupEntry {
+    WgPlArgs a;
+    int variant;                        // body selector inside the family
+    uint32_t nblk;                      // blocks of the problem (the blocks up to the next problem's first one exit)
+};
+struct WgGroupIndex {
+    int count;
+    int blk0[WGG_MAX + 1];              // first block of problem i (multiples of 8: the XCD remap of a problem keeps its meaning)
+};
+struct WgGroupChunk {
+    WgGroupEntry e[WGG_WRITE];
+    int count;
+};
+__global__ __launch_bounds__(64) void wgrad_group_write_kernel(WgGroupChunk c, WgGroupEntry* table, int first) {
+    if ((int)threadIdx.x < c.count) table[first + threadIdx.x] = c.e[threadIdx.x];
+}
+__device__ __forceinline__ int group_problem_of_block(const WgGroupIndex& ix, int b) {
+    int lo = 0, hi = ix.count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ix.blk0[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return wave_uniform(lo);
+}
+
+// nine-tap family: 64 x 64 tiles; KG = 2 where the LDS footprint leaves one workgroup per CU
+template <int XP, int KG>
+__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : 2) void wgrad_group9_kernel(const WgGroupEntry* __restrict__ table, WgGroupIndex ix) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[wgpl9_lds_bytes<1, 1, XP>()];
+    const int e = group_problem_of_block(ix, (int)blockIdx.x);
+    const uint32_t bid = blockIdx.x - (uint32_t)ix.blk0[e];
+    const auto* ent = SSN_CONST_PTR(WgGroupEntry, table) + e;      // (scalar loads: the problem lives in SGPRs like a kernel argument)
+    if (bid >= ent->nblk) return;
+    const WgPlArgs p = ent->a;
+    wgrad_pl9_body<9, 1, 1, XP, KG>(p, bid, lds);
+}
+
+// everything else: one-tap bodies 128 x 128 / 96 x 128 / 64 x 64 (any taps, stride, padding) and the chunked 1x1 body 64 x 64
+constexpr int WGG1_LDS = 65536;
+static_assert(wgpl_lds_dwords<2, 2, 2, 2>() * 4 <= WGG1_LDS && wgpl_lds_dwords<1, 4, 3, 1>() * 4 <= WGG1_LDS &&
+              wgpl_lds_dwords<2, 2, 1, 1>() * 4 <= WGG1_LDS && wgpl9_lds_bytes<1, 1, 4>() <= WGG1_LDS, "group LDS");
+__global__ __launch_bounds__(256, 2) void wgrad_group1_kernel(const WgGroupEntry* __restrict__ table, WgGroupIndex ix) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[WGG1_LDS];
+    const int e = group_problem_of_block(ix, (int)blockIdx.x);
+    const uint32_t bid = blockIdx.x - (uint32_t)ix.blk0[e];
+    const auto* ent = SSN_CONST_PTR(WgGroupEntry, table) + e;
+    if (bid >= ent->nblk) return;
+    const WgPlArgs p = ent->a;
+    switch (wave_uniform(ent->variant)) {
+        case 0: wgrad_pl_body<2, 2, 2, 2>(p, bid, reinterpret_cast<uint32_t*>(lds)); break;
+        case 1: wgrad_pl_body<1, 4, 3, 1>(p, bid, reinterpret_cast<uint32_t*>(lds)); break;
+        case 2: wgrad_pl_body<2, 2, 1, 1>(p, bid, reinterpret_cast<uint32_t*>(lds)); break;
+        default: wgrad_pl9_body<1, 1, 1, 4>(p, bid, lds); break;
+    }
+}
+
 #undef WG_DMA_B128
 #undef WG_RD_FRAG
 
@@ -735,6 +850,181 @@ int fix_cfg(int tile_cfg, int M, int Cin) {
 unsigned long long* g_wg_trace = nullptr;
 int g_wg_dbg = 0;
 
+// the shape / operand fields of a problem (everything but the tile and split plan)
+int fill_wgpl(WgPlArgs& a, const void* g_hi, const void* g_lo, const void* x_hi, const void* x_lo, int N, int Cin, int H, int W,
+              long x_img_groups, int Cout, int Ho, int Wo, long g_img_groups, int kh, int kw, int stride, int pad_h, int pad_w,
+              const float* g_scale, const float* x_scale, int g_row_split, int g_row_gap) {
+    SSN_CHECK_ARG(g_hi && g_lo && x_hi && x_lo && g_scale && x_scale, "conv wgrad pl: null pointer");
+    SSN_CHECK_ARG(Cout > 0 && Cin > 0 && kh >= 1 && kw >= 1 && (stride == 1 || stride == 2), "conv wgrad pl: bad shape");
+    SSN_CHECK_ARG(g_row_gap >= 0 && (g_row_gap == 0 || (g_row_split > 0 && g_row_split < Cout && g_row_split % 32 == 0 && g_row_gap % 8 == 0)),
+                  "conv wgrad pl: bad row split");
+    a.g_hi = g_hi;
+    a.g_lo = g_lo;
+    a.x_hi = x_hi;
+    a.x_lo = x_lo;
+    a.part = nullptr;
+    a.trace = g_wg_trace;
+    a.dbg = g_wg_dbg;
+    a.g_scale = g_scale;
+    a.x_scale = x_scale;
+    a.g_row_split = g_row_gap ? g_row_split : 0x7fffffff;
+    a.g_row_gap = g_row_gap;
+    a.N = N;
+    a.Cin = Cin;
+    a.H = H;
+    a.W = W;
+    a.M = Cout;
+    a.Ho = Ho;
+    a.Wo = Wo;
+    a.kh = kh;
+    a.kw = kw;
+    a.stride = stride;
+    a.pad_h = pad_h;
+    a.pad_w = pad_w;
+    a.K = Cin * kh * kw;
+    a.ldp = a.K + 1;
+    a.P = N * Ho * Wo;
+    const long gg = (long)Ho * Wo * 16, xg = (long)H * W * 16;
+    const long gb = (long)N * g_img_groups * gg, xb = (long)N * x_img_groups * xg;
+    SSN_CHECK_ARG(gb < (1l << 31) && xb < (1l << 31), "conv wgrad pl: operand plane larger than 2 GiB (buffer addressing)");
+    a.g_grp_bytes = (uint32_t)gg;
+    a.x_grp_bytes = (uint32_t)xg;
+    a.g_img_bytes = (uint32_t)(g_img_groups * gg);
+    a.x_img_bytes = (uint32_t)(x_img_groups * xg);
+    // the descriptors end with the SLICES in the last image (a fragment may reach past the slice -- rows / columns that are never
+    // stored: in earlier images it reads the neighbouring channels, behind the last image it must read nothing: a slice at the end
+    // of its tensor would otherwise be over-read past the allocation)
+    a.g_bytes = (uint32_t)((long)(N - 1) * a.g_img_bytes + (long)((Cout + g_row_gap + 7) / 8) * gg);
+    a.x_bytes = (uint32_t)((long)(N - 1) * a.x_img_bytes + (long)((Cin + 7) / 8) * xg);
+    a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
+    a.div_w = make_fastdiv((uint32_t)Wo);
+    a.magic_wp = 0;
+    a.splits = 1;
+    a.ksteps_per_split = 0;
+    a.n_mtiles = a.n_ctiles = 0;
+    a.div_tiles = a.div_ct = a.div_kk = make_fastdiv(1u);
+    return SSN_OK;
+}
+
+// ---- grouped launches (see wgrad_group9_kernel): host side ----
+// planner constants {nine-tap families, one-tap / chunked family}: fixed cost of an item in matrix-instruction slots of a wave
+// (prologue + first fetch + partial-slab store + its share of the reduction), fewest reduction units an item may have
+double g_group_fixed[2] = {450.0, 150.0};
+int g_group_min_units[2] = {4, 32};
+enum { WGF_9_XP6 = 0, WGF_9_XP8 = 1, WGF_9_XP12 = 2, WGF_1 = 3, WGF_COUNT = 4 };
+// one-tap / chunked variants of the WGF_1 family: tile (output x input channels), reduction units per item step, cost per unit
+const int kG1BM[4] = {128, 96, 64, 64};
+const int kG1BC[4] = {128, 128, 64, 64};
+struct WgGroupItem {
+    WgPlArgs a;
+    int family, variant;
+    long units;            // reduction range in the body's own units: k-steps (one-tap) or 64-slot chunks (chunked bodies)
+    double unit_cost;      // matrix instructions per wave and unit (what an item's length is measured in)
+    long tiles;            // output tiles (x taps for the one-tap bodies)
+    int kg;                // partial slabs per split
+    int taps;              // tap-major slabs (nine-tap bodies): 9, else 1
+    long ws_off;           // byte offset of the problem's slabs in the workspace
+    float* dw;
+    float* db;
+};
+// family + variant of a problem; hint: a single-launch tile_cfg (0, 3, 8: one-tap 64 x 64 / 128 x 128 / 96 x 128; 200: chunked 1x1) or -1
+int classify_group(WgGroupItem& it, int hint) {
+    WgPlArgs& a = it.a;
+    it.kg = 1;
+    it.taps = 1;
+    if (hint < 0 || (hint >= 100 && hint < 200)) {
+        if (nine_tap_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w, a.H, a.W, a.Ho, a.Wo)) {
+            const int xp = xp_for(a.W);
+            it.family = xp <= 6 ? WGF_9_XP6 : (xp <= 8 ? WGF_9_XP8 : WGF_9_XP12);
+            it.variant = 0;
+            it.kg = it.family == WGF_9_XP6 ? 1 : 2;
+            it.taps = 9;
+            const long T = (long)a.N * (a.H + 1) * (a.W + 1);
+            it.units = (T + 63) / 64;
+            it.unit_cost = 4 * 9 * 3 / (double)it.kg;
+            a.n_mtiles = (a.M + 63) / 64;
+            a.n_ctiles = (a.Cin + 63) / 64;
+            it.tiles = (long)a.n_mtiles * a.n_ctiles;
+            a.div_tiles = make_fastdiv((uint32_t)it.tiles);
+            a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
+            a.magic_wp = 0xFFFFFFFFu / (uint32_t)(a.W + 1) + 1u;
+            a.div_hw = make_fastdiv((uint32_t)((a.H + 1) * (a.W + 1)));
+            a.div_w = make_fastdiv((uint32_t)(a.W + 1));
+            return SSN_OK;
+        }
+        SSN_CHECK_ARG(hint < 0, "conv wgrad pl group: the nine-tap bodies take 3x3 / stride 1 / pad 1 layers only");
+    }
+    it.family = WGF_1;
+    const bool can_chunk = chunked_1x1_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w);
+    int v;
+    if (hint >= 200) {
+        SSN_CHECK_ARG(can_chunk, "conv wgrad pl group: the chunked body takes 1x1 / stride-1 layers only");
+        v = 3;
+    } else if (hint == 3) {
+        v = 0;
+    } else if (hint == 8) {
+        v = 1;
+    } else if (hint == 0) {
+        v = 2;
+    } else {
+        SSN_CHECK_ARG(hint < 0, "conv wgrad pl group: tile %d is not compiled into the grouped kernels", hint);
+        if (can_chunk && a.M <= 128) {
+            v = 3;      // (what the per-layer table picks for the narrow 1x1 layers: 64 -> 64 at 56 x 56, 1024 -> 128 at 7 x 7)
+        } else {
+            double best = 1e300;
+            v = 0;
+            for (int c = 0; c < 3; ++c) {
+                const double padded = (double)((a.M + kG1BM[c] - 1) / kG1BM[c]) * kG1BM[c] * (double)((a.Cin + kG1BC[c] - 1) / kG1BC[c]) * kG1BC[c];
+                const double small = c == 0 ? 1.0 : (c == 1 ? 1.04 : 1.3);      // (operand fetch per MAC grows as the tile shrinks)
+                if (padded * small < best) {
+                    best = padded * small;
+                    v = c;
+                }
+            }
+        }
+    }
+    it.variant = v;
+    a.n_mtiles = (a.M + kG1BM[v] - 1) / kG1BM[v];
+    a.n_ctiles = (a.Cin + kG1BC[v] - 1) / kG1BC[v];
+    a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
+    if (v == 3) {
+        it.tiles = (long)a.n_mtiles * a.n_ctiles;
+        it.units = ((long)a.P + 63) / 64;
+        it.unit_cost = 4 * 3;
+        a.magic_wp = 0xFFFFFFFFu / (uint32_t)a.W + 1u;
+        a.div_hw = make_fastdiv((uint32_t)(a.H * a.W));
+        a.div_w = make_fastdiv((uint32_t)a.W);
+    } else {
+        const int KK = a.kh * a.kw;
+        it.tiles = (long)a.n_mtiles * a.n_ctiles * KK;
+        it.units = ((long)a.P + 15) / 16;
+        it.unit_cost = 3.0 * (kG1BM[v] / 32) * (kG1BC[v] / 32) / 4;
+        a.div_kk = make_fastdiv((uint32_t)KK);
+    }
+    a.div_tiles = make_fastdiv((uint32_t)it.tiles);
+    return SSN_OK;
+}
+// Split plan of a family's problems.  Model: an item costs (its units x unit_cost + F) matrix-instruction slots of a wave, F = the
+// fixed part (prologue, first fetch, partial-slab store, its share of the reduction); `slots` items run at a time; list scheduling
+// of n items of length L on S slots ends within L of the mean load.  Total ~ W / S x (1 + F / L) + L / 2, minimal at L = sqrt(2 F W / S).
+void plan_group(std::vector<WgGroupItem*>& fam, int slots, double fixed_cost, int min_units, bool even_units) {
+    double work = 0;
+    for (WgGroupItem* it : fam) work += (double)it->tiles * (double)it->units * it->unit_cost;
+    double target = std::sqrt(2.0 * fixed_cost * work / slots);
+    if (target < fixed_cost) target = fixed_cost;
+    for (WgGroupItem* it : fam) {
+        long per = (long)(target / it->unit_cost + 0.5);
+        if (per < min_units) per = min_units;
+        if (per > it->units) per = it->units;
+        long splits = (it->units + per - 1) / per;
+        per = (it->units + splits - 1) / splits;           // (equal shares)
+        if (even_units && it->variant != 3 && (per & 1)) ++per;   // the one-tap pipeline runs two k-steps per trip
+        splits = (it->units + per - 1) / per;
+        it->a.splits = (int)splits;
+        it->a.ksteps_per_split = (int)per;
+    }
+}
+
 }  // namespace
 
 // tooling (tools/trace_wgrad_pl.py): per-block phase stamps of the next launches into buf (8 qwords per block), null = off
@@ -771,6 +1061,163 @@ extern "C" long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int 
     return (long)splits * Cout * ((long)Cin * kh * kw + 1) * (long)sizeof(float);
 }
 
+// ---- grouped weight gradients: ALL weight (+ bias) gradients of a backward pass in <= 4 launches + one reduction -------------------
+// (replaces the per-layer cuDNN wgrad calls behind loss.backward(), /root/reference/ssn_train.py:236).  Problem i is described like
+// the arguments of ssn_conv_wgrad_pl: plane pointers g_hi/g_lo/x_hi/x_lo[i], dw[i], db[i] (may be null), g_scale / x_scale[i],
+// shape[i * 16 + ...] = {N, Cin, H, W, Cout, Ho, Wo, kh, kw, stride, pad_h, pad_w, g_row_split, g_row_gap, tile hint (-1: choose;
+// 0 / 3 / 8: one-tap 64 x 64 / 128 x 128 / 96 x 128; 100: nine taps; 200: chunked 1x1), 0}, groups[i * 2 + ...] = {x_img_groups,
+// g_img_groups}.  workspace: ssn_conv_wgrad_pl_group_workspace_bytes() bytes (partial slabs of every problem, each in its own
+// region); table: ssn_conv_wgrad_pl_group_table_bytes(count) bytes of device memory the launches read their problems from (written
+// by this call, every call: operand addresses change from pass to pass).  Nothing is synchronised; capturable.
+namespace {
+int plan_group_all(int count, const int* shape, const long* groups, const void* const* g_hi, const void* const* g_lo,
+                   const void* const* x_hi, const void* const* x_lo, float* const* dw, float* const* db, const float* const* g_scale,
+                   const float* const* x_scale, std::vector<WgGroupItem>& items, long* ws_total) {
+    items.resize((size_t)count);
+    static const float one = 1.f;
+    for (int i = 0; i < count; ++i) {
+        const int* sh = shape + (size_t)i * 16;
+        WgGroupItem& it = items[(size_t)i];
+        // (planning only: no pointers given -- any non-null value passes the checks)
+        const void* dummy = &one;
+        int rc = fill_wgpl(it.a, g_hi ? g_hi[i] : dummy, g_lo ? g_lo[i] : dummy, x_hi ? x_hi[i] : dummy, x_lo ? x_lo[i] : dummy, sh[0], sh[1],
+                           sh[2], sh[3], groups[i * 2], sh[4], sh[5], sh[6], groups[i * 2 + 1], sh[7], sh[8], sh[9], sh[10], sh[11],
+                           g_scale ? g_scale[i] : &one, x_scale ? x_scale[i] : &one, sh[12], sh[13]);
+        if (rc != SSN_OK) return rc;
+        it.dw = dw ? dw[i] : nullptr;
+        it.db = db ? db[i] : nullptr;
+        rc = classify_group(it, sh[14]);
+        if (rc != SSN_OK) return rc;
+    }
+    for (int f = 0; f < WGF_COUNT; ++f) {
+        std::vector<WgGroupItem*> fam;
+        for (WgGroupItem& it : items)
+            if (it.family == f) fam.push_back(&it);
+        if (fam.empty()) continue;
+        if (f == WGF_1)
+            plan_group(fam, 512, g_group_fixed[1], g_group_min_units[1], true);
+        else
+            plan_group(fam, f == WGF_9_XP6 ? 512 : 256, g_group_fixed[0], g_group_min_units[0], false);
+    }
+    long off = 0;
+    for (WgGroupItem& it : items) {
+        it.ws_off = off;
+        off += ((long)it.a.splits * it.kg * it.a.M * it.a.ldp * (long)sizeof(float) + 1023) / 1024 * 1024;
+    }
+    *ws_total = off;
+    return SSN_OK;
+}
+}  // namespace
+
+// tooling / tests: planner constants of the grouped launches (values <= 0 keep the current one); see plan_group
+extern "C" void ssn_conv_wgrad_pl_group_tuning(double fixed_nine, double fixed_one, int min_units_nine, int min_units_one) {
+    if (fixed_nine > 0) g_group_fixed[0] = fixed_nine;
+    if (fixed_one > 0) g_group_fixed[1] = fixed_one;
+    if (min_units_nine > 0) g_group_min_units[0] = min_units_nine;
+    if (min_units_one > 0) g_group_min_units[1] = min_units_one;
+}
+extern "C" long ssn_conv_wgrad_pl_group_table_bytes(int count) { return (long)(count > 0 ? count : 1) * (long)sizeof(WgGroupEntry); }
+
+// workspace bytes of a group (the same planner as the launch); plan_out (optional): [count][4] = {family, variant, splits, units per split}
+extern "C" long ssn_conv_wgrad_pl_group_workspace_bytes(int count, const int* shape, const long* groups, int* plan_out) {
+    if (count <= 0 || !shape || !groups) return 0;
+    std::vector<WgGroupItem> items;
+    long total = 0;
+    if (plan_group_all(count, shape, groups, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, items, &total) != SSN_OK)
+        return -1;
+    if (plan_out)
+        for (int i = 0; i < count; ++i) {
+            plan_out[i * 4] = items[(size_t)i].family;
+            plan_out[i * 4 + 1] = items[(size_t)i].variant;
+            plan_out[i * 4 + 2] = items[(size_t)i].a.splits;
+            plan_out[i * 4 + 3] = items[(size_t)i].a.ksteps_per_split;
+        }
+    return total;
+}
+
+extern "C" int ssn_wgrad_reduce_multi(int count, const float* const* part, float* const* dw, float* const* db, const int* M,
+                                      const int* K, const int* splits, const int* taps, hipStream_t stream);
+
+extern "C" int ssn_conv_wgrad_pl_group(int count, const void* const* g_hi, const void* const* g_lo, const void* const* x_hi,
+                                       const void* const* x_lo, float* const* dw, float* const* db, const int* shape,
+                                       const long* groups, const float* const* g_scale, const float* const* x_scale, void* workspace,
+                                       long ws_bytes, void* table, long table_bytes, hipStream_t stream) {
+    if (count == 0) return SSN_OK;
+    SSN_CHECK_ARG(count > 0 && g_hi && g_lo && x_hi && x_lo && dw && db && shape && groups && g_scale && x_scale && workspace && table,
+                  "conv wgrad pl group: null pointer");
+    for (int i = 0; i < count; ++i) SSN_CHECK_ARG(dw[i], "conv wgrad pl group: problem %d has no dw", i);
+    std::vector<WgGroupItem> items;
+    long need = 0;
+    int rc = plan_group_all(count, shape, groups, g_hi, g_lo, x_hi, x_lo, dw, db, g_scale, x_scale, items, &need);
+    if (rc != SSN_OK) return rc;
+    if (ws_bytes < need) {
+        ssn_set_error("conv wgrad pl group: workspace %ld < %ld bytes", ws_bytes, need);
+        return SSN_ERR_WORKSPACE;
+    }
+    if (table_bytes < ssn_conv_wgrad_pl_group_table_bytes(count)) {
+        ssn_set_error("conv wgrad pl group: table %ld < %ld bytes", table_bytes, ssn_conv_wgrad_pl_group_table_bytes(count));
+        return SSN_ERR_WORKSPACE;
+    }
+    WgGroupEntry* dev = static_cast<WgGroupEntry*>(table);
+    int first = 0;      // table position of the next launch's problems
+    for (int f = 0; f < WGF_COUNT; ++f) {
+        std::vector<WgGroupItem*> fam;
+        for (WgGroupItem& it : items)
+            if (it.family == f) fam.push_back(&it);
+        if (fam.empty()) continue;
+        // longest item first (ties: the caller's order)
+        std::stable_sort(fam.begin(), fam.end(), [](const WgGroupItem* x, const WgGroupItem* y) {
+            return x->a.ksteps_per_split * x->unit_cost > y->a.ksteps_per_split * y->unit_cost;
+        });
+        for (size_t base = 0; base < fam.size(); base += WGG_MAX) {
+            const int n = (int)std::min<size_t>(WGG_MAX, fam.size() - base);
+            WgGroupIndex ix;
+            ix.count = n;
+            long blocks = 0;
+            for (int c0 = 0; c0 < n; c0 += WGG_WRITE) {
+                WgGroupChunk ch;
+                ch.count = std::min(WGG_WRITE, n - c0);
+                for (int j = 0; j < ch.count; ++j) {
+                    WgGroupItem& it = *fam[base + (size_t)(c0 + j)];
+                    it.a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + it.ws_off);
+                    ch.e[j].a = it.a;
+                    ch.e[j].variant = it.variant;
+                    ch.e[j].nblk = (uint32_t)(it.tiles * it.a.splits);
+                    ix.blk0[c0 + j] = (int)blocks;
+                    blocks += (it.tiles * it.a.splits + 7) / 8 * 8;
+                }
+                hipLaunchKernelGGL(wgrad_group_write_kernel, dim3(1), dim3(64), 0, stream, ch, dev, first + c0);
+            }
+            SSN_CHECK_ARG(blocks < (1l << 31), "conv wgrad pl group: too many blocks");
+            for (int j = n; j <= WGG_MAX; ++j) ix.blk0[j] = (int)blocks;
+            const WgGroupEntry* tab = dev + first;
+            switch (f) {
+                case WGF_9_XP6: hipLaunchKernelGGL((wgrad_group9_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, tab, ix); break;
+                case WGF_9_XP8: hipLaunchKernelGGL((wgrad_group9_kernel<8, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
+                case WGF_9_XP12: hipLaunchKernelGGL((wgrad_group9_kernel<12, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
+                default: hipLaunchKernelGGL(wgrad_group1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, ix); break;
+            }
+            first += n;
+        }
+    }
+    SSN_CHECK_LAUNCH("conv_wgrad_pl_group");
+    // the reduction of every problem's slabs, in the fixed order of the single launches
+    std::vector<const float*> parts((size_t)count);
+    std::vector<float*> dws((size_t)count), dbs((size_t)count);
+    std::vector<int> Ms((size_t)count), Ks((size_t)count), sp((size_t)count), tp((size_t)count);
+    for (int i = 0; i < count; ++i) {
+        const WgGroupItem& it = items[(size_t)i];
+        parts[(size_t)i] = reinterpret_cast<const float*>(static_cast<char*>(workspace) + it.ws_off);
+        dws[(size_t)i] = it.dw;
+        dbs[(size_t)i] = it.db;
+        Ms[(size_t)i] = it.a.M;
+        Ks[(size_t)i] = it.a.K;
+        sp[(size_t)i] = it.a.splits * it.kg;
+        tp[(size_t)i] = it.taps;
+    }
+    return ssn_wgrad_reduce_multi(count, parts.data(), dws.data(), dbs.data(), Ms.data(), Ks.data(), sp.data(), tp.data(), stream);
+}
+
 // Weight + bias gradient on planes slices: g = dY [N, Cout, Ho, Wo] (final: its ReLU / BN backward applied), x = the layer's
 // input [N, Cin (padded to 8), H, W]; any stride / padding / kh x kw taps.  dw [Cout][Cin][kh][kw] fp32, db [Cout] or null.
 // *_img_groups: channel groups of the whole tensors.  g_row_gap > 0: rows >= g_row_split of g sit g_row_gap channels further
@@ -780,51 +1227,12 @@ extern "C" int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void*
                                  int kh, int kw, int stride, int pad_h, int pad_w, void* workspace, long ws_bytes, int tile_cfg,
                                  const float* g_scale, const float* x_scale, int g_row_split, int g_row_gap,
                                  int* deferred_reduce, hipStream_t stream) {
-    SSN_CHECK_ARG(g_hi && g_lo && x_hi && x_lo && dw && workspace && g_scale && x_scale, "conv wgrad pl: null pointer");
-    SSN_CHECK_ARG(Cout > 0 && Cin > 0 && kh >= 1 && kw >= 1 && (stride == 1 || stride == 2), "conv wgrad pl: bad shape");
-    SSN_CHECK_ARG(g_row_gap >= 0 && (g_row_gap == 0 || (g_row_split > 0 && g_row_split < Cout && g_row_split % 32 == 0 && g_row_gap % 8 == 0)),
-                  "conv wgrad pl: bad row split");
+    SSN_CHECK_ARG(dw && workspace, "conv wgrad pl: null pointer");
     WgPlArgs a;
-    a.g_hi = g_hi;
-    a.g_lo = g_lo;
-    a.x_hi = x_hi;
-    a.x_lo = x_lo;
+    const int rcf = fill_wgpl(a, g_hi, g_lo, x_hi, x_lo, N, Cin, H, W, x_img_groups, Cout, Ho, Wo, g_img_groups, kh, kw, stride, pad_h, pad_w,
+                              g_scale, x_scale, g_row_split, g_row_gap);
+    if (rcf != SSN_OK) return rcf;
     a.part = (float*)workspace;
-    a.trace = g_wg_trace;
-    a.dbg = g_wg_dbg;
-    a.g_scale = g_scale;
-    a.x_scale = x_scale;
-    a.g_row_split = g_row_gap ? g_row_split : 0x7fffffff;
-    a.g_row_gap = g_row_gap;
-    a.N = N;
-    a.Cin = Cin;
-    a.H = H;
-    a.W = W;
-    a.M = Cout;
-    a.Ho = Ho;
-    a.Wo = Wo;
-    a.kh = kh;
-    a.kw = kw;
-    a.stride = stride;
-    a.pad_h = pad_h;
-    a.pad_w = pad_w;
-    a.K = Cin * kh * kw;
-    a.ldp = a.K + 1;
-    a.P = N * Ho * Wo;
-    const long gg = (long)Ho * Wo * 16, xg = (long)H * W * 16;
-    const long gb = (long)N * g_img_groups * gg, xb = (long)N * x_img_groups * xg;
-    SSN_CHECK_ARG(gb < (1l << 31) && xb < (1l << 31), "conv wgrad pl: operand plane larger than 2 GiB (buffer addressing)");
-    a.g_grp_bytes = (uint32_t)gg;
-    a.x_grp_bytes = (uint32_t)xg;
-    a.g_img_bytes = (uint32_t)(g_img_groups * gg);
-    a.x_img_bytes = (uint32_t)(x_img_groups * xg);
-    // the descriptors end with the SLICES in the last image (a fragment may reach past the slice -- rows / columns that are never
-    // stored: in earlier images it reads the neighbouring channels, behind the last image it must read nothing: a slice at the end
-    // of its tensor would otherwise be over-read past the allocation)
-    a.g_bytes = (uint32_t)((long)(N - 1) * a.g_img_bytes + (long)((Cout + g_row_gap + 7) / 8) * gg);
-    a.x_bytes = (uint32_t)((long)(N - 1) * a.x_img_bytes + (long)((Cin + 7) / 8) * xg);
-    a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
-    a.div_w = make_fastdiv((uint32_t)Wo);
     // tile_cfg >= 200: the chunked 1x1 kernel with tile tile_cfg - 200
     if (tile_cfg >= 200) {
         SSN_CHECK_ARG(chunked_1x1_layer(kh, kw, stride, pad_h, pad_w) && tile_cfg - 200 < N1,

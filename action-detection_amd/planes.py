@@ -124,35 +124,6 @@ class PSlice:
         return self.t.g
 
 
-    def images(self, n0, n1):
-        """The same channels of images [n0, n1) only (a launch on a sub-range of the batch)."""
-        return PImages(self, n0, n1)
-
-
-class PImages(PSlice):
-    """Images [n0, n1) of a PSlice: same tensor / scale / amax slots, plane pointers moved to image n0, n = n1 - n0."""
-
-    def __init__(self, base, n0, n1):
-        assert 0 <= n0 < n1 <= base.t.n
-        self.t, self.c0, self.c = base.t, base.c0, base.c
-        self.n0, self.n1 = int(n0), int(n1)
-
-    def _off(self):
-        return self.n0 * self.t.g * self.t.h * self.t.w * 16
-
-    @property
-    def hi(self):
-        return self.t.plane_ptr(0, self.c0) + self._off()
-
-    @property
-    def lo(self):
-        return self.t.plane_ptr(1, self.c0) + self._off()
-
-    @property
-    def n(self):
-        return self.n1 - self.n0
-
-
 def pfull(t):
     return PSlice(t, 0, t.c)
 
@@ -267,6 +238,78 @@ def wgrad_reduce_multi(entries):
     lib.call("ssn_wgrad_reduce_multi", n, ctypes.addressof(parts), ctypes.addressof(dws), ctypes.addressof(dbs),
              ctypes.addressof(arr[0]), ctypes.addressof(arr[1]), ctypes.addressof(arr[2]), ctypes.addressof(arr[3]),
              _stream(lib, entries[0][0]))
+
+
+class WgradJob:
+    """One problem of a grouped weight-gradient launch: the arguments of ``conv_wgrad`` (g: final output gradient slice, x: the layer's
+    input slice, dw / db: fp32 destinations) + an optional tile hint (-1: the library chooses)."""
+
+    __slots__ = ("g", "x", "dw", "db", "kh", "kw", "stride", "pad_h", "pad_w", "cin", "g_row_split", "g_row_gap", "hint")
+
+    def __init__(self, g, x, dw, db, kh, kw, stride, pad_h, pad_w, cin=None, g_row_split=0, g_row_gap=0, hint=-1):
+        self.g, self.x, self.dw, self.db = g, x, dw, db
+        self.kh, self.kw, self.stride, self.pad_h, self.pad_w = int(kh), int(kw), int(stride), int(pad_h), int(pad_w)
+        self.cin = x.c if cin is None else int(cin)
+        self.g_row_split, self.g_row_gap, self.hint = int(g_row_split), int(g_row_gap), int(hint)
+
+    def shape16(self):
+        h, w = self.x.hw
+        ho, wo = self.g.hw
+        return [self.x.n, self.cin, h, w, self.g.c, ho, wo, self.kh, self.kw, self.stride, self.pad_h, self.pad_w,
+                self.g_row_split, self.g_row_gap, self.hint, 0]
+
+
+def _wgrad_group_arrays(jobs):
+    import ctypes
+    n = len(jobs)
+    shape = (ctypes.c_int * (16 * n))(*[v for j in jobs for v in j.shape16()])
+    groups = (ctypes.c_long * (2 * n))(*[v for j in jobs for v in (j.x.groups, j.g.groups)])
+    return shape, groups
+
+
+def wgrad_group_plan(jobs):
+    """(workspace bytes, table bytes, [(family, variant, splits, units per split)]) of a grouped launch -- host-side planning only."""
+    import ctypes
+    lib = _lib.get_lib()
+    n = len(jobs)
+    if n == 0:
+        return 0, 0, []
+    shape, groups = _wgrad_group_arrays(jobs)
+    plan = (ctypes.c_int * (4 * n))()
+    ws = int(lib.cdll.ssn_conv_wgrad_pl_group_workspace_bytes(n, ctypes.addressof(shape), ctypes.addressof(groups), ctypes.addressof(plan)))
+    if ws < 0:
+        raise RuntimeError("ssn_conv_wgrad_pl_group_workspace_bytes failed: %s" % lib.cdll.ssn_last_error().decode())
+    return ws, int(lib.cdll.ssn_conv_wgrad_pl_group_table_bytes(n)), [tuple(plan[4 * i:4 * i + 4]) for i in range(n)]
+
+
+def conv_wgrad_group(jobs, workspace=None, table=None):
+    """Every weight + bias gradient of ``jobs`` (WgradJob) in at most four launches + one reduction (ssn_conv_wgrad_pl_group).
+    workspace (fp32 tensor) / table (uint8 tensor): buffers of at least ``wgrad_group_plan(jobs)`` bytes, allocated when None."""
+    import ctypes
+    if not jobs:
+        return
+    first = jobs[0].g
+    lib = _lib_for(first.t)
+    n = len(jobs)
+    dev = first.t.device
+    assert all(j.g.t.device == dev and j.x.t.device == dev for j in jobs)
+    shape, groups = _wgrad_group_arrays(jobs)
+    if workspace is None or table is None:
+        ws_bytes, tb_bytes, _ = wgrad_group_plan(jobs)
+        if workspace is None:
+            workspace = torch.empty(ws_bytes // 4 + 4, device=dev, dtype=torch.float32)
+        if table is None:
+            table = torch.empty(tb_bytes, device=dev, dtype=torch.uint8)
+    vp = ctypes.c_void_p * n
+    g_hi, g_lo = vp(*[j.g.hi for j in jobs]), vp(*[j.g.lo for j in jobs])
+    x_hi, x_lo = vp(*[j.x.hi for j in jobs]), vp(*[j.x.lo for j in jobs])
+    dws = vp(*[_p(j.dw) for j in jobs])
+    dbs = vp(*[_p(j.db) for j in jobs])
+    gs, xs = vp(*[j.g.t.scale_ptr for j in jobs]), vp(*[j.x.t.scale_ptr for j in jobs])
+    lib.call("ssn_conv_wgrad_pl_group", n, ctypes.addressof(g_hi), ctypes.addressof(g_lo), ctypes.addressof(x_hi),
+             ctypes.addressof(x_lo), ctypes.addressof(dws), ctypes.addressof(dbs), ctypes.addressof(shape), ctypes.addressof(groups),
+             ctypes.addressof(gs), ctypes.addressof(xs), _p(workspace), workspace.numel() * workspace.element_size(), _p(table),
+             table.numel() * table.element_size(), _st(lib, first.t))
 
 
 def conv_dgrad_s2(dy, wt_packed, dx, pad, accumulate=False, tile_cfg=-1, mask=None, mask_scale=None):

@@ -208,15 +208,6 @@ def _pool_out(h, k, s, p):
     return o
 
 
-def _image_parts(net, kind, op, n, shapes):
-    """[(first image, end image, tile)] of a forward / dgrad launch: one part, or bulk + tail (BNInception._pl_split)."""
-    tile = net._pl_tile(kind, op, n, shapes)
-    split = net._pl_split(kind, op, n, shapes)
-    if split is None:
-        return [(0, n, tile)]
-    return [(0, split[0], tile), (split[0], n, split[1])]
-
-
 def _dgrad_is_s2(op):
     return len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3 and op["s"] == 2
 
@@ -336,13 +327,9 @@ def run_forward(net, x, keep):
                         src = PSlice(acts["data"], 0, acts["data"].g * 8)
                     else:
                         src = PSlice(acts[op["src"]], op["src_c0"], cin)
-                    parts = _image_parts(net, "fwd", op, n, shapes)
-
-                    def run_fwd():
-                        for n0, n1, tcfg in parts:
-                            P.conv_fwd(src.images(n0, n1), wp, scale, shift, dst.images(n0, n1), kh, kw, op["s"], ph, pw, not raw, tcfg,
-                                       raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0))
-                    net._timed("conv_fwd_pl", op["lids"][0], flops, run_fwd)
+                    net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
+                        src, wp, scale, shift, dst, kh, kw, op["s"], ph, pw, not raw, net._pl_tile("fwd", op, n, shapes),
+                        raw_from=op.get("raw_from", 0), row_split=op.get("row_split", 0), row_gap=op.get("row_gap", 0)))
             elif op["kind"] == "pool" and op["pool"] == "avg":
                 c = op["c"]
                 P.avgpool_affine(PSlice(acts[op["src"]], 0, c), PSlice(get(op["dst"]), op["dst_c0"], c), None, None, False,
@@ -452,6 +439,8 @@ def run_backward(net, dfeat, saved, hook=True):
         else:
             need = P.wgrad_workspace_bytes(n, op["cin"], op["cout"], ho, wo, kh, kw, net._pl_tile("wgrad", op, n, shapes))
         need = (need + 1023) // 1024 * 1024
+        if net.group_wgrad and not op.get("s2d"):
+            continue                                   # (grouped: the slabs live in the group's own workspace)
         if not net.defer_wgrad_reduce:
             ws_off[op["lids"][0]] = (0, need)
             ws_bytes = max(ws_bytes, need)
@@ -461,6 +450,8 @@ def run_backward(net, dfeat, saved, hook=True):
     ws_all = net._workspace(ws_bytes, dev)
 
     def ws_of(op):
+        if op["lids"][0] not in ws_off:
+            return None
         o, nb = ws_off[op["lids"][0]]
         return ws_all[o // 4:(o + nb) // 4]
     # (the bias sums of the projections in front of their pools are deferred with the reductions and issued together: the scratch
@@ -493,13 +484,22 @@ def run_backward(net, dfeat, saved, hook=True):
         pending_end = total
         pending_reduce, pending_sums = [], []     # deferred split-K reductions / the channel sums that must follow them
 
+        pending_wgrad = []                        # grouped mode: (planes.WgradJob, flops) of the weight gradients not yet launched
+
         def flush():
+            if pending_wgrad:
+                # every weight gradient recorded since the last flush: <= 4 launches over a device-resident problem table + ONE
+                # reduction (ssn_conv_wgrad_pl_group) -- their output gradients are all final by now, and they depend on nothing else
+                jobs = [j for j, _ in pending_wgrad]
+                net._timed("conv_wgrad_pl", "group", sum(f for _, f in pending_wgrad),
+                           lambda: P.conv_wgrad_group(jobs, *net._wgrad_group_buffers(jobs, dev)))
             if pending_reduce:       # (timed with the weight-gradient family it belongs to: bench.py's roofline_detail)
                 entries = list(pending_reduce)
                 net._timed("conv_wgrad_pl", "reduce_multi", 0.0, lambda: P.wgrad_reduce_multi(entries))
             if pending_sums:
                 P.channel_sum_multi(list(pending_sums), cs_ws)
-            del pending_reduce[:], pending_sums[:]
+            del pending_reduce[:], pending_sums[:], pending_wgrad[:]
+        group = net.group_wgrad
         defer = pending_reduce if net.defer_wgrad_reduce else None
 
         def gbuf(name):
@@ -633,8 +633,14 @@ def run_backward(net, dfeat, saved, hook=True):
                         K.s2d_weights_bwd(dw2, dw)
                 else:
                     xin = PSlice(acts[op["src"]], op["src_c0"], cin) if op["src"] != "data" else PSlice(acts["data"], 0, acts["data"].g * 8)
+                    grouped = group
 
                     def run_wgrad(ws=ws_of(op)):
+                        if grouped:      # recorded; launched with the other weight gradients of the pass at the next flush
+                            pending_wgrad.append((P.WgradJob(gs, xin, dw, db, kh, kw, s, ph, pw, cin=cin, g_row_split=op.get("row_split", 0),
+                                                             g_row_gap=op.get("row_gap", 0), hint=net._pl_tile("wgradg", op, n, shapes)),
+                                                  flops))
+                            return
                         P.conv_wgrad(gs, xin, dw, db, kh, kw, s, ph, pw, ws, wcfg, cin=cin, g_row_split=op.get("row_split", 0),
                                      g_row_gap=op.get("row_gap", 0), defer=defer)
                 def run_wgrad_and_bias(run_wgrad=run_wgrad, op=op, db=db, cout=cout):
@@ -646,11 +652,14 @@ def run_backward(net, dfeat, saved, hook=True):
                         cp = cout - op.get("raw_from", 0)
 
                         entry = (PSlice(grads[fin[0]], fin[1], cp), db[op.get("raw_from", 0):])
-                        if defer is not None:
+                        if defer is not None or group:
                             pending_sums.append(entry)
                         else:
                             P.channel_sum_multi([entry], cs_ws)
-                net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
+                if group and not op.get("s2d"):
+                    run_wgrad_and_bias()         # (only records: the group is timed as a whole at its flush)
+                else:
+                    net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)
                 if op["src"] != "data":
                     wt = packed_dg[lids[0]]
                     key = src_key(op)
@@ -663,14 +672,9 @@ def run_backward(net, dfeat, saved, hook=True):
                                    lambda: P.conv_dgrad_s2(gs, wt, dx, op["p"], acc_flag, tcfg, mask=my, mask_scale=ms))
                     else:
                         # (a fused block-input launch reads its rows behind the split k_gap channels further up dy's tensor)
-                        parts = _image_parts(net, "dgrad", op, n, shapes)
-
-                        def run_dgrad():
-                            for n0, n1, tc in parts:
-                                P.conv_dgrad(gs.images(n0, n1), wt, dx.images(n0, n1), kh, kw, ph, pw, acc_flag, tc,
-                                             mask=my.images(n0, n1) if my is not None else None, mask_scale=ms,
-                                             k_split=op.get("row_split", 0), k_gap=op.get("row_gap", 0), taps_reversed=op["rect"])
-                        net._timed("conv_dgrad_pl", lids[0], flops, run_dgrad)
+                        net._timed("conv_dgrad_pl", lids[0], flops, lambda: P.conv_dgrad(
+                            gs, wt, dx, kh, kw, ph, pw, acc_flag, tcfg, mask=my, mask_scale=ms, k_split=op.get("row_split", 0),
+                            k_gap=op.get("row_gap", 0), taps_reversed=op["rect"]))
                     inited.add(key)
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))

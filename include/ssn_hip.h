@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define SSN_ERR_WORKSPACE (-3)
 
 const char* ssn_last_error(void);
-int ssn_abi_version(void);   /* 7 */
+int ssn_abi_version(void);   /* 8 */
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
@@ -484,6 +484,22 @@ int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void* x_hi, cons
 int ssn_wgrad_reduce_multi(int count, const float* const* part, float* const* dw, float* const* db, const int* M, const int* K,
                            const int* splits, const int* taps, hipStream_t stream);
 long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int tile_cfg);
+/* GROUPED weight gradients: every weight + bias gradient of a backward pass (all the cuDNN wgrad calls behind loss.backward(),
+ * /root/reference/ssn_train.py:236) in at most four launches + one reduction.  Problem i takes the arguments of ssn_conv_wgrad_pl as
+ * array entries (HOST arrays): plane pointers, dw[i], db[i] (may be NULL), scale pointers, shape[16 i ..] = {N, Cin, H, W, Cout, Ho,
+ * Wo, kh, kw, stride, pad_h, pad_w, g_row_split, g_row_gap, tile hint, 0} (hint -1: chosen; 0 / 3 / 8: one-tap 64x64 / 128x128 /
+ * 96x128; 100: nine taps; 200: chunked 1x1), groups[2 i ..] = {x_img_groups, g_img_groups}.  The problems travel in a device-resident
+ * table (`table`: ssn_conv_wgrad_pl_group_table_bytes(count) bytes, written by the call); each kernel family runs ONE grid over all its
+ * problems, items ordered longest first, the reduction ranges split only as far as the whole group needs; partial slabs
+ * (`workspace`: ssn_conv_wgrad_pl_group_workspace_bytes bytes; plan_out, optional: [count][4] = family, variant, splits, units per
+ * split) are reduced in a fixed order: deterministic.  Capturable, no host sync. */
+int ssn_conv_wgrad_pl_group(int count, const void* const* g_hi, const void* const* g_lo, const void* const* x_hi,
+                            const void* const* x_lo, float* const* dw, float* const* db, const int* shape, const long* groups,
+                            const float* const* g_scale, const float* const* x_scale, void* workspace, long ws_bytes, void* table,
+                            long table_bytes, hipStream_t stream);
+long ssn_conv_wgrad_pl_group_workspace_bytes(int count, const int* shape, const long* groups, int* plan_out);
+long ssn_conv_wgrad_pl_group_table_bytes(int count);
+void ssn_conv_wgrad_pl_group_tuning(double fixed_nine, double fixed_one, int min_units_nine, int min_units_one); /* tooling / tests: planner constants (<= 0: keep) */
 int ssn_conv_wgrad_pl_tiles(void);
 int ssn_conv_pl_tiles(void);
 int ssn_conv_pl_halo_taken(int N, int H, int W, int tile_cfg);

@@ -100,14 +100,9 @@ CASES_GPU = [
 
 
 HALO_TILES = [32 + c for c in (0, 1, 2, 3, 4, 7, 8, 9, 11)]
-# the haloed kernel with per-image tiles (tile_cfg 48 + c): prepared for the 56 x 56 layer, not selected by any committed table and not
-# yet run on a GPU -- the emulator tier covers it, the GPU tier only with SSN_TEST_EXPERIMENTAL=1
+# the haloed kernel with per-image tiles (tile_cfg 48 + c): conv2's 56 x 56 layer (its image-crossing tiles do not fit the halo buffer);
+# round 5 measured it on the MI355X (profiles/r5_off_code_measured.txt: dgrad -8 %, picked by the tile table) -- default tier now
 HALO_PI_TILES = [48 + c for c in (0, 1, 4, 7, 8, 9)]
-
-
-def _experimental(backend):
-    import os
-    return (not backend.is_gpu) or os.environ.get("SSN_TEST_EXPERIMENTAL") == "1"
 
 
 def _pack_fwd(w, backend):
@@ -136,8 +131,7 @@ def test_conv_pl_forward(backend):
         tiles = list(range(ntiles)) if ci == 0 else [-1]
         if (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1):
             tiles += HALO_TILES if (ci == 0 or backend.is_gpu) else [32, 36]      # the haloed 3x3 kernel (tile 32 + c)
-            if _experimental(backend):
-                tiles += HALO_PI_TILES if (ci == 0 or backend.is_gpu) else [55]
+            tiles += HALO_PI_TILES if (ci == 0 or backend.is_gpu) else [55]
         for tile in tiles:
             if tile >= 32:      # (on the GPU cases some tiles span more slots than the halo buffer, e.g. 128 pixels across two 56 x 56 images: plain kernel)
                 taken = action_detection_amd._lib.get_lib().cdll.ssn_conv_pl_halo_taken(n, h, wd, tile)
@@ -206,7 +200,7 @@ def test_conv_pl_dgrad(backend):
         gp = P.from_f32(backend.put(gy))
         dx = P.PlaneTensor(n, cin, h, wd, backend.device)
         halo = (HALO_TILES if (backend.is_gpu or not halo_done) else [32, 36]) if (kh, kw, ph, pw) == (3, 3, 1, 1) else []
-        if halo and _experimental(backend):
+        if halo:
             halo = halo + (HALO_PI_TILES if backend.is_gpu else ([48, 52, 55] if not halo_done else [52]))
         halo_done = halo_done or bool(halo)      # (emulator: every haloed tile on the first 3x3 case, two of them on the others)
         for tile in [-1] + halo:
@@ -260,6 +254,86 @@ def test_conv_pl_wgrad(backend):
             P.conv_wgrad(P.PSlice(gt, 8, cout), P.PSlice(xt, 8, cin), dw, db, kh, kw, s, ph, pw, ws, tile)
             assert rel_err(dw, w.grad) < 5e-6, ("wgrad", n, cin, h, cout, kh, kw, s, tile)
             assert rel_err(db, b.grad) < 5e-6, ("bias", n, cin, h, cout, kh, kw, s, tile)
+
+
+def test_conv_pl_wgrad_group(backend):
+    """ssn_conv_wgrad_pl_group: ALL problems of the case list as ONE grouped call (<= 4 launches + one reduction) vs autograd in
+    float64 -- every family (nine taps on rows of <= 14 / <= 30 / <= 56 pixels, one-tap bodies with any taps / stride / padding,
+    chunked 1x1), operands in slices of wider tensors, a problem without a bias gradient, a fused block-input problem (row gap);
+    then every variant forced by hint on the problems that take it; a second call must reproduce the first bit by bit."""
+    g = torch.Generator().manual_seed(41)
+    cases = list(CASES_GPU if backend.is_gpu else CASES_SMALL)
+    # rows of 28 / 56 pixels for the XP = 8 / 12 nine-tap families (emulator: narrow slices of such rows keep it affordable)
+    cases += [] if backend.is_gpu else [(1, 8, 5, 28, 16, 3, 3, 1, 1, 1), (1, 8, 3, 56, 16, 3, 3, 1, 1, 1), (2, 72, 4, 4, 136, 1, 1, 1, 0, 0)]
+    jobs, want, keep = [], [], []
+    for ci, (n, cin, h, wd, cout, kh, kw, s, ph, pw) in enumerate(cases):
+        x = torch.randn(n, cin, h, wd, generator=g)
+        w = (torch.randn(cout, cin, kh, kw, generator=g, dtype=torch.float64) * 0.1).requires_grad_()
+        b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x.double(), w, b, s, (ph, pw))
+        gy = torch.randn(y.shape, generator=g) * 1e-3
+        y.backward(gy.double())
+        ho, wo = y.shape[2], y.shape[3]
+        gap = 16 if (ci == 1 and cout > 32) else 0      # rows >= 32 of this problem's dY sit 16 channels further up (fused block input)
+        gt = P.PlaneTensor(n, cout + 16 + gap, ho, wo, backend.device).zero_()
+        if gap:
+            P.from_f32(backend.put(gy[:, :32].contiguous()), P.PSlice(gt, 8, 32))
+            P.from_f32(backend.put(gy[:, 32:].contiguous()), P.PSlice(gt, 8 + 32 + gap, cout - 32), exact=False)
+            # (both slices must share one scale: the second is stored with the scale the first derived)
+        else:
+            P.from_f32(backend.put(gy), P.PSlice(gt, 8, cout))
+        xt = P.PlaneTensor(n, cin + 8, h, wd, backend.device).zero_()
+        P.from_f32(backend.put(x), P.PSlice(xt, 8, cin))
+        dw = backend.put(torch.full(w.shape, 9.0))
+        db = None if ci == 2 else backend.put(torch.full((cout,), 9.0))
+        jobs.append(P.WgradJob(P.PSlice(gt, 8, cout), P.PSlice(xt, 8, cin), dw, db, kh, kw, s, ph, pw,
+                               g_row_split=32 if gap else 0, g_row_gap=gap))
+        want.append((w.grad, b.grad))
+        keep.append((gt, xt))
+    ws_bytes, tb_bytes, plan = P.wgrad_group_plan(jobs)
+    fams = sorted({f for f, _, _, _ in plan})
+    print("  group plan (family, variant, splits, units):", plan, flush=True)
+    assert fams == [0, 1, 2, 3], fams                      # every kernel family has a problem
+    assert {v for f, v, _, _ in plan if f == 3} >= {2, 3} or backend.is_gpu
+    P.conv_wgrad_group(jobs)
+    first = [(j.dw.clone(), None if j.db is None else j.db.clone()) for j in jobs]
+    for i, (j, (dwr, dbr)) in enumerate(zip(jobs, want)):
+        assert rel_err(j.dw, dwr) < 5e-6, ("group wgrad", i, cases[i], plan[i])
+        if j.db is not None:
+            assert rel_err(j.db, dbr) < 5e-6, ("group bias", i, cases[i], plan[i])
+    # same buffers, caller-provided workspace / table, poisoned destinations: bit-identical
+    ws = backend.put(torch.full((ws_bytes // 4 + 4,), float("nan")))
+    tb = backend.put(torch.zeros(tb_bytes, dtype=torch.uint8))
+    for j in jobs:
+        j.dw.fill_(3.0)
+        if j.db is not None:
+            j.db.fill_(3.0)
+    P.conv_wgrad_group(jobs, ws, tb)
+    for i, (j, (dw0, db0)) in enumerate(zip(jobs, first)):
+        assert torch.equal(j.dw.cpu(), dw0.cpu()), i
+        assert j.db is None or torch.equal(j.db.cpu(), db0.cpu()), i
+    # every compiled variant, forced by hint, on the problems that take it (a hint the problem cannot take is an error)
+    for hint in (0, 3, 8, 200, 100):
+        sub, idx = [], []
+        for i, (j, c) in enumerate(zip(jobs, cases)):
+            n, cin, h, wd, cout, kh, kw, s, ph, pw = c
+            ok = {200: (kh, kw, s, ph, pw) == (1, 1, 1, 0, 0), 100: (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1)}.get(hint, True)
+            if ok and (backend.is_gpu or i < 6 or hint >= 100):
+                j.hint = hint
+                j.dw.fill_(5.0)
+                sub.append(j)
+                idx.append(i)
+        if not sub:
+            continue
+        P.conv_wgrad_group(sub)
+        for j, i in zip(sub, idx):
+            assert rel_err(j.dw, want[i][0]) < 5e-6, ("hint", hint, i, cases[i])
+            if j.db is not None:
+                assert rel_err(j.db, want[i][1]) < 5e-6, ("hint bias", hint, i, cases[i])
+            j.hint = -1
+    jobs[2].hint = 200                                        # a 3x3 / stride-2 problem cannot take the chunked 1x1 body
+    with pytest.raises(RuntimeError):
+        P.conv_wgrad_group([jobs[2]])
 
 
 def test_wgrad_deferred_reduce_multi(backend):

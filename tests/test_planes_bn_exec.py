@@ -99,39 +99,3 @@ def test_switch_sends_training_bn_to_the_fp32_layout(emu):
 def test_partial_and_full_bn_on_planes_gpu(hip_library):
     _run(torch.device("cuda:0"), ("conv1_3x3",))
     _run(torch.device("cuda:0"), LAYERS)
-
-
-def test_launches_split_by_images_give_the_same_results(emu):
-    """BNInception._pl_split (tuned table "splits"): a forward / dgrad launch run as images [0, n1) on the tuned tile + images [n1, n)
-    on another tile.  Every output element is the same dot product in the same order whatever tile computes it: features and
-    gradients must be IDENTICAL to the one-launch run."""
-    from action_detection_amd import bninception as B
-    dev = torch.device("cpu")
-    g = torch.Generator().manual_seed(9)
-    x = torch.randn(3, 3, 16, 16, generator=g) * 30.0
-    w = torch.randn(3, 32, generator=g)
-    results = []
-    saved_table = dict(B._TUNED_PL)
-    try:
-        for splits in (None, "on"):
-            B._TUNED_PL.clear()
-            B._TUNED_PL.update(saved_table)
-            net = init_tiny(TinyBackbone()).to(dev).train()
-            if splits:
-                plan, shapes = net._plan(x)
-                table = {}
-                for op in plan:
-                    if op["kind"] == "conv":
-                        for kind, tail in (("fwd", 3), ("dgrad", 1)):
-                            table["%s|%d|%d|%d|%d|%d|%d" % (kind, op["cin"], op["cout"], op["k"], op["k"], op["s"], shapes[op["src"]][1])] = [2, tail]
-                B._TUNED_PL.update({"n_images": 3, "tiles": {"none": 0}, "splits": table})
-                assert net._pl_split("fwd", [op for op in plan if op["kind"] == "conv"][0], 3, shapes) == (2, 3)
-            f = net.features(x)
-            (f * w).sum().backward()
-            results.append((f.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
-    finally:
-        B._TUNED_PL.clear()
-        B._TUNED_PL.update(saved_table)
-    (f0, g0), (f1, g1) = results
-    assert torch.equal(f0, f1)
-    assert sorted(g0) == sorted(g1) and all(torch.equal(g0[k], g1[k]) for k in g0)

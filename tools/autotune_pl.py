@@ -31,28 +31,6 @@ def timeit(fn, reps=12, warm=2):
     return s.elapsed_time(e) / reps
 
 
-def split_plan(lib, rows, hw, n, tile):
-    """Images of the bulk launch such that its workgroups fill whole rounds of slots with `tile` (None: the launch ends on a nearly
-    full round anyway, or is shorter than one round)."""
-    import ctypes
-    import math
-    bm, bn = ctypes.c_int(), ctypes.c_int()
-    lib.cdll.ssn_conv_pl_tile_shape(tile - 32 if tile >= 32 else tile, ctypes.byref(bm), ctypes.byref(bn))
-    slots = 256 * (1 if bm.value * bn.value >= 256 * 128 else 2)
-    mt = math.ceil(rows / bm.value)
-
-    def wgs(k):
-        return mt * math.ceil(k * hw / bn.value)
-    rounds = wgs(n) / slots
-    full = int(rounds)
-    if full < 1 or not 0.03 < rounds - full < 0.7:
-        return None
-    n1 = n
-    while n1 > 0 and wgs(n1) > full * slots:
-        n1 -= 1
-    return n1 if 0 < n1 < n else None
-
-
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
     arch = sys.argv[2] if len(sys.argv) > 2 else "BNInception"
@@ -80,8 +58,6 @@ def main():
     except (OSError, ValueError):
         table = {}
     tiles, ms = table.get("tiles", {}), table.get("ms", {})
-    splits = table.get("splits", {})      # SPLITS=1: bulk + tail launches by images (BNInception._pl_split)
-    do_splits = os.environ.get("SPLITS") == "1"
     kinds = os.environ.get("KINDS", "fwd,dgrad,wgrad").split(",")      # KINDS=wgrad: re-tune the weight gradients only
     g = torch.Generator().manual_seed(0)
     for plan, shapes in plans:
@@ -133,18 +109,6 @@ def main():
                 line += " fwd tile %2d %.4f ms" % (best, res[best])
                 if halo:
                     line += " (plain %.4f)" % min(v for t, v in res.items() if t < 32)
-                n1 = split_plan(lib, cout, ho * wo, n, best) if (do_splits and not stem) else None
-                splits.pop("fwd|" + key, None)
-                if n1 is not None:
-                    def both(tt, n1=n1, best=best):
-                        P.conv_fwd(xs.images(0, n1), wp, sc, sh, P.pfull(yp).images(0, n1), k_, kw_, s_, p_, pw_, True, best)
-                        P.conv_fwd(xs.images(n1, n), wp, sc, sh, P.pfull(yp).images(n1, n), k_, kw_, s_, p_, pw_, True, tt)
-                    sres = {tt: timeit(lambda tt=tt: both(tt)) for tt in range(nfwd)}
-                    tb = min(sres, key=sres.get)
-                    line += " split %d+%d tail tile %d %.4f" % (n1, n - n1, tb, sres[tb])
-                    if sres[tb] < 0.97 * res[best]:
-                        splits["fwd|" + key] = [n1, tb]
-                        line += " *"
             # ---- dgrad (not for the first layer)
             gy = (torch.randn(n, cout, ho, wo, generator=g) * 1e-3).to(dev)
             gp = P.from_f32(gy)
@@ -173,19 +137,6 @@ def main():
                 line += " | dgrad tile %2d %.4f ms" % (best, res[best])
                 if halo:
                     line += " (plain %.4f)" % min(v for t, v in res.items() if t < 32)
-                n1 = split_plan(lib, cin, hin * hin, n, best) if (do_splits and s == 1) else None
-                splits.pop("dgrad|" + key, None)
-                if n1 is not None:
-                    def both_d(tt, n1=n1, best=best):
-                        for (a, b, tc) in ((0, n1, best), (n1, n, tt)):
-                            P.conv_dgrad(P.pfull(gp).images(a, b), wt, P.pfull(dxp).images(a, b), kh, kw, ph, pw, False, tc,
-                                         mask=P.pfull(xp).images(a, b), mask_scale=msc, taps_reversed=rect)
-                    sres = {tt: timeit(lambda tt=tt: both_d(tt)) for tt in range(nfwd)}
-                    tb = min(sres, key=sres.get)
-                    line += " split %d+%d tail tile %d %.4f" % (n1, n - n1, tb, sres[tb])
-                    if sres[tb] < 0.97 * res[best]:
-                        splits["dgrad|" + key] = [n1, tb]
-                        line += " *"
             # ---- wgrad
             if "wgrad" not in kinds:
                 print(line, flush=True)
@@ -204,8 +155,7 @@ def main():
     for path in (OUT, os.path.join(ROOT, "gpurun_out", "tuned_tiles_pl.json")):      # (gpurun_out/ is what travels back from the GPU box)
         if os.path.isdir(os.path.dirname(path)):
             with open(path, "w") as f:
-                json.dump(dict({"n_images": n, "tiles": tiles, "ms": ms}, **({"splits": splits} if splits else {})), f, indent=0,
-                          sort_keys=True)
+                json.dump({"n_images": n, "tiles": tiles, "ms": ms}, f, indent=0, sort_keys=True)
     print("wrote", OUT, "fwd %.3f dgrad %.3f wgrad %.3f ms (one launch per distinct shape)" % tuple(
         sum(v for k, v in ms.items() if k.startswith(p + "|")) for p in ("fwd", "dgrad", "wgrad")))
 
