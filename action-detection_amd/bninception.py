@@ -193,6 +193,13 @@ class BNInception(nn.Module):
             from . import _lib
             f9, f1, m9, m1 = (os.environ["SSN_GROUP_TUNING"].split(",") + ["0"] * 4)[:4]
             _lib.get_lib().cdll.ssn_conv_wgrad_pl_group_tuning(float(f9), float(f1), int(m9), int(m1))
+        # planes_exec: the two independent branch chains of an Inception block (3x3 + pool | double 3x3) on two streams -- parallel
+        # branches of the captured step; the tails and ramps of the 200 - 900-workgroup launches at 14 x 14 / 7 x 7 overlap.
+        # Measured (profiles/r5_branch_lanes_ab.txt, three alternating pairs on one box): 16.20 -> 15.96 ms per step (-1.4 %).
+        # Results are unchanged bit for bit: the lanes write disjoint slices, amax slots are raised by atomic max (order-free),
+        # scales are the previous step's.
+        self.branch_lanes = os.environ.get("SSN_BRANCH_LANES", "1") != "0"
+        self._side_streams = {}
         self.infer_cache = os.environ.get("SSN_INFER_CACHE", "1") != "0"   # planes_exec: packed weights / folded BN reused across no-grad forwards
         self.pooled_mask = os.environ.get("SSN_POOLED_MASK", "1") != "0"   # planes_exec: stem pools' backward reads the pooled sign
         # planes_exec: all weight operands of a pass packed in three launches through a device-resident plan (kernels.PackBatch)
@@ -788,6 +795,12 @@ class BNInception(nn.Module):
         if self._ws is None or self._ws.numel() * 4 < nbytes or self._ws.device != dev:
             self._ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
         return self._ws
+
+    def _side_stream(self, dev):
+        st = self._side_streams.get(dev)
+        if st is None:
+            st = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        return st
 
     def _wgrad_group_buffers(self, jobs, dev):
         """(workspace, table) of a grouped weight-gradient call: persistent buffers, grown on demand (planes_exec.run_backward)."""

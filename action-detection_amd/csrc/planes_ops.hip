@@ -61,17 +61,34 @@ struct CvtArgs {
     int G;                   // channel groups written (ceil(C' / 8), C' = C or 4C)
     long img_groups;         // groups of the whole planes tensor
     int s2d;                 // space-to-depth: planes channel (c*2+a)*2+b at (h', w') = x[c][2h'+a][2w'+b]
+    FastDiv dv_hw, dv_g, dv_wo;   // output pixels per plane, channel groups, output row length (s2d)
 };
+
+// Index arithmetic of the kernels below is 32-bit with host-computed magic divisions: a plane holds < 2^27 16-byte groups (2 GiB
+// buffer addressing), and a 64-bit `idx % W` costs ~100 instructions on this ISA -- with three or four of them per element the pool
+// kernels of rounds 3 - 4 were bound by integer division, not by memory (round 5: profiles/r5_pool_lab.txt).
+struct PoolIdx {
+    uint32_t n, g, h, w;
+};
+__device__ __forceinline__ PoolIdx pool_decode(uint32_t idx, const FastDiv& dw, const FastDiv& dh, const FastDiv& dg) {
+    PoolIdx r;
+    uint32_t t, ng;
+    fd_divmod(idx, dw, t, r.w);
+    fd_divmod(t, dh, ng, r.h);
+    fd_divmod(ng, dg, r.n, r.g);
+    return r;
+}
 
 __global__ __launch_bounds__(256) void pl_from_f32_kernel(CvtArgs p) {
     const int HWo = p.s2d ? (p.H / 2) * (p.W / 2) : p.H * p.W;
-    const long total = (long)p.N * p.G * HWo;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)HWo;
     const float s = *p.scale;
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int q = (int)(idx % HWo);
-        const long ng = idx / HWo;
-        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        uint32_t qq, ng, gg, nn;
+        fd_divmod(idx, p.dv_hw, ng, qq);
+        fd_divmod(ng, p.dv_g, nn, gg);
+        const int q = (int)qq, g = (int)gg, n = (int)nn;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -80,8 +97,10 @@ __global__ __launch_bounds__(256) void pl_from_f32_kernel(CvtArgs p) {
             if (!p.s2d) {
                 if (c < p.C) x = p.x[(long)n * p.x_img_stride + (long)c * HWo + q];
             } else if (c < 4 * p.C) {
-                const int cc = c >> 2, a = (c >> 1) & 1, b = c & 1, Wo = p.W / 2;
-                const int ho = q / Wo, wo = q - ho * Wo;
+                const int cc = c >> 2, a = (c >> 1) & 1, b = c & 1;
+                uint32_t hq, wq;
+                fd_divmod((uint32_t)q, p.dv_wo, hq, wq);
+                const int ho = (int)hq, wo = (int)wq;
                 x = p.x[(long)n * p.x_img_stride + ((long)cc * p.H + 2 * ho + a) * p.W + 2 * wo + b];
             }
             vmax = fmaxf(vmax, fabsf(x));
@@ -97,14 +116,16 @@ __global__ __launch_bounds__(256) void pl_from_f32_kernel(CvtArgs p) {
 }
 
 __global__ __launch_bounds__(256) void pl_to_f32_kernel(const void* hi, const void* lo, long img_groups, float* y,
-                                                       long y_img_stride, int N, int C, int HW, const float* scale) {
+                                                       long y_img_stride, int N, int C, int HW, const float* scale, FastDiv dv_hw,
+                                                       FastDiv dv_g) {
     const int G = (C + 7) / 8;
-    const long total = (long)N * G * HW;
+    const uint32_t total = (uint32_t)N * (uint32_t)G * (uint32_t)HW;
     const float inv = 1.f / *scale;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int q = (int)(idx % HW);
-        const long ng = idx / HW;
-        const int g = (int)(ng % G), n = (int)(ng / G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        uint32_t qq, ng, gg, nn;
+        fd_divmod(idx, dv_hw, ng, qq);
+        fd_divmod(ng, dv_g, nn, gg);
+        const int q = (int)qq, g = (int)gg, n = (int)nn;
         const long o = (((long)n * img_groups + g) * HW + q);
         float v[8];
         pl_join8(reinterpret_cast<const u32x4*>(hi)[o], reinterpret_cast<const u32x4*>(lo)[o], v);
@@ -135,6 +156,8 @@ struct PoolArgs {
     int relu, accumulate;
     float* y_f32;            // backward kernels: store fp32 NCHW here instead of planes (a gradient only a fp32-layout kernel reads)
     long y_f32_img_stride;
+    FastDiv dv_w, dv_h, dv_wo, dv_ho, dv_g, dv_hw;   // W, H, Wo, Ho, G, H * W (index decoding: pool_decode)
+    FastDiv dv_wb, dv_hb;                            // ceil(W / 2), ceil(H / 2): the 2 x 2 input blocks of the k3s2 backward
 };
 
 __device__ __forceinline__ void load8(const void* hi, const void* lo, long o, float (&v)[8]) {
@@ -146,14 +169,12 @@ __device__ __forceinline__ void load8(const void* hi, const void* lo, long o, fl
 template <int KT, int ST>
 __global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
     const int pk = KT ? KT : p.k, ps = ST ? ST : p.s;
-    const long total = (long)p.N * p.G * p.Ho * p.Wo;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)p.Ho * (uint32_t)p.Wo;
     const float r = *p.y_scale / *p.x_scale;
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int wo = (int)(idx % p.Wo);
-        const int ho = (int)((idx / p.Wo) % p.Ho);
-        const long ng = idx / ((long)p.Wo * p.Ho);
-        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const PoolIdx ix = pool_decode(idx, p.dv_wo, p.dv_ho, p.dv_g);
+        const int wo = (int)ix.w, ho = (int)ix.h, g = (int)ix.g, n = (int)ix.n;
         const long ibase = ((long)n * p.x_img_groups + g) * p.H * p.W;
         float best[8];
         unsigned char arg[8];
@@ -248,8 +269,10 @@ __device__ __forceinline__ float store_grad8(float (&v)[8], const PoolArgs& p, l
     float vmax = 0.f;
     if (p.y_f32) {
         const long hw = (long)p.H * p.W;
-        const long q = o % hw, ng = o / hw;
-        const long n = ng / p.y_img_groups;
+        uint32_t qq, ng, nn, gg;
+        fd_divmod((uint32_t)o, p.dv_hw, ng, qq);      // (fp32 output: y_img_groups == G)
+        fd_divmod(ng, p.dv_g, nn, gg);
+        const long q = qq, n = nn;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             vmax = fmaxf(vmax, fabsf(v[e]));
@@ -277,23 +300,22 @@ __device__ __forceinline__ float finish_grad8(float (&v)[8], const PoolArgs& p, 
 // (x = output gradient [Ho x Wo], y = input gradient [H x W]); deterministic, no atomics
 template <int KT, int ST>
 __global__ __launch_bounds__(256) void pl_maxpool_bwd_kernel(PoolArgs p) {
-    const long total = (long)p.N * p.G * p.H * p.W;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)p.H * (uint32_t)p.W;
     const float r = *p.y_scale / *p.x_scale;
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int w = (int)(idx % p.W);
-        const int h = (int)((idx / p.W) % p.H);
-        const long ng = idx / ((long)p.W * p.H);
-        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const PoolIdx ix = pool_decode(idx, p.dv_w, p.dv_h, p.dv_g);
+        const int w = (int)ix.w, h = (int)ix.h, g = (int)ix.g, n = (int)ix.n;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
         // windows (ho, wo) with ho * s - pad <= h <= ho * s - pad + k - 1
-        int ho_lo = (h + p.pad - p.k + p.s) / p.s;   // ceil((h + pad - k + 1) / s) for non-negative numerators
-        if (h + p.pad - p.k + 1 <= 0) ho_lo = 0;
-        int wo_lo = (w + p.pad - p.k + p.s) / p.s;
-        if (w + p.pad - p.k + 1 <= 0) wo_lo = 0;
-        int ho_hi = (h + p.pad) / p.s, wo_hi = (w + p.pad) / p.s;
+        const int pk = KT ? KT : p.k, ps = ST ? ST : p.s;      // (compile-time in the instantiated cases: no runtime division)
+        int ho_lo = (h + p.pad - pk + ps) / ps;   // ceil((h + pad - k + 1) / s) for non-negative numerators
+        if (h + p.pad - pk + 1 <= 0) ho_lo = 0;
+        int wo_lo = (w + p.pad - pk + ps) / ps;
+        if (w + p.pad - pk + 1 <= 0) wo_lo = 0;
+        int ho_hi = (h + p.pad) / ps, wo_hi = (w + p.pad) / ps;
         if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
         if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
         if constexpr (KT > 0) {
@@ -353,15 +375,13 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_kernel(PoolArgs p) {
 template <int PAD>
 __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
     const int Hb = (p.H + 1) / 2, Wb = (p.W + 1) / 2;
-    const long total = (long)p.N * p.G * Hb * Wb;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)Hb * (uint32_t)Wb;
     const float r = *p.y_scale / *p.x_scale;
     constexpr int base_off = (PAD + 1) / 2 - 1;      // first candidate window of block i is i + base_off (pad 0: i - 1, pad 1: i)
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int j = (int)(idx % Wb);
-        const int i = (int)((idx / Wb) % Hb);
-        const long ng = idx / ((long)Wb * Hb);
-        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const PoolIdx ix = pool_decode(idx, p.dv_wb, p.dv_hb, p.dv_g);
+        const int j = (int)ix.w, i = (int)ix.h, g = (int)ix.g, n = (int)ix.n;
         u32x2 am[4];
         float d[4][8];
         bool wok[4];
@@ -443,14 +463,12 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
 // y = relu?(scale[c] * avgpool_kxk(x) + shift[c]), stride 1, zero padding counted (count_include_pad): the pool BEHIND its 1x1
 // projection (a 1x1 convolution commutes with the zero-padded average)
 __global__ __launch_bounds__(256) void pl_avgpool_affine_kernel(PoolArgs p) {
-    const long total = (long)p.N * p.G * p.H * p.W;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)p.H * (uint32_t)p.W;
     const float inv = 1.f / ((float)(p.k * p.k) * *p.x_scale), so = *p.y_scale;
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int w = (int)(idx % p.W);
-        const int h = (int)((idx / p.W) % p.H);
-        const long ng = idx / ((long)p.W * p.H);
-        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const PoolIdx ix = pool_decode(idx, p.dv_w, p.dv_h, p.dv_g);
+        const int w = (int)ix.w, h = (int)ix.h, g = (int)ix.g, n = (int)ix.n;
         const long ibase = ((long)n * p.x_img_groups + g) * p.H * p.W;
         float acc[8];
 #pragma unroll
@@ -488,12 +506,14 @@ __global__ __launch_bounds__(256) void pl_avgpool_affine_kernel(PoolArgs p) {
 // in place: g <- g * (y > 0) * scale[c]  (NaN scale: channel passes through) -- the ReLU / frozen-BN backward of a slice whose
 // last writer could not fuse it
 __global__ __launch_bounds__(256) void pl_relu_bn_bwd_kernel(PoolArgs p) {
-    const long total = (long)p.N * p.G * p.H * p.W;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)p.H * (uint32_t)p.W;
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long q = idx % ((long)p.H * p.W);
-        const long ng = idx / ((long)p.H * p.W);
-        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        uint32_t qq, ng, gg, nn;
+        fd_divmod(idx, p.dv_hw, ng, qq);
+        fd_divmod(ng, p.dv_g, nn, gg);
+        const long q = qq;
+        const int g = (int)gg, n = (int)nn;
         const long o = ((long)n * p.y_img_groups + g) * p.H * p.W + q;
         const long mo = ((long)n * p.mask_img_groups + g) * p.H * p.W + q;
         float v[8];
@@ -528,13 +548,15 @@ __global__ __launch_bounds__(256) void pl_gap_fwd_kernel(const void* hi, const v
 // (PoolArgs: aff_shift = dy fp32 [N][C], y = dx planes, mask as usual)
 __global__ __launch_bounds__(256) void pl_gap_bwd_kernel(PoolArgs p) {
     const int HW = p.H * p.W;
-    const long total = (long)p.N * p.G * HW;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)HW;
     const float k = *p.y_scale / (float)HW;
     float vmax = 0.f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long q = idx % HW;
-        const long ng = idx / HW;
-        const int g = (int)(ng % p.G), n = (int)(ng / p.G);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        uint32_t qq, ng, gg, nn;
+        fd_divmod(idx, p.dv_hw, ng, qq);
+        fd_divmod(ng, p.dv_g, nn, gg);
+        const long q = qq;
+        const int g = (int)gg, n = (int)nn;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = p.aff_shift[(long)n * p.G * 8 + 8 * g + e] * k;
@@ -559,12 +581,18 @@ __global__ __launch_bounds__(256) void pl_channel_sum_kernel(const void* hi, con
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // (image, pixel) of this thread's first element by ONE division, then carried along: no division in the loop
+    long n = (begin + threadIdx.x) / HW, q = (begin + threadIdx.x) - n * HW;
     for (long i = begin + threadIdx.x; i < end; i += 256) {
-        const long n = i / HW, q = i - n * HW;
         float v[8];
         load8(hi, lo, (n * img_groups + g) * HW + q, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        q += 256;
+        while (q >= HW) {
+            q -= HW;
+            ++n;
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
@@ -611,12 +639,17 @@ __global__ __launch_bounds__(256) void pl_channel_sum_multi_kernel(ChannelSumTab
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    long n = (begin + threadIdx.x) / HW, q = (begin + threadIdx.x) - n * HW;      // (see pl_channel_sum_kernel)
     for (long i = begin + threadIdx.x; i < end; i += 256) {
-        const long n = i / HW, q = i - n * HW;
         float v[8];
         load8(t.hi[ti], t.lo[ti], (n * t.img_groups[ti] + g) * HW + q, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        q += 256;
+        while (q >= HW) {
+            q -= HW;
+            ++n;
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
@@ -697,6 +730,10 @@ extern "C" int ssn_pl_from_f32(const float* x, long x_img_stride, void* hi, void
     a.s2d = s2d;
     SSN_CHECK_ARG(img_groups >= a.G, "pl from f32: slice wider than its tensor");
     const long total = (long)N * a.G * (s2d ? (H / 2) * (W / 2) : H * W);
+    SSN_CHECK_ARG(total < (1l << 27), "pl from f32: more than 2^27 16-byte groups per plane");
+    a.dv_hw = make_fastdiv((uint32_t)(s2d ? (H / 2) * (W / 2) : H * W));
+    a.dv_g = make_fastdiv((uint32_t)a.G);
+    a.dv_wo = make_fastdiv((uint32_t)(s2d ? W / 2 : W));
     hipLaunchKernelGGL(pl_from_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("pl_from_f32");
     return SSN_OK;
@@ -706,8 +743,9 @@ extern "C" int ssn_pl_to_f32(const void* hi, const void* lo, long img_groups, fl
                              int HW, const float* scale, hipStream_t stream) {
     SSN_CHECK_ARG(hi && lo && y && scale && N > 0 && C > 0 && HW > 0, "pl to f32: bad arguments");
     const long total = (long)N * ((C + 7) / 8) * HW;
+    SSN_CHECK_ARG(total < (1l << 27), "pl to f32: more than 2^27 16-byte groups per plane");
     hipLaunchKernelGGL(pl_to_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream, hi, lo, img_groups, y, y_img_stride, N, C,
-                       HW, scale);
+                       HW, scale, make_fastdiv((uint32_t)HW), make_fastdiv((uint32_t)((C + 7) / 8)));
     SSN_CHECK_LAUNCH("pl_to_f32");
     return SSN_OK;
 }
@@ -742,6 +780,16 @@ static int fill_pool(PoolArgs& a, const void* x_hi, const void* x_lo, long x_img
     a.accumulate = 0;
     a.y_f32 = nullptr;
     a.y_f32_img_stride = 0;
+    SSN_CHECK_ARG((long)N * (C / 8) * H * W < (1l << 27) && (long)N * (C / 8) * Ho * Wo < (1l << 27),
+                  "%s: more than 2^27 16-byte groups per plane (32-bit indexing, 2 GiB buffer addressing)", what);
+    a.dv_w = make_fastdiv((uint32_t)W);
+    a.dv_h = make_fastdiv((uint32_t)H);
+    a.dv_wo = make_fastdiv((uint32_t)(Wo > 0 ? Wo : 1));
+    a.dv_ho = make_fastdiv((uint32_t)(Ho > 0 ? Ho : 1));
+    a.dv_g = make_fastdiv((uint32_t)(C / 8));
+    a.dv_hw = make_fastdiv((uint32_t)(H * W));
+    a.dv_wb = make_fastdiv((uint32_t)((W + 1) / 2));
+    a.dv_hb = make_fastdiv((uint32_t)((H + 1) / 2));
     return SSN_OK;
 }
 

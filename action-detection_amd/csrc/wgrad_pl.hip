@@ -912,7 +912,9 @@ int fill_wgpl(WgPlArgs& a, const void* g_hi, const void* g_lo, const void* x_hi,
 double g_group_fixed[2] = {450.0, 150.0};
 int g_group_min_units[2] = {4, 32};
 enum { WGF_9_XP6 = 0, WGF_9_XP8 = 1, WGF_9_XP12 = 2, WGF_1 = 3, WGF_COUNT = 4 };
-// one-tap / chunked variants of the WGF_1 family: tile (output x input channels), reduction units per item step, cost per unit
+// one-tap / chunked variants of the WGF_1 family (3 = the chunked 1x1 body): tile = output x input channels.  (A big-tile family --
+// 256 x 128 / 128 x 256 one-tap, 128 x 128 chunked, one workgroup per CU -- was measured in the group and lost on every layer:
+// profiles/r5_wgrad_group_variants.txt.)
 const int kG1BM[4] = {128, 96, 64, 64};
 const int kG1BC[4] = {128, 128, 64, 64};
 struct WgGroupItem {
@@ -921,6 +923,7 @@ struct WgGroupItem {
     long units;            // reduction range in the body's own units: k-steps (one-tap) or 64-slot chunks (chunked bodies)
     double unit_cost;      // matrix instructions per wave and unit (what an item's length is measured in)
     long tiles;            // output tiles (x taps for the one-tap bodies)
+    bool chunked;          // WGF_1: the chunked 1x1 body (units = 64-slot chunks, any count per share)
     int kg;                // partial slabs per split
     int taps;              // tap-major slabs (nine-tap bodies): 9, else 1
     long ws_off;           // byte offset of the problem's slabs in the workspace
@@ -932,6 +935,7 @@ int classify_group(WgGroupItem& it, int hint) {
     WgPlArgs& a = it.a;
     it.kg = 1;
     it.taps = 1;
+    it.chunked = false;
     if (hint < 0 || (hint >= 100 && hint < 200)) {
         if (nine_tap_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w, a.H, a.W, a.Ho, a.Wo)) {
             const int xp = xp_for(a.W);
@@ -956,9 +960,10 @@ int classify_group(WgGroupItem& it, int hint) {
     }
     it.family = WGF_1;
     const bool can_chunk = chunked_1x1_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w);
-    int v;
+    int v;      // index into kG1BM / kG1BC
     if (hint >= 200) {
         SSN_CHECK_ARG(can_chunk, "conv wgrad pl group: the chunked body takes 1x1 / stride-1 layers only");
+        SSN_CHECK_ARG(hint == 200, "conv wgrad pl group: chunked tile %d is not compiled into the grouped kernels", hint);
         v = 3;
     } else if (hint == 3) {
         v = 0;
@@ -987,10 +992,11 @@ int classify_group(WgGroupItem& it, int hint) {
     a.n_mtiles = (a.M + kG1BM[v] - 1) / kG1BM[v];
     a.n_ctiles = (a.Cin + kG1BC[v] - 1) / kG1BC[v];
     a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
-    if (v == 3) {
+    it.chunked = v == 3;
+    if (it.chunked) {
         it.tiles = (long)a.n_mtiles * a.n_ctiles;
         it.units = ((long)a.P + 63) / 64;
-        it.unit_cost = 4 * 3;
+        it.unit_cost = 4 * 3.0 * (kG1BM[v] / 64) * (kG1BC[v] / 64);
         a.magic_wp = 0xFFFFFFFFu / (uint32_t)a.W + 1u;
         a.div_hw = make_fastdiv((uint32_t)(a.H * a.W));
         a.div_w = make_fastdiv((uint32_t)a.W);
@@ -1014,11 +1020,12 @@ void plan_group(std::vector<WgGroupItem*>& fam, int slots, double fixed_cost, in
     if (target < fixed_cost) target = fixed_cost;
     for (WgGroupItem* it : fam) {
         long per = (long)(target / it->unit_cost + 0.5);
-        if (per < min_units) per = min_units;
+        const long floor_units = (it->family >= WGF_1 && it->chunked) ? (min_units + 3) / 4 : min_units;   // (a chunk = 4 k-steps)
+        if (per < floor_units) per = floor_units;
         if (per > it->units) per = it->units;
         long splits = (it->units + per - 1) / per;
         per = (it->units + splits - 1) / splits;           // (equal shares)
-        if (even_units && it->variant != 3 && (per & 1)) ++per;   // the one-tap pipeline runs two k-steps per trip
+        if (even_units && !it->chunked && (per & 1)) ++per;       // the one-tap pipeline runs two k-steps per trip
         splits = (it->units + per - 1) / per;
         it->a.splits = (int)splits;
         it->a.ksteps_per_split = (int)per;

@@ -208,6 +208,29 @@ def _pool_out(h, k, s, p):
     return o
 
 
+def _branch_lanes(plan):
+    """Two-lane schedule of the Inception blocks (net.branch_lanes): behind a block-input launch the plan holds the SHORT chain
+    (the 3x3 branch, and the pool behind / beside its projection) and the LONG one (double_3x3_1 -> double_3x3_2), which depend on
+    nothing but the block input.  Returns ({plan index: "fork" | "side"} for the ops of the short chain -- they go to a side stream --,
+    {plan indices in front of which the side stream is joined}); forward order.  The backward walks the same sets in reverse."""
+    side, joins = {}, set()
+    i = 0
+    while i < len(plan):
+        op = plan[i]
+        seg = plan[i + 1:i + 5]
+        ok = (op["kind"] == "conv" and len(op["lids"]) >= 2 and len(seg) == 4 and all(q["kind"] == "conv" and len(q["lids"]) == 1 for q in seg[:3])
+              and seg[3]["kind"] in ("pool", "pool_aff") and seg[2]["src"] == seg[1]["dst"] and seg[0]["src"] == op["dst"]
+              and seg[1]["src"] == op["dst"] and seg[1]["dst"] not in (seg[0]["dst"], op["dst"]))
+        if ok:
+            side[i + 1] = "fork"
+            side[i + 4] = "side"
+            joins.add(i + 5)
+            i += 5
+        else:
+            i += 1
+    return side, joins
+
+
 def _dgrad_is_s2(op):
     return len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3 and op["s"] == 2
 
@@ -296,8 +319,9 @@ def run_forward(net, x, keep):
                 acts[name] = PlaneTensor(n, c, h, w, dev, st.pool, st.slot(name, False), snap)
             return acts[name]
 
-        feat = None
-        for op in plan:
+        feat_box = [None]
+
+        def run_op(op):
             if op["kind"] == "conv":
                 cout, cin = op["cout"], op["cin"]
                 raw = bool(op.get("raw"))
@@ -378,9 +402,26 @@ def run_forward(net, x, keep):
                 P.avgpool_affine(PSlice(acts[op["src"]], op.get("src_c0", 0), c), PSlice(get(op["dst"]), op["dst_c0"], c),
                                  scale_slice(op["dst"], op["dst_c0"], c), shift_of[op["conv"]], True, op["k"], op["p"])
             else:
-                feat = torch.empty((n, op["c"]), device=dev, dtype=torch.float32)
-                P.gap_fwd(PSlice(acts[op["src"]], 0, op["c"]), feat)
-        return feat
+                feat_box[0] = torch.empty((n, op["c"]), device=dev, dtype=torch.float32)
+                P.gap_fwd(PSlice(acts[op["src"]], 0, op["c"]), feat_box[0])
+
+        side_ops, joins = _branch_lanes(plan) if (net.branch_lanes and x.is_cuda) else ({}, set())
+        side = net._side_stream(dev) if side_ops else None
+        main = torch.cuda.current_stream(dev) if side_ops else None
+        for pidx, op in enumerate(plan):
+            if pidx in joins:
+                main.wait_stream(side)
+            if pidx in side_ops:
+                get(op["dst"])                          # (every allocation of the pass happens on the caller's stream)
+                if side_ops[pidx] == "fork":
+                    side.wait_stream(main)              # the block-input launch has been issued
+                with torch.cuda.stream(side):
+                    run_op(op)
+            else:
+                run_op(op)
+        if side_ops:
+            main.wait_stream(side)
+        return feat_box[0]
 
     # delayed scales: this pass stores with the scales derived from the previous pass's maxima
     res = {"acts": {}, "feat": None}
@@ -520,7 +561,8 @@ def run_backward(net, dfeat, saved, hook=True):
             assert covered in (0, c), "partially finalised gradient slice %s[%d:%d]" % (name, c0, c0 + c)
             return covered == c
 
-        for idx in range(len(plan) - 1, -1, -1):
+        def run_op(idx):
+            nonlocal pending_end
             op = plan[idx]
             if op["kind"] == "gap":
                 c = op["c"]
@@ -682,6 +724,27 @@ def run_backward(net, dfeat, saved, hook=True):
                     flush()                                   # the block's gradients must be final before their all-reduce
                     net.grad_ready_hook.range_ready(flat, wo, pending_end)
                     pending_end = wo
+
+        side_ops, joins = _branch_lanes(plan) if (net.branch_lanes and dfeat.is_cuda) else ({}, set())
+        side = net._side_stream(dev) if side_ops else None
+        main = torch.cuda.current_stream(dev) if side_ops else None
+        # (backward = the forward's lanes in reverse: the short chain's LAST op -- the pool, three ops behind its "fork" -- forks
+        # behind the next block's input gradient, the block-input launch joins)
+        forks_bwd = {i + 3 for i, kind in side_ops.items() if kind == "fork"}
+        joins_bwd = {i - 1 for i, kind in side_ops.items() if kind == "fork"}
+        for idx in range(len(plan) - 1, -1, -1):
+            if idx in joins_bwd:
+                main.wait_stream(side)
+            if idx in side_ops:
+                gbuf(plan[idx]["src"])                  # (allocations on the caller's stream)
+                if idx in forks_bwd:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    run_op(idx)
+            else:
+                run_op(idx)
+        if side_ops:
+            main.wait_stream(side)
         flush()
         if fire_hook and net.grad_ready_hook is not None:
             if pending_end > 0:

@@ -46,7 +46,9 @@ def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v, neg):
     torch-CPU fp32 path is off the float64 gradient by 2.4e-3 on one tensor for that reason
     (profiles/r2_grad_flip_diag.txt; identical numbers with the exact-f32 MFMA kernels, so it is not a property of the
     operand split).  Which units flip is an accident of rounding; how MANY tensors are affected and how close the bulk
-    is to float64 is what a correct implementation controls, and that is what is asserted."""
+    is to float64 is what a correct implementation controls.  Asserted: every tensor within 5e-3 of the fp32 oracle and of float64
+    (fixed a priori), and -- the bar that does not depend on which units flip -- every tensor within 5e-5 of the float64 referee that
+    is forced to take the HIP forward's ReLU / max-pool decisions."""
     m, o = build(modality, cfg, negative_gamma_frac=neg)
     m.base_model.debug_keep_saved = True
     batch = make_batch(v, modality, 20, seed=5)
@@ -85,11 +87,10 @@ def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v, neg):
           "%.2e, %d above 1e-3" % (len(e_hip), e_hip.median(), e_hip.max(), int((e_hip > 1e-3).sum()), e_cpu.median(),
                                    e_cpu.max(), int((e_cpu > 1e-3).sum())))
     assert e_hip.max() < 5e-3
-    # (median: a single unit near the top of the network that lands on the other side of zero moves EVERY tensor's error by ~1e-4 --
-    # the independent torch-fp32 forward has such units too, other ones; 3x its median, as for Inception-v3.  The statement that does
-    # not depend on that luck is the forced one below: every tensor to 5e-5.  It is asserted first.)
-    stat = (e_hip.median() <= 3.0 * e_cpu.median() + 1e-5,
-            int((e_hip > 1e-3).sum()) <= int((e_cpu > 1e-3).sum()) + max(6, len(e_hip) // 50))
+    # (No bar is derived from the torch-fp32 column: a single unit near the top of the network that lands on the other side of zero
+    # moves EVERY tensor's error by ~1e-4, in either implementation -- round 4 had to move a "2 x the oracle's median" bar to 3 x after
+    # one configuration measured 2.15 x, which is a measurement, not a bar.  The printed line stays as a diagnostic; THE gradient bar
+    # is the forced referee below, every tensor to 5e-5, next to the a-priori 5e-3 cap per tensor above.)
 
     # ---- the tight check: float64 referee with the HIP forward's discrete decisions forced ----
     # The statistical statement above is all that can be said against an INDEPENDENT forward (units within rounding of zero
@@ -112,8 +113,6 @@ def test_fwd_bwd_matches_oracle(hip_library, modality, cfg, v, neg):
             worst = (n1, e)
     print("gradients vs mask-forced float64 referee: worst %s %.2e" % worst)
     assert worst[1] < 5e-5, worst
-    assert stat[0], ("median vs independent float64 forward", e_hip.median(), e_cpu.median())
-    assert stat[1], "tensors above 1e-3 vs the independent float64 forward"
 
 
 def test_negative_bn_gammas(hip_library):

@@ -257,7 +257,7 @@ def test_conv_pl_wgrad(backend):
 
 
 def test_conv_pl_wgrad_group(backend):
-    """ssn_conv_wgrad_pl_group: ALL problems of the case list as ONE grouped call (<= 4 launches + one reduction) vs autograd in
+    """ssn_conv_wgrad_pl_group: ALL problems of the case list as ONE grouped call (one launch per kernel family + one reduction) vs autograd in
     float64 -- every family (nine taps on rows of <= 14 / <= 30 / <= 56 pixels, one-tap bodies with any taps / stride / padding,
     chunked 1x1), operands in slices of wider tensors, a problem without a bias gradient, a fused block-input problem (row gap);
     then every variant forced by hint on the problems that take it; a second call must reproduce the first bit by bit."""
@@ -317,7 +317,8 @@ def test_conv_pl_wgrad_group(backend):
         sub, idx = [], []
         for i, (j, c) in enumerate(zip(jobs, cases)):
             n, cin, h, wd, cout, kh, kw, s, ph, pw = c
-            ok = {200: (kh, kw, s, ph, pw) == (1, 1, 1, 0, 0), 100: (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1)}.get(hint, True)
+            one_by_one = (kh, kw, s, ph, pw) == (1, 1, 1, 0, 0)
+            ok = {200: one_by_one, 100: (kh, kw, s, ph, pw) == (3, 3, 1, 1, 1)}.get(hint, True)
             if ok and (backend.is_gpu or i < 6 or hint >= 100):
                 j.hint = hint
                 j.dw.fill_(5.0)
