@@ -185,10 +185,13 @@ class BNInception(nn.Module):
         # planes_exec: every weight gradient keeps its split-K slabs in its own workspace region and ONE launch reduces them all at the
         # end of the pass (at every gradient-ready range with an overlapping reducer) instead of one launch per layer
         self.defer_wgrad_reduce = os.environ.get("SSN_DEFER_WGRAD_REDUCE", "1") != "0"
-        # planes_exec: ALL weight gradients of a backward pass as one grouped call (<= 4 launches over a device-resident problem table
+        # planes_exec: ALL weight gradients of a backward pass as one grouped call (<= 5 launches over a device-resident problem table
         # + one reduction, csrc/wgrad_pl.hip: ssn_conv_wgrad_pl_group) at the end of the pass -- or, with an overlapping gradient
         # reducer, at every gradient-ready range -- instead of one launch (+ reduction) per layer; 0: per-layer launches
         self.group_wgrad = os.environ.get("SSN_GROUP_WGRAD", "1") != "0"
+        # planes_exec: the stem's weight gradient as a problem of the grouped launch on planes operands (wgrad_stem_body); 0: the
+        # fp32-layout kernel of rounds 2 - 4 (fp32 space-to-depth copy of the frames + fp32 output gradient from the pool's backward)
+        self.stem_planes = os.environ.get("SSN_STEM_PLANES", "1") != "0"
         if os.environ.get("SSN_GROUP_TUNING"):      # tooling: planner constants "fixed9,fixed1,min9,min1" (ssn_conv_wgrad_pl_group_tuning)
             from . import _lib
             f9, f1, m9, m1 = (os.environ["SSN_GROUP_TUNING"].split(",") + ["0"] * 4)[:4]

@@ -65,8 +65,8 @@ struct CvtArgs {
 };
 
 // Index arithmetic of the kernels below is 32-bit with host-computed magic divisions: a plane holds < 2^27 16-byte groups (2 GiB
-// buffer addressing), and a 64-bit `idx % W` costs ~100 instructions on this ISA -- with three or four of them per element the pool
-// kernels of rounds 3 - 4 were bound by integer division, not by memory (round 5: profiles/r5_pool_lab.txt).
+// buffer addressing), and three or four 64-bit `idx % W` per element cost a few hundred instructions (round 5: -4 % on the stem pools'
+// backward; what bounds those kernels is their selection arithmetic and the redundant window loads: profiles/r5_pool_lab.txt).
 struct PoolIdx {
     uint32_t n, g, h, w;
 };
@@ -455,6 +455,105 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (live[q]) vmax = fmaxf(vmax, store_grad8(v[q], p, oq[q], 8 * g));
+        }
+    }
+    amax_emit(p.y_amax, vmax / *p.y_scale);
+}
+
+// The same backward for the cases the training step runs (planes output, no accumulation; MASK: the pooled mask), written for
+// instruction count: the general kernel above spends ~1500 vector + ~850 scalar instructions per 2 x 2 block -- divergent branches
+// around every masked select, per-element scale loads, 64-bit address arithmetic per access -- and runs at 3.1 TB/s where a plain
+// stream of its bytes reaches 6.2 (profiles/r5_pool_lab.txt: 0.11 of the stem pool's 0.41 ms is that arithmetic).  Here: buffer loads
+// with 32-bit offsets (a window that does not exist reads zeros: no predicate reaches the arithmetic), the eight channel factors
+// (scale x r, or r for a pass-through channel) loaded once per thread as two 16-byte loads, selects instead of branches.
+// Same values as the general kernel (r is a power of two: folding it into the channel factor is exact).
+template <int PAD, bool MASK>
+__global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_fast_kernel(PoolArgs p) {
+    const int Hb = (p.H + 1) / 2, Wb = (p.W + 1) / 2;
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)Hb * (uint32_t)Wb;
+    const float r = *p.y_scale / *p.x_scale;
+    constexpr int base_off = (PAD + 1) / 2 - 1;
+    const uint32_t HoWo = (uint32_t)p.Ho * (uint32_t)p.Wo;
+    // descriptors end with the slice in the last image (see ssn_conv_wgrad_pl: nothing is read past a slice at the end of its tensor)
+    const uint32_t x_bytes = (uint32_t)(((long)(p.N - 1) * p.x_img_groups + p.G) * HoWo * 16);
+    const uint32_t m_bytes = MASK ? (uint32_t)(((long)(p.N - 1) * p.mask_img_groups + p.G) * HoWo * 16) : 0u;
+    const __amdgpu_buffer_rsrc_t r_hi = pl_rsrc(p.x_hi, x_bytes), r_lo = pl_rsrc(p.x_lo, x_bytes);
+    const __amdgpu_buffer_rsrc_t r_am = pl_rsrc(p.argmax, (uint32_t)p.N * (uint32_t)p.G * HoWo * 8u);
+    const __amdgpu_buffer_rsrc_t r_mk = pl_rsrc(MASK ? p.mask_hi : p.x_hi, MASK ? m_bytes : 0u);
+    float vmax = 0.f;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const PoolIdx ix = pool_decode(idx, p.dv_wb, p.dv_hb, p.dv_g);
+        const int j = (int)ix.w, i = (int)ix.h;
+        const uint32_t g = ix.g, n = ix.n;
+        float kk[8];          // per channel: what a routed value is multiplied by when its ReLU passed
+        bool pass[8];         // NaN scale: not a ReLU / frozen-BN output -- the gradient passes whatever the sign
+        if (MASK) {
+            const f32x4 s0 = reinterpret_cast<const f32x4*>(p.aff_scale + 8 * g)[0], s1 = reinterpret_cast<const f32x4*>(p.aff_scale + 8 * g)[1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sc = e < 4 ? s0[e] : s1[e - 4];
+                pass[e] = sc != sc;
+                kk[e] = pass[e] ? r : sc * r;
+            }
+        }
+        const uint32_t xb = (n * (uint32_t)p.x_img_groups + g) * HoWo, ab = (n * (uint32_t)p.G + g) * HoWo;
+        const uint32_t mb = MASK ? (n * (uint32_t)p.mask_img_groups + g) * HoWo : 0u;
+        u32x4 hi[4], lo[4], pm[4];
+        u32x2 am[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ho = i + base_off + (t >> 1), wo = j + base_off + (t & 1);
+            const bool ok = (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            const uint32_t q = (uint32_t)(ho * p.Wo + wo);
+            hi[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_hi, ok ? (xb + q) * 16u : PL_OOB, 0, 0));
+            lo[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_lo, ok ? (xb + q) * 16u : PL_OOB, 0, 0));
+            am[t] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_am, ok ? (ab + q) * 8u : PL_OOB, 0, 0));
+            if (MASK) pm[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_mk, ok ? (mb + q) * 16u : PL_OOB, 0, 0));
+        }
+        float d[4][8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (e & 1) ? f16_pair_hi(hi[t][e >> 1]) + f16_pair_hi(lo[t][e >> 1])
+                                        : f16_pair_lo(hi[t][e >> 1]) + f16_pair_lo(lo[t][e >> 1]);
+                if (MASK) {
+                    const float m = (e & 1) ? f16_pair_hi(pm[t][e >> 1]) : f16_pair_lo(pm[t][e >> 1]);
+                    d[t][e] = v * ((m > 0.f || pass[e]) ? kk[e] : 0.f);
+                } else {
+                    d[t][e] = v * r;
+                }
+            }
+        const long obase = (((long)n * p.y_img_groups + g) * p.H + 2 * i) * p.W + 2 * j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = 2 * i + (q >> 1), w = 2 * j + (q & 1);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rr = (q >> 1) - 2 * (base_off + (t >> 1)) + PAD, ss = (q & 1) - 2 * (base_off + (t & 1)) + PAD;   // constants
+                if (rr < 0 || rr > 2 || ss < 0 || ss > 2) continue;
+                const unsigned local = (unsigned)(rr * 3 + ss);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned a = (am[t][e >> 2] >> (8 * (e & 3))) & 0xFFu;
+                    v[e] += (a == local) ? d[t][e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                vmax = fmaxf(vmax, fabsf(v[e]));        // before the clamp: the true magnitude is recorded (a pixel outside the image holds 0)
+                v[e] = pl_clamp(v[e]);
+            }
+            u32x4 ohi, olo;
+            pl_split8(v, ohi, olo);
+            if (h < p.H && w < p.W) {
+                const long o = obase + (long)(q >> 1) * p.W + (q & 1);
+                reinterpret_cast<u32x4*>(p.y_hi)[o] = ohi;
+                reinterpret_cast<u32x4*>(p.y_lo)[o] = olo;
+            }
         }
     }
     amax_emit(p.y_amax, vmax / *p.y_scale);
@@ -849,7 +948,17 @@ extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_
                   "pl maxpool bwd: a pooled mask needs a 3x3 / stride-2 pool (pad 0 / 1) that does not accumulate");
     a.relu = mask_pooled ? 1 : 0;
     const dim3 grid(grid_for((long)N * a.G * H * W));
-    if (k == 3 && s == 2 && (pad == 0 || pad == 1))
+    // the training step's cases (planes output, nothing to accumulate, no mask or the pooled one, 16-byte aligned scale vector) on
+    // the low-instruction-count kernel
+    const bool fast = k == 3 && s == 2 && (pad == 0 || pad == 1) && !dx_f32 && !accumulate && (!a.mask_hi || mask_pooled) &&
+                      (!a.mask_hi || (reinterpret_cast<uintptr_t>(mask_scale) & 15) == 0) && (long)N * C / 8 * Ho * Wo * 16 < (1l << 31);
+    if (fast) {
+        const dim3 gb(grid_for((long)N * a.G * ((H + 1) / 2) * ((W + 1) / 2)));
+        if (pad == 0 && a.mask_hi) hipLaunchKernelGGL((pl_maxpool_bwd_k3s2_fast_kernel<0, true>), gb, dim3(256), 0, stream, a);
+        else if (pad == 0) hipLaunchKernelGGL((pl_maxpool_bwd_k3s2_fast_kernel<0, false>), gb, dim3(256), 0, stream, a);
+        else if (a.mask_hi) hipLaunchKernelGGL((pl_maxpool_bwd_k3s2_fast_kernel<1, true>), gb, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((pl_maxpool_bwd_k3s2_fast_kernel<1, false>), gb, dim3(256), 0, stream, a);
+    } else if (k == 3 && s == 2 && (pad == 0 || pad == 1))
         if (pad == 0)
             hipLaunchKernelGGL(pl_maxpool_bwd_k3s2_kernel<0>, dim3(grid_for((long)N * a.G * ((H + 1) / 2) * ((W + 1) / 2))), dim3(256), 0,
                                stream, a);

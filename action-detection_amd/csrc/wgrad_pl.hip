@@ -479,6 +479,14 @@ __device__ __forceinline__ void wgrad_pl9_body(const WgPlArgs& p, const uint32_t
         SSN_DS_READ_TR16_B64_AT(r1_, base_, (imm_) + 256);                           \
         dst_ = __builtin_bit_cast(f16x8, u32x4{r0_[0], r0_[1], r1_[0], r1_[1]});     \
     } while (0)
+// (the same with 32-byte rows: the second group of four slots is 128 bytes on)
+#define WG_RD_FRAG32(dst_, base_, imm_)                                              \
+    do {                                                                             \
+        u32x2 r0_, r1_;                                                              \
+        SSN_DS_READ_TR16_B64_AT(r0_, base_, imm_);                                   \
+        SSN_DS_READ_TR16_B64_AT(r1_, base_, (imm_) + 128);                           \
+        dst_ = __builtin_bit_cast(f16x8, u32x4{r0_[0], r0_[1], r1_[0], r1_[1]});     \
+    } while (0)
 
 #pragma unroll
     for (int q = 0; q < NPMAX; ++q) issue_piece(ck_begin, 0, q);
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// GROUPED launches: every weight gradient of a backward pass in <= 4 launches (+ one reduction).
+// GROUPED launches: every weight gradient of a backward pass in <= 5 launches (+ one reduction).
 //
 // The weight gradients of a pass are mutually independent, and launched one by one each of them has to fill 256 CUs on its own:
 // split-K factors of 20 - 130, i.e. workgroups that run 8 - 12 chunks and then store a 150 KB partial slab (2.2 GB of slabs per
@@ -625,7 +633,8 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
 //   * the bodies are the single-launch kernels' (wgrad_pl9_body / wgrad_pl_body), selected per problem by a wave-uniform switch;
 //     the partial slabs are reduced in the fixed order of ssn_wgrad_reduce_multi: deterministic, bit-identical from call to call.
 // Families (one launch each, only if it has problems): nine-tap 64 x 64 tiles with XP = 6 / 8 / 12 (rows <= 14 / <= 30 / <= 56
-// pixels; 80 / 96 / 128 KiB of LDS), and everything else (1x1, stride-2, rectangular taps) on the one-tap / chunked 1x1 bodies.
+// pixels; 80 / 96 / 128 KiB of LDS), everything else (1x1, stride-2, rectangular taps) on the one-tap / chunked 1x1 bodies, and the
+// space-to-depth stem (4 x 4 taps on 16-channel sub-blocks: wgrad_stem_body).
 constexpr int WGG_MAX = 96;             // problems per grouped launch (block -> problem search table travels by value)
 constexpr int WGG_WRITE = 12;           // table entries written per plan-write launch (by-value kernel arguments: < 4 KiB)
 struct WgGroupEntry {
@@ -684,8 +693,206 @@ __global__ __launch_bounds__(256, 2) void wgrad_group1_kernel(const WgGroupEntry
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The STEM: 4 x 4 taps / stride 1 / two padding pixels in front, one behind, on the <= 16-channel sub-blocks of a space-to-depth
+// input (conv1 7x7 / 2 of the backbone manifest in its space-to-depth form, planes_exec.py) -- the one layer whose input has too few
+// channels for the bodies above: 12 (RGB) or 40 (flow) real channels against 32-channel fragments, sixteen taps.  Rounds 2 - 4 ran it
+// on the fp32-layout kernel (conv_wgrad_x6.hip: 0.62 ms, 23.7 VALU per MFMA, fed by a 925 MB fp32 copy of the output gradient and an
+// fp32 space-to-depth copy of the frames).  Here a fragment's 32 "channels" are 16 real channels x TWO TAPS: the transposed LDS read
+// takes a per-lane address, so the lanes of channels 0-15 read tap A's pixels and the lanes of channels 16-31 tap B's from ONE staged
+// copy of X ([padded slot][16 channels], 32-byte rows) -- the nine-tap body's trick (one operand copy, taps = read displacements over a
+// padded pixel enumeration: TWO zero columns in front of every row, two zero rows in front of every image, shared with the previous
+// row / image) with the tap pairs (r, s) + (r + 2, s): their displacement differs by 2 (W + 2) slots = 4 mod 8 for W = 0 mod 4, so the
+// two 128-byte row groups of a 32-lane service group fall into disjoint bank halves.  8 tap pairs x 2 output fragments = 16 fragment
+// products per k-step, spread over 4 waves (output fragment x half of the pairs); two wave groups split the k-steps of a chunk.
+// A workgroup = (64 output channels) x (one 16-channel sub-block of X) x (share of the padded slots).  Slabs: tap-major columns
+// t * Cin + ci (ssn_wgrad_reduce_taps with 16 taps puts them back as dW[m][ci][r][s]).
+constexpr int STEM_XP = 13;        // X pieces (32 slots x 16 channels = 1 KiB) per chunk and plane: 64 + 3 (W + 2) + 3 <= 416 slots
+constexpr int STEM_LDS = 2 * (2 * 2 * 4 * 1024 + 2 * STEM_XP * 1024);
+inline bool stem_layer(int kh, int kw, int stride, int pad_h, int pad_w, int H, int W, int Ho, int Wo) {
+    return kh == 4 && kw == 4 && stride == 1 && pad_h == 2 && pad_w == 2 && Ho == H && Wo == W && 64 + 3 * (W + 2) + 3 <= STEM_XP * 32;
+}
+__device__ __forceinline__ void wgrad_stem_body(const WgPlArgs& p, const uint32_t bid, unsigned char* lds) {
+    constexpr int NS = 64, KSC = 4, KG = 2, KSG = KSC / KG;
+    constexpr int A_BYTES = 2 * 2 * KSC * 1024;           // [frag][plane][64 slots][32 ch]
+    constexpr int XPL_BYTES = STEM_XP * 1024;             // one plane of X: [416 slots][16 ch]
+    constexpr int STAGE = A_BYTES + 2 * XPL_BYTES;
+    static_assert(2 * STAGE == STEM_LDS, "LDS size");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave8 = wave_uniform(tid >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;
+    const int wm = wave & 1, wc = wave >> 1;              // output fragment, half of the tap pairs
+    const int li = lane & 31, lh = lane >> 5;
+
+    const uint32_t tiles = (uint32_t)p.n_mtiles * (uint32_t)p.n_ctiles;
+    const uint32_t logical = xcd_remap(bid, tiles * (uint32_t)p.splits);
+    uint32_t z, tile, mt, sub;
+    fd_divmod(logical, p.div_tiles, z, tile);
+    fd_divmod(tile, p.div_ct, mt, sub);
+    const int m0 = (int)mt * 64, c0 = (int)sub * 16;
+    const int Wp = p.W + 2, SP = (p.H + 2) * Wp;
+    const int D = 2 * Wp + 2;                             // slots of X in front of the chunk's first dY slot
+    const uint32_t T = (uint32_t)p.N * (uint32_t)SP;
+
+    // ---- DMA role: operand (0 = dY, 1 = X) and plane; the pieces of a chunk are split between the two wave groups ----
+    const int op = wave >> 1, plane = wave & 1;
+    const void *xh = p.x_hi, *xl = p.x_lo, *gh = p.g_hi, *gl = p.g_lo;
+    const uint32_t xbytes = p.x_bytes, gbytes = p.g_bytes, xgrp = p.x_grp_bytes, ggrp = p.g_grp_bytes, ximg = p.x_img_bytes, gimg = p.g_img_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = op ? pl_rsrc(plane ? xl : xh, xbytes) : pl_rsrc(plane ? gl : gh, gbytes);
+    const uint32_t grp_bytes = op ? xgrp : ggrp;
+    const uint32_t img_bytes = op ? ximg : gimg;
+    // dY: a piece = 16 slots x 4 channel groups (lane -> slot lane / 4, group lane % 4) of each of the two output fragments;
+    // X: a piece = 32 slots x 2 channel groups (lane -> slot lane / 2, group lane % 2) of this sub-block
+    const int dsl = op ? (lane >> 1) : (lane >> 2);
+    const int slots_per_piece = op ? 32 : 16;
+    const uint32_t lane_grp = (uint32_t)(op ? (lane & 1) : (lane & 3)) * grp_bytes;
+    uint32_t frag_so[2];
+    frag_so[0] = (uint32_t)((op ? c0 : m0) / 8) * grp_bytes;
+    frag_so[1] = (uint32_t)((m0 + 32) / 8) * grp_bytes;   // (dY only)
+    const int ck_begin = (int)z * p.ksteps_per_split;
+    const int total_ck = (int)((T + NS - 1) / NS);
+    int ck_end = ck_begin + p.ksteps_per_split;
+    if (ck_end > total_ck) ck_end = total_ck;
+
+    constexpr int NPMAX = (STEM_XP + KG - 1) / KG;        // 7 (X); dY: KSC / KG = 2
+    const int npieces = wave_uniform(op ? (STEM_XP - grp + KG - 1) / KG : KSC / KG);
+    const int lane_slot0 = (op ? -D : 0) + dsl;
+    const uint32_t adv_img = (uint32_t)(NS / SP) * img_bytes, adv_u = (uint32_t)(NS % SP);
+    uint32_t pu[NPMAX], pn[NPMAX];
+#pragma unroll
+    for (int q = 0; q < NPMAX; ++q) {
+        const int sl = ck_begin * NS + lane_slot0 + (q * KG + grp) * slots_per_piece;
+        uint32_t n, u;
+        fd_divmod((uint32_t)(sl < 0 ? sl + SP : sl), p.div_hw, n, u);       // div_hw = SP;  D <= SP: one image back at most
+        pu[q] = u;
+        pn[q] = (n - (sl < 0 ? 1u : 0u)) * img_bytes;
+    }
+    auto issue_piece = [&](int ck, int buf, int q) {
+        if (q >= npieces) return;
+        const int sg = q * KG + grp;
+        const int sl = ck * NS + lane_slot0 + sg * slots_per_piece;
+        const uint32_t hp = __umulhi(pu[q], p.magic_wp), wp = pu[q] - hp * (uint32_t)Wp;
+        const bool real = ck < ck_end && (uint32_t)sl < T && hp >= 2u && wp >= 2u;
+        const uint32_t vo = real ? pn[q] + ((hp - 2u) * (uint32_t)p.W + (wp - 2u)) * 16u + lane_grp : PL_OOB;
+        unsigned char* base = lds + buf * STAGE;
+        if (op == 0) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + ((f * 2 + plane) * KSC + sg) * 1024), vo, frag_so[f]);
+        } else {
+            WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + A_BYTES + plane * XPL_BYTES + sg * 1024), vo, frag_so[0]);
+        }
+        uint32_t u = pu[q] + adv_u, im = pn[q] + adv_img;
+        const bool wrap = u >= (uint32_t)SP;
+        pu[q] = wrap ? u - (uint32_t)SP : u;
+        pn[q] = wrap ? im + img_bytes : im;
+    };
+
+    f32x16 acc[4];
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const bool do_bias = wave_uniform((sub == 0 && wc == 0) ? 1 : 0) != 0;
+
+    // transposed reads: dY as in the bodies above (64-byte rows); X: 32-byte rows, the lanes of channels 16-31 displaced to tap B
+    const int l16 = lane & 15, sg16 = (lane >> 4) & 1;
+    const int a_rd = (8 * lh + (l16 >> 2)) * 64 + sg16 * 32 + (l16 & 3) * 8;
+    int x_rd[4];          // per tap pair of this wave: byte offset of this lane's row piece at k-step 0 inside a plane of X
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pi = wc * 4 + i;                                     // pair: column tap pi & 3, row taps (pi >> 2) and (pi >> 2) + 2
+        const int tr = (pi >> 2) + 2 * sg16, ts = pi & 3;
+        x_rd[i] = (D + (tr - 2) * Wp + (ts - 2) + 8 * lh + (l16 >> 2)) * 32 + (l16 & 3) * 8;
+    }
+    const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u});
+
+#pragma unroll
+    for (int q = 0; q < NPMAX; ++q) issue_piece(ck_begin, 0, q);
+    int buf = 0;
+    for (int ck = ck_begin; ck < ck_end; ++ck) {
+        SSN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();          // chunk ck is complete in `buf`; everybody is done reading the other buffer
+        const unsigned char* ab = lds + buf * STAGE + a_rd + (wm * 2 * KSC + grp * KSG) * 1024;
+        const unsigned char* xb = lds + buf * STAGE + A_BYTES + (grp * KSG) * 16 * 32;
+        f16x8 af[2][2], bf[2][4][2];           // [register set][plane] / [set][pair][plane]
+        auto read_set = [&](int ks, int set) {
+#pragma unroll
+            for (int pn_ = 0; pn_ < 2; ++pn_) WG_RD_FRAG(af[set][pn_], ab, (pn_ * KSC + ks) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pn_ = 0; pn_ < 2; ++pn_) WG_RD_FRAG32(bf[set][i][pn_], xb + x_rd[i], pn_ * XPL_BYTES + ks * 16 * 32);
+        };
+        read_set(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSG; ++ks) {
+            SSN_WAIT_LGKM0();                  // the fragments of this k-step (read during the previous one) are in
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < KSG) read_set(ks + 1, (ks + 1) & 1);
+            // the fetch of the next chunk: this wave's pieces spread over the k-steps
+            constexpr int PPK = (NPMAX + KSG - 1) / KSG;
+#pragma unroll
+            for (int e = 0; e < PPK; ++e)
+                if (ks * PPK + e < NPMAX) issue_piece(ck + 1, buf ^ 1, ks * PPK + e);
+            constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_hi + g_hi x_lo
+            constexpr int PB[3] = {0, 0, 1};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][PA[c]], bf[ks & 1][i][PB[c]], acc[i], 0, 0, 0);
+            if (do_bias) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][0], ones, accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][1], ones, accb, 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    SSN_WAIT_VMCNT(0);
+
+    const float inv = 1.f / (*p.g_scale * *p.x_scale);
+    float* out = p.part + ((long)z * KG + grp) * p.M * p.ldp;
+    const int ci = c0 + (li & 15);
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pi = wc * 4 + i;
+            const int t = ((pi >> 2) + 2 * (li >> 4)) * 4 + (pi & 3);       // tap r * 4 + s of this lane's half of the fragment
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) out[(long)m * p.ldp + t * p.Cin + ci] = acc[i][r] * inv;
+            }
+        }
+    }
+    if (do_bias && li == 0) {
+        const float ginv = 1.f / *p.g_scale;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < p.M) out[(long)m * p.ldp + p.K] = accb[r] * ginv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_group_stem_kernel(const WgGroupEntry* __restrict__ table, WgGroupIndex ix) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[STEM_LDS];
+    const int e = group_problem_of_block(ix, (int)blockIdx.x);
+    const uint32_t bid = blockIdx.x - (uint32_t)ix.blk0[e];
+    const auto* ent = SSN_CONST_PTR(WgGroupEntry, table) + e;
+    if (bid >= ent->nblk) return;
+    const WgPlArgs p = ent->a;
+    wgrad_stem_body(p, bid, lds);
+}
+
 #undef WG_DMA_B128
 #undef WG_RD_FRAG
+#undef WG_RD_FRAG32
 
 template <int KK, int TM, int TC, int XP, int KG = 1>
 int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {
@@ -911,7 +1118,7 @@ int fill_wgpl(WgPlArgs& a, const void* g_hi, const void* g_lo, const void* x_hi,
 // (prologue + first fetch + partial-slab store + its share of the reduction), fewest reduction units an item may have
 double g_group_fixed[2] = {450.0, 150.0};
 int g_group_min_units[2] = {4, 32};
-enum { WGF_9_XP6 = 0, WGF_9_XP8 = 1, WGF_9_XP12 = 2, WGF_1 = 3, WGF_COUNT = 4 };
+enum { WGF_9_XP6 = 0, WGF_9_XP8 = 1, WGF_9_XP12 = 2, WGF_1 = 3, WGF_STEM = 4, WGF_COUNT = 5 };
 // one-tap / chunked variants of the WGF_1 family (3 = the chunked 1x1 body): tile = output x input channels.  (A big-tile family --
 // 256 x 128 / 128 x 256 one-tap, 128 x 128 chunked, one workgroup per CU -- was measured in the group and lost on every layer:
 // profiles/r5_wgrad_group_variants.txt.)
@@ -936,6 +1143,27 @@ int classify_group(WgGroupItem& it, int hint) {
     it.kg = 1;
     it.taps = 1;
     it.chunked = false;
+    if ((hint < 0 || hint == 300) && stem_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w, a.H, a.W, a.Ho, a.Wo)) {
+        // the space-to-depth stem: (64 output channels) x (16-channel sub-block of X) tiles, sixteen taps as eight tap pairs
+        it.family = WGF_STEM;
+        it.variant = 0;
+        it.kg = 2;
+        it.taps = 16;
+        const int Wp = a.W + 2, SP = (a.H + 2) * Wp;
+        it.units = ((long)a.N * SP + 63) / 64;
+        it.unit_cost = 2 * 4 * 3;
+        a.n_mtiles = (a.M + 63) / 64;
+        a.n_ctiles = (a.Cin + 15) / 16;
+        it.tiles = (long)a.n_mtiles * a.n_ctiles;
+        a.div_tiles = make_fastdiv((uint32_t)it.tiles);
+        a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
+        a.magic_wp = 0xFFFFFFFFu / (uint32_t)Wp + 1u;
+        a.div_hw = make_fastdiv((uint32_t)SP);
+        a.div_w = make_fastdiv((uint32_t)Wp);
+        return SSN_OK;
+    }
+    SSN_CHECK_ARG(hint != 300, "conv wgrad pl group: the stem body takes 4x4 / stride 1 / pad 2 layers on rows of <= %d pixels only",
+                  (STEM_XP * 32 - 67) / 3 - 2);
     if (hint < 0 || (hint >= 100 && hint < 200)) {
         if (nine_tap_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w, a.H, a.W, a.Ho, a.Wo)) {
             const int xp = xp_for(a.W);
@@ -1068,11 +1296,11 @@ extern "C" long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int 
     return (long)splits * Cout * ((long)Cin * kh * kw + 1) * (long)sizeof(float);
 }
 
-// ---- grouped weight gradients: ALL weight (+ bias) gradients of a backward pass in <= 4 launches + one reduction -------------------
+// ---- grouped weight gradients: ALL weight (+ bias) gradients of a backward pass in <= 5 launches + one reduction -------------------
 // (replaces the per-layer cuDNN wgrad calls behind loss.backward(), /root/reference/ssn_train.py:236).  Problem i is described like
 // the arguments of ssn_conv_wgrad_pl: plane pointers g_hi/g_lo/x_hi/x_lo[i], dw[i], db[i] (may be null), g_scale / x_scale[i],
 // shape[i * 16 + ...] = {N, Cin, H, W, Cout, Ho, Wo, kh, kw, stride, pad_h, pad_w, g_row_split, g_row_gap, tile hint (-1: choose;
-// 0 / 3 / 8: one-tap 64 x 64 / 128 x 128 / 96 x 128; 100: nine taps; 200: chunked 1x1), 0}, groups[i * 2 + ...] = {x_img_groups,
+// 0 / 3 / 8: one-tap 64 x 64 / 128 x 128 / 96 x 128; 100: nine taps; 200: chunked 1x1; 300: the space-to-depth stem), 0}, groups[i * 2 + ...] = {x_img_groups,
 // g_img_groups}.  workspace: ssn_conv_wgrad_pl_group_workspace_bytes() bytes (partial slabs of every problem, each in its own
 // region); table: ssn_conv_wgrad_pl_group_table_bytes(count) bytes of device memory the launches read their problems from (written
 // by this call, every call: operand addresses change from pass to pass).  Nothing is synchronised; capturable.
@@ -1104,7 +1332,7 @@ int plan_group_all(int count, const int* shape, const long* groups, const void* 
         if (f == WGF_1)
             plan_group(fam, 512, g_group_fixed[1], g_group_min_units[1], true);
         else
-            plan_group(fam, f == WGF_9_XP6 ? 512 : 256, g_group_fixed[0], g_group_min_units[0], false);
+            plan_group(fam, f == WGF_9_XP6 ? 512 : 256, g_group_fixed[0], g_group_min_units[0], false);      // (the stem too)
     }
     long off = 0;
     for (WgGroupItem& it : items) {
@@ -1202,6 +1430,7 @@ extern "C" int ssn_conv_wgrad_pl_group(int count, const void* const* g_hi, const
                 case WGF_9_XP6: hipLaunchKernelGGL((wgrad_group9_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, tab, ix); break;
                 case WGF_9_XP8: hipLaunchKernelGGL((wgrad_group9_kernel<8, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
                 case WGF_9_XP12: hipLaunchKernelGGL((wgrad_group9_kernel<12, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
+                case WGF_STEM: hipLaunchKernelGGL(wgrad_group_stem_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
                 default: hipLaunchKernelGGL(wgrad_group1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, ix); break;
             }
             first += n;

@@ -283,7 +283,7 @@ def wgrad_group_plan(jobs):
 
 
 def conv_wgrad_group(jobs, workspace=None, table=None):
-    """Every weight + bias gradient of ``jobs`` (WgradJob) in at most four launches + one reduction (ssn_conv_wgrad_pl_group).
+    """Every weight + bias gradient of ``jobs`` (WgradJob) in at most five launches + one reduction (ssn_conv_wgrad_pl_group).
     workspace (fp32 tensor) / table (uint8 tensor): buffers of at least ``wgrad_group_plan(jobs)`` bytes, allocated when None."""
     import ctypes
     if not jobs:

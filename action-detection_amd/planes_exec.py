@@ -231,6 +231,13 @@ def _branch_lanes(plan):
     return side, joins
 
 
+def _stem_on_planes(net, x):
+    """The weight gradient of the space-to-depth stem as a problem of the grouped launch (csrc/wgrad_pl.hip: wgrad_stem_body) -- on
+    planes operands like every other layer: no fp32 copy of the frames, no fp32 output gradient.  Needs the grouped launches and
+    rows of at most 114 (space-to-depth) pixels: the body's halo buffer."""
+    return net.group_wgrad and net.stem_planes and x.shape[3] // 2 <= 114
+
+
 def _dgrad_is_s2(op):
     return len(op["lids"]) == 1 and not op["rect"] and op["k"] == 3 and op["s"] == 2
 
@@ -336,7 +343,9 @@ def run_forward(net, x, keep):
                         acts["data_s2d"] = PlaneTensor(n, 4 * cin, x.shape[2] // 2, x.shape[3] // 2, dev, st.pool,
                                                        st.slot("data_s2d", False), snap)
                         measured = None
-                        if keep:     # the stem's weight gradient runs on the fp32-layout kernel (3 real channels: see run_backward)
+                        if keep and not _stem_on_planes(net, x):
+                            # the stem's weight gradient on the fp32-layout kernel (SSN_STEM_PLANES=0 / rows wider than the stem
+                            # body's halo buffer; see run_backward): it reads an fp32 space-to-depth copy of the frames
                             acts["data_s2d_f32"] = K.space_to_depth2(x)
                             measured = acts["data_s2d_f32"]._ssn_amax      # (that pass over the frames also took their maximum)
                         P.from_f32(x, acts["data_s2d"], s2d=True, exact=True, amax=measured)
@@ -480,7 +489,7 @@ def run_backward(net, dfeat, saved, hook=True):
         else:
             need = P.wgrad_workspace_bytes(n, op["cin"], op["cout"], ho, wo, kh, kw, net._pl_tile("wgrad", op, n, shapes))
         need = (need + 1023) // 1024 * 1024
-        if net.group_wgrad and not op.get("s2d"):
+        if net.group_wgrad and (not op.get("s2d") or "data_s2d_f32" not in acts):
             continue                                   # (grouped: the slabs live in the group's own workspace)
         if not net.defer_wgrad_reduce:
             ws_off[op["lids"][0]] = (0, need)
@@ -526,10 +535,11 @@ def run_backward(net, dfeat, saved, hook=True):
         pending_reduce, pending_sums = [], []     # deferred split-K reductions / the channel sums that must follow them
 
         pending_wgrad = []                        # grouped mode: (planes.WgradJob, flops) of the weight gradients not yet launched
+        pending_post = []                         # ... and what has to follow their reduction (the stem: space-to-depth taps -> 7x7)
 
         def flush():
             if pending_wgrad:
-                # every weight gradient recorded since the last flush: <= 4 launches over a device-resident problem table + ONE
+                # every weight gradient recorded since the last flush: <= 5 launches over a device-resident problem table + ONE
                 # reduction (ssn_conv_wgrad_pl_group) -- their output gradients are all final by now, and they depend on nothing else
                 jobs = [j for j, _ in pending_wgrad]
                 net._timed("conv_wgrad_pl", "group", sum(f for _, f in pending_wgrad),
@@ -539,7 +549,9 @@ def run_backward(net, dfeat, saved, hook=True):
                 net._timed("conv_wgrad_pl", "reduce_multi", 0.0, lambda: P.wgrad_reduce_multi(entries))
             if pending_sums:
                 P.channel_sum_multi(list(pending_sums), cs_ws)
-            del pending_reduce[:], pending_sums[:], pending_wgrad[:]
+            for fn in pending_post:
+                fn()
+            del pending_reduce[:], pending_sums[:], pending_wgrad[:], pending_post[:]
         group = net.group_wgrad
         defer = pending_reduce if net.defer_wgrad_reduce else None
 
@@ -671,6 +683,10 @@ def run_backward(net, dfeat, saved, hook=True):
 
                     def run_wgrad(ws=ws_of(op)):
                         dw2 = torch.empty((cout, 4 * cin, 4, 4), device=dev, dtype=torch.float32)
+                        if group:      # a problem of the grouped launch (the stem body: 16 taps as 8 tap pairs on 16-channel sub-blocks)
+                            pending_wgrad.append((P.WgradJob(gs, PSlice(xs, 0, xs.g * 8), dw2, db, 4, 4, 1, 2, 2, cin=4 * cin), flops))
+                            pending_post.append(lambda: K.s2d_weights_bwd(dw2, dw))
+                            return
                         P.conv_wgrad(gs, PSlice(xs, 0, xs.g * 8), dw2, db, 4, 4, 1, 2, 2, ws, wcfg, cin=4 * cin)
                         K.s2d_weights_bwd(dw2, dw)
                 else:
@@ -698,7 +714,7 @@ def run_backward(net, dfeat, saved, hook=True):
                             pending_sums.append(entry)
                         else:
                             P.channel_sum_multi([entry], cs_ws)
-                if group and not op.get("s2d"):
+                if group and not (op.get("s2d") and "__stem_f32__" in grads):
                     run_wgrad_and_bias()         # (only records: the group is timed as a whole at its flush)
                 else:
                     net._timed("conv_wgrad_pl", lids[0], flops, run_wgrad_and_bias)

@@ -485,10 +485,10 @@ int ssn_wgrad_reduce_multi(int count, const float* const* part, float* const* dw
                            const int* splits, const int* taps, hipStream_t stream);
 long ssn_conv_wgrad_pl_workspace_bytes(int N, int Cin, int Cout, int Ho, int Wo, int kh, int kw, int tile_cfg);
 /* GROUPED weight gradients: every weight + bias gradient of a backward pass (all the cuDNN wgrad calls behind loss.backward(),
- * /root/reference/ssn_train.py:236) in at most four launches (one per kernel family that has problems) + one reduction.  Problem i takes the arguments of ssn_conv_wgrad_pl as
+ * /root/reference/ssn_train.py:236) in at most five launches (one per kernel family that has problems) + one reduction.  Problem i takes the arguments of ssn_conv_wgrad_pl as
  * array entries (HOST arrays): plane pointers, dw[i], db[i] (may be NULL), scale pointers, shape[16 i ..] = {N, Cin, H, W, Cout, Ho,
  * Wo, kh, kw, stride, pad_h, pad_w, g_row_split, g_row_gap, tile hint, 0} (hint -1: chosen; 0 / 3 / 8: one-tap 64x64 / 128x128 /
- * 96x128; 100: nine taps; 200: chunked 1x1), groups[2 i ..] = {x_img_groups, g_img_groups}.  The problems travel in a device-resident
+ * 96x128; 100: nine taps; 200: chunked 1x1; 300: the 4x4-tap space-to-depth stem), groups[2 i ..] = {x_img_groups, g_img_groups}.  The problems travel in a device-resident
  * table (`table`: ssn_conv_wgrad_pl_group_table_bytes(count) bytes, written by the call); each kernel family runs ONE grid over all its
  * problems, items ordered longest first, the reduction ranges split only as far as the whole group needs; partial slabs
  * (`workspace`: ssn_conv_wgrad_pl_group_workspace_bytes bytes; plan_out, optional: [count][4] = family, variant, splits, units per

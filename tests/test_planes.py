@@ -265,12 +265,19 @@ def test_conv_pl_wgrad_group(backend):
     cases = list(CASES_GPU if backend.is_gpu else CASES_SMALL)
     # rows of 28 / 56 pixels for the XP = 8 / 12 nine-tap families (emulator: narrow slices of such rows keep it affordable)
     cases += [] if backend.is_gpu else [(1, 8, 5, 28, 16, 3, 3, 1, 1, 1), (1, 8, 3, 56, 16, 3, 3, 1, 1, 1), (2, 72, 4, 4, 136, 1, 1, 1, 0, 0)]
+    # the space-to-depth stem (4x4 taps, two padding pixels in front and ONE behind: outputs = inputs): 12 (RGB) / 40 (flow) real
+    # channels, an output-channel count that is not a multiple of 64, a row length that is not a multiple of 4
+    stem = [(4, 12, 112, 112, 64), (2, 40, 112, 112, 64)] if backend.is_gpu else [(2, 12, 6, 8, 64), (1, 40, 5, 7, 72)]
+    n_plain = len(cases)
+    cases += [(n, cin, h, wd, cout, 4, 4, 1, 2, 2) for (n, cin, h, wd, cout) in stem]
     jobs, want, keep = [], [], []
     for ci, (n, cin, h, wd, cout, kh, kw, s, ph, pw) in enumerate(cases):
         x = torch.randn(n, cin, h, wd, generator=g)
         w = (torch.randn(cout, cin, kh, kw, generator=g, dtype=torch.float64) * 0.1).requires_grad_()
         b = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
         y = F.conv2d(x.double(), w, b, s, (ph, pw))
+        if ci >= n_plain:
+            y = y[:, :, :h, :wd]
         gy = torch.randn(y.shape, generator=g) * 1e-3
         y.backward(gy.double())
         ho, wo = y.shape[2], y.shape[3]
@@ -293,7 +300,8 @@ def test_conv_pl_wgrad_group(backend):
     ws_bytes, tb_bytes, plan = P.wgrad_group_plan(jobs)
     fams = sorted({f for f, _, _, _ in plan})
     print("  group plan (family, variant, splits, units):", plan, flush=True)
-    assert fams == [0, 1, 2, 3], fams                      # every kernel family has a problem
+    assert fams == [0, 1, 2, 3, 4], fams                   # every kernel family has a problem
+    assert [f for f, _, _, _ in plan[n_plain:]] == [4, 4]
     assert {v for f, v, _, _ in plan if f == 3} >= {2, 3} or backend.is_gpu
     P.conv_wgrad_group(jobs)
     first = [(j.dw.clone(), None if j.db is None else j.db.clone()) for j in jobs]

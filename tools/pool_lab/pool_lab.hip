@@ -162,6 +162,20 @@ int main() {
         printf("%s: reads %.0f MB, writes %.0f MB\n", c.name, rd / 1e6, wr / 1e6);
         auto rep = [&](const char* what, float ms, size_t bytes) { printf("   %-44s %.4f ms  %.2f TB/s\n", what, ms, bytes / ms / 1e9); };
         rep("product kernel", tm.run([&] { hipLaunchKernelGGL(pl_maxpool_bwd_k3s2_kernel<0>, grid, dim3(256), 0, 0, a); }), rd + wr);
+        if (!c.f32) {
+            rep("fast kernel (pooled mask)", tm.run([&] { hipLaunchKernelGGL((pl_maxpool_bwd_k3s2_fast_kernel<0, true>), grid, dim3(256), 0, 0, a); }), rd + wr);
+            PoolArgs b = a;
+            b.mask_hi = nullptr;
+            b.relu = 0;
+            rep("fast kernel (no mask)", tm.run([&] { hipLaunchKernelGGL((pl_maxpool_bwd_k3s2_fast_kernel<0, false>), grid, dim3(256), 0, 0, b); }), rd - out_px * 16 + wr);
+            rep("product kernel (no mask)", tm.run([&] { hipLaunchKernelGGL(pl_maxpool_bwd_k3s2_kernel<0>, grid, dim3(256), 0, 0, b); }), rd - out_px * 16 + wr);
+            // forward of the same pool: x = the big tensor (dx buffers), y = the pooled one (dy buffers), argmax written
+            PoolArgs f;
+            fill_pool(f, dx_hi, dx_lo, G, dy_hi, dy_lo, G, c.N, c.C, c.H, c.W, Ho, Wo, 3, 2, c.pad, scales, scales + 1, scales + 2, "lab");
+            f.argmax = (unsigned char*)am;
+            const dim3 gf(grid_for((long)c.N * G * Ho * Wo));
+            rep("FORWARD product kernel", tm.run([&] { hipLaunchKernelGGL((pl_maxpool_fwd_kernel<3, 2>), gf, dim3(256), 0, 0, f); }), in_px * 32 + out_px * 40);
+        }
         rep("loads only", tm.run([&] { hipLaunchKernelGGL((k3s2_ablate_kernel<0, 1>), grid, dim3(256), 0, 0, a); }), rd);
         rep("stores only", tm.run([&] { hipLaunchKernelGGL((k3s2_ablate_kernel<0, 2>), grid, dim3(256), 0, 0, a); }), wr);
         rep("loads + stores, no selection arithmetic", tm.run([&] { hipLaunchKernelGGL((k3s2_ablate_kernel<0, 0>), grid, dim3(256), 0, 0, a); }), rd + wr);
