@@ -246,6 +246,73 @@ __global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
     amax_emit(p.y_amax, vmax / *p.y_scale);
 }
 
+// 3x3 max pool forward written for instruction count (as pl_maxpool_bwd_k3s2_fast_kernel below: buffer loads with 32-bit offsets, no
+// predicate state carried across the nine taps -- a tap outside the image is loaded from nowhere (zeros) and turned into -inf by
+// eight selects on the packed words --, the argmax kept in one register per channel).  The general kernel above spills its nine tap
+// predicates through lane writes (213 of its 1100 vector instructions).  Same results: first maximum in scan order.
+template <int ST>
+__global__ __launch_bounds__(256) void pl_maxpool_fwd_k3_fast_kernel(PoolArgs p) {
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)p.Ho * (uint32_t)p.Wo;
+    const float r = *p.y_scale / *p.x_scale;
+    const uint32_t HW = (uint32_t)p.H * (uint32_t)p.W;
+    const uint32_t x_bytes = (uint32_t)(((long)(p.N - 1) * p.x_img_groups + p.G) * HW * 16);
+    const __amdgpu_buffer_rsrc_t r_hi = pl_rsrc(p.x_hi, x_bytes), r_lo = pl_rsrc(p.x_lo, x_bytes);
+    float vmax = 0.f;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const PoolIdx ix = pool_decode(idx, p.dv_wo, p.dv_ho, p.dv_g);
+        const int wo = (int)ix.w, ho = (int)ix.h;
+        const uint32_t xb = (ix.n * (uint32_t)p.x_img_groups + ix.g) * HW;
+        u32x4 thi[9], tlo[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int h = ho * ST - p.pad + t / 3, w = wo * ST - p.pad + t % 3;
+            const bool ok = ((unsigned)h < (unsigned)p.H) && ((unsigned)w < (unsigned)p.W);
+            const uint32_t off = ok ? (xb + (uint32_t)(h * p.W + w)) * 16u : PL_OOB;
+            thi[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_hi, off, 0, 0));
+            tlo[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_lo, off, 0, 0));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) thi[t][d] = ok ? thi[t][d] : 0xFC00FC00u;      // -inf: never the maximum (its lo word is 0)
+        }
+        float best[8];
+        uint32_t arg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            best[e] = -__builtin_inff();
+            arg[e] = 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float v[8];
+            pl_join8(thi[t], tlo[t], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool gt = v[e] > best[e];
+                best[e] = gt ? v[e] : best[e];
+                arg[e] = gt ? (uint32_t)t : arg[e];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (a tap's eight compare masks die here: hoisted together they spill the scalar file)
+        }
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sv = best[e] * r;
+            vmax = fmaxf(vmax, fabsf(sv));      // the TRUE magnitude (before the clamp)
+            out[e] = pl_clamp(sv);
+        }
+        u32x4 hi, lo;
+        pl_split8(out, hi, lo);
+        const long o = ((long)ix.n * p.y_img_groups + ix.g) * p.Ho * p.Wo + (long)ho * p.Wo + wo;
+        reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
+        reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
+        if (p.argmax) {
+            const uint32_t a0 = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+            const uint32_t a1 = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+            reinterpret_cast<u32x2*>(p.argmax)[idx] = u32x2{a0, a1};
+        }
+    }
+    amax_emit(p.y_amax, vmax / *p.y_scale);
+}
+
 // finish a gradient element group: (+ old), fused ReLU / frozen-BN backward of the producer ...
 __device__ __forceinline__ void prep_grad8(float (&v)[8], const PoolArgs& p, long o, long mo, int c0) {
     if (p.accumulate) {
@@ -905,9 +972,9 @@ extern "C" int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img
     a.argmax = argmax;
     const dim3 grid(grid_for((long)N * a.G * Ho * Wo));
     if (k == 3 && s == 2)
-        hipLaunchKernelGGL((pl_maxpool_fwd_kernel<3, 2>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((pl_maxpool_fwd_k3_fast_kernel<2>), grid, dim3(256), 0, stream, a);
     else if (k == 3 && s == 1)
-        hipLaunchKernelGGL((pl_maxpool_fwd_kernel<3, 1>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((pl_maxpool_fwd_k3_fast_kernel<1>), grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((pl_maxpool_fwd_kernel<0, 0>), grid, dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("pl_maxpool_fwd");

@@ -479,14 +479,6 @@ __device__ __forceinline__ void wgrad_pl9_body(const WgPlArgs& p, const uint32_t
         SSN_DS_READ_TR16_B64_AT(r1_, base_, (imm_) + 256);                           \
         dst_ = __builtin_bit_cast(f16x8, u32x4{r0_[0], r0_[1], r1_[0], r1_[1]});     \
     } while (0)
-// (the same with 32-byte rows: the second group of four slots is 128 bytes on)
-#define WG_RD_FRAG32(dst_, base_, imm_)                                              \
-    do {                                                                             \
-        u32x2 r0_, r1_;                                                              \
-        SSN_DS_READ_TR16_B64_AT(r0_, base_, imm_);                                   \
-        SSN_DS_READ_TR16_B64_AT(r1_, base_, (imm_) + 128);                           \
-        dst_ = __builtin_bit_cast(f16x8, u32x4{r0_[0], r0_[1], r1_[0], r1_[1]});     \
-    } while (0)
 
 #pragma unroll
     for (int q = 0; q < NPMAX; ++q) issue_piece(ck_begin, 0, q);
@@ -707,17 +699,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_group1_kernel(const WgGroupEntry
 // products per k-step, spread over 4 waves (output fragment x half of the pairs); two wave groups split the k-steps of a chunk.
 // A workgroup = (64 output channels) x (one 16-channel sub-block of X) x (share of the padded slots).  Slabs: tap-major columns
 // t * Cin + ci (ssn_wgrad_reduce_taps with 16 taps puts them back as dW[m][ci][r][s]).
-constexpr int STEM_XP = 13;        // X pieces (32 slots x 16 channels = 1 KiB) per chunk and plane: 64 + 3 (W + 2) + 3 <= 416 slots
-constexpr int STEM_LDS = 2 * (2 * 2 * 4 * 1024 + 2 * STEM_XP * 1024);
+// X lives in a RING of 1024 padded slots per plane: consecutive chunks of 128 output slots need windows of X that overlap in all but
+// 128 slots, so a chunk fetches only its 128 new ones (the first version re-staged the whole 409-slot window per 64-slot chunk: 26 KB
+// of X per 16 KB of dY, 27 B / clk / CU -- the L2 -> LDS ceiling, profiles/r4_clock_control.txt -- and ran at 0.52 ms).
+constexpr int STEM_NS = 128;       // output slots per chunk (8 k-steps: four per wave group)
+constexpr int STEM_DA = 256;       // slots of X kept in front of a chunk (>= 2 (W + 2) + 2, a multiple of the 32-slot DMA piece)
+constexpr int STEM_EA = 128;       // ... and behind it (>= W + 3)
+constexpr int STEM_RING = 1024;    // >= STEM_DA + 2 STEM_NS + STEM_EA
+constexpr int STEM_MAX_W = 114;
+constexpr int STEM_LDS = 2 * (2 * 2 * 8 * 1024) + 2 * STEM_RING * 32;
 inline bool stem_layer(int kh, int kw, int stride, int pad_h, int pad_w, int H, int W, int Ho, int Wo) {
-    return kh == 4 && kw == 4 && stride == 1 && pad_h == 2 && pad_w == 2 && Ho == H && Wo == W && 64 + 3 * (W + 2) + 3 <= STEM_XP * 32;
+    return kh == 4 && kw == 4 && stride == 1 && pad_h == 2 && pad_w == 2 && Ho == H && Wo == W && W <= STEM_MAX_W;
 }
 __device__ __forceinline__ void wgrad_stem_body(const WgPlArgs& p, const uint32_t bid, unsigned char* lds) {
-    constexpr int NS = 64, KSC = 4, KG = 2, KSG = KSC / KG;
-    constexpr int A_BYTES = 2 * 2 * KSC * 1024;           // [frag][plane][64 slots][32 ch]
-    constexpr int XPL_BYTES = STEM_XP * 1024;             // one plane of X: [416 slots][16 ch]
-    constexpr int STAGE = A_BYTES + 2 * XPL_BYTES;
-    static_assert(2 * STAGE == STEM_LDS, "LDS size");
+    constexpr int NS = STEM_NS, KSC = NS / 16, KG = 2, KSG = KSC / KG;
+    constexpr int A_BYTES = 2 * 2 * KSC * 1024;           // one dY buffer: [frag][plane][128 slots][32 ch]
+    constexpr int RING_BYTES = STEM_RING * 32;            // one plane of the X ring: [1024 slots][16 ch]
+    constexpr uint32_t RMASK = STEM_RING - 1;
+    static_assert(2 * A_BYTES + 2 * RING_BYTES == STEM_LDS, "LDS size");
+    static_assert(STEM_DA >= 2 * (STEM_MAX_W + 2) + 2 && STEM_EA >= STEM_MAX_W + 3 && STEM_DA + 2 * NS + STEM_EA <= STEM_RING, "window");
+    unsigned char* const xring = lds + 2 * A_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave8 = wave_uniform(tid >> 6);
@@ -732,8 +733,7 @@ __device__ __forceinline__ void wgrad_stem_body(const WgPlArgs& p, const uint32_
     fd_divmod(tile, p.div_ct, mt, sub);
     const int m0 = (int)mt * 64, c0 = (int)sub * 16;
     const int Wp = p.W + 2, SP = (p.H + 2) * Wp;
-    const int D = 2 * Wp + 2;                             // slots of X in front of the chunk's first dY slot
-    const uint32_t T = (uint32_t)p.N * (uint32_t)SP;
+    const int T = p.N * SP;                               // padded slots that can hold data
 
     // ---- DMA role: operand (0 = dY, 1 = X) and plane; the pieces of a chunk are split between the two wave groups ----
     const int op = wave >> 1, plane = wave & 1;
@@ -745,48 +745,34 @@ __device__ __forceinline__ void wgrad_stem_body(const WgPlArgs& p, const uint32_
     // dY: a piece = 16 slots x 4 channel groups (lane -> slot lane / 4, group lane % 4) of each of the two output fragments;
     // X: a piece = 32 slots x 2 channel groups (lane -> slot lane / 2, group lane % 2) of this sub-block
     const int dsl = op ? (lane >> 1) : (lane >> 2);
-    const int slots_per_piece = op ? 32 : 16;
     const uint32_t lane_grp = (uint32_t)(op ? (lane & 1) : (lane & 3)) * grp_bytes;
-    uint32_t frag_so[2];
-    frag_so[0] = (uint32_t)((op ? c0 : m0) / 8) * grp_bytes;
-    frag_so[1] = (uint32_t)((m0 + 32) / 8) * grp_bytes;   // (dY only)
+    const uint32_t frag_so0 = (uint32_t)((op ? c0 : m0) / 8) * grp_bytes;
+    const uint32_t frag_so1 = (uint32_t)((m0 + 32) / 8) * grp_bytes;   // (dY only)
     const int ck_begin = (int)z * p.ksteps_per_split;
-    const int total_ck = (int)((T + NS - 1) / NS);
+    const int total_ck = (T + NS - 1) / NS;
     int ck_end = ck_begin + p.ksteps_per_split;
     if (ck_end > total_ck) ck_end = total_ck;
 
-    constexpr int NPMAX = (STEM_XP + KG - 1) / KG;        // 7 (X); dY: KSC / KG = 2
-    const int npieces = wave_uniform(op ? (STEM_XP - grp + KG - 1) / KG : KSC / KG);
-    const int lane_slot0 = (op ? -D : 0) + dsl;
-    const uint32_t adv_img = (uint32_t)(NS / SP) * img_bytes, adv_u = (uint32_t)(NS % SP);
-    uint32_t pu[NPMAX], pn[NPMAX];
-#pragma unroll
-    for (int q = 0; q < NPMAX; ++q) {
-        const int sl = ck_begin * NS + lane_slot0 + (q * KG + grp) * slots_per_piece;
+    // byte offset of padded slot `sl` (this lane's) inside a plane, or out of range: borders, slots outside [0, T), chunks past the end
+    auto slot_offset = [&](int sl, bool live) -> uint32_t {
+        const bool in = live && sl >= 0 && sl < T;
         uint32_t n, u;
-        fd_divmod((uint32_t)(sl < 0 ? sl + SP : sl), p.div_hw, n, u);       // div_hw = SP;  D <= SP: one image back at most
-        pu[q] = u;
-        pn[q] = (n - (sl < 0 ? 1u : 0u)) * img_bytes;
-    }
-    auto issue_piece = [&](int ck, int buf, int q) {
-        if (q >= npieces) return;
-        const int sg = q * KG + grp;
-        const int sl = ck * NS + lane_slot0 + sg * slots_per_piece;
-        const uint32_t hp = __umulhi(pu[q], p.magic_wp), wp = pu[q] - hp * (uint32_t)Wp;
-        const bool real = ck < ck_end && (uint32_t)sl < T && hp >= 2u && wp >= 2u;
-        const uint32_t vo = real ? pn[q] + ((hp - 2u) * (uint32_t)p.W + (wp - 2u)) * 16u + lane_grp : PL_OOB;
-        unsigned char* base = lds + buf * STAGE;
-        if (op == 0) {
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-                WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + ((f * 2 + plane) * KSC + sg) * 1024), vo, frag_so[f]);
-        } else {
-            WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + A_BYTES + plane * XPL_BYTES + sg * 1024), vo, frag_so[0]);
-        }
-        uint32_t u = pu[q] + adv_u, im = pn[q] + adv_img;
-        const bool wrap = u >= (uint32_t)SP;
-        pu[q] = wrap ? u - (uint32_t)SP : u;
-        pn[q] = wrap ? im + img_bytes : im;
+        fd_divmod((uint32_t)(in ? sl : 0), p.div_hw, n, u);                  // div_hw = SP
+        const uint32_t hp = __umulhi(u, p.magic_wp), wp = u - hp * (uint32_t)Wp;
+        return (in && hp >= 2u && wp >= 2u) ? n * img_bytes + ((hp - 2u) * (uint32_t)p.W + (wp - 2u)) * 16u + lane_grp : PL_OOB;
+    };
+    // dY pieces sg = 0 .. 7 of chunk ck -> buffer buf (this wave: its plane, both fragments)
+    auto issue_dy = [&](int ck, int buf, int sg) {
+        const uint32_t vo = slot_offset(ck * NS + sg * 16 + dsl, ck < ck_end);
+        unsigned char* base = lds + buf * A_BYTES;
+        WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + ((0 * 2 + plane) * KSC + sg) * 1024), vo, frag_so0);
+        WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(base + ((1 * 2 + plane) * KSC + sg) * 1024), vo, frag_so1);
+    };
+    // the X piece that starts at padded slot s0 (a multiple of 32 from -STEM_DA) -> its place in the ring
+    auto issue_x = [&](int s0, bool live) {
+        const uint32_t vo = slot_offset(s0 + dsl, live);
+        const uint32_t row = (uint32_t)(s0 + STEM_DA) & RMASK;             // (s0 + STEM_DA >= 0, a multiple of 32: no piece wraps)
+        WG_DMA_B128(rsrc, reinterpret_cast<uint32_t*>(xring + plane * RING_BYTES + row * 32), vo, frag_so0);
     };
 
     f32x16 acc[4];
@@ -799,34 +785,50 @@ __device__ __forceinline__ void wgrad_stem_body(const WgPlArgs& p, const uint32_
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const bool do_bias = wave_uniform((sub == 0 && wc == 0) ? 1 : 0) != 0;
 
-    // transposed reads: dY as in the bodies above (64-byte rows); X: 32-byte rows, the lanes of channels 16-31 displaced to tap B
+    // transposed reads: dY as in the bodies above (64-byte rows); X: 32-byte rows of the ring, the lanes of channels 16-31 displaced
+    // to tap B; ring row of this lane's first row piece for output slot 0 (+ chunk and k-step offsets, masked, per read)
     const int l16 = lane & 15, sg16 = (lane >> 4) & 1;
     const int a_rd = (8 * lh + (l16 >> 2)) * 64 + sg16 * 32 + (l16 & 3) * 8;
-    int x_rd[4];          // per tap pair of this wave: byte offset of this lane's row piece at k-step 0 inside a plane of X
+    int x_row[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pi = wc * 4 + i;                                     // pair: column tap pi & 3, row taps (pi >> 2) and (pi >> 2) + 2
         const int tr = (pi >> 2) + 2 * sg16, ts = pi & 3;
-        x_rd[i] = (D + (tr - 2) * Wp + (ts - 2) + 8 * lh + (l16 >> 2)) * 32 + (l16 & 3) * 8;
+        x_row[i] = STEM_DA + (tr - 2) * Wp + (ts - 2) + 8 * lh + (l16 >> 2);
     }
+    const unsigned char* const x_lane = xring + (l16 & 3) * 8;
     const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u});
 
+    // first chunk: its dY pieces and the whole X window [-DA, NS + EA) around it (16 pieces per plane, 8 per wave group)
+    if (op == 0) {
 #pragma unroll
-    for (int q = 0; q < NPMAX; ++q) issue_piece(ck_begin, 0, q);
+        for (int q = 0; q < KSC / KG; ++q) issue_dy(ck_begin, 0, q * KG + grp);
+    } else {
+#pragma unroll
+        for (int q = 0; q < (STEM_DA + NS + STEM_EA) / 32 / KG; ++q) issue_x(ck_begin * NS - STEM_DA + (q * KG + grp) * 32, true);
+    }
     int buf = 0;
     for (int ck = ck_begin; ck < ck_end; ++ck) {
         SSN_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();          // chunk ck is complete in `buf`; everybody is done reading the other buffer
-        const unsigned char* ab = lds + buf * STAGE + a_rd + (wm * 2 * KSC + grp * KSG) * 1024;
-        const unsigned char* xb = lds + buf * STAGE + A_BYTES + (grp * KSG) * 16 * 32;
+        __builtin_amdgcn_s_barrier();          // chunk ck (dY buffer `buf`, X window) is complete; everybody is done with chunk ck - 1
+        const unsigned char* ab = lds + buf * A_BYTES + a_rd + (wm * 2 * KSC + grp * KSG) * 1024;
+        const int xs0 = ck * NS + grp * KSG * 16;      // first output slot of this group's k-steps
         f16x8 af[2][2], bf[2][4][2];           // [register set][plane] / [set][pair][plane]
         auto read_set = [&](int ks, int set) {
 #pragma unroll
             for (int pn_ = 0; pn_ < 2; ++pn_) WG_RD_FRAG(af[set][pn_], ab, (pn_ * KSC + ks) * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t r0 = (uint32_t)(x_row[i] + xs0 + ks * 16) & RMASK, r1 = (r0 + 4u) & RMASK;
+                const unsigned char *q0 = x_lane + r0 * 32, *q1 = x_lane + r1 * 32;
 #pragma unroll
-                for (int pn_ = 0; pn_ < 2; ++pn_) WG_RD_FRAG32(bf[set][i][pn_], xb + x_rd[i], pn_ * XPL_BYTES + ks * 16 * 32);
+                for (int pn_ = 0; pn_ < 2; ++pn_) {
+                    u32x2 v0, v1;
+                    SSN_DS_READ_TR16_B64_AT(v0, q0, pn_ * RING_BYTES);
+                    SSN_DS_READ_TR16_B64_AT(v1, q1, pn_ * RING_BYTES);
+                    bf[set][i][pn_] = __builtin_bit_cast(f16x8, u32x4{v0[0], v0[1], v1[0], v1[1]});
+                }
+            }
         };
         read_set(0, 0);
 #pragma unroll
@@ -834,11 +836,13 @@ __device__ __forceinline__ void wgrad_stem_body(const WgPlArgs& p, const uint32_
             SSN_WAIT_LGKM0();                  // the fragments of this k-step (read during the previous one) are in
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 1 < KSG) read_set(ks + 1, (ks + 1) & 1);
-            // the fetch of the next chunk: this wave's pieces spread over the k-steps
-            constexpr int PPK = (NPMAX + KSG - 1) / KSG;
-#pragma unroll
-            for (int e = 0; e < PPK; ++e)
-                if (ks * PPK + e < NPMAX) issue_piece(ck + 1, buf ^ 1, ks * PPK + e);
+            // the fetch of the next chunk, spread over the k-steps: dY wave: piece ks of its four (x two fragments); X wave: one of
+            // its two new pieces in each of the first two k-steps
+            if (op == 0) {
+                issue_dy(ck + 1, buf ^ 1, ks * KG + grp);
+            } else if (ks < NS / 32 / KG) {
+                issue_x((ck + 1) * NS + STEM_EA + (ks * KG + grp) * 32, ck + 1 < ck_end);
+            }
             constexpr int PA[3] = {1, 0, 0};   // g_lo x_hi + g_hi x_hi + g_hi x_lo
             constexpr int PB[3] = {0, 0, 1};
 #pragma unroll
@@ -892,7 +896,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_group_stem_kernel(const WgGroupE
 
 #undef WG_DMA_B128
 #undef WG_RD_FRAG
-#undef WG_RD_FRAG32
 
 template <int KK, int TM, int TC, int XP, int KG = 1>
 int launch_wgpl9(WgPlArgs& a, hipStream_t stream) {
@@ -1150,8 +1153,8 @@ int classify_group(WgGroupItem& it, int hint) {
         it.kg = 2;
         it.taps = 16;
         const int Wp = a.W + 2, SP = (a.H + 2) * Wp;
-        it.units = ((long)a.N * SP + 63) / 64;
-        it.unit_cost = 2 * 4 * 3;
+        it.units = ((long)a.N * SP + STEM_NS - 1) / STEM_NS;
+        it.unit_cost = 4 * 4 * 3;
         a.n_mtiles = (a.M + 63) / 64;
         a.n_ctiles = (a.Cin + 15) / 16;
         it.tiles = (long)a.n_mtiles * a.n_ctiles;
@@ -1162,8 +1165,7 @@ int classify_group(WgGroupItem& it, int hint) {
         a.div_w = make_fastdiv((uint32_t)Wp);
         return SSN_OK;
     }
-    SSN_CHECK_ARG(hint != 300, "conv wgrad pl group: the stem body takes 4x4 / stride 1 / pad 2 layers on rows of <= %d pixels only",
-                  (STEM_XP * 32 - 67) / 3 - 2);
+    SSN_CHECK_ARG(hint != 300, "conv wgrad pl group: the stem body takes 4x4 / stride 1 / pad 2 layers on rows of <= %d pixels only", STEM_MAX_W);
     if (hint < 0 || (hint >= 100 && hint < 200)) {
         if (nine_tap_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w, a.H, a.W, a.Ho, a.Wo)) {
             const int xp = xp_for(a.W);

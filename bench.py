@@ -319,6 +319,7 @@ def main():
     if args.single_stream:
         model.base_model.overlap_wgrad = False
         model.base_model.branch_streams = False
+        model.base_model.branch_lanes = False
     model.to(dev).train()
     policies = model.get_optim_policies()
     # (Inception-v3 with these synthetic weights diverges at the reference's default lr = 0.001 -- loss 1e9 after a dozen steps on the
@@ -460,8 +461,10 @@ def main():
         K_.HBM_PROFILER = hbm_prof
         model.base_model.profiler = prof
         overlap, lanes = model.base_model.overlap_wgrad, model.base_model.branch_streams
+        lanes_pl = model.base_model.branch_lanes
         model.base_model.overlap_wgrad = False   # one kernel at a time, so an event pair times exactly one launch
         model.base_model.branch_streams = False
+        model.base_model.branch_lanes = False    # (planes executor: the two branch chains of a block back on one stream)
         # rank 0 only: no collectives in this pass (the other ranks are already waiting at the fence below)
         hook, model.base_model.grad_ready_hook = model.base_model.grad_ready_hook, None
         opt.zero_grad(set_to_none=True)
@@ -470,6 +473,7 @@ def main():
         torch.cuda.synchronize()
         model.base_model.grad_ready_hook = hook
         model.base_model.overlap_wgrad, model.base_model.branch_streams = overlap, lanes
+        model.base_model.branch_lanes = lanes_pl
         model.base_model.profiler = None
         K_.HBM_PROFILER = None
     fence()

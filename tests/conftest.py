@@ -28,12 +28,40 @@ def emu_library():
     return _lib.SsnLibrary(os.path.join(ROOT, "tests", "emu", "libssn_emu.so"), is_emulator=True)
 
 
+def _emu_violations(lib):
+    import ctypes
+    buf = ctypes.create_string_buffer(300)
+    lib.cdll.ssn_emu_alloc_violations.restype = ctypes.c_long
+    n = lib.cdll.ssn_emu_alloc_violations(buf, 300)
+    return int(n), buf.value.decode()
+
+
 @pytest.fixture
-def emu(emu_library):
-    from action_detection_amd import _lib
+def emu(emu_library, monkeypatch):
+    """The emulator as the active library -- with every planes tensor created during the test REGISTERED as an allocation, so that
+    a buffer descriptor that starts inside one and claims bytes past its end (an over-read the GPU's range check would let through)
+    fails the test (tests/emu/emu_globals.cpp)."""
+    import ctypes
+    import weakref
+    from action_detection_amd import _lib, planes
     _lib.use_library_for_testing(emu_library)
+    cd = emu_library.cdll
+    cd.ssn_emu_alloc_register.argtypes = [ctypes.c_void_p, ctypes.c_long]
+    cd.ssn_emu_alloc_unregister.argtypes = [ctypes.c_void_p]
+    init = planes.PlaneTensor.__init__
+
+    def registering_init(self, *a, **k):
+        init(self, *a, **k)
+        if not self.data.is_cuda:
+            ptr = self.data.data_ptr()
+            cd.ssn_emu_alloc_register(ptr, self.data.numel() * self.data.element_size())
+            weakref.finalize(self.data, cd.ssn_emu_alloc_unregister, ptr)
+    monkeypatch.setattr(planes.PlaneTensor, "__init__", registering_init)
+    _emu_violations(emu_library)
     yield emu_library
     _lib.use_library_for_testing(None)
+    n, msg = _emu_violations(emu_library)
+    assert n == 0, "%d buffer descriptor(s) reached past their allocation; first: %s" % (n, msg)
 
 
 @pytest.fixture(scope="session")
@@ -68,10 +96,8 @@ def backend(request):
     """Run a kernel test through the host emulator (CPU tier) or the real library (GPU tier)."""
     from action_detection_amd import _lib
     if request.param == "emu":
-        lib = request.getfixturevalue("emu_library")
-        _lib.use_library_for_testing(lib)
+        request.getfixturevalue("emu")      # (installs the emulator + the allocation registry; its teardown checks the descriptors)
         yield Backend("emu", "cpu")
-        _lib.use_library_for_testing(None)
     else:
         request.getfixturevalue("hip_library")
         yield Backend("gpu", "cuda:0")

@@ -375,7 +375,16 @@ struct __amdgpu_buffer_rsrc_t {
     const char* base;
     uint32_t bytes;
 };
+// Allocation registry (tests/conftest.py registers every planes tensor it sees created): a buffer descriptor whose base lies inside
+// a registered allocation must END inside it too.  On the GPU the range check of a descriptor is the only thing between a per-lane
+// gather and the memory behind a tensor; a descriptor that claims more bytes than its allocation holds reads whatever follows it
+// (round 4: 60 KB past the last image of a slice at the end of its tensor -- found on the GPU, invisible here).  Violations are
+// counted, the first one described; the test fixture fails the test that caused them.
+namespace emu {
+void descriptor_check(const void* base, uint32_t bytes);
+}
 static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
+    emu::descriptor_check(p, (uint32_t)bytes);
     return __amdgpu_buffer_rsrc_t{(const char*)p, (uint32_t)bytes};
 }
 typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));

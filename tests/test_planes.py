@@ -267,7 +267,8 @@ def test_conv_pl_wgrad_group(backend):
     cases += [] if backend.is_gpu else [(1, 8, 5, 28, 16, 3, 3, 1, 1, 1), (1, 8, 3, 56, 16, 3, 3, 1, 1, 1), (2, 72, 4, 4, 136, 1, 1, 1, 0, 0)]
     # the space-to-depth stem (4x4 taps, two padding pixels in front and ONE behind: outputs = inputs): 12 (RGB) / 40 (flow) real
     # channels, an output-channel count that is not a multiple of 64, a row length that is not a multiple of 4
-    stem = [(4, 12, 112, 112, 64), (2, 40, 112, 112, 64)] if backend.is_gpu else [(2, 12, 6, 8, 64), (1, 40, 5, 7, 72)]
+    # (emulator: the third case is 1452 padded slots in ONE share -- the X ring of 1024 slots wraps)
+    stem = [(4, 12, 112, 112, 64), (2, 40, 112, 112, 64)] if backend.is_gpu else [(2, 12, 6, 8, 64), (1, 40, 5, 7, 72), (3, 12, 20, 20, 64)]
     n_plain = len(cases)
     cases += [(n, cin, h, wd, cout, 4, 4, 1, 2, 2) for (n, cin, h, wd, cout) in stem]
     jobs, want, keep = [], [], []
@@ -301,7 +302,7 @@ def test_conv_pl_wgrad_group(backend):
     fams = sorted({f for f, _, _, _ in plan})
     print("  group plan (family, variant, splits, units):", plan, flush=True)
     assert fams == [0, 1, 2, 3, 4], fams                   # every kernel family has a problem
-    assert [f for f, _, _, _ in plan[n_plain:]] == [4, 4]
+    assert all(f == 4 for f, _, _, _ in plan[n_plain:]) and len(plan) - n_plain == len(stem)
     assert {v for f, v, _, _ in plan if f == 3} >= {2, 3} or backend.is_gpu
     P.conv_wgrad_group(jobs)
     first = [(j.dw.clone(), None if j.db is None else j.db.clone()) for j in jobs]

@@ -426,3 +426,80 @@ def test_graph_replay_protocol_on_changing_data_gpu(hip_library):
         torch.cuda.synchronize()
         same()
     assert twin.guard_stats()["fwd"] >= 1                 # the eager twin repaired the same jumps by itself
+
+
+@pytest.mark.gpu
+def test_graph_replay_protocol_on_the_real_ssn_gpu(hip_library):
+    """The same protocol on the model and the step bench.py runs: the real BN-Inception SSN (2 videos = 144 frames of 224 x 224, three
+    losses, the reference's parameter groups), forward + losses + backward + SGD captured into ONE hipGraph -- with the two-lane branch
+    schedule, the grouped weight gradients and the stem on planes inside the capture -- and replayed on a static batch that is
+    overwritten with frames of three magnitudes (x 1, x 12, x 1/40).  A replay that flagged itself must not have moved a weight; after
+    ``recalibrate_scales()`` + the eager redo the weights must equal those of a twin that ran the same sequence eagerly (sync guard)."""
+    import copy
+    from action_detection_amd.ops.ssn_ops import ActivityLoss, ClassWiseRegressionLoss, CompletenessLoss
+    from action_detection_amd.ssn_models import SSN
+    from action_detection_amd.synthetic import init_backbone_synthetic, init_heads_synthetic, make_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = SSN(20, 2, 5, 2, "RGB", dropout=0, stpp_cfg=(1, 1, 1))
+    init_backbone_synthetic(net.base_model)
+    init_heads_synthetic(net, std=0.05)
+    net.to(dev).train()
+    twin = copy.deepcopy(net)
+    net.base_model.scale_guard = "deferred"
+    assert twin.scale_fault_flag(dev) is not net.scale_fault_flag(dev)
+
+    def opt_for(m):
+        return SSNSGD(m.get_optim_policies(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    opt, opt2 = opt_for(net), opt_for(twin)
+    batch0 = make_batch(2, "RGB", 20, seed=13)
+    static = [t.to(dev) for t in batch0]
+    flag = net.scale_fault_flag(dev)
+    crit = (ActivityLoss(), CompletenessLoss(), ClassWiseRegressionLoss())
+
+    def step(m, o, skip=None):
+        o.zero_grad(set_to_none=True)
+        out = m(*static)
+        loss = crit[0](out[0], out[1]) + 0.1 * crit[1](out[2], out[3], 1, 7) + 0.1 * crit[2](out[4], out[5], out[6])
+        loss.backward()
+        o.step(skip_flag=skip)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            net.base_model.scale_guard = "sync"           # (eager warm-up calibrates; the capture then runs deferred)
+            step(net, opt, flag)
+            step(twin, opt2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    net.base_model.scale_guard = "deferred"
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step(net, opt, flag)
+    step(twin, opt2)
+
+    def same(tol=1e-5):
+        for (n1, p1), (n2, p2) in zip(net.named_parameters(), twin.named_parameters()):
+            assert rel_err(p1, p2) < tol, (n1, rel_err(p1, p2))
+    graph.replay()
+    torch.cuda.synchronize()
+    same()
+    flagged = 0
+    for k in (1.0, 12.0, 1.0 / 40.0, 1.0):
+        static[0].copy_((batch0[0] * k).to(dev))
+        before = [p.detach().clone() for p in net.parameters()]
+        graph.replay()
+        torch.cuda.synchronize()
+        if net.scale_fault():
+            flagged += 1
+            assert all(torch.equal(p, q) for p, q in zip(net.parameters(), before)), k
+            net.recalibrate_scales()
+            net.base_model.scale_guard = "sync"
+            step(net, opt, flag)
+            net.base_model.scale_guard = "deferred"
+            assert not net.scale_fault()
+        step(twin, opt2)
+        torch.cuda.synchronize()
+        same()
+    assert flagged >= 1, "the magnitude jumps were meant to trip the range guard inside the replayed graph"

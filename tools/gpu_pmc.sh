@@ -6,7 +6,7 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$R/gpurun_out/pmc/pmc$i" -o p -- python "$R/bench.py" --steps 2 --warmup 1 --cpu-baseline-videos 0 --no-graph --no-kernel-events > "$R/gpurun_out/pmc/pmc$i.log" 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$R/gpurun_out/pmc/pmc$i" -o p -- python "$R/bench.py" --steps 2 --warmup 1 --cpu-baseline-videos 0 --no-graph --single-stream --no-kernel-events > "$R/gpurun_out/pmc/pmc$i.log" 2>&1
   echo "pmc $i rc=$?"
 done
 cd "$R"

@@ -22,6 +22,14 @@ import sys
 FAMILIES = [  # (family, regex on the kernel name, wide 16-byte reads?)
     ("conv_pl_kernel_fwd", r"conv_pl_kernel<0,", True),
     ("conv_pl_kernel_dgrad", r"conv_pl_kernel<1,", True),
+    ("conv_pl9_kernel_fwd", r"conv_pl9_kernel<0,", True),
+    ("conv_pl9_kernel_dgrad", r"conv_pl9_kernel<1,", True),
+    ("wgrad_group9_kernel_rows14", r"wgrad_group9_kernel<6,", True),
+    ("wgrad_group9_kernel_rows28", r"wgrad_group9_kernel<8,", True),
+    ("wgrad_group9_kernel_rows56", r"wgrad_group9_kernel<12,", True),
+    ("wgrad_group1_kernel", r"wgrad_group1_kernel", True),
+    ("wgrad_group_stem_kernel", r"wgrad_group_stem_kernel", True),
+    ("wgrad_reduce_multi_kernel", r"wgrad_reduce_multi_kernel", True),
     ("wgrad_pl9_kernel", r"wgrad_pl9_kernel", True),
     ("wgrad_pl_kernel", r"wgrad_pl_kernel", True),
     ("pl_maxpool_fwd_kernel", r"pl_maxpool_fwd_kernel", True),

@@ -174,7 +174,8 @@ int main() {
             fill_pool(f, dx_hi, dx_lo, G, dy_hi, dy_lo, G, c.N, c.C, c.H, c.W, Ho, Wo, 3, 2, c.pad, scales, scales + 1, scales + 2, "lab");
             f.argmax = (unsigned char*)am;
             const dim3 gf(grid_for((long)c.N * G * Ho * Wo));
-            rep("FORWARD product kernel", tm.run([&] { hipLaunchKernelGGL((pl_maxpool_fwd_kernel<3, 2>), gf, dim3(256), 0, 0, f); }), in_px * 32 + out_px * 40);
+            rep("FORWARD general kernel", tm.run([&] { hipLaunchKernelGGL((pl_maxpool_fwd_kernel<3, 2>), gf, dim3(256), 0, 0, f); }), in_px * 32 + out_px * 40);
+            rep("FORWARD fast kernel", tm.run([&] { hipLaunchKernelGGL((pl_maxpool_fwd_k3_fast_kernel<2>), gf, dim3(256), 0, 0, f); }), in_px * 32 + out_px * 40);
         }
         rep("loads only", tm.run([&] { hipLaunchKernelGGL((k3s2_ablate_kernel<0, 1>), grid, dim3(256), 0, 0, a); }), rd);
         rep("stores only", tm.run([&] { hipLaunchKernelGGL((k3s2_ablate_kernel<0, 2>), grid, dim3(256), 0, 0, a); }), wr);
