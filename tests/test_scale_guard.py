@@ -477,22 +477,34 @@ def test_graph_replay_protocol_on_the_real_ssn_gpu(hip_library):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         step(net, opt, flag)
-    step(twin, opt2)
+    # (the capture executed nothing: both models have taken two steps)
 
-    def same(tol=1e-5):
-        for (n1, p1), (n2, p2) in zip(net.named_parameters(), twin.named_parameters()):
-            assert rel_err(p1, p2) < tol, (n1, rel_err(p1, p2))
-    graph.replay()
-    torch.cuda.synchronize()
-    same()
-    flagged = 0
-    for k in (1.0, 12.0, 1.0 / 40.0, 1.0):
-        static[0].copy_((batch0[0] * k).to(dev))
+    prev = {"net": [p.detach().clone() for p in net.parameters()], "twin": [p.detach().clone() for p in twin.parameters()]}
+
+    def same():
+        """The step just taken moved every parameter tensor of the net like the twin's: the UPDATES agree to 1e-2 of the largest
+        update of the tensor (a skipped, doubled or clamped step is off by ~1; two fp32 executions of one step differ by the
+        ReLU-flip level ~1e-3: the net's scales after a recalibration are not bit for bit the twin's).  (No bound on the weights
+        themselves: a bias tensor of magnitude 0.03 takes updates of 1e-3 per step here, so 1e-2 of an update is already 3e-4 of it.)"""
+        worst = 0.0
+        for (n1, p1), p2, q1, q2 in zip(net.named_parameters(), twin.parameters(), prev["net"], prev["twin"]):
+            d1, d2 = (p1.detach() - q1).double(), (p2.detach() - q2).double()
+            if float(d2.abs().max()) > 0:
+                e = float((d1 - d2).abs().max() / d2.abs().max())
+                worst = max(worst, e)
+                assert e < 1e-2, ("update of", n1, e)
+        prev["net"] = [p.detach().clone() for p in net.parameters()]
+        prev["twin"] = [p.detach().clone() for p in twin.parameters()]
+        return worst
+    flagged = [0]
+
+    def replay_and_repair(k):
+        """One replayed step of the net (+ the host side of the protocol when it flagged itself) and the twin's eager step."""
         before = [p.detach().clone() for p in net.parameters()]
         graph.replay()
         torch.cuda.synchronize()
         if net.scale_fault():
-            flagged += 1
+            flagged[0] += 1
             assert all(torch.equal(p, q) for p, q in zip(net.parameters(), before)), k
             net.recalibrate_scales()
             net.base_model.scale_guard = "sync"
@@ -502,4 +514,9 @@ def test_graph_replay_protocol_on_the_real_ssn_gpu(hip_library):
         step(twin, opt2)
         torch.cuda.synchronize()
         same()
-    assert flagged >= 1, "the magnitude jumps were meant to trip the range guard inside the replayed graph"
+
+    replay_and_repair(1.0)      # (gradient maxima still move several-fold in the first steps on fresh head weights: may flag)
+    for k in (1.0, 12.0, 1.0 / 40.0, 1.0):
+        static[0].copy_((batch0[0] * k).to(dev))
+        replay_and_repair(k)
+    assert flagged[0] >= 1, "the magnitude jumps were meant to trip the range guard inside the replayed graph"
