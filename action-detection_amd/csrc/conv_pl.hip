@@ -243,6 +243,21 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl_kernel(Pl
     const float sb = *p.x_scale;
     const float so = *p.y_scale;
     const float inv = so / (sa * sb);     // accumulator -> scaled output units
+    // the epilogue's per-row parameters, requested NOW (their round trip hides behind the first fetch of the K loop): row tid of the
+    // tile -- multiplier, shift (scaled), mask scale (NaN: pass through), floor.  Fetched in the epilogue they cost every workgroup a
+    // memory round trip between its last MFMA and its first store, and the two workgroups of a CU reach that point together.
+    float ep_mul = inv, ep_add = 0.f, ep_msc = __builtin_nanf(""), ep_flo = -__builtin_inff();
+    if (tid < BM) {
+        const int m = m0 + tid;
+        const bool ok = m < p.M;
+        const bool aff = ok && p.scale && m < p.raw_from;
+        if (aff) {
+            ep_mul = p.scale[m + (m >= p.row_split ? p.row_gap : 0)] * inv;
+            ep_add = p.shift[m] * so;
+        }
+        if (ok && p.mask_scale) ep_msc = p.mask_scale[m];
+        if (p.relu && m < p.raw_from) ep_flo = 0.f;
+    }
 
     // fragment addressing: A row (wm*TM+i)*32 + li, 16-byte chunk (2*plane + lh) ^ ((row >> 2) & 3)
     const int swz = (li >> 2) & 3;
@@ -495,6 +510,21 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
     const float sb = *p.x_scale;
     const float so = *p.y_scale;
     const float inv = so / (sa * sb);
+    // the epilogue's per-row parameters, requested NOW (their round trip hides behind the first fetch of the K loop): row tid of the
+    // tile -- multiplier, shift (scaled), mask scale (NaN: pass through), floor.  Fetched in the epilogue they cost every workgroup a
+    // memory round trip between its last MFMA and its first store, and the two workgroups of a CU reach that point together.
+    float ep_mul = inv, ep_add = 0.f, ep_msc = __builtin_nanf(""), ep_flo = -__builtin_inff();
+    if (tid < BM) {
+        const int m = m0 + tid;
+        const bool ok = m < p.M;
+        const bool aff = ok && p.scale && m < p.raw_from;
+        if (aff) {
+            ep_mul = p.scale[m + (m >= p.row_split ? p.row_gap : 0)] * inv;
+            ep_add = p.shift[m] * so;
+        }
+        if (ok && p.mask_scale) ep_msc = p.mask_scale[m];
+        if (p.relu && m < p.raw_from) ep_flo = 0.f;
+    }
 
     // fragment addressing.  A as in conv_pl_kernel; B: the lane's pixel -> its centre slot inside the halo
     const int swz = (li >> 2) & 3;

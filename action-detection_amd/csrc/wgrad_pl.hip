@@ -1210,7 +1210,7 @@ int classify_group(WgGroupItem& it, int hint) {
             v = 0;
             for (int c = 0; c < 3; ++c) {
                 const double padded = (double)((a.M + kG1BM[c] - 1) / kG1BM[c]) * kG1BM[c] * (double)((a.Cin + kG1BC[c] - 1) / kG1BC[c]) * kG1BC[c];
-                const double small = c == 0 ? 1.0 : (c == 1 ? 1.04 : 1.3);      // (operand fetch per MAC grows as the tile shrinks)
+                const double small = c == 0 ? 1.0 : (c == 1 ? 1.04 : 1.5);      // (operand fetch per MAC grows as the tile shrinks)
                 if (padded * small < best) {
                     best = padded * small;
                     v = c;
