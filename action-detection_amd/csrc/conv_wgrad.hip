@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceTable t) 
     float* db = t.db[ti];
     const int M = t.M[ti], K = t.K[ti], ldp = K + 1, splits = t.splits[ti], taps = t.taps[ti];
     const long total = (long)M * ldp;
+    const uint32_t cin_t = (uint32_t)(K / (taps > 0 ? taps : 1));
     const long nb = t.blk0[ti + 1] - t.blk0[ti];
     for (long idx = (long)((int)blockIdx.x - t.blk0[ti]) * 256 + threadIdx.x; idx < total; idx += nb * 256) {
         float s = 0.f;
@@ -301,13 +302,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceTable t) 
             for (int q = 0; q < 8; ++q) s += v[q];
         }
         for (; z < splits; ++z) s += part[(long)z * total + idx];
-        const int m = (int)(idx / ldp);
-        const int kk = (int)(idx - (long)m * ldp);
+        const int m = (int)((uint32_t)idx / (uint32_t)ldp);      // (32-bit: a slab holds < 2^31 elements -- checked by the host)
+        const int kk = (int)((uint32_t)idx - (uint32_t)m * (uint32_t)ldp);
         if (kk < K) {
             int col = kk;
             if (taps > 1) {
-                const int cin = K / taps, tt = kk / cin;
-                col = (kk - tt * cin) * taps + tt;
+                const int tt = (int)((uint32_t)kk / cin_t);
+                col = (kk - tt * (int)cin_t) * taps + tt;
             }
             dw[(long)m * K + col] = s;
         } else if (db) {
@@ -403,7 +404,8 @@ extern "C" int ssn_wgrad_reduce_multi(int count, const float* const* part, float
         int blocks = 0;
         for (int i = 0; i < t.count; ++i) {
             const int j = base + i;
-            SSN_CHECK_ARG(part[j] && dw[j] && M[j] > 0 && K[j] > 0 && splits[j] > 0 && taps[j] >= 1 && K[j] % taps[j] == 0,
+            SSN_CHECK_ARG(part[j] && dw[j] && M[j] > 0 && K[j] > 0 && splits[j] > 0 && taps[j] >= 1 && K[j] % taps[j] == 0 &&
+                              (long)M[j] * (K[j] + 1) < (1l << 31),
                           "wgrad reduce multi: bad entry %d", j);
             t.part[i] = part[j];
             t.dw[i] = dw[j];

@@ -348,7 +348,10 @@ def run_forward(net, x, keep):
                             # body's halo buffer; see run_backward): it reads an fp32 space-to-depth copy of the frames
                             acts["data_s2d_f32"] = K.space_to_depth2(x)
                             measured = acts["data_s2d_f32"]._ssn_amax      # (that pass over the frames also took their maximum)
-                        P.from_f32(x, acts["data_s2d"], s2d=True, exact=True, amax=measured)
+                        # stem on planes: the frames take a DELAYED scale like every other tensor of the pass (their maximum barely
+                        # moves between batches; the range guard covers the rest) -- no measuring pass over the 173 MB of frames
+                        delayed = keep and measured is None and net.delayed_input_scale
+                        P.from_f32(x, acts["data_s2d"], s2d=True, exact=not delayed, amax=measured)
                     src = P.pfull(acts["data_s2d"])
                     net._timed("conv_fwd_pl", op["lids"][0], flops, lambda: P.conv_fwd(
                         PSlice(src.t, 0, src.t.g * 8), wp, scale, shift, dst, 4, 4, 1, 2, 2, not raw, net._pl_tile("fwd", op, n, shapes)))
