@@ -669,6 +669,57 @@ __global__ __launch_bounds__(256) void pl_avgpool_affine_kernel(PoolArgs p) {
     amax_emit(p.y_amax, vmax / so);
 }
 
+// The 3x3 case (every average pool of the two backbones) with all nine taps in flight at once: buffer loads with 32-bit offsets, a tap
+// outside the image reads zeros (zero padding is counted: the divisor stays 9).  The general kernel above walks a runtime k x k window
+// tap by tap -- nine dependent round trips per thread: 70 % of its wave cycles wait (PMC), 2.3 TB/s.
+__global__ __launch_bounds__(256) void pl_avgpool3_fast_kernel(PoolArgs p) {
+    const uint32_t total = (uint32_t)p.N * (uint32_t)p.G * (uint32_t)p.H * (uint32_t)p.W;
+    const float inv = 1.f / (9.f * *p.x_scale), so = *p.y_scale;
+    const uint32_t HW = (uint32_t)p.H * (uint32_t)p.W;
+    const uint32_t x_bytes = (uint32_t)(((long)(p.N - 1) * p.x_img_groups + p.G) * HW * 16);
+    const __amdgpu_buffer_rsrc_t r_hi = pl_rsrc(p.x_hi, x_bytes), r_lo = pl_rsrc(p.x_lo, x_bytes);
+    float vmax = 0.f;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const PoolIdx ix = pool_decode(idx, p.dv_w, p.dv_h, p.dv_g);
+        const int w = (int)ix.w, h = (int)ix.h;
+        const uint32_t xb = (ix.n * (uint32_t)p.x_img_groups + ix.g) * HW;
+        u32x4 thi[9], tlo[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int hh = h - 1 + t / 3, ww = w - 1 + t % 3;
+            const bool ok = ((unsigned)hh < (unsigned)p.H) && ((unsigned)ww < (unsigned)p.W);
+            const uint32_t off = ok ? (xb + (uint32_t)(hh * p.W + ww)) * 16u : PL_OOB;
+            thi[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_hi, off, 0, 0));
+            tlo[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_lo, off, 0, 0));
+        }
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {      // (row-major tap order: the summation order of the general kernel)
+            float v[8];
+            pl_join8(thi[t], tlo[t], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[e] * inv;
+            if (p.aff_scale) v = v * p.aff_scale[8 * ix.g + e] + p.aff_shift[8 * ix.g + e];
+            if (p.relu) v = fmaxf(v, 0.f);
+            vmax = fmaxf(vmax, fabsf(v * so));
+            out[e] = pl_clamp(v * so);
+        }
+        u32x4 hi, lo;
+        pl_split8(out, hi, lo);
+        const long o = ((long)ix.n * p.y_img_groups + ix.g) * HW + (long)h * p.W + w;
+        reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
+        reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
+    }
+    amax_emit(p.y_amax, vmax / so);
+}
+
 // in place: g <- g * (y > 0) * scale[c]  (NaN scale: channel passes through) -- the ReLU / frozen-BN backward of a slice whose
 // last writer could not fuse it
 __global__ __launch_bounds__(256) void pl_relu_bn_bwd_kernel(PoolArgs p) {
@@ -1056,7 +1107,10 @@ extern "C" int ssn_pl_avgpool_affine(const void* x_hi, const void* x_lo, long x_
     a.aff_scale = scale;
     a.aff_shift = shift;
     a.relu = relu;
-    hipLaunchKernelGGL(pl_avgpool_affine_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
+    if (k == 3 && pad == 1)
+        hipLaunchKernelGGL(pl_avgpool3_fast_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(pl_avgpool_affine_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
     SSN_CHECK_LAUNCH("pl_avgpool_affine");
     return SSN_OK;
 }

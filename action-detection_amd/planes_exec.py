@@ -538,6 +538,8 @@ def run_backward(net, dfeat, saved, hook=True):
         pending_reduce, pending_sums = [], []     # deferred split-K reductions / the channel sums that must follow them
 
         pending_wgrad = []                        # grouped mode: (planes.WgradJob, flops) of the weight gradients not yet launched
+        wgrad_flops_total = sum(2.0 * n * shapes[q["dst"]][1] * shapes[q["dst"]][2] * q["cout"] * q["cin"] * _conv_taps(q)[0] * _conv_taps(q)[1]
+                                for q in plan if q["kind"] == "conv")
         pending_post = []                         # ... and what has to follow their reduction (the stem: space-to-depth taps -> 7x7)
 
         def flush():
@@ -740,9 +742,13 @@ def run_backward(net, dfeat, saved, hook=True):
                 closes_block = (lids[0].endswith("_1x1") or lids[0] == first_conv
                                 or lids[0] in ("inception_3c_3x3_reduce", "inception_4e_3x3_reduce"))
                 if fire_hook and net.grad_ready_hook is not None and closes_block:
-                    flush()                                   # the block's gradients must be final before their all-reduce
-                    net.grad_ready_hook.range_ready(flat, wo, pending_end)
-                    pending_end = wo
+                    # grouped weight gradients: a flush per block would undo the grouping (ten small groups: measured +1 ms per step
+                    # in `--collectives overlapped`); the recorded problems are flushed -- and their range handed to the reducer --
+                    # once they hold a third of the pass's weight-gradient work, i.e. three all-reduce rounds per backward
+                    if not (group and pending_wgrad) or sum(f for _, f in pending_wgrad) >= wgrad_flops_total / 3.0 or wo == 0:
+                        flush()                               # the range's gradients must be final before their all-reduce
+                        net.grad_ready_hook.range_ready(flat, wo, pending_end)
+                        pending_end = wo
 
         side_ops, joins = _branch_lanes(plan) if (net.branch_lanes and dfeat.is_cuda) else ({}, set())
         side = net._side_stream(dev) if side_ops else None

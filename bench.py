@@ -42,7 +42,7 @@ import torch.distributed as dist  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
 F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense f16 / bf16 MFMA (no 2:1 sparsity)
 X6_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3  # algorithmic fp32 flops through the 2-way f16 split (3 MFMA products)
-PMC_SUMMARY = "r4_pmc_summary_planes.json"
+PMC_SUMMARY = "r5_pmc_summary.json"
 FWD_GFLOP_PER_IMAGE = {"RGB": 4.063152128, "Flow": 4.613883904}  # 2 * conv MACs
 # conv1 (7x7/2, 64 outputs of 112x112): 2 * Cin * 49 * 64 * 112^2 flop that a dgrad would cost and nobody needs
 CONV1_DGRAD_GFLOP_PER_IMAGE = {"RGB": 2 * 3 * 49 * 64 * 112 * 112 / 1e9, "Flow": 2 * 10 * 49 * 64 * 112 * 112 / 1e9}
@@ -592,7 +592,7 @@ def main():
                             "their producers, 3 v_mfma_f32_32x32x16_f16 per k16 step, no operand conversion in the K loop; "
                             "fwd + dgrad launches)")
                 dom_fl, dom_ms, dom_n, dom_peak = pl_fl, pl_ms, pl_n, X6_PEAK_TFLOPS
-                pmc_keys = ("conv_pl_kernel_fwd", "conv_pl_kernel_dgrad")
+                pmc_keys = ("conv_pl_kernel_fwd", "conv_pl_kernel_dgrad", "conv_pl9_kernel_fwd", "conv_pl9_kernel_dgrad")
             elif x6_n:
                 dom_name = ("conv_x6_kernel (implicit GEMM, fp32 operands scaled per tensor and split into 2 f16 terms, 3 "
                             "v_mfma_f32_32x32x16_f16 per k16 step; fwd + dgrad launches)")
@@ -611,7 +611,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as f:
                     pm = json.load(f)
-                fam_p = [pm[k] for k in pmc_keys]
+                fam_p = [pm[k] for k in pmc_keys if k in pm and "hbm_bytes_per_launch" in pm[k]]
                 nl = sum(x["launches_sampled"] for x in fam_p)
                 traffic = round(sum(x["hbm_bytes_per_launch"] * x["launches_sampled"] for x in fam_p) / nl)
             except (OSError, KeyError, ValueError, ZeroDivisionError):
