@@ -102,6 +102,7 @@ _SIGS = {
     "ssn_pl_range_check": "pppiip",
     "ssn_pl_from_f32": "plppiiiilippp",
     "ssn_pl_to_f32": "pplpliiipp",
+    "ssn_pl_im2col": "pplppliiiiiiiiiiip",
     "ssn_conv_pl_fwd": "pppppppiiiiliiiliiiiiiipppiiip",
     "ssn_conv_pl_dgrad": "pppppiiiiliiiliiiiiplpipppiiip",
     "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiipp",

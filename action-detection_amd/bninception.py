@@ -192,6 +192,9 @@ class BNInception(nn.Module):
         # planes_exec: the stem's weight gradient as a problem of the grouped launch on planes operands (wgrad_stem_body); 0: the
         # fp32-layout kernel of rounds 2 - 4 (fp32 space-to-depth copy of the frames + fp32 output gradient from the pool's backward)
         self.stem_planes = os.environ.get("SSN_STEM_PLANES", "1") != "0"
+        # planes_exec: weight gradient of a first convolution that is NOT in space-to-depth form (Inception-v3's 3x3 / 2) as a 1x1
+        # problem on the im2col of the frames (ssn_pl_im2col)
+        self.first_conv_im2col = os.environ.get("SSN_FIRST_CONV_IM2COL", "1") != "0"
         # planes_exec (training passes with the stem on planes): the frames are stored with last pass's scale, like every activation
         self.delayed_input_scale = os.environ.get("SSN_DELAYED_INPUT_SCALE", "1") != "0"
         if os.environ.get("SSN_GROUP_TUNING"):      # tooling: planner constants "fixed9,fixed1,min9,min1" (ssn_conv_wgrad_pl_group_tuning)

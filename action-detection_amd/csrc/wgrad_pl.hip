@@ -351,11 +351,15 @@ constexpr int wgpl9_lds_bytes() {
 }
 
 // (`bid`, `lds`: see wgrad_pl_body; wgpl9_lds_bytes() bytes, 1 KiB aligned)
-template <int KK, int TM, int TC, int XP, int KG = 1>
+// KH x KW taps with PH / PW padding pixels in front (same-size output): 3 x 3 / pad 1 (the default), and -- Inception-v3's 17 x 17 stage --
+// 1 x 7 / pad (0, 3) and 7 x 1 / pad (3, 0): the padded enumeration keeps max(PW, KW - 1 - PW) zero columns in front of every row and
+// max(PH, KH - 1 - PH) zero rows in front of every image, a tap (r, s) is the read displacement (r - PH) Wp + (s - PW).
+template <int KK, int TM, int TC, int XP, int KG = 1, int KH = 3, int KW = 3, int PH = 1, int PW = 1>
 __device__ __forceinline__ void wgrad_pl9_body(const WgPlArgs& p, const uint32_t bid, unsigned char* lds) {
     constexpr int NS = 64, KSC = NS / 16;
     constexpr int KSG = KSC / KG;                      // k-steps of a chunk per wave group
-    static_assert(KK == 1 || KK == 9, "1x1 or 3x3");
+    static_assert(KK == 1 || KK == KH * KW, "1x1, or all taps of the window");
+    static_assert((KSG * KK) % 2 == 0, "steps come in pairs");
     static_assert(KG == 1 || KG == 2, "one or two wave groups");
     static_assert(XP % KG == 0, "X pieces split evenly between the wave groups");
     constexpr int BM = 2 * TM * 32, BC = 2 * TC * 32;
@@ -379,9 +383,10 @@ __device__ __forceinline__ void wgrad_pl9_body(const WgPlArgs& p, const uint32_t
     fd_divmod(logical, p.div_tiles, z, tile);
     fd_divmod(tile, p.div_ct, mt, ct);
     const int m0 = (int)mt * BM, c0 = (int)ct * BC;
-    constexpr int BORDER = KK > 1 ? 1 : 0;             // zero row / column in front of every image row (3x3); none for 1x1
-    const int Wp = p.W + BORDER, SP = (p.H + BORDER) * Wp;
-    const int D = BORDER * (Wp + 1);                   // slots of X in front of the chunk's first dY slot
+    // zero rows in front of every image / zero columns in front of every row (shared with the previous image / row); none for 1x1
+    constexpr int BH = KK > 1 ? (PH > KH - 1 - PH ? PH : KH - 1 - PH) : 0, BW = KK > 1 ? (PW > KW - 1 - PW ? PW : KW - 1 - PW) : 0;
+    const int Wp = p.W + BW, SP = (p.H + BH) * Wp;
+    const int D = KK > 1 ? PH * Wp + PW : 0;           // slots of X in front of the chunk's first dY slot
     const uint32_t T = (uint32_t)p.N * (uint32_t)SP;   // padded slots that can hold data
 
     // ---- DMA role: operand (0 = dY, 1 = X) and plane ----
@@ -430,8 +435,8 @@ __device__ __forceinline__ void wgrad_pl9_body(const WgPlArgs& p, const uint32_t
         const int sg = q * KG + grp;
         const int sl = ck * NS + lane_slot0 + sg * 16;
         const uint32_t hp = __umulhi(pu[q], p.magic_wp), wp = pu[q] - hp * (uint32_t)Wp;
-        const bool real = ck < ck_end && (uint32_t)sl < T && hp >= (uint32_t)BORDER && wp >= (uint32_t)BORDER && !WG_DBG(1);
-        const uint32_t vo = real ? pn[q] + ((hp - BORDER) * (uint32_t)p.W + (wp - BORDER)) * 16u + lane_grp : PL_OOB;
+        const bool real = ck < ck_end && (uint32_t)sl < T && hp >= (uint32_t)BH && wp >= (uint32_t)BW && !WG_DBG(1);
+        const uint32_t vo = real ? pn[q] + ((hp - BH) * (uint32_t)p.W + (wp - BW)) * 16u + lane_grp : PL_OOB;
         unsigned char* base = lds + buf * STAGE;
         if (op == 0) {
 #pragma unroll
@@ -468,7 +473,7 @@ __device__ __forceinline__ void wgrad_pl9_body(const WgPlArgs& p, const uint32_t
     const int lane_rd = (8 * lh + (l16 >> 2)) * 64 + sg16 * 32 + (l16 & 3) * 8;
     int tapoff[KK];      // byte displacement of tap t inside the X rows: (D + (r - 1) Wp + (s - 1)) * 64
 #pragma unroll
-    for (int t = 0; t < KK; ++t) tapoff[t] = KK > 1 ? (D + (t / 3 - 1) * Wp + (t % 3 - 1)) * 64 : 0;
+    for (int t = 0; t < KK; ++t) tapoff[t] = KK > 1 ? (D + (t / KW - PH) * Wp + (t % KW - PW)) * 64 : 0;
     const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u});
 
     // (asm reads, see planes.h: the SSN_WAIT_LGKM0 at the head of every step pair is what waits for them)
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// GROUPED launches: every weight gradient of a backward pass in <= 5 launches (+ one reduction).
+// GROUPED launches: every weight gradient of a backward pass in <= 5 launches (BN-Inception; 7 kernel families in all) + one reduction.
 //
 // The weight gradients of a pass are mutually independent, and launched one by one each of them has to fill 256 CUs on its own:
 // split-K factors of 20 - 130, i.e. workgroups that run 8 - 12 chunks and then store a 150 KB partial slab (2.2 GB of slabs per
@@ -626,7 +631,8 @@ __global__ __launch_bounds__(256 * KG, (KG > 1 || KK * TM * TC >= 18 || TM * TC 
 //     the partial slabs are reduced in the fixed order of ssn_wgrad_reduce_multi: deterministic, bit-identical from call to call.
 // Families (one launch each, only if it has problems): nine-tap 64 x 64 tiles with XP = 6 / 8 / 12 (rows <= 14 / <= 30 / <= 56
 // pixels; 80 / 96 / 128 KiB of LDS), everything else (1x1, stride-2, rectangular taps) on the one-tap / chunked 1x1 bodies, and the
-// space-to-depth stem (4 x 4 taps on 16-channel sub-blocks: wgrad_stem_body).
+// space-to-depth stem (4 x 4 taps on 16-channel sub-blocks: wgrad_stem_body); Inception-v3 adds the seven-tap forms of the nine-tap body
+// for its 1 x 7 / 7 x 1 layers.
 constexpr int WGG_MAX = 96;             // problems per grouped launch (block -> problem search table travels by value)
 constexpr int WGG_WRITE = 12;           // table entries written per plan-write launch (by-value kernel arguments: < 4 KiB)
 struct WgGroupEntry {
@@ -655,7 +661,7 @@ __device__ __forceinline__ int group_problem_of_block(const WgGroupIndex& ix, in
 }
 
 // nine-tap family: 64 x 64 tiles; KG = 2 where the LDS footprint leaves one workgroup per CU
-template <int XP, int KG>
+template <int XP, int KG, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : 2) void wgrad_group9_kernel(const WgGroupEntry* __restrict__ table, WgGroupIndex ix) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[wgpl9_lds_bytes<1, 1, XP>()];
     const int e = group_problem_of_block(ix, (int)blockIdx.x);
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : 2) void wgrad_group9_kernel(
     const auto* ent = SSN_CONST_PTR(WgGroupEntry, table) + e;      // (scalar loads: the problem lives in SGPRs like a kernel argument)
     if (bid >= ent->nblk) return;
     const WgPlArgs p = ent->a;
-    wgrad_pl9_body<9, 1, 1, XP, KG>(p, bid, lds);
+    wgrad_pl9_body<KH * KW, 1, 1, XP, KG, KH, KW, KH / 2, KW / 2>(p, bid, lds);
 }
 
 // everything else: one-tap bodies 128 x 128 / 96 x 128 / 64 x 64 (any taps, stride, padding) and the chunked 1x1 body 64 x 64
@@ -1121,7 +1127,7 @@ int fill_wgpl(WgPlArgs& a, const void* g_hi, const void* g_lo, const void* x_hi,
 // (prologue + first fetch + partial-slab store + its share of the reduction), fewest reduction units an item may have
 double g_group_fixed[2] = {450.0, 150.0};
 int g_group_min_units[2] = {4, 32};
-enum { WGF_9_XP6 = 0, WGF_9_XP8 = 1, WGF_9_XP12 = 2, WGF_1 = 3, WGF_STEM = 4, WGF_COUNT = 5 };
+enum { WGF_9_XP6 = 0, WGF_9_XP8 = 1, WGF_9_XP12 = 2, WGF_1 = 3, WGF_STEM = 4, WGF_7_ROW = 5, WGF_7_COL = 6, WGF_COUNT = 7 };
 // one-tap / chunked variants of the WGF_1 family (3 = the chunked 1x1 body): tile = output x input channels.  (A big-tile family --
 // 256 x 128 / 128 x 256 one-tap, 128 x 128 chunked, one workgroup per CU -- was measured in the group and lost on every layer:
 // profiles/r5_wgrad_group_variants.txt.)
@@ -1186,7 +1192,29 @@ int classify_group(WgGroupItem& it, int hint) {
             a.div_w = make_fastdiv((uint32_t)(a.W + 1));
             return SSN_OK;
         }
-        SSN_CHECK_ARG(hint < 0, "conv wgrad pl group: the nine-tap bodies take 3x3 / stride 1 / pad 1 layers only");
+        // Inception-v3's 17 x 17 stage: 1 x 7 / pad (0, 3) and 7 x 1 / pad (3, 0) on the same body with seven taps
+        const bool same = a.stride == 1 && a.Ho == a.H && a.Wo == a.W;
+        const bool row7 = same && a.kh == 1 && a.kw == 7 && a.pad_h == 0 && a.pad_w == 3;
+        const bool col7 = same && a.kh == 7 && a.kw == 1 && a.pad_h == 3 && a.pad_w == 0 && 64 + 6 * a.W <= 12 * 16;
+        if (row7 || col7) {
+            it.family = row7 ? WGF_7_ROW : WGF_7_COL;
+            it.variant = 0;
+            it.kg = row7 ? 1 : 2;
+            it.taps = 7;
+            const int Wp = a.W + (row7 ? 3 : 0), Hp = a.H + (row7 ? 0 : 3);
+            it.units = ((long)a.N * Hp * Wp + 63) / 64;
+            it.unit_cost = 4 * 7 * 3 / (double)it.kg;
+            a.n_mtiles = (a.M + 63) / 64;
+            a.n_ctiles = (a.Cin + 63) / 64;
+            it.tiles = (long)a.n_mtiles * a.n_ctiles;
+            a.div_tiles = make_fastdiv((uint32_t)it.tiles);
+            a.div_ct = make_fastdiv((uint32_t)a.n_ctiles);
+            a.magic_wp = 0xFFFFFFFFu / (uint32_t)Wp + 1u;
+            a.div_hw = make_fastdiv((uint32_t)(Hp * Wp));
+            a.div_w = make_fastdiv((uint32_t)Wp);
+            return SSN_OK;
+        }
+        SSN_CHECK_ARG(hint < 0, "conv wgrad pl group: the multi-tap bodies take 3x3 / pad 1, 1x7 / pad (0,3) and 7x1 / pad (3,0) stride-1 layers only");
     }
     it.family = WGF_1;
     const bool can_chunk = chunked_1x1_layer(a.kh, a.kw, a.stride, a.pad_h, a.pad_w);
@@ -1334,7 +1362,7 @@ int plan_group_all(int count, const int* shape, const long* groups, const void* 
         if (f == WGF_1)
             plan_group(fam, 512, g_group_fixed[1], g_group_min_units[1], true);
         else
-            plan_group(fam, f == WGF_9_XP6 ? 512 : 256, g_group_fixed[0], g_group_min_units[0], false);      // (the stem too)
+            plan_group(fam, (f == WGF_9_XP6 || f == WGF_7_ROW) ? 512 : 256, g_group_fixed[0], g_group_min_units[0], false);   // (the stem too)
     }
     long off = 0;
     for (WgGroupItem& it : items) {
@@ -1433,6 +1461,8 @@ extern "C" int ssn_conv_wgrad_pl_group(int count, const void* const* g_hi, const
                 case WGF_9_XP8: hipLaunchKernelGGL((wgrad_group9_kernel<8, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
                 case WGF_9_XP12: hipLaunchKernelGGL((wgrad_group9_kernel<12, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
                 case WGF_STEM: hipLaunchKernelGGL(wgrad_group_stem_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
+                case WGF_7_ROW: hipLaunchKernelGGL((wgrad_group9_kernel<6, 1, 1, 7>), dim3((unsigned)blocks), dim3(256), 0, stream, tab, ix); break;
+                case WGF_7_COL: hipLaunchKernelGGL((wgrad_group9_kernel<12, 2, 7, 1>), dim3((unsigned)blocks), dim3(512), 0, stream, tab, ix); break;
                 default: hipLaunchKernelGGL(wgrad_group1_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab, ix); break;
             }
             first += n;

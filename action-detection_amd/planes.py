@@ -176,6 +176,18 @@ def to_f32(src, out=None):
     return out
 
 
+def im2col(x, kh, kw, stride, pad_h, pad_w, ho, wo):
+    """PSlice x [N, C, H, W] with few channels -> PlaneTensor [N, C kh kw, ho, wo] of its window elements (channel c kh kw + r kw + s),
+    sharing x's scale: the operand that turns the weight gradient of a first convolution into a 1x1 problem."""
+    t = x.t
+    lib = _lib_for(t)
+    h, w = x.hw
+    y = PlaneTensor(x.n, x.c * kh * kw, ho, wo, t.device, t.pool, t.slot, t.scale_store)
+    lib.call("ssn_pl_im2col", x.hi, x.lo, x.groups, y.plane_ptr(0), y.plane_ptr(1), y.g, x.n, x.c, h, w, ho, wo, kh, kw, stride, pad_h, pad_w,
+             _st(lib, t))
+    return y
+
+
 def conv_fwd(x, w_packed, scale, shift, y, kh, kw, stride, pad_h, pad_w, relu=True, tile_cfg=-1, raw_from=0, row_split=0,
              row_gap=0):
     """y <- relu?(scale * conv(x) + shift) on planes slices.  w_packed: kernels.pack_weights_multi(x6=True) /

@@ -448,6 +448,11 @@ int ssn_pl_range_check(const float* amax, const float* scale, int* flag, int n, 
 /* fp32 NCHW <-> planes (the caller's frames, test inputs, the fp32 feature boundary); s2d: the space-to-depth view of the stem. */
 int ssn_pl_from_f32(const float* x, long x_img_stride, void* hi, void* lo, int N, int C, int H, int W, long img_groups, int s2d,
                     const float* scale, float* amax, hipStream_t stream);
+/* im2col of a planes slice with few channels: y[n][c kh kw + r kw + s][ho][wo] = x[n][c][ho stride + r - pad_h][wo stride + s - pad_w]
+ * (both planes copied, y carries x's scale): the weight gradient of a first convolution that is not run in space-to-depth form becomes a
+ * 1x1 problem on C kh kw channels (cuDNN wgrad of the first layer behind ssn_train.py:236 for --arch InceptionV3). */
+int ssn_pl_im2col(const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups, int N, int C, int H,
+                  int W, int Ho, int Wo, int kh, int kw, int stride, int pad_h, int pad_w, hipStream_t stream);
 int ssn_pl_to_f32(const void* hi, const void* lo, long img_groups, float* y, long y_img_stride, int N, int C, int HW,
                   const float* scale, hipStream_t stream);
 /* conv + frozen-BN affine + ReLU (cuDNN conv / BN(eval) / ReLU behind ssn_models.py:266) on planes slices: any kh x kw taps,

@@ -264,7 +264,8 @@ def test_conv_pl_wgrad_group(backend):
     g = torch.Generator().manual_seed(41)
     cases = list(CASES_GPU if backend.is_gpu else CASES_SMALL)
     # rows of 28 / 56 pixels for the XP = 8 / 12 nine-tap families (emulator: narrow slices of such rows keep it affordable)
-    cases += [] if backend.is_gpu else [(1, 8, 5, 28, 16, 3, 3, 1, 1, 1), (1, 8, 3, 56, 16, 3, 3, 1, 1, 1), (2, 72, 4, 4, 136, 1, 1, 1, 0, 0)]
+    cases += [] if backend.is_gpu else [(1, 8, 5, 28, 16, 3, 3, 1, 1, 1), (1, 8, 3, 56, 16, 3, 3, 1, 1, 1), (2, 72, 4, 4, 136, 1, 1, 1, 0, 0),
+                                        (2, 16, 9, 6, 40, 7, 1, 1, 3, 0)]      # (7 x 1: the seven-tap column family)
     # the space-to-depth stem (4x4 taps, two padding pixels in front and ONE behind: outputs = inputs): 12 (RGB) / 40 (flow) real
     # channels, an output-channel count that is not a multiple of 64, a row length that is not a multiple of 4
     # (emulator: the third case is 1452 padded slots in ONE share -- the X ring of 1024 slots wraps)
@@ -301,7 +302,7 @@ def test_conv_pl_wgrad_group(backend):
     ws_bytes, tb_bytes, plan = P.wgrad_group_plan(jobs)
     fams = sorted({f for f, _, _, _ in plan})
     print("  group plan (family, variant, splits, units):", plan, flush=True)
-    assert fams == [0, 1, 2, 3, 4], fams                   # every kernel family has a problem
+    assert fams == [0, 1, 2, 3, 4, 5, 6], fams             # every kernel family has a problem (5 / 6: 1 x 7 and 7 x 1 on seven taps)
     assert all(f == 4 for f, _, _, _ in plan[n_plain:]) and len(plan) - n_plain == len(stem)
     assert {v for f, v, _, _ in plan if f == 3} >= {2, 3} or backend.is_gpu
     P.conv_wgrad_group(jobs)
@@ -344,6 +345,31 @@ def test_conv_pl_wgrad_group(backend):
     jobs[2].hint = 200                                        # a 3x3 / stride-2 problem cannot take the chunked 1x1 body
     with pytest.raises(RuntimeError):
         P.conv_wgrad_group([jobs[2]])
+
+
+def test_planes_im2col(backend):
+    """ssn_pl_im2col against F.unfold: 3 / 10 channels, 3x3 / 2 unpadded (Inception-v3's first layer), 3x3 / 1 padded, 5x5 / 2; and the
+    weight gradient of such a layer as a 1x1 problem on it (= dW of the k x k convolution, flattened)."""
+    g = torch.Generator().manual_seed(77)
+    for (n, c, h, w, k, s_, p_) in [(2, 3, 11, 9, 3, 2, 0), (1, 10, 8, 8, 3, 1, 1), (2, 3, 12, 12, 5, 2, 2)]:
+        x = torch.randn(n, c, h, w, generator=g)
+        xp = P.from_f32(backend.put(x))
+        ho, wo = (h + 2 * p_ - k) // s_ + 1, (w + 2 * p_ - k) // s_ + 1
+        y = P.im2col(P.PSlice(xp, 0, c), k, k, s_, p_, p_, ho, wo)
+        ref = F.unfold(P.to_f32(P.PSlice(xp, 0, c)).cpu(), k, padding=p_, stride=s_).view(n, c * k * k, ho, wo)
+        assert torch.equal(P.to_f32(P.PSlice(y, 0, c * k * k)).cpu(), ref), (n, c, h, w, k, s_, p_)
+        assert y.g * 8 == (c * k * k + 7) // 8 * 8
+        if y.g * 8 > c * k * k:       # the channels that pad K to a multiple of 8 hold zeros
+            assert float(P.to_f32(P.PSlice(y, 0, y.g * 8)).cpu()[:, c * k * k:].abs().max()) == 0.0
+        cout = 32
+        wt = (torch.randn(cout, c, k, k, generator=g, dtype=torch.float64) * 0.1).requires_grad_()
+        out = F.conv2d(x.double(), wt, None, s_, p_)
+        gy = torch.randn(out.shape, generator=g) * 1e-3
+        out.backward(gy.double())
+        gp = P.from_f32(backend.put(gy))
+        dw, db = backend.put(torch.full((cout, c, k, k), 9.0)), backend.put(torch.full((cout,), 9.0))
+        P.conv_wgrad_group([P.WgradJob(P.pfull(gp), P.PSlice(y, 0, c * k * k), dw.view(cout, c * k * k, 1, 1), db, 1, 1, 1, 0, 0)])
+        assert rel_err(dw, wt.grad) < 5e-6 and rel_err(db, gy.double().sum((0, 2, 3))) < 5e-6
 
 
 def test_wgrad_deferred_reduce_multi(backend):

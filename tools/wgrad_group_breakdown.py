@@ -2,7 +2,7 @@
 is timed whole and with one problem left out; the difference is what that problem costs BESIDE the others (its launch shares the GPU
 with them).  Printed next to the problem's algorithmic flops: TF per problem, per family.
 
-    python tools/wgrad_group_breakdown.py [n_images]
+    python tools/wgrad_group_breakdown.py [n_images] [BNInception|InceptionV3]
 """
 import os
 import sys
@@ -32,18 +32,25 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
     pkg.build()
     dev = torch.device("cuda:0")
-    from action_detection_amd.bninception import BNInception
-    net = BNInception(in_channels=3)
-    net.eval()
-    plan, shapes = net._plan(torch.zeros(1, 3, 224, 224))
+    arch = sys.argv[2] if len(sys.argv) > 2 else "BNInception"
+    if arch == "InceptionV3":
+        from action_detection_amd.inceptionv3 import InceptionV3
+        net = InceptionV3()
+        net.eval()
+        plan, shapes = net._plan(torch.zeros(1, 3, 299, 299))
+    else:
+        from action_detection_amd.bninception import BNInception
+        net = BNInception(in_channels=3)
+        net.eval()
+        plan, shapes = net._plan(torch.zeros(1, 3, 224, 224))
     g = torch.Generator().manual_seed(0)
     jobs, keys, flops, cache = [], [], [], {}
     for op in plan:
-        if op["kind"] != "conv" or op["src"] == "data":
+        if op["kind"] != "conv" or (op["src"] == "data" and arch != "InceptionV3"):
             continue
         kh, kw, ph, pw = op.get("kh", op["k"]), op.get("kw", op["k"]), op.get("ph", op["p"]), op.get("pw", op["p"])
         cin, cout, s = op["cin"], op["cout"], op["s"]
-        hin = shapes[op["src"]][1]
+        hin = shapes[op["src"]][1] if op["src"] != "data" else 299
         _, ho, wo = shapes[op["dst"]]
         key = "%d|%d|%d|%d|%d|%d" % (cin, cout, kh, kw, s, hin)
         if key not in cache:
