@@ -764,16 +764,15 @@ class BNInception(nn.Module):
                     invstd = torch.empty(c, device=dev, dtype=torch.float32)
                     zs = ChanSlice(acts[op["src"]], off, c)
                     track = bn.track_running_stats and bn.running_mean is not None
-                    if bn.momentum is None and track:
-                        # torch: momentum=None is a CUMULATIVE average with factor 1 / num_batches_tracked (counted first);
-                        # reading the counter needs a host sync per layer and step, which this executor does not do
-                        raise NotImplementedError("BatchNorm2d(momentum=None) in training mode (cumulative moving average) is "
-                                                  "not supported; the reference's models use the default momentum 0.1")
                     if track and bn.num_batches_tracked is not None:
                         bn.num_batches_tracked.add_(1)      # torch increments BEFORE it updates the running statistics
+                    mom = bn.momentum
+                    if mom is None:
+                        # torch: momentum=None is a CUMULATIVE average with factor 1 / num_batches_tracked (counted first): one host
+                        # read per layer and call, as torch's own module does
+                        mom = 1.0 / float(bn.num_batches_tracked.item()) if (track and bn.num_batches_tracked is not None) else 0.0
                     K.bn_train_stats(zs, conv.bias.detach(), mean, invstd, bn.running_mean if track else None,
-                                     bn.running_var if track else None, bn.eps, 0.1 if bn.momentum is None else bn.momentum,
-                                     bws)
+                                     bn.running_var if track else None, bn.eps, mom, bws)
                     K.bn_train_apply(zs, ChanSlice(get(op["dst"]), op["dst_c0"] + off, c), mean, invstd,
                                      bn.weight.detach(), bn.bias.detach(), True)
                     bnstat[lid] = (mean, invstd)

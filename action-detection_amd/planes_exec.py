@@ -314,6 +314,7 @@ def run_forward(net, x, keep):
             net.__dict__["_infer_cache"] = (ckey, (tscale, shift_of, scale_slice, packed))
 
     bnstat, bn_before = {}, {}      # training-mode BatchNorm layers: layer id -> (batch mean of z, 1 / sqrt(var + eps))
+    bn_factor = {}                  # ... with momentum=None: the cumulative-average factor of this call
 
     def launch_all(acts, argmax):
         # the scales this pass stores with, frozen: the pool's entries move on with the next pass (another sub-batch, an
@@ -380,21 +381,25 @@ def run_forward(net, x, keep):
                     invstd = torch.empty(c, device=dev, dtype=torch.float32)
                     zs = PSlice(acts[op["src"]], off, c)
                     track = bn.track_running_stats and bn.running_mean is not None
-                    if bn.momentum is None and track:
-                        raise NotImplementedError("BatchNorm2d(momentum=None) in training mode (cumulative moving average) is "
-                                                  "not supported; the reference's models use the default momentum 0.1")
                     rm, rv = (None, None)
                     if track:
                         if lid not in bn_before:
                             bn_before[lid] = (bn.running_mean.clone(), bn.running_var.clone())
                             if bn.num_batches_tracked is not None:
                                 bn.num_batches_tracked.add_(1)      # torch increments BEFORE it updates the running statistics
+                            if bn.momentum is None:
+                                # torch: a CUMULATIVE moving average, factor 1 / num_batches_tracked (counted first) -- one host
+                                # read per layer and call, as torch's own module does; not capturable
+                                if capturing:
+                                    raise RuntimeError("BatchNorm2d(momentum=None) in training mode reads its batch counter on the "
+                                                       "host and cannot be captured into a hipGraph")
+                                bn_factor[lid] = 1.0 / float(bn.num_batches_tracked.item())
                         else:      # a pass repeated by the calibration / the range guard restarts from the statistics it found
                             bn.running_mean.copy_(bn_before[lid][0])
                             bn.running_var.copy_(bn_before[lid][1])
                         rm, rv = bn.running_mean, bn.running_var
                     P.bn_train_stats(zs, conv.bias.detach(), mean, invstd, rm, rv, bn.eps,
-                                     0.1 if bn.momentum is None else bn.momentum, bws)
+                                     bn_factor.get(lid, 0.0) if bn.momentum is None else bn.momentum, bws)
                     P.bn_train_apply(zs, PSlice(get(op["dst"]), op["dst_c0"] + off, c), mean, invstd, bn.weight.detach(),
                                      bn.bias.detach(), True)
                     bnstat[lid] = (mean, invstd)

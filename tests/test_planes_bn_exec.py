@@ -21,7 +21,7 @@ def rel_err(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
 
 
-def _pair(dev, train_ids):
+def _pair(dev, train_ids, momentum=0.1):
     net = init_tiny(TinyBackbone()).to(dev).train()
     net.debug_keep_saved = True
     ref = TinyRef()
@@ -29,13 +29,14 @@ def _pair(dev, train_ids):
     for lid in train_ids:
         for m in (getattr(net, lid + "_bn"), getattr(ref, lid + "_bn")):
             m.train()
+            m.momentum = momentum
             m.weight.requires_grad = True
             m.bias.requires_grad = True
     return net, ref
 
 
-def _run(dev, train_ids):
-    net, ref = _pair(dev, train_ids)
+def _run(dev, train_ids, momentum=0.1):
+    net, ref = _pair(dev, train_ids, momentum)
     assert net._train_bn_ids() == list(train_ids)
     g = torch.Generator().manual_seed(5)
     for call, (n, mag) in enumerate([(3, 40.0), (4, 40.0), (3, 900.0)]):      # the last batch leaves the calibrated range
@@ -86,6 +87,12 @@ def test_partial_bn_on_planes(emu):
 
 def test_full_bn_on_planes(emu):
     _run(torch.device("cpu"), LAYERS)
+
+
+def test_cumulative_average_bn_on_planes(emu):
+    """BatchNorm2d(momentum=None): torch's cumulative moving average (factor 1 / num_batches_tracked, counted first) -- the running
+    statistics must follow torch's module over three calls (incl. the one the range guard repeats)."""
+    _run(torch.device("cpu"), ("conv1_3x3", "branch_3x3"), momentum=None)
 
 
 def test_switch_sends_training_bn_to_the_fp32_layout(emu):
