@@ -100,11 +100,11 @@ def main():
     try:
         pm = json.load(open(os.path.join(O, "pmc_summary.json")))
         out += ["", "PMC (tools/gpu_pmc.sh, separate passes; `pmc_summary.json`):", "",
-                "| family | launches | MFMA pipe busy | non-MFMA instr per MFMA | HBM MB per launch |", "|---|---|---|---|---|"]
+                "| family | launches sampled | MFMA pipe busy | non-MFMA instr per MFMA | HBM MB per launch |", "|---|---|---|---|---|"]
         for fam, v in pm.items():
-            if not isinstance(v, dict) or "launches" not in v:
+            if not isinstance(v, dict) or "launches_sampled" not in v:
                 continue
-            out.append("| %s | %s | %s | %s | %s |" % (fam, v.get("launches"), v.get("mfma_pipe_busy_frac", ""),
+            out.append("| %s | %s | %s | %s | %s |" % (fam, v.get("launches_sampled"), v.get("mfma_pipe_busy_frac", ""),
                                                       v.get("non_mfma_insts_per_mfma", v.get("valu_salu_per_mfma", "")),
                                                       ("%.0f" % (v["hbm_bytes_per_launch"] / 1e6)) if v.get("hbm_bytes_per_launch") else ""))
     except (OSError, ValueError):
