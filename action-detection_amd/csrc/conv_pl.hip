@@ -460,32 +460,24 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
     }
     const __amdgpu_buffer_rsrc_t arsrc = pl_rsrc(p.ap, p.a_bytes);
     const uint32_t a_step = (uint32_t)(p.M * APITCH) * 4u;
-    const int nslab = p.ngroups * 9;
 
-    // A producer: slab index of the next fetch
-    int pf_slab = 0;
+    // A producer: byte offset of the packed weight slab fetched next (one slab further per slab; slabs past the end are requested with
+    // every offset out of range -- `dead` -- and deposit zeros)
     uint32_t pf_a = 0;
-    uint32_t d_aso, d_dead;
-    uint32_t* d_a;
-    auto issue_a_begin = [&](uint32_t st_off) {
-        d_dead = pf_slab < nslab ? 0u : PL_OOB;
-        d_aso = pf_a;
-        d_a = lds + st_off + wave * 256;
-        pf_a += a_step;
-        ++pf_slab;
+    auto issue_a = [&](uint32_t st_off, uint32_t dead, int q) {     // piece q of this wave into the ring slot at dword st_off
+        PL_DMA_B128(arsrc, lds + st_off + wave * 256 + q * NW * 256, aoff[q] | dead, pf_a);
     };
-    // halo producer: piece `sg` of channel group `g` into buffer g & 1 (sg >= NSEG: the dummy piece)
-    auto issue_halo = [&](int g, int sg) {
-        const bool real = sg < NSEG;
-        const bool live = real && g < p.ngroups && !(hkhalf && c_half && g == p.ngroups - 1);
-        uint32_t v = PL_OOB;
-#pragma unroll
-        for (int q = 0; q < NSEG; ++q)
-            if (q == sg) v = hoff[q];
-        if (!live) v = PL_OOB;
-        uint32_t* dst = real ? lds + HALO0 + (g & 1) * HBUF + (2 * hplane + hkhalf) * HROW + sg * 256 : lds + DUMMY;
-        PL_DMA_B128(hrsrc, dst, v, (uint32_t)g * 2u * p.x_grp_bytes + (hkhalf ? p.x_grp_bytes : 0u));
+    // halo producer: piece `sg` (compile-time; >= NSEG: the dummy piece that keeps the per-slab vmcnt constant) of a channel group into
+    // halo buffer `hb` (compile-time); `live` / `so`: the group exists (and this wave's k-half of it) / its scalar source offset
+    auto issue_halo = [&](bool live, uint32_t so, int hb, int sg) {
+        if (sg < NSEG) {
+            PL_DMA_B128(hrsrc, lds + HALO0 + hb * HBUF + (2 * hplane + hkhalf) * HROW + sg * 256, live ? hoff[sg] : PL_OOB, so);
+        } else {
+            PL_DMA_B128(hrsrc, lds + DUMMY, PL_OOB, 0u);
+        }
     };
+    const uint32_t h_khalf = hkhalf ? p.x_grp_bytes : 0u;
+    auto halo_live = [&](int g) { return g < p.ngroups && !(hkhalf && c_half && g == p.ngroups - 1); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -496,14 +488,17 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // prologue: the whole halo of group 0, then the first NSTAGE weight slabs (each with its dummy piece: constant count per slab)
+    {
+        const bool l0 = halo_live(0);
 #pragma unroll
-    for (int sg = 0; sg < NSEG; ++sg) issue_halo(0, sg);
+        for (int sg = 0; sg < NSEG; ++sg) issue_halo(l0, h_khalf, 0, sg);
+    }
 #pragma unroll
     for (int st = 0; st < NSTAGE; ++st) {
-        issue_a_begin(st * A_STAGE);
 #pragma unroll
-        for (int q = 0; q < NA; ++q) PL_DMA_B128(arsrc, d_a + q * NW * 256, aoff[q] | d_dead, d_aso);
-        issue_halo(0, NSEG);
+        for (int q = 0; q < NA; ++q) issue_a(st * A_STAGE, 0u, q);
+        pf_a += a_step;
+        issue_halo(false, 0u, 0, NSEG);
     }
 
     const float sa = f16_scale_of(__builtin_bit_cast(float, p.ap[p.a_bytes >> 2]));
@@ -526,7 +521,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
         if (p.relu && m < p.raw_from) ep_flo = 0.f;
     }
 
-    // fragment addressing.  A as in conv_pl_kernel; B: the lane's pixel -> its centre slot inside the halo
+    // fragment addressing.  A as in conv_pl_kernel; B: the lane's pixel -> the slot one row and one column in front of its centre slot
+    // inside the halo, so that the window row / column of a tap is a non-negative displacement: row * Wp (a scalar) + column (an immediate)
     const int swz = (li >> 2) & 3;
     int achunk[2];
 #pragma unroll
@@ -536,8 +532,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pp = p0 + (wn * TN + j) * 32 + li;
-        bcen[j] = HALO0 + lh * HROW + ((pp < (PI ? pl_pend : p.P) ? slot_of(pp) - ubase : Wp + 1)) * 4;      // (dwords; lh = the k-half row)
+        bcen[j] = HALO0 + lh * HROW + ((pp < (PI ? pl_pend : p.P) ? slot_of(pp) - ubase : Wp + 1) - (Wp + 1)) * 4;   // (dwords; lh = the k-half row)
     }
+    const int wrow[3] = {0, Wp * 4, 2 * Wp * 4};     // dwords
 
     struct Frags {
         f16x8 af[2][TM];
@@ -545,45 +542,54 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
     };
     Frags fr0, fr1;
     constexpr int NREAD = 2 * TN + 2 * TM;
-    // consumer state of the slab whose fragments are read next: ring slot of its weights, halo buffer + tap displacement of its B
-    const uint32_t* rd_a;
-    int rd_boff;                          // dword offset added to bcen[j]: buffer, plane row pair and tap displacement
-    int rd_g = 0, rd_r = 0, rd_s = 0;     // (group, tap row, tap column) of the slab read_begin() was last called for
-    auto read_begin = [&](uint32_t st_off) {
-        rd_a = lds + st_off;
-        const int disp = (MODE == MODE_FWD) ? (rd_r - 1) * Wp + (rd_s - 1) : (1 - rd_r) * Wp + (1 - rd_s);
-        rd_boff = (rd_g & 1) * HBUF + disp * 4;
-        if (++rd_s == 3) {
-            rd_s = 0;
-            if (++rd_r == 3) {
-                rd_r = 0;
-                ++rd_g;
-            }
-        }
-    };
-    auto read_step = [&](Frags& f, int k) {
+    // Fragment reads of the slab (tap `tap` -- compile-time -- of the group in halo buffer `hb`, weights in the ring slot at `st_off`):
+    // forward reads window position (r, s), dgrad the mirrored one
+    auto read_step = [&](Frags& f, int k, uint32_t st_off, int hb, int tap) {
         if (k < 2 * TN) {
             const int pn = k / TN, j = k % TN;
-            f.bf[pn][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds + bcen[j] + rd_boff + pn * 2 * HROW));
+            const int r = (MODE == MODE_FWD) ? tap / 3 : 2 - tap / 3, c = (MODE == MODE_FWD) ? tap % 3 : 2 - tap % 3;
+            f.bf[pn][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds + bcen[j] + wrow[r] + (hb * HBUF + pn * 2 * HROW + c * 4)));
         } else {
             const int q = k - 2 * TN, pn = q / TM, i = q % TM;
-            f.af[pn][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(rd_a + arow + i * 32 * APITCH + achunk[pn]));
+            f.af[pn][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds + st_off + arow + i * 32 * APITCH + achunk[pn]));
         }
     };
-    // compute-side slab counters: the halo piece issued during slab (cg, ctap) is piece ctap of group cg + 1
-    int cg = 0, ctap = 0;
-    auto mfma = [&](const Frags& f, uint32_t dma_stage, Frags& nxt) {
+
+    SSN_WAIT_VMCNT((NSTAGE - 1) * NLOAD);
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int k = 0; k < NREAD; ++k) read_step(fr0, k, 0u, 0, 0);
+    uint32_t s_cur = 0, s_n1 = A_STAGE, s_n2 = 2 * A_STAGE, s_n3 = 3 * A_STAGE;    // ring slots of slabs t, t+1, t+2 (, t+3)
+    // Per-group scalars of the trip: the halo of the NEXT group (fetched during the first NSEG slabs of this one) and whether the weight
+    // slabs requested from this group's last NSTAGE slabs on exist
+    bool nx_live;
+    uint32_t nx_so, tail_dead;
+    auto group_begin = [&](int g) {
+        nx_live = halo_live(g + 1);
+        nx_so = (uint32_t)(g + 1) * 2u * p.x_grp_bytes + h_khalf;
+        tail_dead = g + 1 < p.ngroups ? 0u : PL_OOB;
+    };
+    // One slab = tap `tap` of the group in halo buffer `hb` (both compile-time at every call site: the nine taps of a group are unrolled,
+    // so the tap displacement, the halo piece and its destination, the read addresses are immediates -- as a runtime state machine they
+    // were 65 scalar instructions per slab, 16 per MFMA on the 64 x 128 tile: more than two waves per SIMD can hide).  Three partial
+    // products per accumulator tile; between the MFMAs: the LDS reads of the next slab (other register set), the halo piece `tap` of the
+    // next group, and the weight pieces of slab t + NSTAGE into the slot of slab t.
+    auto slab = [&](const Frags& f, Frags& nxt, int tap, int hb) {
         constexpr int PA[3] = {1, 0, 0};
         constexpr int PB[3] = {0, 0, 1};
         constexpr int NM = 3 * TM * TN;
         constexpr int EVERY = NM / NLOAD > 0 ? NM / NLOAD : 1;
-        issue_a_begin(dma_stage);
+        SSN_WAIT_VMCNT((NSTAGE - 2) * NLOAD);   // this wave's pieces of slab t+1 (the later slabs' may still be in flight)
+        SSN_WAIT_LGKM0();                       // ... and its reads of slab t are back
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        const int ntap = tap == 8 ? 0 : tap + 1, nhb = tap == 8 ? hb ^ 1 : hb;
+        const uint32_t dead = (tap + NSTAGE >= 9) ? tail_dead : 0u;
         auto piece = [&](int k) {          // k compile-time: 0 = the halo / dummy piece, 1.. = the A pieces
             if (k == 0)
-                issue_halo(cg + 1, ctap);
+                issue_halo(nx_live, nx_so, hb ^ 1, tap);
             else
-                PL_DMA_B128(arsrc, d_a + (k - 1) * NW * 256, aoff[k - 1] | d_dead, d_aso);
+                issue_a(s_cur, dead, k - 1);
         };
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -595,31 +601,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
                     const int idx = (c * TM + i) * TN + j;
 #pragma unroll
                     for (int k = idx * NREAD / NM; k < (idx + 1) * NREAD / NM; ++k)
-                        if (!PL_DBG(4)) read_step(nxt, k);
+                        if (!PL_DBG(4)) read_step(nxt, k, s_n1, nhb, ntap);
                     if ((idx + 1) % EVERY == 0 && (idx + 1) / EVERY <= NLOAD) piece((idx + 1) / EVERY - 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
         for (int k = NM / EVERY; k < NLOAD; ++k) piece(k);
-        if (++ctap == 9) {
-            ctap = 0;
-            ++cg;
-        }
-    };
-
-    SSN_WAIT_VMCNT((NSTAGE - 1) * NLOAD);
-    __builtin_amdgcn_s_barrier();
-    read_begin(0);
-#pragma unroll
-    for (int k = 0; k < NREAD; ++k) read_step(fr0, k);
-    uint32_t s_cur = 0, s_n1 = A_STAGE, s_n2 = 2 * A_STAGE, s_n3 = 3 * A_STAGE;
-    auto half = [&](Frags& cur, Frags& nxt) {
-        SSN_WAIT_VMCNT((NSTAGE - 2) * NLOAD);
-        SSN_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        read_begin(s_n1);
-        mfma(cur, s_cur, nxt);
+        pf_a += a_step;
         const uint32_t o = s_cur;
         s_cur = s_n1;
         s_n1 = s_n2;
@@ -630,10 +618,25 @@ __global__ __launch_bounds__(256, (TM * TN >= 8) ? 1 : 2) void conv_pl9_kernel(P
             s_n2 = o;
         }
     };
-    for (int t = 0; t < nslab; t += 2) {
-        half(fr0, fr1);
-        half(fr1, fr0);
+    // two groups per trip (nine is odd: the register sets swap roles from one group to the next); the last group of an odd count runs
+    // behind the loop (a `break` between the two halves of the trip cost 50 - 80 registers and spills on the two largest tiles: the
+    // allocator then has to reconcile two exits)
+    auto group = [&](int g, Frags& fa, Frags& fb, int hb) {
+        group_begin(g);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap & 1)
+                slab(fb, fa, tap, hb);
+            else
+                slab(fa, fb, tap, hb);
+        }
+    };
+    int g = 0;
+    for (; g + 1 < p.ngroups; g += 2) {
+        group(g, fr0, fr1, 0);
+        group(g + 1, fr1, fr0, 1);
     }
+    if (g < p.ngroups) group(g, fr0, fr1, 0);
     SSN_WAIT_LGKM0();
     SSN_WAIT_VMCNT(0);
 

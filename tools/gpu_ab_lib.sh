@@ -5,7 +5,7 @@
 O=gpurun_out/r5; mkdir -p $O
 L=action-detection_amd/libssn_hip.so
 cp $L /tmp/new.so
-for rep in 1 2 3; do
+for rep in ${REPS:-1 2 3}; do
   for which in prev new; do
     if [ $which = prev ]; then cp tools/.ab/libssn_prev.so $L; else cp /tmp/new.so $L; fi
     timeout 300 python bench.py --cpu-baseline-videos 0 ${BENCH_ARGS:-} > $O/ab_${which}_$rep.json 2> $O/ab_${which}_$rep.err
