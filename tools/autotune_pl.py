@@ -155,7 +155,8 @@ def main():
     for path in (OUT, os.path.join(ROOT, "gpurun_out", "tuned_tiles_pl.json")):      # (gpurun_out/ is what travels back from the GPU box)
         if os.path.isdir(os.path.dirname(path)):
             with open(path, "w") as f:
-                json.dump({"n_images": n, "tiles": tiles, "ms": ms}, f, indent=0, sort_keys=True)
+                # (the table's batch-size gate stays BN-Inception's)
+                json.dump({"n_images": n if arch == "BNInception" else table.get("n_images", n), "tiles": tiles, "ms": ms}, f, indent=0, sort_keys=True)
     print("wrote", OUT, "fwd %.3f dgrad %.3f wgrad %.3f ms (one launch per distinct shape)" % tuple(
         sum(v for k, v in ms.items() if k.startswith(p + "|")) for p in ("fwd", "dgrad", "wgrad")))
 
