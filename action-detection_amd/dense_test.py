@@ -29,7 +29,7 @@ class DenseTester(object):
     """``net``: an ``SSN(..., test_mode=True)`` with ``prepare_test_fc()`` done, in eval mode, on a HIP device.
     ``stats``: the 2x2 regression statistics array of the checkpoint (``[[mean0, mean1], [std0, std1]]``)."""
 
-    def __init__(self, net, num_class, stpp_cfg=(1, 1, 1), stats=None, tick_batch=32):
+    def __init__(self, net, num_class, stpp_cfg=(1, 1, 1), stats=None, tick_batch=32, max_keep_bytes=None):
         if net.test_fc is None:
             raise RuntimeError("call net.prepare_test_fc() first (ssn_test.py:61)")
         self.net = net
@@ -41,7 +41,9 @@ class DenseTester(object):
         self.stats = stats
         self.tick_batch = int(tick_batch)
         self.length = (3 if net.modality == "RGB" else 2) * net.new_length
-        self.max_keep_bytes = 24 << 30      # inputs kept referenced for a possible repeat; beyond it the calls poll one by one
+        # inputs kept referenced for a possible repeat (the once-per-video poll); beyond the cap the calls poll one by one.  None: half of
+        # the device memory that is free when a video starts, at most 24 GiB
+        self.max_keep_bytes = max_keep_bytes
         self.repeated_calls = 0             # backbone calls the once-per-video poll had to repeat
 
     @torch.no_grad()
@@ -56,6 +58,12 @@ class DenseTester(object):
         lag = {"on": (getattr(bm, "scale_guard", "") == "sync" and dev.type == "cuda" and getattr(bm, "layout", "") == "planes"),
                "kept": [], "marks": [], "bytes": 0}
         word = bm.planes_flag(dev)[0:1] if lag["on"] else None
+        # the fault word is shared by every user of the backbone on this device (a graph owner polls it): what it held before this video
+        # is put back at the end -- the tester only ever clears what its own calls set
+        prior = word.clone() if lag["on"] else None
+        keep_cap = self.max_keep_bytes
+        if keep_cap is None:
+            keep_cap = min(24 << 30, torch.cuda.mem_get_info(dev)[0] // 2) if dev.type == "cuda" else 0
 
         def score(x, row0, ticks):
             base = self.net._backbone(x)                                    # [num_crop * b, feat]
@@ -74,7 +82,7 @@ class DenseTester(object):
                 x = torch.cat([p.reshape((num_crop, -1) + tuple(p.shape[1:])) for p in pending], dim=1)
                 x = x.reshape((-1,) + tuple(pending[0].shape[1:]))
             x = x.contiguous()
-            if lag["on"] and lag["bytes"] + x.numel() * x.element_size() > self.max_keep_bytes:
+            if lag["on"] and lag["bytes"] + x.numel() * x.element_size() > keep_cap:
                 lag["on"] = False                                           # (a very long video: poll call by call from here on)
             if lag["on"]:
                 bm.scale_guard = "deferred"                                 # the call launches its range check, polls nothing
@@ -105,6 +113,8 @@ class DenseTester(object):
             for i in bad:                                                   # repeat exactly the calls that left their range
                 self.repeated_calls += 1
                 score(*lag["kept"][i])                                      # (sync guard: repairs itself)
+        if prior is not None:
+            torch.maximum(word, prior, out=word)
         if cnt != frame_cnt:
             raise ValueError("the frame source gave %d ticks, expected %d" % (cnt, frame_cnt))
         return output

@@ -591,6 +591,8 @@ def bn_train_workspace_floats(n, c):
 
 def bn_train_stats(z, conv_bias, mean, invstd, running_mean, running_var, eps, momentum, workspace):
     """Batch statistics of the ChanSlice z (the convolution WITHOUT its bias) + running-statistics update."""
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1        # (the running statistics are written through raw pointers)
     lib = _check(z, conv_bias, mean, invstd, running_mean, running_var, workspace)
     h, w = z.hw
     lib.call("ssn_bn_train_stats", _p(z), _p(conv_bias), _p(mean), _p(invstd), _p(running_mean), _p(running_var), z.n,

@@ -9,6 +9,7 @@ magnitude the step's producers stored).  ``SlotPool`` owns the slots of an execu
 import torch
 
 from . import _lib
+from . import kernels as K
 from .kernels import _p, _stream
 
 
@@ -433,6 +434,8 @@ def bn_train_workspace_bytes(c):
 def bn_train_stats(z, conv_bias, mean, invstd, running_mean, running_var, eps, momentum, workspace):
     """Batch statistics of the planes slice z (the convolution WITHOUT its bias): mean / invstd (real units) and the running
     statistics update of torch.nn.BatchNorm2d (running_mean / running_var None: not tracked)."""
+    if running_mean is not None:
+        K.PARAM_EPOCH += 1      # (written through raw pointers: invisible to torch's version counters; see planes_exec's inference cache)
     lib = _lib_for(z.t)
     h, w = z.hw
     lib.call("ssn_pl_bn_train_stats", z.hi, z.lo, z.groups, z.t.scale_ptr, _p(conv_bias), _p(mean), _p(invstd), _p(running_mean),

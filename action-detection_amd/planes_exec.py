@@ -273,7 +273,7 @@ def run_forward(net, x, keep):
     ckey = None
     hit = None
     if not keep and net.infer_cache:
-        ckey = (dev, tuple(x.shape[1:]), K.PARAM_EPOCH,
+        ckey = (dev, tuple(x.shape[1:]), K.PARAM_EPOCH, bool(net.training), tuple(net._train_bn_ids()),      # (the last two: the plan)
                 tuple((t._version, t.data_ptr()) for t in itertools.chain(net.parameters(), net.buffers())))
         hit = net.__dict__.get("_infer_cache")
         if hit is not None and hit[0] == ckey:

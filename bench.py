@@ -336,10 +336,16 @@ def main():
     # carries the range check, the optimizer launches take the fault word and skip a flagged step (weights and momentum stay as
     # they were: the step is retryable), and the host looks at a pinned copy of the word behind every replay.
     fault_word = model.scale_fault_flag(dev)
-    fault_host = torch.zeros(1, dtype=torch.int32)
+    # the host reads the word with a FIXED lag of GUARD_LAG steps (a ring of pinned copies, each behind its own event): the copy queued
+    # behind step i is looked at behind step i + GUARD_LAG, after its event -- long complete -- has been waited for.  Every rank therefore
+    # looks at the word of the SAME step (MAX-reduced over the ranks inside that step), so with N > 1 all ranks redo the same iteration
+    # or none does: a rank that redid a step eagerly -- with its collectives -- beside peers replaying their graphs would hang the job.
+    GUARD_LAG = 2
+    fault_ring = [torch.zeros(1, dtype=torch.int32) for _ in range(GUARD_LAG + 1)]
     if not emulator:
-        fault_host = fault_host.pin_memory()
-    guard = {"faults": 0}
+        fault_ring = [t.pin_memory() for t in fault_ring]
+    fault_events = [None if emulator else torch.cuda.Event() for _ in fault_ring]
+    guard = {"faults": 0, "skipped_steps": 0, "polls": 0, "pending": []}
 
     def fwd_bwd():
         out = model(*batch)
@@ -374,15 +380,28 @@ def main():
         return loss
 
     def poll_guard():
-        """Behind every step: queue a copy of the fault word into pinned memory and look at what the previous copies brought
-        (no sync: the value lags by a step or two, during which the optimizer skips on its own).  On a fault: drain, clear,
+        """Behind every step: queue a copy of the fault word into pinned memory and look at the copy queued GUARD_LAG steps ago (no
+        stall: that step finished long ago; meanwhile the optimizer skips flagged steps on its own).  On a fault: drain, clear,
         recalibrate and redo the step eagerly -- it calibrates as a first step does."""
-        fault_host.copy_(fault_word, non_blocking=True)
-        if int(fault_host[0]) != 0:
+        k = guard["polls"] % len(fault_ring)
+        guard["polls"] += 1
+        fault_ring[k].copy_(fault_word, non_blocking=True)
+        if fault_events[k] is not None:
+            fault_events[k].record()
+        guard["pending"].append(k)
+        if len(guard["pending"]) <= GUARD_LAG:
+            return
+        k0 = guard["pending"].pop(0)
+        if fault_events[k0] is not None:
+            fault_events[k0].synchronize()
+        if int(fault_ring[k0][0]) != 0:
             torch.cuda.synchronize()
             guard["faults"] += 1
+            guard["skipped_steps"] += GUARD_LAG + 1      # (the flagged step and the ones queued behind it: their updates were skipped)
             model.recalibrate_scales()
-            fault_host.zero_()
+            for t in fault_ring:
+                t.zero_()
+            guard["pending"].clear()
             step()
 
     def fence():
@@ -449,6 +468,9 @@ def main():
         poll_guard()
     fence()
     elapsed = time.perf_counter() - t0
+    if any(int(fault_ring[k][0]) != 0 for k in guard["pending"]):      # (the last GUARD_LAG steps: reported, not redone)
+        guard["faults"] += 1
+        guard["skipped_steps"] += len(guard["pending"])
     rank_ms = 1e3 * elapsed / args.steps
 
     # ---- per-launch HIP events for the roofline: the same K steps once more, launched eagerly (events cannot
@@ -557,9 +579,9 @@ def main():
                                       if args.precision == "split" else "exact-f32 MFMA everywhere")},
         "final_loss": float(loss.item()),
         "scale_guard": {"protocol": "range check of the delayed scales captured in the step; optimizer launches skip a flagged step "
-                                    "(device fault word); host polls a pinned copy behind every step and redoes a flagged step "
-                                    "eagerly after recalibration" + ("; the word is MAX-reduced over the ranks" if use_dist else ""),
-                        "scale_overflows": guard["faults"], "repeated_eager_passes": model.base_model.guard_stats(),
+                                    "(device fault word); host looks at a pinned copy of the word with a fixed lag of 2 steps and redoes a "
+                                    "flagged step eagerly after recalibration" + ("; the word is MAX-reduced over the ranks" if use_dist else ""),
+                        "scale_overflows": guard["faults"], "steps_with_skipped_update": guard["skipped_steps"], "repeated_eager_passes": model.base_model.guard_stats(),
                         "eager_fault_log": [[w, [[n_, round(v_, 3)] for n_, v_ in bad[:6]]]
                                             for st_ in model.base_model._planes_states.values() for w, bad in st_.fault_log]},
     }
