@@ -112,6 +112,20 @@ def main():
     if others:
         out += ["", "(largest 'everything else' kernels: " + "; ".join("%s %.3f ms" % (k, v / 1e6 / steps) for k, v in
                                                                         sorted(others.items(), key=lambda kv: -kv[1])[:6]) + ")"]
+    boxes = []
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if name.startswith("r5_bench_box") or name == "r5_bench_final.json":
+            try:
+                d = json.loads([l for l in open(os.path.join(ROOT, "profiles", name)) if l.startswith("{")][-1])
+                boxes.append((d["ms_per_step"], d["value"], name))
+            except (OSError, ValueError, IndexError, KeyError):
+                pass
+    if boxes:
+        boxes.sort()
+        med = boxes[len(boxes) // 2][0] if len(boxes) % 2 else 0.5 * (boxes[len(boxes) // 2 - 1][0] + boxes[len(boxes) // 2][0])
+        out += ["", "Boxes at the closing library (default `bench.py` line, 10 timed steps, hipGraph replay; `r5_bench_final.json` is the evidence box "
+                "every other file of this summary comes from): " + "; ".join("`%s` %.3f ms = %.1f proposals/s" % (n, ms, v) for ms, v, n in boxes)
+                + ".  Median %.2f ms." % med]
     with open(os.path.join(ROOT, "profiles", "r5_summary.md"), "w") as f:
         f.write("\n".join(out) + "\n")
     print("\n".join(out))
