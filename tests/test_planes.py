@@ -89,6 +89,7 @@ CASES_SMALL = [
     (1, 24, 6, 8, 64, 1, 1, 1, 0, 0), (2, 16, 5, 5, 72, 5, 5, 1, 2, 2), (1, 32, 8, 8, 48, 1, 7, 1, 0, 3),
     (1, 16, 9, 9, 32, 3, 3, 1, 0, 0), (1, 16, 12, 12, 64, 4, 4, 1, 2, 2), (2, 16, 9, 9, 32, 3, 3, 2, 0, 0),
     (5, 24, 7, 7, 48, 3, 3, 1, 1, 1), (3, 40, 6, 11, 72, 3, 3, 1, 1, 1),      # 3x3 / pad 1: tiles that cross images, an 8-channel tail group
+    (3, 16, 5, 5, 32, 3, 3, 2, 0, 0), (5, 8, 3, 3, 16, 1, 1, 1, 0, 0),        # images of 4 / 9 output pixels: a 16-slot k-step spans several images
 ]
 CASES_GPU = [
     (9, 64, 56, 56, 192, 3, 3, 1, 1, 1), (18, 192, 28, 28, 224, 1, 1, 1, 0, 0), (18, 128, 28, 28, 160, 3, 3, 2, 1, 1),
