@@ -240,17 +240,28 @@ def build(force=False, verbose=False):
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             objs = []
             procs = []
+            headers = deps[len(srcs):]
             for s in srcs:
                 o = os.path.join(CSRC, os.path.basename(s) + ".o")
                 objs.append(o)
+                # per-object stamp (source + every header + flags): an edit to one translation unit recompiles that one only
+                ostamp = _source_stamp([s] + headers, flags)
+                try:
+                    with open(o + ".stamp") as f:
+                        if not force and os.path.exists(o) and f.read().strip() == ostamp:
+                            continue
+                except OSError:
+                    pass
                 cmd = [hipcc] + flags + ["-c", s, "-o", o]
-                procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-            for cmd, p in procs:
+                procs.append((cmd, o, ostamp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            for cmd, o, ostamp, p in procs:
                 out, _ = p.communicate()
                 if verbose and out:
                     print(out.decode())
                 if p.returncode != 0:
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode()))
+                with open(o + ".stamp", "w") as f:
+                    f.write(ostamp + "\n")
             tmp = LIB_PATH + ".tmp.%d" % os.getpid()
             subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
             os.replace(tmp, LIB_PATH)      # readers never see a half-written library

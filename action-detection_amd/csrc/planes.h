@@ -88,8 +88,18 @@ __device__ __forceinline__ void pl_split8(const float (&v)[8], u32x4& hi, u32x4&
 __device__ __forceinline__ void pl_store_b64(u32x2 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
+// 16-byte buffer store.  HAZARD (found on the MI355X in round 6, profiles/r6_b128_store_hazard.txt): a VMEM store with more than 64 bits
+// of data reads its data VGPRs over more than one cycle, and a VALU instruction issued right behind it may overwrite the LAST data
+// dword before it has been read (the GCN ">64-bit store data" hazard, one wait state).  The compiler's hazard recognizer only pads
+// that case when the store's soffset is NOT a register -- these stores use an SGPR soffset, it padded nothing, and the compiled
+// epilogue of the TM = 3 / TN = 1 tiles had `buffer_store_dwordx4 v[42:45] ...; v_or_b32 v45, ...` back to back: a few elements in
+// 10^8 lost the last dword of their low plane.  The asm below keeps the data registers alive until two wait states behind the store
+// (an instruction scheduled in between cannot be given those registers), which closes the window whatever the scheduler does.
 __device__ __forceinline__ void pl_store_b128(u32x4 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1" : : "v"(v) : "memory");
+#endif
 }
 
 }  // namespace pl

@@ -220,7 +220,10 @@ def _branch_lanes(plan):
         seg = plan[i + 1:i + 5]
         ok = (op["kind"] == "conv" and len(op["lids"]) >= 2 and len(seg) == 4 and all(q["kind"] == "conv" and len(q["lids"]) == 1 for q in seg[:3])
               and seg[3]["kind"] in ("pool", "pool_aff") and seg[2]["src"] == seg[1]["dst"] and seg[0]["src"] == op["dst"]
-              and seg[1]["src"] == op["dst"] and seg[1]["dst"] not in (seg[0]["dst"], op["dst"]))
+              and seg[1]["src"] == op["dst"] and seg[1]["dst"] not in (seg[0]["dst"], op["dst"])
+              # the pool runs on the side lane with no wait on the main lane behind the fork: it may only read what existed at the
+              # fork (the block input, the block-input launch's rows) or what its own lane wrote
+              and seg[3]["src"] in (op["src"], op["dst"], seg[0]["dst"]))
         if ok:
             side[i + 1] = "fork"
             side[i + 4] = "side"
@@ -486,6 +489,9 @@ def run_backward(net, dfeat, saved, hook=True):
     # workspace: the split-K slabs of EVERY weight gradient of the pass (each layer its own region: the reductions are deferred and
     # issued together, one launch instead of one per layer; 2.2 GB at the bench batch), channel-sum scratch
     ws_off, ws_bytes = {}, 0
+    # two lanes: the 3x3 branch's weight gradient (+ its reduction) runs on the side stream beside double_3x3_1/2's on the main one, so
+    # per-layer launches must not share ONE slab region even when their reductions are not deferred
+    lanes_on = bool(net.branch_lanes and dfeat.is_cuda and _branch_lanes(plan)[0])
     for op in plan:
         if op["kind"] != "conv":
             continue
@@ -499,7 +505,7 @@ def run_backward(net, dfeat, saved, hook=True):
         need = (need + 1023) // 1024 * 1024
         if net.group_wgrad and (not op.get("s2d") or "data_s2d_f32" not in acts):
             continue                                   # (grouped: the slabs live in the group's own workspace)
-        if not net.defer_wgrad_reduce:
+        if not net.defer_wgrad_reduce and not lanes_on:
             ws_off[op["lids"][0]] = (0, need)
             ws_bytes = max(ws_bytes, need)
         else:

@@ -335,6 +335,22 @@ static inline T __shfl_down(T v, int delta, int width = 64) {
     int src = emu::g_cur->lane + delta;
     return emu::shfl_idx(v, src > 63 ? emu::g_cur->lane : src);
 }
+// v_permlane32_swap_b32 vdst, src (gfx950): lanes 32-63 of vdst swap with lanes 0-31 of src; returns {vdst', src'}
+typedef uint32_t emu_u32x2_swap __attribute__((ext_vector_type(2)));
+static inline emu_u32x2_swap __builtin_amdgcn_permlane32_swap(uint32_t vdst, uint32_t src, bool, bool) {
+    uint32_t u[2] = {vdst, src};
+    auto* buf = emu::wave_exchange(u, 2);
+    const int lane = emu::g_cur->lane;
+    emu_u32x2_swap r;
+    if (lane < 32) {
+        r[0] = vdst;
+        r[1] = buf[lane + 32][0];
+    } else {
+        r[0] = buf[lane - 32][1];
+        r[1] = src;
+    }
+    return r;
+}
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 static inline float atomicAdd(float* p, float v) {
     float o = *p;

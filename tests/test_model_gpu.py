@@ -211,3 +211,35 @@ def test_chunked_execution_matches_single_pass(hip_library):
     assert torch.equal(f1, f3)                                     # per-image results do not depend on the batch they run in
     for n in g1:
         assert rel_err(g3[n], g1[n]) < 2e-5, (n, rel_err(g3[n], g1[n]))   # (sums over 7 images in a different order)
+
+
+def test_per_layer_wgrad_launches_with_two_lanes_are_bit_identical(hip_library):
+    """with the grouped weight-gradient launches AND the deferred reductions switched off, every layer's split-K slabs
+    used to share ONE workspace region -- safe on one stream, a race once the 3x3 branch's weight gradient runs on the side lane beside
+    double_3x3_1/2's on the main one.  With lanes on each layer owns its region: the gradients must equal the one-stream run's bit for
+    bit (same kernels, same split plans, same reduction order), three times in a row."""
+    from action_detection_amd.bninception import BNInception
+    torch.manual_seed(0)
+    m = BNInception()
+    init_backbone_synthetic(m)
+    m.eval().cuda()
+    m.group_wgrad = False
+    m.defer_wgrad_reduce = False
+    x = (torch.randn(6, 3, 224, 224) * 50).cuda()
+    w = torch.randn(6, 1024, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def run(lanes):
+        m.branch_lanes = lanes
+        m.zero_grad(set_to_none=True)
+        f = m.features(x)
+        (f * w).sum().backward()
+        torch.cuda.synchronize()
+        return f.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    run(False)                      # (calibrates the delayed scales of both passes)
+    f0, g0 = run(False)
+    for _ in range(3):
+        f1, g1 = run(True)
+        assert torch.equal(f0, f1)
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), n

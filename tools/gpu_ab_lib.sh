@@ -2,7 +2,7 @@
 # A/B of two builds of the library on ONE box: the in-tree libssn_hip.so (NEW) against tools/.ab/libssn_prev.so (PREV, built from the
 # previous commit on the build host; *.so files travel with the snapshot).  The stamp next to the library stays the NEW sources', so
 # build() does not recompile on the box.  Alternating bench runs.
-O=gpurun_out/r5; mkdir -p $O
+O=${O:-gpurun_out/r6}; mkdir -p $O
 L=action-detection_amd/libssn_hip.so
 cp $L /tmp/new.so
 for rep in ${REPS:-1 2 3}; do
