@@ -95,11 +95,12 @@ __device__ __forceinline__ void pl_store_b64(u32x2 v, __amdgpu_buffer_rsrc_t r, 
 // epilogue of the TM = 3 / TN = 1 tiles had `buffer_store_dwordx4 v[42:45] ...; v_or_b32 v45, ...` back to back: a few elements in
 // 10^8 lost the last dword of their low plane.  The asm below keeps the data registers alive until two wait states behind the store
 // (an instruction scheduled in between cannot be given those registers), which closes the window whatever the scheduler does.
+#ifndef SSN_STORE_DATA_GUARD      // (the host emulator of the CPU test tier defines it away)
+#define SSN_STORE_DATA_GUARD(v) asm volatile("s_nop 1" : : "v"(v) : "memory")
+#endif
 __device__ __forceinline__ void pl_store_b128(u32x4 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_nop 1" : : "v"(v) : "memory");
-#endif
+    SSN_STORE_DATA_GUARD(v);
 }
 
 }  // namespace pl

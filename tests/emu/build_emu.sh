@@ -11,10 +11,12 @@ OBJS=()
 for f in "$SRC"/*.hip "$HERE/emu_globals.cpp"; do
   o="$OBJ/.obj_$(basename "$f").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ "$SRC/ssn_common.h" -nt "$o" ] || [ "$SRC/conv_epilogue.h" -nt "$o" ] || [ "$SRC/conv_x6_kernel.h" -nt "$o" ] || [ "$SRC/planes.h" -nt "$o" ] || [ "$SRC/conv_pl_epilogue.inc" -nt "$o" ]; then
+    rm -f "$o"      # (a failed compile must not leave the previous object to be linked)
     "$CXX" -x c++ -std=c++17 -O1 -fPIC -w -I "$HERE" -I "$SRC" -c "$f" -o "$o" &
   fi
   OBJS+=("$o")
 done
 wait
+for o in "${OBJS[@]}"; do [ -f "$o" ] || { echo "emulator build FAILED: $o missing" >&2; exit 1; }; done
 "$CXX" -shared -o "$OUT" "${OBJS[@]}"
 echo "built $OUT"

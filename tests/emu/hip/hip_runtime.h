@@ -496,6 +496,7 @@ static inline emu_u32x2 emu_ds_read_tr16_b64(const void* addr) {
 #define SSN_LDS_PTR(p) ((void*)(p))
 #define SSN_CONST_PTR(T, p) ((const T*)(p))
 #define SSN_WAIT_VMCNT(n) ((void)0)
+#define SSN_STORE_DATA_GUARD(v) ((void)0)
 #define SSN_WAIT_LGKM0() ((void)0)
 static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds, int size, uint32_t voff,
                                                             uint32_t soff, int imm, int) {

@@ -3,6 +3,10 @@ backbones at the bench batch: every launch shape of the plan is timed with every
 is written to action-detection_amd/tuned_tiles_pl.json (read by bninception.BNInception._pl_tile).
 
     python tools/autotune_pl.py [n_images] [BNInception|InceptionV3]
+
+COLD=1 (round 6): forward / dgrad launches are timed rotating over R independent operand sets (R x (input + output) > 1.2 GB, beyond the
+256 MiB Infinity Cache), as they run inside the step -- the same buffers 12 times in a row keep the operands on die and pick tiles that
+lose 6 % inside the step (profiles/r6_cold_operands.txt).
 """
 import json
 import os
@@ -31,8 +35,26 @@ def timeit(fn, reps=12, warm=2):
     return s.elapsed_time(e) / reps
 
 
+def timeit_rot(fns, reps=12, warm=1):
+    """mean ms per call of fns[0], fns[1], ... called round robin (cold operands)"""
+    if len(fns) == 1:
+        return timeit(fns[0], reps)
+    reps = max(reps, 2 * len(fns))
+    for i in range(warm * len(fns)):
+        fns[i]()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for i in range(reps):
+        fns[i % len(fns)]()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 288
+    cold = os.environ.get("COLD") == "1"
     arch = sys.argv[2] if len(sys.argv) > 2 else "BNInception"
     pkg.build()
     dev = torch.device("cuda:0")
@@ -83,12 +105,18 @@ def main():
                     and lib.cdll.ssn_conv_pl_halo_taken(n, hin, hin, b + c) == 1]      # the haloed 3x3 kernel (48 + c: per-image tiles)
             if os.environ.get("HALO_ONLY") and not halo:
                 continue
+            if os.environ.get("ONLY") and os.environ["ONLY"] not in key:
+                continue
             x = torch.randn(n, xc, xh, xh, generator=g).clamp(min=0).to(dev)
             w = (torch.randn(cout, xc, k_, k_ if not rect else kw, generator=g) * 0.05).to(dev)
             sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-            xp = P.from_f32(x)
+            R = 1
+            if cold:
+                R = max(2, int(1.2e9 / (4.0 * n * (xc * xh * xh + cout * ho * wo))) + 1)
+            xps = [P.from_f32(x) for _ in range(R)]
+            yps = [P.PlaneTensor(n, cout, ho, wo, dev) for _ in range(R)]
+            xp, yp = xps[0], yps[0]
             xs = P.PSlice(xp, 0, xp.g * 8)
-            yp = P.PlaneTensor(n, cout, ho, wo, dev)
             if rect or stem:
                 wp = K.pack_weights_rect(w)
             else:
@@ -98,10 +126,12 @@ def main():
             # ---- forward
             res = {}
             for t in ((list(range(nfwd)) + halo) if "fwd" in kinds else []):
-                fn = lambda: P.conv_fwd(xs, wp, sc, sh, P.pfull(yp), k_, kw_, s_, p_, pw_, True, t)  # noqa: E731
-                fn()
-                yp.pool.update()
-                res[t] = timeit(fn)
+                fns = [(lambda i=i: P.conv_fwd(P.PSlice(xps[i], 0, xps[i].g * 8), wp, sc, sh, P.pfull(yps[i]), k_, kw_, s_, p_, pw_, True, t))
+                       for i in range(R)]
+                for i in range(R):
+                    fns[i]()
+                    yps[i].pool.update()
+                res[t] = timeit_rot(fns)
             line = "%-28s" % key
             if res:
                 best = min(res, key=res.get)
@@ -109,29 +139,34 @@ def main():
                 line += " fwd tile %2d %.4f ms" % (best, res[best])
                 if halo:
                     line += " (plain %.4f)" % min(v for t, v in res.items() if t < 32)
+                if stem:
+                    line += " all " + " ".join("%d:%.3f" % (t, v) for t, v in sorted(res.items()))
             # ---- dgrad (not for the first layer)
             gy = (torch.randn(n, cout, ho, wo, generator=g) * 1e-3).to(dev)
-            gp = P.from_f32(gy)
+            gps = [P.from_f32(gy) for _ in range(R if (op["src"] != "data" and "dgrad" in kinds) else 1)]
+            gp = gps[0]
             if op["src"] != "data" and "dgrad" in kinds:
-                dxp = P.PlaneTensor(n, cin, hin, hin, dev)
+                dxps = [P.PlaneTensor(n, cin, hin, hin, dev) for _ in range(R)]
                 msc = torch.ones(cin, device=dev)
                 res = {}
                 if s == 2:
                     wt = K.pack_dgrad_s2(w)
-                    mk = lambda t: (lambda: P.conv_dgrad_s2(P.pfull(gp), wt, P.pfull(dxp), ph, False, t, mask=P.pfull(xp), mask_scale=msc))  # noqa: E731
+                    mk = lambda t, i: (lambda: P.conv_dgrad_s2(P.pfull(gps[i]), wt, P.pfull(dxps[i]), ph, False, t, mask=P.pfull(xps[i]), mask_scale=msc))  # noqa: E731
                 elif rect:
                     wt = K.pack_dgrad_rect(w)
-                    mk = lambda t: (lambda: P.conv_dgrad(P.pfull(gp), wt, P.pfull(dxp), kh, kw, ph, pw, False, t, mask=P.pfull(xp),  # noqa: E731
-                                                         mask_scale=msc, taps_reversed=True))
+                    mk = lambda t, i: (lambda: P.conv_dgrad(P.pfull(gps[i]), wt, P.pfull(dxps[i]), kh, kw, ph, pw, False, t, mask=P.pfull(xps[i]),  # noqa: E731
+                                                            mask_scale=msc, taps_reversed=True))
                 else:
                     wt = K.pack_weights_multi([([w], 1)], x6=True)[0]
-                    mk = lambda t: (lambda: P.conv_dgrad(P.pfull(gp), wt, P.pfull(dxp), kh, kw, ph, pw, False, t, mask=P.pfull(xp),  # noqa: E731
-                                                         mask_scale=msc))
+                    mk = lambda t, i: (lambda: P.conv_dgrad(P.pfull(gps[i]), wt, P.pfull(dxps[i]), kh, kw, ph, pw, False, t, mask=P.pfull(xps[i]),  # noqa: E731
+                                                            mask_scale=msc))
                 for t in list(range(nfwd)) + halo:
-                    fn = mk(t)
-                    fn()
-                    dxp.pool.update()
-                    res[t] = timeit(fn)
+                    fns = [mk(t, i) for i in range(R)]
+                    for i in range(R):
+                        fns[i]()
+                        dxps[i].pool.update()
+                    res[t] = timeit_rot(fns)
+                del dxps
                 best = min(res, key=res.get)
                 tiles["dgrad|" + key], ms["dgrad|" + key] = best, round(res[best], 4)
                 line += " | dgrad tile %2d %.4f ms" % (best, res[best])
@@ -140,6 +175,7 @@ def main():
             # ---- wgrad
             if "wgrad" not in kinds:
                 print(line, flush=True)
+                del xps, yps, gps
                 continue
             dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
             res = {}
