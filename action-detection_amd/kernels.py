@@ -704,8 +704,11 @@ def heads_bwd(scaling, ws, bs, pos, idx, douts, act_ft, stpp_ft, table, d_ft, dw
 
 def stpp_reorg(scores, ranges, act_range, scaling, part_scale_col, act_len, comp_len, reg_len, out_act, out_comp,
                out_reg):
-    lib = _check(scores, ranges, act_range, scaling, part_scale_col, out_act, out_comp, out_reg)
-    lib.call("ssn_stpp_reorg", _p(scores), scores.shape[0], scores.shape[1], _p(ranges), _p(act_range),
+    lib = _check(ranges, act_range, scaling, part_scale_col, out_act, out_comp, out_reg)
+    # scores: [T, D], or a column range of one (rows D_total apart): the kernel addresses row r at r * (row stride)
+    assert scores.dim() == 2 and scores.stride(1) == 1 and scores.dtype == torch.float32
+    assert scores.stride(0) >= act_len + ranges.shape[1] * (comp_len + (reg_len if out_reg is not None else 0))
+    lib.call("ssn_stpp_reorg", _p(scores), scores.shape[0], scores.stride(0), _p(ranges), _p(act_range),
              _p(scaling), _p(part_scale_col), ranges.shape[0], ranges.shape[1], act_len, comp_len, reg_len,
              _p(out_act), _p(out_comp), _p(out_reg), _stream(lib, scores))
 

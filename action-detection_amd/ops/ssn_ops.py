@@ -116,8 +116,6 @@ class STPPReorgainzed:
         self.act_slice = slice(0, self.act_len if self.sc else (self.act_len * feature_multiplie))
         self.comp_slice = slice(self.act_slice.stop, self.act_slice.stop + self.comp_len * feature_multiplie)
         self.reg_slice = slice(self.comp_slice.stop, self.comp_slice.stop + self.reg_len * feature_multiplie)
-        if not self.sc:
-            raise NotImplementedError("only the stand-alone activity classifier form (what SSN uses) is built")
         cols = []
         for stage_idx, stage_cfg in enumerate(self.stpp_cfg):
             col = 0 if stage_idx == 0 else (1 if stage_idx == len(self.stpp_cfg) - 1 else -1)
@@ -177,9 +175,18 @@ class STPPReorgainzed:
         out_act = torch.empty((n_out, self.act_len), device=dev, dtype=torch.float32)
         out_comp = torch.empty((n_out, self.comp_len), device=dev, dtype=torch.float32)
         out_reg = torch.empty((n_out, self.reg_len), device=dev, dtype=torch.float32) if self.with_regression else None
-        K.stpp_reorg(scores.contiguous().float(), torch.from_numpy(ranges).to(dev), torch.from_numpy(act).to(dev),
-                     sc, torch.tensor(self._part_cols, dtype=torch.int32, device=dev), self.act_len, self.comp_len,
-                     self.reg_len, out_act, out_comp, out_reg)
+        scores = scores.contiguous().float()
+        ranges_d, act_d = torch.from_numpy(ranges).to(dev), torch.from_numpy(act).to(dev)
+        cols = torch.tensor(self._part_cols, dtype=torch.int32, device=dev)
+        if self.sc:
+            K.stpp_reorg(scores, ranges_d, act_d, sc, cols, self.act_len, self.comp_len, self.reg_len, out_act, out_comp, out_reg)
+        else:
+            # no stand-alone classifier (ops/ssn_ops.py:160-161): the activity scores are pooled by stages and parts like the other two,
+            # out of a block of act_len * multiplier columns -- the same launch on that block as its "completeness" block, then on the
+            # columns behind it for the real completeness / regression blocks (no activity columns in either)
+            none = torch.empty(1, device=dev, dtype=torch.float32)
+            K.stpp_reorg(scores[:, self.act_slice], ranges_d, act_d, sc, cols, 0, self.act_len, 0, none, out_act, None)
+            K.stpp_reorg(scores[:, self.comp_slice.start:], ranges_d, act_d, sc, cols, 0, self.comp_len, self.reg_len, none, out_comp, out_reg)
         return out_act, out_comp, out_reg
 
 

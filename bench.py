@@ -18,9 +18,8 @@ Workload per GPU = BASELINE.json configs[1]: 4 videos x 8 proposals x 9 segments
 of 224x224 (weak scaling: per-GPU work is fixed as N grows).
 
 Rank 0 prints ONE JSON line.  `roofline` is the MFMA roofline of the dominant kernel family (the
-split-operand (f16 x 3) implicit-GEMM convolution `conv_x6_kernel`, forward + dgrad launches; with
---precision f32 the exact-f32 `conv_igemm_kernel`), measured live with HIP events around every
-launch of the same K steps (re-run eagerly right after the timed region, because events cannot be
+planes implicit-GEMM convolutions `conv_pl_kernel` / `conv_pl9_kernel`, 3 f16 MFMA products per multiply,
+forward + dgrad launches), measured live with HIP events around every launch of the same K steps (re-run eagerly right after the timed region, because events cannot be
 recorded inside a hipGraph replay); `roofline_detail` lists every conv kernel family; `cpu_baseline` times the CPU oracle
 (oracle/ssn_oracle.py, torch fp32 on the host cores) on a bounded sample of the same workload.
 """
@@ -423,7 +422,7 @@ def main():
     if not emulator:
         fault_ring = [t.pin_memory() for t in fault_ring]
     fault_events = [None if emulator else torch.cuda.Event() for _ in fault_ring]
-    guard = {"faults": 0, "skipped_steps": 0, "polls": 0, "pending": []}
+    guard = {"faults": 0, "skipped_steps": 0, "polls": 0, "pending": [], "fault_polls": [], "redone_steps": 0}
 
     def fwd_bwd():
         out = model(*batch)
@@ -445,12 +444,21 @@ def main():
         if use_dist:
             reducer.agree_flag_(fault_word)
 
+    # TEST TOOLING (tests/test_bench_selflaunch.py): SSN_BENCH_INJECT_FAULT="rank:step" raises the fault word on ONE rank in ONE step, as a
+    # range fault of that rank's backbone would; everything behind it -- the MAX-reduction, the skipped updates, the lagged poll, the redo --
+    # is the product protocol
+    inject = tuple(int(x) for x in os.environ.get("SSN_BENCH_INJECT_FAULT", "-1:-1").split(":"))
+    step_no = [0]
+
     def step(collectives=True):
         loss = fwd_bwd()
         if collectives and overlapped:
             reducer.reduce_heads()
         elif collectives and use_dist:
             allreduce_grads()
+        if collectives and inject == (rank, step_no[0]):
+            fault_word.fill_(1)
+        step_no[0] += 1
         if collectives:
             agree_fault()
         update()
@@ -475,12 +483,17 @@ def main():
         if int(fault_ring[k0][0]) != 0:
             torch.cuda.synchronize()
             guard["faults"] += 1
+            guard["fault_polls"].append(guard["polls"] - 1 - GUARD_LAG)     # (which step's word it was: the same on every rank)
             guard["skipped_steps"] += GUARD_LAG + 1      # (the flagged step and the ones queued behind it: their updates were skipped)
             model.recalibrate_scales()
             for t in fault_ring:
                 t.zero_()
             guard["pending"].clear()
-            step()
+            # the word is sticky: the flagged step AND the GUARD_LAG steps queued behind it skipped their updates -- all of them are redone
+            # (eagerly; the first one calibrates as a first step does), so the run ends with as many updates as it has steps
+            for _ in range(GUARD_LAG + 1):
+                step()
+                guard["redone_steps"] += 1
 
     def fence():
         if use_dist:
@@ -593,7 +606,7 @@ def main():
             pr = torch.cuda.get_device_properties(dev)
             return str(getattr(pr, "uuid", None) or "%s@%s" % (pr.name, getattr(pr, "pci_bus_id", local_rank)))
         mine = {"rank": rank, "local_rank": local_rank, "device": _dev_id(), "ms_per_step": round(rank_ms, 3),
-                "guard_faults": guard["faults"]}
+                "guard_faults": guard["faults"], "guard_fault_steps": list(guard["fault_polls"]), "redone_steps": guard["redone_steps"]}
         seen = [None] * dist.get_world_size()
         dist.all_gather_object(seen, mine)
         ar_ms = None
@@ -660,8 +673,9 @@ def main():
         "final_loss": float(loss.item()),
         "scale_guard": {"protocol": "range check of the delayed scales captured in the step; optimizer launches skip a flagged step "
                                     "(device fault word); host looks at a pinned copy of the word with a fixed lag of 2 steps and redoes a "
-                                    "flagged step eagerly after recalibration" + ("; the word is MAX-reduced over the ranks" if use_dist else ""),
-                        "scale_overflows": guard["faults"], "steps_with_skipped_update": guard["skipped_steps"], "repeated_eager_passes": model.base_model.guard_stats(),
+                                    "flagged step (and the 2 queued behind it, whose updates the sticky word also skipped) eagerly after recalibration" + ("; the word is MAX-reduced over the ranks" if use_dist else ""),
+                        "scale_overflows": guard["faults"], "steps_with_skipped_update": guard["skipped_steps"], "steps_redone_eagerly": guard["redone_steps"],
+                        "effective_updates": args.steps + args.warmup - guard["skipped_steps"] + guard["redone_steps"], "repeated_eager_passes": model.base_model.guard_stats(),
                         "repeated_eager_passes_inside_timed_region": eager_repeats_timed,
                         "repeated_eager_passes_note": "passes the range guard repeated while running EAGERLY: the two un-captured warm-up steps in "
                                                       "front of the graph capture (first steps of a fresh state: scales still settling; eager_fault_log "
@@ -734,6 +748,8 @@ def main():
                 "issued_f16_mfma_tflops": round(3 * achieved, 1) if x6_n else None,
                 "traffic_note": "HBM bytes/launch, rocprofv3 PMC (profiles/%s)" % PMC_SUMMARY,
                 "avg_launch_us": round(1e3 * dom_ms / dom_n, 2), "launches": dom_n,
+                "launches_note": "event pairs = API calls: the data gradient of a stride-2 3x3 layer is ONE call that issues four parity-class "
+                                 "kernels (rocprofv3 counts those separately: ~101 conv_pl* kernels per step for 87 calls)",
                 "algorithmic_gflop_per_launch": round(dom_fl / dom_n / 1e9, 4),
             }
             det = {}

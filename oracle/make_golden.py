@@ -132,7 +132,28 @@ def golden_reorg(ref_ops):
         oa, oc, orr = mod.forward(torch.from_numpy(scores), torch.from_numpy(ticks.astype(np.int64)), scaling)
         out.update({"r%d_scores" % ci: scores, "r%d_ticks" % ci: ticks.astype(np.int64), "r%d_scaling" % ci: scaling,
                     "r%d_act" % ci: oa.numpy(), "r%d_comp" % ci: oc.numpy(), "r%d_reg" % ci: orr.numpy()})
+    # [r6] the form WITHOUT the stand-alone activity classifier (ops/ssn_ops.py:160-161: the activity scores go through pspool too; their
+    # block is act_len * multiplier wide).  Own generator, behind the cases above: r0 / r1 stay byte-identical.
+    rng = np.random.RandomState(131)
+    cfg = (1, (1, 2), 1)
+    mult, (a, c, r), t = 5, (21, 20, 40), 40
+    d = (a + c + r) * mult
+    scores = rng.standard_normal((t, d)).astype(np.float32)
+    starts = rng.randint(0, t - 2, size=10)
+    ends = np.minimum(starts + rng.randint(1, 12, size=10), t)
+    dur = ends - starts
+    ticks = np.stack([np.maximum(starts - dur // 2, 0), starts, ends, np.minimum(ends + dur // 2, t)], 1)
+    ticks[0] = [0, 0, 3, 6]
+    ticks[1] = [30, 38, 40, 40]
+    ticks[2] = [5, 5, 5, 5]
+    scaling = rng.uniform(0, 1, (10, 2))
+    mod = ref_ops.STPPReorgainzed(d, a, c, r, False, True, stpp_cfg=cfg)
+    oa, oc, orr = mod.forward(torch.from_numpy(scores), torch.from_numpy(ticks.astype(np.int64)), scaling)
+    out.update({"r2_scores": scores, "r2_ticks": ticks.astype(np.int64), "r2_scaling": scaling,
+                "r2_act": oa.numpy(), "r2_comp": oc.numpy(), "r2_reg": orr.numpy()})
     np.savez_compressed(os.path.join(OUT, "ref_reorg.npz"), **out)
+    if os.environ.get("GOLDEN_ONLY") == "reorg":
+        raise SystemExit(0)
 
 
 def golden_ssn(ref_models, ref_ops):

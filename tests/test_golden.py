@@ -158,6 +158,15 @@ def test_product_reorg_matches_reference(backend):
                               g["r%d_scaling" % ci])
         for got, key in ((a, "act"), (c, "comp"), (r, "reg")):
             assert rel_err(got, torch.from_numpy(g["r%d_%s" % (ci, key)])) < 1e-6, key
+    # [r6] without the stand-alone activity classifier: the activity scores pooled by stages and parts (ops/ssn_ops.py:160-161)
+    scores = g["r2_scores"]
+    mod = P.STPPReorgainzed(scores.shape[1], 21, 20, 40, False, True, stpp_cfg=(1, (1, 2), 1))
+    a, c, r = mod.forward(backend.put(torch.from_numpy(scores)), torch.from_numpy(g["r2_ticks"]), g["r2_scaling"])
+    for got, key in ((a, "act"), (c, "comp"), (r, "reg")):
+        assert rel_err(got, torch.from_numpy(g["r2_%s" % key])) < 1e-6, key
+    want = O.stpp_reorganized(scores, g["r2_ticks"], g["r2_scaling"], 21, 20, 40, stpp_cfg=(1, (1, 2), 1), standalone_classifier=False)
+    for w_, key in zip(want, ("act", "comp", "reg")):
+        np.testing.assert_allclose(w_, g["r2_%s" % key], rtol=1e-5, atol=1e-6)      # (the oracle against the reference's own class)
 
 
 def _product_vs_golden(tag, device):
@@ -225,8 +234,10 @@ def test_sharded_completeness_loss_averages_to_the_gathered_loss(backend):
     the gradient all-reduce does -- equals the reference loss on the gathered batch, values and gradients; V = 100
     videos is a case where the global int() truncation differs from the sum of the per-rank ones."""
     rng = np.random.RandomState(5)
-    for v, world in ((4, 2), (100, 4)):
+    # (32, 8) = BASELINE.json configs[3]: 4 videos per GPU on 8 GPUs, denominator V + int(6 V 0.17) = 32 + 32
+    for v, world in ((4, 2), (100, 4), (32, 8)):
         c = 20
+        assert int(6 * v * 0.17) == {4: 4, 100: 102, 32: 32}[v]
         pred = torch.from_numpy((rng.standard_normal((7 * v, c)) * 1.5).astype(np.float32))
         labels = torch.from_numpy(rng.randint(1, c + 1, size=7 * v).astype(np.int64))
         full_loss, full_grad = O.completeness_loss(pred, labels.numpy(), 1, 7)
