@@ -86,6 +86,9 @@ _SIGS = {
     "ssn_completeness_loss_fwd": "pppppiiiiiifp",
     "ssn_completeness_loss_bwd": "ppppiifp",
     "ssn_cw_smoothl1_fwd": "pppppiip",
+    "ssn_total_loss_fwd": "ppiippiiiiiifpppiiffpppppp",
+    "ssn_total_loss_bwd": "ppiipiifpiiffpppppppp",
+    "ssn_label_select": "pppipipippppp",
     "ssn_cw_smoothl1_bwd": "ppppiip",
     "ssn_sgd_step": "ppplffffipp",
     "ssn_sgd_step_multi": "ippppppffipp",

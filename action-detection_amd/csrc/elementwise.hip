@@ -15,7 +15,7 @@ void ssn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* ssn_last_error(void) { return g_err; }
-extern "C" int ssn_abi_version(void) { return 8; }
+extern "C" int ssn_abi_version(void) { return 9; }
 
 namespace {
 

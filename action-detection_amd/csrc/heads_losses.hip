@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void fill_kernel(float* x, long n, float v) {
 
 // ---------------------------------------------------------------------------- cross entropy
 // single workgroup; rows are distributed over the 4 waves.  ws: [R] lse, then [R] row losses.
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const long* target, float* loss, float* lse,
-                                                     float* rowloss, int R, int C) {
+__device__ __forceinline__ void ce_fwd_body(const float* logits, const long* target, float* loss, float* lse, float* rowloss, int R,
+                                            int C) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int r = wave; r < R; r += 4) {
         const float* x = logits + (long)r * C;
@@ -111,24 +111,32 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const 
         if (lane == 0) loss[0] = s / (float)R;
     }
 }
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, const long* target, const float* lse,
-                                                     const float* gout, float* dlogits, int R, int C) {
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const long* target, float* loss, float* lse,
+                                                     float* rowloss, int R, int C) {
+    ce_fwd_body(logits, target, loss, lse, rowloss, R, C);
+}
+// elements [first, first + count) of the concatenated gradient outputs of a launch are this body's; g: d loss / d (this loss)
+__device__ __forceinline__ void ce_bwd_body(const float* logits, const long* target, const float* lse, float g0, float* dlogits, int R,
+                                            int C, long i0, long stride) {
     const long total = (long)R * C;
-    const float g = gout[0] / (float)R;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float g = g0 / (float)R;
+    for (long i = i0; i < total; i += stride) {
         const int r = (int)(i / C), c = (int)(i - (long)r * C);
         const float p = expf(logits[i] - lse[r]);
         dlogits[i] = (p - (c == (int)target[r] ? 1.f : 0.f)) * g;
     }
+}
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, const long* target, const float* lse,
+                                                     const float* gout, float* dlogits, int R, int C) {
+    ce_bwd_body(logits, target, lse, gout[0], dlogits, R, C, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
 }
 
 // ---------------------------------------------------------------------------- completeness (OHEM hinge)
 // pred [R][C], labels [R] (1-based class; label-1 == -1 wraps to the last column like the
 // reference's Python indexing), rows grouped per video: `group` rows, the first `split` positive.
 // coef[R] (out): d(loss * den)/d pred[i][col_i]  (= slope if the row is kept, else 0)
-__global__ __launch_bounds__(256) void completeness_fwd_kernel(const float* pred, const long* labels, float* loss,
-                                                               float* coef, int R, int C, int group, int split,
-                                                               int keep_pos, int keep_neg, float den, float* rowloss) {
+__device__ __forceinline__ void completeness_fwd_body(const float* pred, const long* labels, float* loss, float* coef, int R, int C,
+                                                      int group, int split, int keep_pos, int keep_neg, float den, float* rowloss) {
     // pass 1: hinge losses
     for (int i = threadIdx.x; i < R; i += 256) {
         const int gi = i % group;
@@ -172,24 +180,32 @@ __global__ __launch_bounds__(256) void completeness_fwd_kernel(const float* pred
         loss[0] = pos_ls / den + neg_ls / den;
     }
 }
-__global__ __launch_bounds__(256) void completeness_bwd_kernel(const long* labels, const float* coef,
-                                                               const float* gout, float* dpred, int R, int C,
-                                                               float den) {
+__global__ __launch_bounds__(256) void completeness_fwd_kernel(const float* pred, const long* labels, float* loss,
+                                                               float* coef, int R, int C, int group, int split,
+                                                               int keep_pos, int keep_neg, float den, float* rowloss) {
+    completeness_fwd_body(pred, labels, loss, coef, R, C, group, split, keep_pos, keep_neg, den, rowloss);
+}
+__device__ __forceinline__ void completeness_bwd_body(const long* labels, const float* coef, float g0, float* dpred, int R, int C,
+                                                      float den, long i0, long stride) {
     const long total = (long)R * C;
-    const float g = gout[0] / den;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float g = g0 / den;
+    for (long i = i0; i < total; i += stride) {
         const int r = (int)(i / C), c = (int)(i - (long)r * C);
         int col = (int)labels[r] - 1;
         if (col < 0) col += C;
         dpred[i] = (c == col) ? coef[r] * g : 0.f;
     }
 }
+__global__ __launch_bounds__(256) void completeness_bwd_kernel(const long* labels, const float* coef,
+                                                               const float* gout, float* dpred, int R, int C,
+                                                               float den) {
+    completeness_bwd_body(labels, coef, gout[0], dpred, R, C, den, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+}
 
 // ---------------------------------------------------------------------------- class-wise smooth L1
 // pred [n][C][2], labels [n], targets [n][2]; loss = mean_{2n}(smoothl1(pred[i][l_i-1][:] - t_i)) * 2
-__global__ __launch_bounds__(256) void cw_smoothl1_fwd_kernel(const float* pred, const long* labels,
-                                                              const float* targets, float* loss, float* diff, int n,
-                                                              int C) {
+__device__ __forceinline__ void cw_smoothl1_fwd_body(const float* pred, const long* labels, const float* targets, float* loss,
+                                                     float* diff, int n, int C) {
     for (int e = threadIdx.x; e < 2 * n; e += 256) {
         const int i = e >> 1, j = e & 1;
         int col = (int)labels[i] - 1;
@@ -206,11 +222,16 @@ __global__ __launch_bounds__(256) void cw_smoothl1_fwd_kernel(const float* pred,
         loss[0] = (s / (float)(2 * n)) * 2.f;
     }
 }
-__global__ __launch_bounds__(256) void cw_smoothl1_bwd_kernel(const long* labels, const float* diff,
-                                                              const float* gout, float* dpred, int n, int C) {
+__global__ __launch_bounds__(256) void cw_smoothl1_fwd_kernel(const float* pred, const long* labels,
+                                                              const float* targets, float* loss, float* diff, int n,
+                                                              int C) {
+    cw_smoothl1_fwd_body(pred, labels, targets, loss, diff, n, C);
+}
+__device__ __forceinline__ void cw_smoothl1_bwd_body(const long* labels, const float* diff, float g0, float* dpred, int n, int C,
+                                                     long i0, long stride) {
     const long total = (long)n * C * 2;
-    const float g = gout[0] * 2.f / (float)(2 * n);
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const float g = g0 * 2.f / (float)(2 * n);
+    for (long idx = i0; idx < total; idx += stride) {
         const int j = (int)(idx & 1);
         const long rc = idx >> 1;
         const int i = (int)(rc / C), c = (int)(rc - (long)i * C);
@@ -222,6 +243,66 @@ __global__ __launch_bounds__(256) void cw_smoothl1_bwd_kernel(const long* labels
             v = (fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f)) * g;
         }
         dpred[idx] = v;
+    }
+}
+__global__ __launch_bounds__(256) void cw_smoothl1_bwd_kernel(const long* labels, const float* diff,
+                                                              const float* gout, float* dpred, int n, int C) {
+    cw_smoothl1_bwd_body(labels, diff, gout[0], dpred, n, C, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+}
+
+// ---------------------------------------------------------------------------- [r6] the training objective in one launch each way
+// act + w_comp * comp + w_reg * reg (/root/reference/ssn_train.py:210-214): the three losses above run one after the other in ONE
+// workgroup (they are a few hundred numbers), the mix is the last instruction -- instead of three launches + five torch micro-kernels
+// forward and three + six backward.  Same bodies, same summation orders: every component is bit-identical to its own launch.
+struct TotalLossArgs {
+    const float* act_logits; const long* act_target; int Ra, Ca;
+    const float* comp_pred; const long* comp_labels; int Rc, Cc, group, split, keep_pos, keep_neg; float den;
+    const float* reg_pred; const long* reg_labels; const float* reg_targets; int n_reg, Cr;      // reg_pred == nullptr: no regression
+    float w_comp, w_reg;
+    float* losses;        // [4]: activity, completeness, regression (0 without), total
+    float* lse;           // [Ra]          kept for the backward
+    float* coef;          // [Rc]          kept
+    float* diff;          // [2 n_reg]     kept
+    float* scratch;       // [max(Ra, 2 Rc)]
+    const float* gout;    // backward: d objective / d total ([1])
+    float* d_act; float* d_comp; float* d_reg;
+};
+__global__ __launch_bounds__(256) void total_loss_fwd_kernel(TotalLossArgs a) {
+    ce_fwd_body(a.act_logits, a.act_target, a.losses, a.lse, a.scratch, a.Ra, a.Ca);
+    __syncthreads();
+    completeness_fwd_body(a.comp_pred, a.comp_labels, a.losses + 1, a.coef, a.Rc, a.Cc, a.group, a.split, a.keep_pos, a.keep_neg, a.den,
+                          a.scratch);
+    __syncthreads();
+    if (a.reg_pred) cw_smoothl1_fwd_body(a.reg_pred, a.reg_labels, a.reg_targets, a.losses + 2, a.diff, a.n_reg, a.Cr);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (every loss was written by thread 0 of this workgroup -- lane 0 of wave 0 in the CE body: program order, nothing to fence)
+        if (!a.reg_pred) a.losses[2] = 0.f;
+        const float c = a.losses[1] * a.w_comp;
+        const float r = a.reg_pred ? a.losses[2] * a.w_reg : 0.f;
+        a.losses[3] = (a.losses[0] + c) + r;      // the reference's association: (act + comp * w) + reg * w
+    }
+}
+__global__ __launch_bounds__(256) void total_loss_bwd_kernel(TotalLossArgs a) {
+    const long i0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    const float g = a.gout[0];
+    ce_bwd_body(a.act_logits, a.act_target, a.lse, g, a.d_act, a.Ra, a.Ca, i0, stride);
+    completeness_bwd_body(a.comp_labels, a.coef, g * a.w_comp, a.d_comp, a.Rc, a.Cc, a.den, i0, stride);
+    if (a.reg_pred) cw_smoothl1_bwd_body(a.reg_labels, a.diff, g * a.w_reg, a.d_reg, a.n_reg, a.Cr, i0, stride);
+}
+
+// the label / target bookkeeping of SSN.train_forward (ssn_models.py:275-289: target[act_indexer], target[comp_indexer],
+// target[reg_indexer], reg_target[reg_indexer]) in one launch instead of four index_select
+__global__ __launch_bounds__(256) void label_select_kernel(const long* target, const float* reg_target, const long* idx0, int n0,
+                                                           const long* idx1, int n1, const long* idx2, int n2, long* out0, long* out1,
+                                                           long* out2, float* out_reg) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n0) out0[t] = target[idx0[t]];
+    if (t < n1) out1[t] = target[idx1[t]];
+    if (t < n2) {
+        out2[t] = target[idx2[t]];
+        out_reg[2 * t] = reg_target[2 * idx2[t]];
+        out_reg[2 * t + 1] = reg_target[2 * idx2[t] + 1];
     }
 }
 
@@ -331,6 +412,64 @@ extern "C" int ssn_cw_smoothl1_bwd(const long* labels, const float* diff, const 
     hipLaunchKernelGGL(cw_smoothl1_bwd_kernel, dim3(grid_for((long)n * C * 2)), dim3(256), 0, stream, labels, diff,
                        gout, dpred, n, C);
     SSN_CHECK_LAUNCH("cw_smoothl1_bwd");
+    return SSN_OK;
+}
+
+// [r6] act + w_comp * comp + w_reg * reg of /root/reference/ssn_train.py:210-214 in one launch: losses[4] = activity, completeness,
+// regression, total.  lse [Ra], coef [Rc], diff [2 n_reg]: kept for ssn_total_loss_bwd; scratch: max(2 Ra, 2 Rc) floats.
+// reg_pred == nullptr: no regression head (ssn_models.py:288-289).
+extern "C" int ssn_total_loss_fwd(const float* act_logits, const long* act_target, int Ra, int Ca, const float* comp_pred,
+                                  const long* comp_labels, int Rc, int Cc, int group, int split, int keep_pos, int keep_neg, float den,
+                                  const float* reg_pred, const long* reg_labels, const float* reg_targets, int n_reg, int Cr,
+                                  float w_comp, float w_reg, float* losses, float* lse, float* coef, float* diff, float* scratch,
+                                  hipStream_t stream) {
+    SSN_CHECK_ARG(act_logits && act_target && comp_pred && comp_labels && losses && lse && coef && scratch && Ra > 0 && Rc > 0,
+                  "total_loss_fwd: bad arguments");
+    SSN_CHECK_ARG(group > 0 && split >= 0 && split <= group && Rc % group == 0, "total_loss_fwd: %d rows do not form groups of %d", Rc,
+                  group);
+    SSN_CHECK_ARG(!reg_pred || (reg_labels && reg_targets && diff && n_reg > 0), "total_loss_fwd: bad regression arguments");
+    TotalLossArgs a{};
+    a.act_logits = act_logits; a.act_target = act_target; a.Ra = Ra; a.Ca = Ca;
+    a.comp_pred = comp_pred; a.comp_labels = comp_labels; a.Rc = Rc; a.Cc = Cc; a.group = group; a.split = split;
+    a.keep_pos = keep_pos; a.keep_neg = keep_neg; a.den = den;
+    a.reg_pred = reg_pred; a.reg_labels = reg_labels; a.reg_targets = reg_targets; a.n_reg = n_reg; a.Cr = Cr;
+    a.w_comp = w_comp; a.w_reg = w_reg; a.losses = losses; a.lse = lse; a.coef = coef; a.diff = diff; a.scratch = scratch;
+    hipLaunchKernelGGL(total_loss_fwd_kernel, dim3(1), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("total_loss_fwd");
+    return SSN_OK;
+}
+// gout [1] = d objective / d total; writes d_act [Ra, Ca], d_comp [Rc, Cc], d_reg [n_reg, Cr, 2] (complete tensors, zeros included)
+extern "C" int ssn_total_loss_bwd(const float* act_logits, const long* act_target, int Ra, int Ca, const long* comp_labels, int Rc,
+                                  int Cc, float den, const long* reg_labels, int n_reg, int Cr, float w_comp, float w_reg,
+                                  const float* lse, const float* coef, const float* diff, const float* gout, float* d_act,
+                                  float* d_comp, float* d_reg, hipStream_t stream) {
+    SSN_CHECK_ARG(act_logits && act_target && comp_labels && lse && coef && gout && d_act && d_comp, "total_loss_bwd: null pointer");
+    TotalLossArgs a{};
+    a.act_logits = act_logits; a.act_target = act_target; a.Ra = Ra; a.Ca = Ca;
+    a.comp_labels = comp_labels; a.Rc = Rc; a.Cc = Cc; a.den = den;
+    a.reg_pred = d_reg;      // (non-null = there is a regression head)
+    a.reg_labels = reg_labels; a.n_reg = n_reg; a.Cr = Cr; a.w_comp = w_comp; a.w_reg = w_reg;
+    a.lse = const_cast<float*>(lse); a.coef = const_cast<float*>(coef); a.diff = const_cast<float*>(diff); a.gout = gout;
+    a.d_act = d_act; a.d_comp = d_comp; a.d_reg = d_reg;
+    long most = (long)Ra * Ca;
+    if ((long)Rc * Cc > most) most = (long)Rc * Cc;
+    if (d_reg && (long)n_reg * Cr * 2 > most) most = (long)n_reg * Cr * 2;
+    hipLaunchKernelGGL(total_loss_bwd_kernel, dim3(grid_for(most)), dim3(256), 0, stream, a);
+    SSN_CHECK_LAUNCH("total_loss_bwd");
+    return SSN_OK;
+}
+// target [P] (int64), reg_target [P, 2] -> target[idx0], target[idx1], target[idx2], reg_target[idx2] (ssn_models.py:275-289); idx2 /
+// out2 / out_reg may be null (no regression)
+extern "C" int ssn_label_select(const long* target, const float* reg_target, const long* idx0, int n0, const long* idx1, int n1,
+                                const long* idx2, int n2, long* out0, long* out1, long* out2, float* out_reg, hipStream_t stream) {
+    SSN_CHECK_ARG(target && (n0 == 0 || (idx0 && out0)) && (n1 == 0 || (idx1 && out1)) && (n2 == 0 || (idx2 && out2 && out_reg && reg_target)),
+                  "label_select: null pointer");
+    int most = n0 > n1 ? n0 : n1;
+    if (n2 > most) most = n2;
+    if (most == 0) return SSN_OK;
+    hipLaunchKernelGGL(label_select_kernel, dim3((most + 255) / 256), dim3(256), 0, stream, target, reg_target, idx0, n0, idx1, n1, idx2, n2,
+                       out0, out1, out2, out_reg);
+    SSN_CHECK_LAUNCH("label_select");
     return SSN_OK;
 }
 

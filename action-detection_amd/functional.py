@@ -196,6 +196,45 @@ class CompletenessFn(torch.autograd.Function):
         return d, None, None, None, None, None, None
 
 
+class TotalLossFn(torch.autograd.Function):
+    """[r6] activity CE + w_comp * CompletenessLoss + w_reg * ClassWiseRegressionLoss (/root/reference/ssn_train.py:210-214) as one
+    launch forward and one backward (csrc/heads_losses.hip: ssn_total_loss_*): the same loss bodies and summation orders as CeLossFn /
+    CompletenessFn / ClassWiseRegressionFn, bit-identical components.  Returns (total [], parts [3] = the three losses, not
+    differentiable: for the meters of ssn_train.py:216-224)."""
+
+    @staticmethod
+    def forward(ctx, act, act_t, comp, comp_t, reg, reg_lbl, reg_t, group, split, keep_pos, keep_neg, den, w_comp, w_reg):
+        act, comp = act.contiguous(), comp.contiguous()
+        act_t, comp_t = act_t.contiguous().long(), comp_t.contiguous().long()
+        has = reg is not None
+        if has:
+            reg, reg_lbl, reg_t = reg.contiguous(), reg_lbl.contiguous().long(), reg_t.contiguous().float()
+        ra, rc = act.shape[0], comp.shape[0]
+        losses = _new(act, (4,))
+        lse, coef = _new(act, (ra,)), _new(act, (rc,))
+        diff = _new(act, (2 * reg.shape[0],)) if has else None
+        K.total_loss_fwd(act, act_t, comp, comp_t, reg, reg_lbl, reg_t, group, split, keep_pos, keep_neg, den, w_comp, w_reg, losses, lse,
+                         coef, diff, _new(act, (max(2 * ra, 2 * rc),)))
+        ctx.save_for_backward(act, act_t, comp_t, lse, coef, *([reg_lbl, diff] if has else []))
+        ctx.meta = (tuple(comp.shape), tuple(reg.shape) if has else None, den, w_comp, w_reg)
+        parts = losses[:3]
+        ctx.mark_non_differentiable(parts)
+        return losses[3], parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        saved = ctx.saved_tensors
+        act, act_t, comp_t, lse, coef = saved[:5]
+        comp_shape, reg_shape, den, w_comp, w_reg = ctx.meta
+        has = reg_shape is not None
+        reg_lbl, diff = (saved[5], saved[6]) if has else (None, None)
+        d_act, d_comp = _new(act, act.shape), _new(act, comp_shape)
+        d_reg = _new(act, reg_shape) if has else None
+        K.total_loss_bwd(act, act_t, comp_t, comp_shape, reg_lbl, reg_shape, den, w_comp, w_reg, lse, coef, diff,
+                         g_total.contiguous().reshape(1), d_act, d_comp, d_reg)
+        return (d_act, None, d_comp, None, d_reg) + (None,) * 9
+
+
 class ClassWiseRegressionFn(torch.autograd.Function):
     """ClassWiseRegressionLoss (/root/reference/ops/ssn_ops.py:242-258)."""
 

@@ -875,6 +875,35 @@ def cw_smoothl1_bwd(labels, diff, gout, dpred):
              _stream(lib, dpred))
 
 
+@_hbm_timed
+def total_loss_fwd(act, act_t, comp, comp_t, reg, reg_lbl, reg_t, group, split, keep_pos, keep_neg, den, w_comp, w_reg, losses, lse, coef,
+                   diff, scratch):
+    """ssn_total_loss_fwd: losses[4] = activity CE, completeness, regression, act + w_comp * comp + w_reg * reg (reg may be None)."""
+    lib = _check(act, act_t, comp, comp_t, reg, reg_lbl, reg_t, losses, lse, coef, diff, scratch)
+    has = reg is not None
+    lib.call("ssn_total_loss_fwd", _p(act), _p(act_t), act.shape[0], act.shape[1], _p(comp), _p(comp_t), comp.shape[0], comp.shape[1],
+             group, split, keep_pos, keep_neg, float(den), _p(reg), _p(reg_lbl) if has else None, _p(reg_t) if has else None,
+             reg.shape[0] if has else 0, reg.shape[1] if has else 0, float(w_comp), float(w_reg), _p(losses), _p(lse), _p(coef),
+             _p(diff), _p(scratch), _stream(lib, act))
+
+
+@_hbm_timed
+def total_loss_bwd(act, act_t, comp_t, comp_shape, reg_lbl, reg_shape, den, w_comp, w_reg, lse, coef, diff, gout, d_act, d_comp, d_reg):
+    lib = _check(act, act_t, comp_t, reg_lbl, lse, coef, diff, gout, d_act, d_comp, d_reg)
+    has = d_reg is not None
+    lib.call("ssn_total_loss_bwd", _p(act), _p(act_t), act.shape[0], act.shape[1], _p(comp_t), comp_shape[0], comp_shape[1], float(den),
+             _p(reg_lbl) if has else None, reg_shape[0] if has else 0, reg_shape[1] if has else 0, float(w_comp), float(w_reg), _p(lse),
+             _p(coef), _p(diff), _p(gout), _p(d_act), _p(d_comp), _p(d_reg), _stream(lib, act))
+
+
+def label_select(target, reg_target, idx, outs, out_reg):
+    """target[idx[k]] -> outs[k] (k = 0, 1, and 2 with reg_target[idx[2]] -> out_reg when idx[2] is not None): one launch."""
+    lib = _check(target, reg_target, *[t for t in list(idx) + list(outs) + [out_reg] if t is not None])
+    n = [0 if i is None else i.numel() for i in idx]
+    lib.call("ssn_label_select", _p(target), _p(reg_target), _p(idx[0]), n[0], _p(idx[1]), n[1], _p(idx[2]), n[2], _p(outs[0]), _p(outs[1]),
+             _p(outs[2]), _p(out_reg), _stream(lib, target))
+
+
 # ------------------------------------------------------------------------------------ optimiser
 # Counts the in-place parameter updates issued through this module (they go through raw pointers: torch's version counters do not
 # see them).  planes_exec keys its inference cache of packed weights on it.

@@ -255,6 +255,41 @@ class CompletenessLoss(torch.nn.Module):
                                        den)
 
 
+class SSNObjective(torch.nn.Module):
+    """[r6] The training objective of /root/reference/ssn_train.py:210-214 in one launch each way:
+
+        loss = CrossEntropyLoss()(act, act_target) + comp_loss_weight * CompletenessLoss()(comp, comp_target, sample_split, group)
+               + reg_loss_weight * ClassWiseRegressionLoss()(reg, reg_labels, reg_target)
+
+    ``forward(*ssn_outputs)`` takes the tuple ``SSN.forward`` returns (7 tensors, or 4 without regression) and returns the total;
+    ``self.parts`` then holds the three component losses (a [3] tensor) for the driver's meters.  Not a class of the reference: its
+    driver mixes the three criterions with Python arithmetic (five tiny kernels forward, six backward); the criterions themselves
+    (ActivityLoss / CompletenessLoss / ClassWiseRegressionLoss) remain and give bit-identical components."""
+
+    def __init__(self, comp_loss_weight=0.1, reg_loss_weight=0.1, ohem_ratio=0.17):
+        super(SSNObjective, self).__init__()
+        self.comp_loss_weight, self.reg_loss_weight, self.ohem_ratio = comp_loss_weight, reg_loss_weight, ohem_ratio
+        self.parts = None
+
+    def forward(self, act, act_target, comp, comp_target, reg=None, reg_labels=None, reg_target=None, sample_split=1,
+                sample_group_size=7, global_rows=None):
+        comp = comp.reshape(-1, comp.size()[1])
+        n_rows = comp.size(0)
+        if n_rows % sample_group_size:
+            raise RuntimeError("%d completeness rows cannot be viewed as groups of %d" % (n_rows, sample_group_size))
+        if reg is not None and (reg.dim() != 3 or reg_labels.dim() != 1):
+            raise IndexError("ClassWiseRegressionLoss needs pred [n, C, 2] and labels [n] with n >= 2")      # (as the reference: ops/ssn_ops.py:253)
+        neg_group_size = sample_group_size - sample_split
+        keep_pos, keep_neg = int(sample_split * 1.0), int(neg_group_size * self.ohem_ratio)
+        rows = n_rows if global_rows is None else global_rows
+        n_groups = rows // sample_group_size
+        den = float(n_groups * sample_split + int(n_groups * neg_group_size * self.ohem_ratio)) * (float(n_rows) / float(rows))
+        total, self.parts = FN.TotalLossFn.apply(act, act_target, comp, comp_target.reshape(-1), reg, reg_labels, reg_target,
+                                                 sample_group_size, sample_split, keep_pos, keep_neg, den, self.comp_loss_weight,
+                                                 self.reg_loss_weight)
+        return total
+
+
 class ClassWiseRegressionLoss(torch.nn.Module):
     """Location regression loss for each class (/root/reference/ops/ssn_ops.py:242-258)."""
 

@@ -160,7 +160,12 @@ def _fold_bn(net, plan, shapes, dev):
             continue
         offs[name_] = o
         o += (v[0] + 7) // 8 * 8          # (every vector starts 32-byte aligned, as separate allocations did)
-    flat = torch.full((o,), float("nan"), device=dev, dtype=torch.float32)
+    # (kept across passes: the entries nobody folds into stay NaN, the others are rewritten by every pass with what the parameters
+    # say -- one fill launch per state instead of one per forward)
+    keep = net.__dict__.setdefault("_nan_scale_flat", {})
+    flat = keep.get((dev, o))
+    if flat is None:
+        flat = keep[(dev, o)] = torch.full((o,), float("nan"), device=dev, dtype=torch.float32)
 
     def scale_slice(name, c0, c):
         if name not in tscale:

@@ -264,20 +264,31 @@ class SSN(torch.nn.Module):
         dev = base_out.device
         idx = self._row_indexers(prop_type, dev)
         pos = self._indexer_cache[4]
-        target = target.reshape(-1).to(dev)
         reg = self.regressor_fc if self.with_regression else None
         outs = FN.HeadsFn.apply(base_out, aug_scaling, table, seg_split[2], idx if reg is not None else idx[:2] + (None,),
                                 pos if reg is not None else pos[:2] + (None,),
                                 self.activity_fc.weight, self.activity_fc.bias, self.completeness_fc.weight, self.completeness_fc.bias,
                                 None if reg is None else reg.weight, None if reg is None else reg.bias)
 
-        def sel(t, i):
-            return t.index_select(0, i)
+        labels = self._select_labels(target, reg_target if reg is not None else None, idx, dev)
         if reg is not None:
-            reg_target = reg_target.reshape(-1, 2).to(dev)
-            return (outs[0], sel(target, idx[0]), outs[1], sel(target, idx[1]),
-                    outs[2].reshape(-1, self.completeness_fc.out_features, 2), sel(target, idx[2]), sel(reg_target, idx[2]))
-        return (outs[0], sel(target, idx[0]), outs[1], sel(target, idx[1]))
+            return (outs[0], labels[0], outs[1], labels[1], outs[2].reshape(-1, self.completeness_fc.out_features, 2), labels[2], labels[3])
+        return (outs[0], labels[0], outs[1], labels[1])
+
+    @staticmethod
+    def _select_labels(target, reg_target, idx, dev):
+        """target[act rows], target[comp rows], target[reg rows], reg_target[reg rows] (ssn_models.py:275-289): integer / target
+        bookkeeping, one launch (ssn_label_select) instead of four index_select."""
+        from . import kernels as K
+        target = target.reshape(-1).to(dev).long().contiguous()
+        has = reg_target is not None
+        outs = [torch.empty(idx[k].numel(), device=dev, dtype=torch.int64) for k in range(3 if has else 2)] + ([] if has else [None])
+        out_reg = None
+        if has:
+            reg_target = reg_target.reshape(-1, 2).to(dev).float().contiguous()
+            out_reg = torch.empty((idx[2].numel(), 2), device=dev, dtype=torch.float32)
+        K.label_select(target, reg_target, (idx[0], idx[1], idx[2] if has else None), outs, out_reg)
+        return outs[0], outs[1], outs[2], out_reg
 
     def train_forward(self, input, aug_scaling, target, reg_target, prop_type):
         base_out = self._backbone(input)
@@ -295,21 +306,16 @@ class SSN(torch.nn.Module):
         # the reference's three nonzero() calls (ssn_models.py:275-282) -> one host read of prop_type
         dev = raw_act_fc.device
         act_indexer, comp_indexer, reg_indexer = self._row_indexers(prop_type, dev)
-        target = target.reshape(-1).to(dev)
-
-        def sel(t, idx):
-            return t.index_select(0, idx)  # integer / target bookkeeping (not arithmetic)
-
+        idx = (act_indexer, comp_indexer, reg_indexer)
+        labels = self._select_labels(target, reg_target if self.with_regression else None, idx, dev)
         if self.with_regression:
-            reg_target = reg_target.reshape(-1, 2).to(dev)
             raw_regress_fc = self.regressor_fc(completeness_ft).reshape(-1, self.completeness_fc.out_features, 2)
-            return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), sel(target, act_indexer),
-                    FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), sel(target, comp_indexer),
-                    FN.RowGatherFn.apply(raw_regress_fc, reg_indexer), sel(target, reg_indexer),
-                    sel(reg_target, reg_indexer))
+            return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), labels[0],
+                    FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), labels[1],
+                    FN.RowGatherFn.apply(raw_regress_fc, reg_indexer), labels[2], labels[3])
         else:
-            return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), sel(target, act_indexer),
-                    FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), sel(target, comp_indexer))
+            return (FN.RowGatherFn.apply(raw_act_fc, act_indexer), labels[0],
+                    FN.RowGatherFn.apply(raw_comp_fc, comp_indexer), labels[1])
 
     def _row_indexers(self, prop_type, dev):
         """Rows of the activity / completeness / regression heads by proposal type (ssn_models.py:275-282).  The

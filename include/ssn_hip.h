@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define SSN_ERR_WORKSPACE (-3)
 
 const char* ssn_last_error(void);
-int ssn_abi_version(void);   /* 8 */
+int ssn_abi_version(void);   /* 9 */
 
 /* ------------------------------------------------------------------ backbone: conv + BN + ReLU
  * Weight re-layout for the implicit-GEMM kernels (what cuDNN does internally with its filter
@@ -390,6 +390,23 @@ int ssn_cw_smoothl1_fwd(const float* pred, const long* labels, const float* targ
                         int n, int C, hipStream_t stream);
 int ssn_cw_smoothl1_bwd(const long* labels, const float* diff, const float* gout, float* dpred, int n, int C,
                         hipStream_t stream);
+
+/* [r6] The training objective of ssn_train.py:210-214 -- activity CE + w_comp * completeness + w_reg * regression -- in ONE launch
+ * (the three losses above, same bodies and summation orders, then the mix) and ONE backward launch.  losses[4] = activity,
+ * completeness, regression (0 without that head), total.  lse [Ra], coef [Rc], diff [2 n_reg] are kept for the backward; scratch:
+ * max(2 Ra, 2 Rc) floats.  reg_pred == NULL (d_reg == NULL in the backward): no regression head (ssn_models.py:288-289). */
+int ssn_total_loss_fwd(const float* act_logits, const long* act_target, int Ra, int Ca, const float* comp_pred,
+                       const long* comp_labels, int Rc, int Cc, int group, int split, int keep_pos, int keep_neg, float den,
+                       const float* reg_pred, const long* reg_labels, const float* reg_targets, int n_reg, int Cr, float w_comp,
+                       float w_reg, float* losses, float* lse, float* coef, float* diff, float* scratch, hipStream_t stream);
+int ssn_total_loss_bwd(const float* act_logits, const long* act_target, int Ra, int Ca, const long* comp_labels, int Rc, int Cc,
+                       float den, const long* reg_labels, int n_reg, int Cr, float w_comp, float w_reg, const float* lse,
+                       const float* coef, const float* diff, const float* gout, float* d_act, float* d_comp, float* d_reg,
+                       hipStream_t stream);
+/* The label / target bookkeeping of SSN.train_forward (ssn_models.py:275-289): target[idx0], target[idx1], target[idx2],
+ * reg_target[idx2] in one launch (the reference: four index_select behind three nonzero()).  n2 == 0: no regression. */
+int ssn_label_select(const long* target, const float* reg_target, const long* idx0, int n0, const long* idx1, int n1,
+                     const long* idx2, int n2, long* out0, long* out1, long* out2, float* out_reg, hipStream_t stream);
 
 /* ------------------------------------------------------------------ optimiser step
  * torch.optim.SGD(momentum, weight_decay) over one flat segment (ssn_train.py:141-144,252);

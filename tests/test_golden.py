@@ -188,6 +188,18 @@ def _product_vs_golden(tag, device):
     np.testing.assert_allclose([a.item(), c.item(), r.item(), total.item()], g["%s_losses" % tag], rtol=1e-4)
     total.backward()
     grads = dict((n, p.grad) for n, p in m.named_parameters() if p.grad is not None)
+    # [r6] the one-launch objective (ops.ssn_ops.SSNObjective): same loss bodies -> bit-identical components, the total within one
+    # rounding of the Python mix (0.1 is a double there, a float in the kernel), the same gradients at the logits
+    fresh = [t.detach().clone().requires_grad_() if t.is_floating_point() and i in (0, 2, 4) else t for i, t in enumerate(out)]
+    obj = P.SSNObjective()
+    tot2 = obj(*fresh)
+    assert torch.equal(obj.parts.cpu(), torch.stack([a.detach().reshape(()), c.detach().reshape(()), r.detach().reshape(())]).cpu())
+    assert abs(tot2.item() - total.item()) <= 2e-7 * abs(total.item())
+    tot2.backward()
+    sep = [t.detach().clone().requires_grad_() for t in (out[0], out[2], out[4])]
+    (P.ActivityLoss()(sep[0], out[1]) + 0.1 * P.CompletenessLoss()(sep[1], out[3], 1, 7) + 0.1 * P.ClassWiseRegressionLoss()(sep[2], out[5], out[6])).backward()
+    for f_, s_ in zip((fresh[0], fresh[2], fresh[4]), sep):
+        assert rel_err(f_.grad, s_.grad) < 1e-6
     # gradient norms, as a distribution.  The loss is only piecewise smooth: a ReLU unit whose pre-activation is within
     # rounding of zero takes different branches in two fp32 implementations, and at 32^2 -- the 7x7-stage planes are
     # single pixels -- one such unit moves a whole tensor by 1e-3..1e-2 (profiles/r2_grad_flip_diag.txt: the reference's

@@ -141,7 +141,7 @@ def test_abi_exports_match_header():
     for name in declared:
         assert hasattr(cdll, name), name
     cdll.ssn_abi_version.restype = ctypes.c_int
-    assert cdll.ssn_abi_version() == 8
+    assert cdll.ssn_abi_version() == 9
     cdll.ssn_conv_pick_tile.argtypes = [ctypes.c_int, ctypes.c_long]
     assert 0 <= cdll.ssn_conv_pick_tile(192, 288 * 56 * 56) < 8
     # argument validation happens before any launch: a null-pointer call fails cleanly without a GPU
