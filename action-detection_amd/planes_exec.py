@@ -57,6 +57,7 @@ class PlanesState:
         self.calibration_passes = [0, 0]
         self.recalibrations = [0, 0]     # passes the range guard had repeated (forward, backward)
         self.fault_log = []              # diagnostics: the last few faults as (pass, [(tensor, amax * scale), ...])
+        self.nonfinite = False           # the last settle() gave up on a pass whose maxima were inf / NaN
 
     def slot(self, name, grad):
         table = self.grad_slot if grad else self.act_slot
@@ -95,7 +96,17 @@ class PlanesState:
         """Repeat a pass (``relaunch``) until no scale moves and nothing leaves its range; returns the number of repeats.  The
         pass must already have run once.  (Host syncs: eager only.)"""
         trail = []
+        self.nonfinite = False
         for it in range(12):
+            # a NON-FINITE recorded maximum is not a scale problem: the pass itself produced inf / NaN (diverged weights, an inf in
+            # the input) -- fp32 storage would carry it forward, no scale can hold it.  Stop repeating, leave the fault word raised
+            # (the optimizer skips the step), and let the caller poison its result like the reference's would be.
+            if not bool(torch.isfinite(self.pool.amax[:self.pool.used]).all()):
+                self.nonfinite = True
+                self.pool.amax[:self.pool.used].zero_()
+                self.pool.flag[0] = 1
+                self.fault_log = (self.fault_log + [(what, [("non-finite maximum: pass not repeated", float("inf"))])])[-8:]
+                return it
             if it >= 9:      # diagnostics for the error below: which tensors are still out of range / moving
                 a = (self.pool.amax[:self.pool.used] * self.pool.scale[:self.pool.used]).tolist()
                 names = {v: ("grad:" if g else "act:") + k for g, tab in ((0, self.act_slot), (1, self.grad_slot))
@@ -457,6 +468,7 @@ def run_forward(net, x, keep):
         res["acts"] = {}
         res["feat"] = launch_all(res["acts"], argmax)
 
+    st.nonfinite = False
     if not st.fwd_calibrated:
         # first pass of this state: no history.  Activations start at 1/4 (head-room up to 2.6e5), then the pass is repeated
         # until no scale moves (each pass fixes every tensor whose inputs were already right)
@@ -479,7 +491,14 @@ def run_forward(net, x, keep):
                 st.describe_fault("forward")
                 st.recalibrations[0] += 1 + st.settle(again, "forward")
     acts, feat = res["acts"], res["feat"]
-    saved = (plan, shapes, acts, argmax, tscale, {"packed": packed, "packed_dg": packed_dg, "bnstat": bnstat}, st) if keep else None
+    if st.nonfinite:
+        # the pass overflowed fp32 itself (settle() gave up): the planes hold clamped values, the reference would hold inf / NaN --
+        # hand out what IT would: non-finite features (the loss and every gradient follow; the raised fault word makes
+        # SSNSGD.step(skip_flag=) leave the weights alone, the next finite pass recalibrates and clears it)
+        feat.fill_(float("nan"))
+        st.fwd_calibrated = True
+        st.nonfinite_passes = getattr(st, "nonfinite_passes", 0) + 1
+    saved = (plan, shapes, acts, argmax, tscale, {"packed": packed, "packed_dg": packed_dg, "bnstat": bnstat, "nonfinite": st.nonfinite}, st) if keep else None
     return feat, saved
 
 
@@ -813,6 +832,7 @@ def run_backward(net, dfeat, saved, hook=True):
     def silent_pass():
         launch_all(grads, False)
 
+    st.nonfinite = False
     if not st.bwd_calibrated:
         # no history: every gradient tensor starts from the magnitude of the incoming feature gradient spread over the 7x7 pool
         # (2^11 at that magnitude: f16 then covers 2^-25 .. 2^5 of it), then passes until no scale moves
@@ -820,6 +840,8 @@ def run_backward(net, dfeat, saved, hook=True):
             raise RuntimeError("planes executor: the first backward of a state calibrates its scales with host syncs and cannot "
                                "be captured into a hipGraph; run one eager step first")
         amax0 = float(dfeat.abs().max().item())
+        if not math.isfinite(amax0):
+            amax0 = 0.0              # (a non-finite feature gradient: the pass below records it and settle() gives up on it)
         hw = 1
         for op in plan:
             if op["kind"] == "gap":
@@ -852,6 +874,14 @@ def run_backward(net, dfeat, saved, hook=True):
         elif not overlapping:
             hook_obj.range_ready(flat, 0, total)
             hook_obj.finish()
+    if st.nonfinite or extras.get("nonfinite"):
+        # (see run_forward: what fp32 storage would have produced -- the backward of a forward that held inf / NaN is non-finite whatever
+        # the incoming gradient; the fault word is raised)
+        st.pool.flag[0] = 1
+        flat.fill_(float("nan"))
+        for dg, db_ in bn_grads.values():
+            dg.fill_(float("nan"))
+            db_.fill_(float("nan"))
     out = []
     for lid in net._conv_ids:
         conv = getattr(net, lid)

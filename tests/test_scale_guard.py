@@ -520,3 +520,41 @@ def test_graph_replay_protocol_on_the_real_ssn_gpu(hip_library):
         static[0].copy_((batch0[0] * k).to(dev))
         replay_and_repair(k)
     assert flagged[0] >= 1, "the magnitude jumps were meant to trip the range guard inside the replayed graph"
+
+
+def test_a_pass_that_overflows_fp32_behaves_like_the_reference(emu):
+    """weights that make the ACTIVATIONS overflow fp32 (a diverged run).  The reference carries inf / NaN forward and
+    keeps running; the planes path used to raise "scales did not settle".  Now: no exception, non-finite features (what fp32 storage
+    would hold), non-finite gradients, the fault word raised so that SSNSGD.step(skip_flag=) leaves the weights untouched -- and once the
+    weights are sane again the very next call is correct and clears the word."""
+    dev = torch.device("cpu")
+    net, ref = _pair(dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 16, 16, generator=g) * 40
+    f0 = net.features(x)                                   # a sane, calibrated state first
+    w = torch.randn(f0.shape, generator=g)
+    (f0 * w).sum().backward()
+    good = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = SSNSGD([{"params": [p for p in net.parameters() if p.requires_grad], "lr_mult": 1, "decay_mult": 1, "name": "all"}], lr=0.01,
+                 momentum=0.9, weight_decay=0.0)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.endswith("weight") and p_.dim() == 4:
+                p_.mul_(1e20)                              # two layers of this: ~1e22, then ~1e43 > 3.4e38 -- fp32 overflows to inf
+    net.zero_grad(set_to_none=True)
+    f = net.features(x)                                    # must not raise
+    assert not torch.isfinite(f).any()
+    assert net.scale_fault()
+    (f * w).sum().backward()                               # must not raise either
+    grads = [p.grad for p in net.parameters() if p.grad is not None]
+    assert grads and all(not torch.isfinite(g_).any() for g_ in grads)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    opt.step(skip_flag=net.planes_flag(dev)[0:1])          # the flagged step's update is skipped
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    # sane weights again (a reloaded checkpoint): the next call recalibrates by itself, is correct, and clears the word
+    net.load_state_dict(good)
+    ref.load_state_dict({k: v.double() for k, v in good.items()})
+    _check_call(net, ref, x, w, dev)
+    assert not net.scale_fault()
+
