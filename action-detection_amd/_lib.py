@@ -89,6 +89,7 @@ _SIGS = {
     "ssn_total_loss_fwd": "ppiippiiiiiifpppiiffpppppp",
     "ssn_total_loss_bwd": "ppiipiifpiiffpppppppp",
     "ssn_label_select": "pppipipippppp",
+    "ssn_param_checksum": "pipppip",
     "ssn_cw_smoothl1_bwd": "ppppiip",
     "ssn_sgd_step": "ppplffffipp",
     "ssn_sgd_step_multi": "ippppppffipp",

@@ -350,6 +350,53 @@ extern "C" int ssn_relu_bn_bwd(float* dy, const float* y, const float* scale, in
     return SSN_OK;
 }
 
+// ---- [r6] parameter checksum: does a cached derivative of the parameters (packed weights, folded BatchNorm) still belong to them?
+// A write through `p.data` / raw pointers is invisible to torch's version counters; the bits are not.  sum over all words of
+// word * (2 * position + 1) * tensor odd-multiplier, mod 2^64 (order-free: unsigned atomics), ~45 MB read per BN-Inception check.
+struct SsnChecksumEntry {
+    const uint32_t* ptr;
+    long n;      // 32-bit words
+};
+namespace {
+__global__ __launch_bounds__(256) void param_checksum_kernel(const SsnChecksumEntry* table, unsigned long long* slot) {
+    const SsnChecksumEntry e = table[blockIdx.y];
+    unsigned long long acc = 0ull;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < e.n; i += (long)gridDim.x * 256)
+        acc += (unsigned long long)e.ptr[i] * (unsigned long long)(2 * i + 1);
+    acc *= 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * blockIdx.y + 1);
+    // wave reduction of the 64-bit partial sums, one atomic per wave
+    uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_down((int)hi, off) << 32) | (uint32_t)__shfl_down((int)lo, off);
+        acc += o;
+        lo = (uint32_t)acc;
+        hi = (uint32_t)(acc >> 32);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(slot, acc);
+}
+// flag |= bit when the fresh sum differs from the expected one; the fresh slot is cleared for the next check
+__global__ void checksum_compare_kernel(unsigned long long* fresh, const unsigned long long* expected, int* flag, int bit) {
+    if (threadIdx.x == 0) {
+        if (*fresh != *expected) atomicOr(flag, bit);
+        *fresh = 0ull;
+    }
+}
+}  // namespace
+
+// table: device array of n_entries {pointer, 32-bit word count}; slot: device uint64, must be 0 on entry; adds the checksum of all
+// entries.  expected == NULL: just accumulate (recording the reference value).  Otherwise: flag |= bit if slot != *expected, slot <- 0.
+extern "C" int ssn_param_checksum(const void* table, int n_entries, unsigned long long* slot, const unsigned long long* expected,
+                                  int* flag, int bit, hipStream_t stream) {
+    SSN_CHECK_ARG(table && slot && n_entries > 0 && (!expected || flag), "param_checksum: bad arguments");
+    hipLaunchKernelGGL(param_checksum_kernel, dim3(16, n_entries), dim3(256), 0, stream, (const SsnChecksumEntry*)table, slot);
+    SSN_CHECK_LAUNCH("param_checksum");
+    if (expected) {
+        hipLaunchKernelGGL(checksum_compare_kernel, dim3(1), dim3(64), 0, stream, slot, expected, flag, bit);
+        SSN_CHECK_LAUNCH("checksum_compare");
+    }
+    return SSN_OK;
+}
+
 extern "C" int ssn_tensor_amax(const float* x, long n, float* slot, hipStream_t stream) {
     SSN_CHECK_ARG(x && slot && n >= 0, "tensor_amax: bad arguments");
     if (n == 0) return SSN_OK;

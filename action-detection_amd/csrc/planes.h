@@ -55,12 +55,29 @@ __device__ __forceinline__ float pl_clamp(float v) { return __builtin_fminf(__bu
 // v_med3_f32: relu / no-relu floor and the f16 ceiling in one instruction (floor = 0 or -65504)
 __device__ __forceinline__ float pl_clamp_floor(float v, float floor) { return __builtin_amdgcn_fmed3f(v, floor, PL_F16_MAX); }
 
+// low-plane word of a channel pair: f16(v0 - hi.lo), f16(v1 - hi.hi).  [r6] v_fma_mixlo / mixhi_f16 take the f16 half of `hi` as an
+// operand and round v * 1 - hi straight to f16: two instructions per pair instead of four (2 x cvt_f32_f16, pk_add, cvt_pk) -- a
+// seventh of the convolution epilogue's VALU work.  Bit-identical: v - hi is exact in fp32 (hi is v rounded to 11 bits), so both
+// forms round the same number once.  (The host emulator of the CPU test tier defines its own.)
+#ifndef PL_LO_PAIR
+#define PL_LO_PAIR(dst, v0, v1, hi)                                                                       \
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"                            \
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"                                 \
+        : "=&v"(dst)                                                                                      \
+        : "v"(v0), "v"(v1), "v"(hi))
+#endif
+__device__ __forceinline__ uint32_t pl_lo_pair(float v0, float v1, uint32_t hi) {
+    uint32_t lo;
+    PL_LO_PAIR(lo, v0, v1, hi);
+    return lo;
+}
+
 // split four (already scaled and clamped) values into the two plane words of 4 consecutive channels
 __device__ __forceinline__ void pl_split4(const float (&v)[4], u32x2& hi, u32x2& lo) {
     hi[0] = f16_pair_rne(v[0], v[1]);
     hi[1] = f16_pair_rne(v[2], v[3]);
-    lo[0] = f16_pair_rne(v[0] - f16_pair_lo(hi[0]), v[1] - f16_pair_hi(hi[0]));
-    lo[1] = f16_pair_rne(v[2] - f16_pair_lo(hi[1]), v[3] - f16_pair_hi(hi[1]));
+    lo[0] = pl_lo_pair(v[0], v[1], hi[0]);
+    lo[1] = pl_lo_pair(v[2], v[3], hi[1]);
 }
 // the scaled values (hi + lo) of 4 consecutive channels
 __device__ __forceinline__ void pl_join4(const u32x2& hi, const u32x2& lo, float (&v)[4]) {
@@ -80,7 +97,7 @@ __device__ __forceinline__ void pl_split8(const float (&v)[8], u32x4& hi, u32x4&
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         hi[d] = f16_pair_rne(v[2 * d], v[2 * d + 1]);
-        lo[d] = f16_pair_rne(v[2 * d] - f16_pair_lo(hi[d]), v[2 * d + 1] - f16_pair_hi(hi[d]));
+        lo[d] = pl_lo_pair(v[2 * d], v[2 * d + 1], hi[d]);
     }
 }
 

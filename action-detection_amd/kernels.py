@@ -904,6 +904,34 @@ def label_select(target, reg_target, idx, outs, out_reg):
              _p(outs[2]), _p(out_reg), _stream(lib, target))
 
 
+class ParamChecksum(object):
+    """Device-side fingerprint of a set of tensors (csrc/elementwise.hip: ssn_param_checksum): recorded once, checked later WITHOUT a
+    host read -- a mismatch raises `bit` in a device flag word (the planes path's fault word: the pass that used the stale derivative is
+    then repeated by the range guard's poll, see planes_exec.run_forward)."""
+
+    def __init__(self, tensors, device):
+        import numpy as np
+        self.tensors = [t for t in tensors]      # (kept alive: the table holds raw pointers)
+        tab = np.zeros((len(self.tensors), 2), dtype=np.int64)
+        for i, t in enumerate(self.tensors):
+            assert t.is_contiguous() and t.element_size() == 4, "checksummed tensors are contiguous 32-bit"
+            tab[i] = (t.data_ptr(), t.numel())
+        self.table = torch.from_numpy(tab).to(device)
+        self.expected = torch.zeros(1, device=device, dtype=torch.int64)
+        self.fresh = torch.zeros(1, device=device, dtype=torch.int64)
+        self.ptrs = tuple(int(v) for v in tab[:, 0])
+        lib = _lib.get_lib()
+        lib.call("ssn_param_checksum", _p(self.table), len(self.tensors), _p(self.expected), None, None, 0, _stream(lib, self.table))
+
+    def same_storage(self, tensors):
+        return self.ptrs == tuple(t.data_ptr() for t in tensors)
+
+    def check(self, flag, bit):
+        lib = _lib.get_lib()
+        lib.call("ssn_param_checksum", _p(self.table), len(self.tensors), _p(self.fresh), _p(self.expected), _p(flag), int(bit),
+                 _stream(lib, self.table))
+
+
 # ------------------------------------------------------------------------------------ optimiser
 # Counts the in-place parameter updates issued through this module (they go through raw pointers: torch's version counters do not
 # see them).  planes_exec keys its inference cache of packed weights on it.

@@ -287,8 +287,9 @@ def run_forward(net, x, keep):
     # reused while no parameter / buffer has been written (dense testing calls the backbone ten times per video: 3 pack launches,
     # the fold and ~2 ms of Python per call)
     # Validity: torch's version counters (optimizers, load_state_dict, init functions, anything under no_grad) + the counter of this
-    # package's own optimizer kernels + the storage addresses; a write through `.data` is invisible to all three -- after one, call
-    # net.recalibrate() (it drops this cache too).  SSN_INFER_CACHE=0 switches it off.
+    # package's own optimizer kernels + the storage addresses; a write through `.data` is invisible to all three -- [r6] so every hit
+    # also compares a device-side checksum of the parameter bits (kernels.ParamChecksum; with scale_guard "off" nothing polls the
+    # word: call net.recalibrate() after such a write).  SSN_INFER_CACHE=0 switches the cache off.
     ckey = None
     hit = None
     if not keep and net.infer_cache:
@@ -297,6 +298,11 @@ def run_forward(net, x, keep):
         hit = net.__dict__.get("_infer_cache")
         if hit is not None and hit[0] == ckey:
             tscale, shift_of, scale_slice, packed = hit[1]
+            # [r6] ... and a write through `.data` / a raw pointer (checkpoint averaging, EMA scripts) that none of the above sees: the
+            # parameters' BITS are compared with the ones the cache was built from, on the device (no host read) -- a mismatch raises
+            # bit 2 of the fault word and this pass is repeated without the cache by the guard's poll below
+            if net.scale_guard != "off":
+                hit[2].check(st.pool.flag, 4)
         else:
             hit = None
     if keep or hit is None:
@@ -330,7 +336,9 @@ def run_forward(net, x, keep):
             if keep:
                 packed_dg = _pack_dgrad(net, plan)
         if ckey is not None:
-            net.__dict__["_infer_cache"] = (ckey, (tscale, shift_of, scale_slice, packed))
+            fingerprint = K.ParamChecksum([t.detach() for t in itertools.chain(net.parameters(), net.buffers())
+                                           if t.element_size() == 4 and t.numel() > 0], dev)
+            net.__dict__["_infer_cache"] = (ckey, (tscale, shift_of, scale_slice, packed), fingerprint)
 
     bnstat, bn_before = {}, {}      # training-mode BatchNorm layers: layer id -> (batch mean of z, 1 / sqrt(var + eps))
     bn_factor = {}                  # ... with momentum=None: the cumulative-average factor of this call
@@ -487,7 +495,14 @@ def run_forward(net, x, keep):
             # training steps, reloaded weights ...)  Eager: poll and repeat the pass before anyone reads it; capture: the owner of
             # the graph polls the word (the optimizer kernel skips a flagged step)
             st.check()
-            if net.scale_guard == "sync" and not capturing and st.fault():
+            word = st.fault() if (net.scale_guard == "sync" and not capturing) else 0
+            if word & 4:
+                # the inference cache was built from other parameter bits (a `.data` write): drop it and run the pass from the parameters
+                net.__dict__.pop("_infer_cache", None)
+                st.pool.flag[0] = word & ~4
+                st.stale_cache_hits = getattr(st, "stale_cache_hits", 0) + 1
+                return run_forward(net, x, keep)
+            if word:
                 st.describe_fault("forward")
                 st.recalibrations[0] += 1 + st.settle(again, "forward")
     acts, feat = res["acts"], res["feat"]

@@ -408,6 +408,14 @@ int ssn_total_loss_bwd(const float* act_logits, const long* act_target, int Ra, 
 int ssn_label_select(const long* target, const float* reg_target, const long* idx0, int n0, const long* idx1, int n1,
                      const long* idx2, int n2, long* out0, long* out1, long* out2, float* out_reg, hipStream_t stream);
 
+/* [r6] Checksum of the parameters a cached derivative (packed weights, folded BatchNorm vectors of the inference cache,
+ * planes_exec.py) was built from -- the reference re-reads its parameters in every forward (ssn_models.py:298), so a write through
+ * `p.data` is seen at once; torch's version counters do not see it, the bits do.  table: device array of n_entries {const void* ptr;
+ * long n_words}; slot: device uint64, 0 on entry.  expected == NULL: slot += checksum (recording).  Otherwise additionally
+ * flag |= bit when slot != *expected, and slot <- 0. */
+int ssn_param_checksum(const void* table, int n_entries, unsigned long long* slot, const unsigned long long* expected, int* flag,
+                       int bit, hipStream_t stream);
+
 /* ------------------------------------------------------------------ optimiser step
  * torch.optim.SGD(momentum, weight_decay) over one flat segment (ssn_train.py:141-144,252);
  * per-group lr_mult / decay_mult of ssn_models.py:240-251 are folded into lr / weight_decay. */

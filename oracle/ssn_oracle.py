@@ -47,6 +47,39 @@ INCEPTION_ROWS = (
 )
 
 
+def _audit_relu(audit, name, z, mask):
+    """Mask audit of a forced evaluation (tests/test_model_gpu.py, __graft_entry__.smoke): where does the FORCED ReLU decision differ from
+    the sign of this evaluation's own pre-activation, and how far from zero is the pre-activation there (relative to the layer's
+    largest)?  A correct exporter differs only on units within rounding of zero; a wrong one (shifted / transposed / stale masks) on
+    about half of them."""
+    if audit is None:
+        return
+    own = z > 0
+    bad = own != mask.to(torch.bool)
+    nbad = int(bad.sum())
+    far = float((z.abs() * bad).max() / (z.abs().max() + 1e-300)) if nbad else 0.0
+    audit.setdefault("relu", {})[name] = (nbad, z.numel(), far)
+
+
+def _audit_pool(audit, idx, x, picked, k, s, p, ceil_mode):
+    """... and for a forced max pool: how far below its window's true maximum is the element the forced argmax picked?"""
+    if audit is None:
+        return
+    true = F.max_pool2d(x, k, s, p, ceil_mode=ceil_mode)
+    gap = float(((true - picked).abs().max()) / (x.abs().max() + 1e-300))
+    audit.setdefault("pool", {})[idx] = (int((true != picked).sum()), picked.numel(), gap)
+
+
+
+def audit_summary(audit):
+    """(fraction of ReLU units whose forced decision differs, largest |pre-activation| among them relative to its layer's largest,
+    fraction of pool windows whose forced pick is not the maximum, largest (maximum - pick) relative to the pool input's largest)"""
+    r, q = audit.get("relu", {}), audit.get("pool", {})
+    nr, tr = sum(v[0] for v in r.values()), sum(v[1] for v in r.values())
+    nq, tq = sum(v[0] for v in q.values()), sum(v[1] for v in q.values())
+    return (nr / max(tr, 1), max([v[2] for v in r.values()] + [0.0]), nq / max(tq, 1), max([v[2] for v in q.values()] + [0.0]))
+
+
 class OracleBNInception(nn.Module):
     """torch-CPU BN-Inception with upstream layer ids as attribute names.
 
@@ -88,12 +121,14 @@ class OracleBNInception(nn.Module):
     # the given mask and every max pool picks the given element.  The network is then smooth in its weights, so two correct
     # implementations must agree on the gradients to rounding (no "which side of zero did this unit land on" term).
     forced = None
+    audit = None      # a dict: the forced evaluation records where the forced decisions differ from its own (_audit_relu / _audit_pool)
 
     def _cbr(self, name, x):
         conv = getattr(self, name)
         bn = getattr(self, name + "_bn")
         z = bn(conv(x))
         if self.forced is not None:
+            _audit_relu(self.audit, name, z.detach(), self.forced[0][name])
             return z * self.forced[0][name].to(z.dtype)
         return F.relu(z)
 
@@ -106,7 +141,9 @@ class OracleBNInception(nn.Module):
         ho, wo = local.shape[2], local.shape[3]
         hh = torch.arange(ho).view(1, 1, ho, 1) * s - p + local // k
         ww = torch.arange(wo).view(1, 1, 1, wo) * s - p + local % k
-        return x.flatten(2).gather(2, (hh * w + ww).flatten(2)).view(n, c, ho, wo)
+        picked = x.flatten(2).gather(2, (hh * w + ww).flatten(2)).view(n, c, ho, wo)
+        _audit_pool(self.audit, self._pool_i - 1, x.detach(), picked.detach(), k, s, p, True)
+        return picked
 
     def features(self, x):
         self._pool_i = 0
@@ -220,10 +257,12 @@ class OracleInceptionV3(nn.Module):
     # Mask-forced evaluation (see OracleBNInception.forced): ({layer id: bool mask}, [window-local argmax per max pool, in forward
     # order]) taken from another implementation's forward; every ReLU multiplies by the mask, every max pool gathers the given element.
     forced = None
+    audit = None
 
     def _cbr(self, name, x):
         z = getattr(self, name + "_bn")(getattr(self, name)(x))
         if self.forced is not None:
+            _audit_relu(self.audit, name, z.detach(), self.forced[0][name])
             return z * self.forced[0][name].to(z.dtype)
         return F.relu(z)
 
@@ -236,7 +275,9 @@ class OracleInceptionV3(nn.Module):
         ho, wo = local.shape[2], local.shape[3]
         hh = torch.arange(ho).view(1, 1, ho, 1) * 2 + local // 3
         ww = torch.arange(wo).view(1, 1, 1, wo) * 2 + local % 3
-        return x.flatten(2).gather(2, (hh * w + ww).flatten(2)).view(n, c, ho, wo)
+        picked = x.flatten(2).gather(2, (hh * w + ww).flatten(2)).view(n, c, ho, wo)
+        _audit_pool(self.audit, self._pool_i - 1, x.detach(), picked.detach(), 3, 2, 0, False)
+        return picked
 
     def features(self, x):
         c = self._cbr

@@ -357,6 +357,11 @@ static inline float atomicAdd(float* p, float v) {
     *p = o + v;
     return o;
 }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+    unsigned long long o = *p;
+    *p = o + v;
+    return o;
+}
 static inline int atomicAdd(int* p, int v) {
     int o = *p;
     *p = o + v;
@@ -497,6 +502,7 @@ static inline emu_u32x2 emu_ds_read_tr16_b64(const void* addr) {
 #define SSN_CONST_PTR(T, p) ((const T*)(p))
 #define SSN_WAIT_VMCNT(n) ((void)0)
 #define SSN_STORE_DATA_GUARD(v) ((void)0)
+#define PL_LO_PAIR(dst, v0, v1, hi) ((dst) = f16_pair_rne((v0) - f16_pair_lo(hi), (v1) - f16_pair_hi(hi)))
 #define SSN_WAIT_LGKM0() ((void)0)
 static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds, int size, uint32_t voff,
                                                             uint32_t soff, int imm, int) {

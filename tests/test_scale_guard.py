@@ -364,6 +364,19 @@ def test_inference_cache_follows_parameter_updates(emu):
     check()                                                            # BatchNorm buffers are part of the key
     net.load_state_dict({k: v * 0.5 if k.endswith("branch_3x3.bias") else v for k, v in net.state_dict().items()})
     check()
+    # [r6] a write through `.data` (what checkpoint-averaging / EMA scripts do): no version counter moves, the key still matches --
+    # the device-side checksum of the parameter bits notices, the pass is repeated from the parameters, the cache is rebuilt
+    check()
+    key1 = net.__dict__["_infer_cache"][0]
+    v0 = net.conv1_3x3.weight._version
+    net.conv1_3x3.weight.data.mul_(0.7)
+    net.branch_3x3_bn.running_mean.data.add_(0.05)
+    assert net.conv1_3x3.weight._version == v0
+    check()
+    assert sum(getattr(st, "stale_cache_hits", 0) for st in net._planes_states.values()) == 1
+    assert net.__dict__["_infer_cache"][0] == key1 and not net.scale_fault()
+    check()                                                            # (a hit again: nothing to repeat)
+    assert sum(getattr(st, "stale_cache_hits", 0) for st in net._planes_states.values()) == 1
 
 
 @pytest.mark.gpu
