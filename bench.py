@@ -41,7 +41,7 @@ import torch.distributed as dist  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
 F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense f16 / bf16 MFMA (no 2:1 sparsity)
 X6_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3  # algorithmic fp32 flops through the 2-way f16 split (3 MFMA products)
-PMC_SUMMARY = "r5_pmc_summary.json"
+PMC_SUMMARY = "r6_pmc_summary.json"
 FWD_GFLOP_PER_IMAGE = {"RGB": 4.063152128, "Flow": 4.613883904}  # 2 * conv MACs
 # conv1 (7x7/2, 64 outputs of 112x112): 2 * Cin * 49 * 64 * 112^2 flop that a dgrad would cost and nobody needs
 CONV1_DGRAD_GFLOP_PER_IMAGE = {"RGB": 2 * 3 * 49 * 64 * 112 * 112 / 1e9, "Flow": 2 * 10 * 49 * 64 * 112 * 112 / 1e9}
