@@ -106,3 +106,41 @@ def test_switch_sends_training_bn_to_the_fp32_layout(emu):
 def test_partial_and_full_bn_on_planes_gpu(hip_library):
     _run(torch.device("cuda:0"), ("conv1_3x3",))
     _run(torch.device("cuda:0"), LAYERS)
+
+
+def test_switching_the_bn_policy_on_one_net_keeps_the_gradients_right(emu):
+    """[r6] One backbone object, its BatchNorm policy switched between calls (SSN.train() / .eval() around validation, a test that toggles
+    layers): the per-tensor vectors of folded-BN scales are kept across passes (NaN = "not a frozen ReLU / BN output: the fused backward
+    leaves this gradient alone"), and an entry a frozen plan wrote must read NaN again once its layer is in training mode.  Round 6's
+    first version of that cache was keyed by size only: Inception-v3's fused vs per-layer plans differed by 0.4 in their gradients
+    (tests/test_inceptionv3.py::test_inceptionv3_backbone_backward_gpu caught it on the GPU; this is its CPU-tier guard)."""
+    dev = torch.device("cpu")
+    net, ref = _pair(dev, ())
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 3, 16, 16, generator=g) * 40.0
+    w = torch.randn(3, 32, generator=g)
+
+    def check(train_ids):
+        for lid in LAYERS:
+            for m in (getattr(net, lid + "_bn"), getattr(ref, lid + "_bn")):
+                m.train(lid in train_ids)
+                m.weight.requires_grad = m.bias.requires_grad = lid in train_ids
+        ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        net.zero_grad(set_to_none=True)
+        ref.zero_grad(set_to_none=True)
+        f = net.features(x)
+        relu, pool = net.export_decisions()
+        ref.forced = ({k: t.cpu() for k, t in relu.items()}, {k: t.cpu() for k, t in pool.items()})
+        fr = ref(x)
+        assert rel_err(f, fr) < 1e-5
+        (f * w).sum().backward()
+        (fr * w.double()).sum().backward()
+        for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+            if p2.grad is None or (n1.endswith(".bias") and n1.rsplit(".", 1)[0] in train_ids):
+                continue
+            assert rel_err(p1.grad, p2.grad) < 5e-5, (train_ids, n1, rel_err(p1.grad, p2.grad))
+
+    check(())                          # frozen: every scale vector folded
+    check(("branch_3x3",))             # that layer's entries must be NaN now
+    check(("conv1_3x3",))              # ... and folded again, another layer's NaN
+    check(())
