@@ -112,7 +112,7 @@ _SIGS = {
     "ssn_conv_wgrad_pl": "ppppppiiiiliiiliiiiiplippiipp",
     "ssn_wgrad_reduce_multi": "ipppppppp",
     "ssn_conv_wgrad_pl_group": "ippppppppppplplp",
-    "ssn_conv_pl_dgrad_s2": "pppppiiiiliiiliiplpipppip",
+    "ssn_conv_pl_dgrad_s2": "pppppiiiiliiiliiplpipppp",
     "ssn_pl_maxpool_fwd": "pplpplpiiiiiiiiipppp",
     "ssn_pl_maxpool_bwd": "pplpppl" + "i" * 10 + "plpipppplp",
     "ssn_pl_avgpool_affine": "pplpplppiiiiiiipppp",

@@ -208,9 +208,6 @@ class BNInception(nn.Module):
         # scales are the previous step's.
         self.branch_lanes = os.environ.get("SSN_BRANCH_LANES", "1") != "0"
         self._side_streams = {}
-        # planes_exec: the parity-class launches of a stride-2 data gradient on two streams (round 6)
-        self.s2_class_lanes = os.environ.get("SSN_S2_CLASS_LANES", "1") != "0"
-        self._class_streams = {}
         self.infer_cache = os.environ.get("SSN_INFER_CACHE", "1") != "0"   # planes_exec: packed weights / folded BN reused across no-grad forwards
         self.pooled_mask = os.environ.get("SSN_POOLED_MASK", "1") != "0"   # planes_exec: stem pools' backward reads the pooled sign
         # planes_exec: all weight operands of a pass packed in three launches through a device-resident plan (kernels.PackBatch)
@@ -810,12 +807,6 @@ class BNInception(nn.Module):
         st = self._side_streams.get(dev)
         if st is None:
             st = self._side_streams[dev] = torch.cuda.Stream(device=dev)
-        return st
-
-    def _class_stream(self, dev):
-        st = self._class_streams.get(dev)
-        if st is None:
-            st = self._class_streams[dev] = torch.cuda.Stream(device=dev)
         return st
 
     def _wgrad_group_buffers(self, jobs, dev):

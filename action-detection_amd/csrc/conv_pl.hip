@@ -969,12 +969,11 @@ extern "C" int ssn_conv_pl_dgrad(const void* dy_hi, const void* dy_lo, const flo
 
 // Data gradient of a 3x3 / stride-2 convolution (pad 1 on an even input, or pad 0) on planes slices: four stride-1 launches,
 // one per parity class of the input pixel, each a (1 + a) x (1 + b)-tap gather over dy stored at the class's pixels of dx
-// (no tap is multiplied that does not contribute).  wt_packed: ssn_conv_x6_pack_dgrad_s2 (four sections).  class_mask: bit c = launch
-// class c (15: all four; the classes write disjoint pixels, so a caller may issue complementary masks on two streams).
+// (no tap is multiplied that does not contribute).  wt_packed: ssn_conv_x6_pack_dgrad_s2 (four sections).
 extern "C" int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const float* wt_packed, void* dx_hi, void* dx_lo, int N,
                                     int Cout, int Ho, int Wo, long dy_img_groups, int Cin, int H, int W, long dx_img_groups,
                                     int pad, int accumulate, const void* mask_hi, long mask_img_groups, const float* mask_scale,
-                                    int tile_cfg, const float* dy_scale, const float* dx_scale, float* dx_amax, int class_mask,
+                                    int tile_cfg, const float* dy_scale, const float* dx_scale, float* dx_amax,
                                     hipStream_t stream) {
     SSN_CHECK_ARG((pad == 1 && H % 2 == 0 && W % 2 == 0 && Ho == H / 2 && Wo == W / 2) ||
                       (pad == 0 && H >= 3 && W >= 3 && Ho == (H - 3) / 2 + 1 && Wo == (W - 3) / 2 + 1),
@@ -983,10 +982,6 @@ extern "C" int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const 
     long off = 0;
     for (int cls = 0; cls < 4; ++cls) {
         const int ca = cls >> 1, cb = cls & 1, kh = 1 + ca, kw = 1 + cb;
-        if (!((class_mask >> cls) & 1)) {      // (this call leaves the class to another one: the caller runs the classes on two streams)
-            off += (long)((Cout + 15) / 16) * kh * kw * Cin * APITCH + 4;
-            continue;
-        }
         const int sub_a = pad ? ca : 1 - ca, sub_b = pad ? cb : 1 - cb;     // parity of the class's input rows / columns
         const int gh = pad ? Ho : (H - sub_a + 1) / 2, gw = pad ? Wo : (W - sub_b + 1) / 2;
         PlConvArgs a;

@@ -219,6 +219,7 @@ class TotalLossFn(torch.autograd.Function):
         ctx.meta = (tuple(comp.shape), tuple(reg.shape) if has else None, den, w_comp, w_reg)
         parts = losses[:3]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)      # (no zero tensor for the parts' absent gradient: one fill launch per step)
         return losses[3], parts
 
     @staticmethod
@@ -230,6 +231,8 @@ class TotalLossFn(torch.autograd.Function):
         reg_lbl, diff = (saved[5], saved[6]) if has else (None, None)
         d_act, d_comp = _new(act, act.shape), _new(act, comp_shape)
         d_reg = _new(act, reg_shape) if has else None
+        if g_total is None:
+            return (None,) * 14
         K.total_loss_bwd(act, act_t, comp_t, comp_shape, reg_lbl, reg_shape, den, w_comp, w_reg, lse, coef, diff,
                          g_total.contiguous().reshape(1), d_act, d_comp, d_reg)
         return (d_act, None, d_comp, None, d_reg) + (None,) * 9

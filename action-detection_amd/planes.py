@@ -325,15 +325,14 @@ def conv_wgrad_group(jobs, workspace=None, table=None):
              table.numel() * table.element_size(), _st(lib, first.t))
 
 
-def conv_dgrad_s2(dy, wt_packed, dx, pad, accumulate=False, tile_cfg=-1, mask=None, mask_scale=None, class_mask=15):
-    """dgrad of a 3x3 / stride-2 conv on planes slices (pad 1 on an even input, or pad 0).  wt_packed: kernels.pack_dgrad_s2(w).
-    class_mask: which of the four parity-class launches this call issues (they write disjoint pixels of dx)."""
+def conv_dgrad_s2(dy, wt_packed, dx, pad, accumulate=False, tile_cfg=-1, mask=None, mask_scale=None):
+    """dgrad of a 3x3 / stride-2 conv on planes slices (pad 1 on an even input, or pad 0).  wt_packed: kernels.pack_dgrad_s2(w)."""
     lib = _lib_for(dy.t)
     ho, wo = dy.hw
     h, w = dx.hw
     lib.call("ssn_conv_pl_dgrad_s2", dy.hi, dy.lo, _p(wt_packed), dx.hi, dx.lo, dy.n, dy.c, ho, wo, dy.groups, dx.c, h, w, dx.groups,
              int(pad), int(bool(accumulate)), mask.hi if mask is not None else None, mask.groups if mask is not None else 0,
-             _p(mask_scale), tile_cfg, dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, int(class_mask), _st(lib, dy.t))
+             _p(mask_scale), tile_cfg, dy.t.scale_ptr, dx.t.scale_ptr, dx.t.amax_ptr, _st(lib, dy.t))
 
 
 def maxpool_fwd(x, y, argmax, k, s, pad):

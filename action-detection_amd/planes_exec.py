@@ -796,21 +796,8 @@ def run_backward(net, dfeat, saved, hook=True):
                     dx = PSlice(gbuf(op["src"]), op["src_c0"], cin)
                     tcfg = net._pl_tile("dgrad", op, n, shapes)
                     if dg_s2[lids[0]]:
-                        def dgrad_s2(gs=gs, wt=wt, dx=dx, pad=op["p"], acc_flag=acc_flag, tcfg=tcfg, my=my, ms=ms):
-                            # [r6] four parity-class launches of 220-440 workgroups each (one round of the chip or less, 15-50 us): the
-                            # 4-tap + 1-tap classes stay on this lane, the two 2-tap classes go to the class stream (disjoint pixels of
-                            # dx, order-free amax): fork / join inside this call, so an event pair around it times the overlapped whole
-                            cs = net._class_stream(dev) if (net.s2_class_lanes and dfeat.is_cuda) else None
-                            if cs is None:
-                                P.conv_dgrad_s2(gs, wt, dx, pad, acc_flag, tcfg, mask=my, mask_scale=ms)
-                                return
-                            cur = torch.cuda.current_stream(dev)
-                            cs.wait_stream(cur)
-                            with torch.cuda.stream(cs):
-                                P.conv_dgrad_s2(gs, wt, dx, pad, acc_flag, tcfg, mask=my, mask_scale=ms, class_mask=0b0110)
-                            P.conv_dgrad_s2(gs, wt, dx, pad, acc_flag, tcfg, mask=my, mask_scale=ms, class_mask=0b1001)
-                            cur.wait_stream(cs)
-                        net._timed("conv_dgrad_pl", lids[0], flops, dgrad_s2)
+                        net._timed("conv_dgrad_pl", lids[0], flops,
+                                   lambda: P.conv_dgrad_s2(gs, wt, dx, op["p"], acc_flag, tcfg, mask=my, mask_scale=ms))
                     else:
                         # (a fused block-input launch reads its rows behind the split k_gap channels further up dy's tensor)
                         net._timed("conv_dgrad_pl", lids[0], flops, lambda: P.conv_dgrad(

@@ -404,7 +404,6 @@ def main():
         model.base_model.overlap_wgrad = False
         model.base_model.branch_streams = False
         model.base_model.branch_lanes = False
-        model.base_model.s2_class_lanes = False
     model.to(dev).train()
     policies = model.get_optim_policies()
     # (Inception-v3 with these synthetic weights diverges at the reference's default lr = 0.001 -- loss 1e9 after a dozen steps on the

@@ -501,7 +501,7 @@ int ssn_conv_pl_dgrad(const void* dy_hi, const void* dy_lo, const float* wt_pack
 int ssn_conv_pl_dgrad_s2(const void* dy_hi, const void* dy_lo, const float* wt_packed, void* dx_hi, void* dx_lo, int N, int Cout,
                          int Ho, int Wo, long dy_img_groups, int Cin, int H, int W, long dx_img_groups, int pad, int accumulate,
                          const void* mask_hi, long mask_img_groups, const float* mask_scale, int tile_cfg, const float* dy_scale,
-                         const float* dx_scale, float* dx_amax, int class_mask, hipStream_t stream);
+                         const float* dx_scale, float* dx_amax, hipStream_t stream);
 /* weight + bias gradient (cuDNN wgrad behind ssn_train.py:236): the reduction index is the pixel, so the operands are read
  * with the LDS transpose read; tile_cfg >= 100 / < 0: the nine-tap kernel for 3x3 / stride 1 / pad 1 layers. */
 int ssn_conv_wgrad_pl(const void* g_hi, const void* g_lo, const void* x_hi, const void* x_lo, float* dw, float* db, int N, int Cin,
