@@ -51,18 +51,27 @@ def loops(lines, want):
             continue
         body = lines[i:end]
         meta = {k: next((l.split(":")[1].strip() for l in body if l.startswith("; " + k + ":")), "?") for k in ("NumVgprs", "ScratchSize")}
+        # Loop membership from the compiler's block annotations ("=>This Loop Header" on the header block, "in Loop: Header=BBx_y" on
+        # the others -- also on fall-through blocks printed as "; %bb.N:").  (Scanning from the header for a branch back to its label
+        # misses rotated loops, whose latch blocks are laid out IN FRONT of the header and fall through into it: round 6's epilogue
+        # change made the compiler rotate the K loop of most conv_pl_kernel variants.)
+        member = {}
+        cur = None
+        for l in body:
+            m = re.match(r"^(\.LBB\d+_\d+):|^; %bb\.\d+:", l)
+            if m:
+                h = re.search(r"in Loop: Header=(BB\d+_\d+)", l)
+                if "Loop Header" in l and m.group(1):
+                    cur = m.group(1)[2:]              # ".LBB15_68" -> "BB15_68"
+                elif h:
+                    cur = h.group(1)
+                else:
+                    cur = None
+                continue
+            if cur is not None and l.startswith("\t") and not l.strip().startswith((";", ".")):
+                member.setdefault(cur, []).append(l.split()[0])
         best = None
-        for k, l in enumerate(body):
-            if "Loop Header" not in l:
-                continue
-            lab = l.split(":")[0]
-            last = None
-            for k2 in range(k, len(body)):
-                if re.search(r"s_c?branch\w*\s+" + re.escape(lab) + r"\b", body[k2]):
-                    last = k2
-            if last is None:
-                continue
-            ops = [x.split()[0] for x in body[k:last + 1] if x.startswith("\t") and not x.strip().startswith((";", "."))]
+        for ops in member.values():
             nm = sum(o.startswith("v_mfma") for o in ops)
             if nm and (best is None or nm > best[0]):
                 best = (nm, ops)
