@@ -1045,7 +1045,13 @@ extern "C" int ssn_pl_im2col(const void* x_hi, const void* x_lo, long x_img_grou
     return SSN_OK;
 }
 
-static int fill_pool(PoolArgs& a, const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups,
+static // the fast pool kernels address with 32-bit byte offsets and descriptor sizes computed from the WHOLE tensor's groups per image: a
+// narrow slice of a wide, large tensor must not wrap -- such calls take the general (64-bit indexing) kernels
+// (2 GiB, not 4: a lane outside the image is sent to offset 0x80000000, which must lie BEHIND the descriptor's end)
+inline bool pool_fits32(int N, long img_groups, int G, long hw) {
+    return ((long)(N - 1) * img_groups + G) * hw * 16 <= (1l << 31);
+}
+int fill_pool(PoolArgs& a, const void* x_hi, const void* x_lo, long x_img_groups, void* y_hi, void* y_lo, long y_img_groups,
                      int N, int C, int H, int W, int Ho, int Wo, int k, int s, int pad, const float* x_scale, const float* y_scale,
                      float* y_amax, const char* what) {
     SSN_CHECK_ARG(y_scale && N > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0, "%s: bad arguments", what);
@@ -1100,9 +1106,10 @@ extern "C" int ssn_pl_maxpool_fwd(const void* x_hi, const void* x_lo, long x_img
     SSN_CHECK_ARG(x_hi && x_lo && x_scale && k >= 1 && k <= 15 && s >= 1, "pl maxpool fwd: bad arguments");
     a.argmax = argmax;
     const dim3 grid(grid_for((long)N * a.G * Ho * Wo));
-    if (k == 3 && s == 2)
+    const bool fits = pool_fits32(N, x_img_groups, a.G, (long)H * W);
+    if (k == 3 && s == 2 && fits)
         hipLaunchKernelGGL((pl_maxpool_fwd_k3_fast_kernel<2>), grid, dim3(256), 0, stream, a);
-    else if (k == 3 && s == 1)
+    else if (k == 3 && s == 1 && fits)
         hipLaunchKernelGGL((pl_maxpool_fwd_k3_fast_kernel<1>), grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL((pl_maxpool_fwd_kernel<0, 0>), grid, dim3(256), 0, stream, a);
@@ -1147,7 +1154,9 @@ extern "C" int ssn_pl_maxpool_bwd(const void* dy_hi, const void* dy_lo, long dy_
     // the training step's cases (planes output, nothing to accumulate, no mask or the pooled one, 16-byte aligned scale vector) on
     // the low-instruction-count kernel
     const bool fast = k == 3 && s == 2 && (pad == 0 || pad == 1) && !dx_f32 && !accumulate && (!a.mask_hi || mask_pooled) &&
-                      (!a.mask_hi || (reinterpret_cast<uintptr_t>(mask_scale) & 15) == 0) && (long)N * C / 8 * Ho * Wo * 16 < (1l << 31);
+                      (!a.mask_hi || (reinterpret_cast<uintptr_t>(mask_scale) & 15) == 0) && (long)N * C / 8 * Ho * Wo * 16 < (1l << 31) &&
+                      pool_fits32(N, dy_img_groups, a.G, (long)Ho * Wo) && pool_fits32(N, dx_img_groups, a.G, (long)H * W) &&
+                      (!a.mask_hi || pool_fits32(N, mask_img_groups, a.G, (long)Ho * Wo));
     if (fast) {
         const dim3 gb(grid_for((long)N * a.G * ((H + 1) / 2) * ((W + 1) / 2)));
         if (pad == 0 && a.mask_hi) hipLaunchKernelGGL((pl_maxpool_bwd_k3s2_fast_kernel<0, true>), gb, dim3(256), 0, stream, a);
@@ -1185,7 +1194,7 @@ extern "C" int ssn_pl_avgpool_affine(const void* x_hi, const void* x_lo, long x_
     a.aff_scale = scale;
     a.aff_shift = shift;
     a.relu = relu;
-    if (k == 3 && pad == 1)
+    if (k == 3 && pad == 1 && pool_fits32(N, x_img_groups, a.G, (long)H * W) && pool_fits32(N, y_img_groups, a.G, (long)H * W))
         hipLaunchKernelGGL(pl_avgpool3_fast_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(pl_avgpool_affine_kernel, dim3(grid_for((long)N * a.G * H * W)), dim3(256), 0, stream, a);
