@@ -525,6 +525,11 @@ def main():
     launch = "eager"
     run_step = step
     static = {}
+    if use_dist and overlapped and backend != "nccl" and not args.no_graph:
+        # (a gloo collective on device tensors goes through the host and cannot be captured; a failed capture leaves the stream
+        # unusable.  Only the one-GPU control-flow check runs this combination: RCCL collectives are captured as usual)
+        args.no_graph = True
+        launch = "eager (gloo collectives inside the step cannot be captured)"
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
