@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import action_detection_amd  # noqa: F401
 import ssn_oracle as O
@@ -147,6 +148,50 @@ def test_product_losses_match_reference(backend):
     loss.backward()
     assert rel_err(loss, torch.from_numpy(g["ohem_loss"])) < 1e-6
     assert np.array_equal(pred.grad.cpu().numpy(), g["ohem_grad"])
+
+
+def test_objective_in_one_launch_matches_the_reference_losses(backend):
+    """[r6] ops.ssn_ops.SSNObjective on the reference-generated loss fixtures: its completeness / regression components equal the
+    reference's own CompletenessLoss / ClassWiseRegressionLoss values (fixture), the activity component torch's CrossEntropyLoss, the
+    total the driver's mix (ssn_train.py:210-214), gradients those of the separate criterions -- with and without the regression head
+    (ssn_models.py:288-289), with weights other than the defaults, and with a data-parallel share of the denominator."""
+    g = load("ref_losses.npz")
+    rng = np.random.RandomState(3)
+    comp = torch.from_numpy(g["comp0_pred"])
+    comp_t = torch.from_numpy(g["comp0_labels"])
+    reg, reg_lbl, reg_t = torch.from_numpy(g["reg_pred"]), torch.from_numpy(g["reg_labels"]), torch.from_numpy(g["reg_targets"])
+    act = torch.from_numpy(rng.standard_normal((2 * comp.shape[0] // 7, 21)).astype(np.float32) * 2)
+    act_t = torch.from_numpy(rng.randint(0, 21, size=act.shape[0]).astype(np.int64))
+    ce = F.cross_entropy(act.double(), act_t).item()
+    for with_reg, (wc, wr), rows in ((True, (0.1, 0.1), None), (False, (0.1, 0.1), None), (True, (0.3, 0.7), None),
+                                     (True, (0.1, 0.1), 4 * comp.shape[0])):
+        leaves = [backend.put(t.clone()).requires_grad_() for t in (act, comp, reg)]
+        obj = P.SSNObjective(wc, wr)
+        args = [leaves[0], backend.put(act_t), leaves[1], backend.put(comp_t)]
+        if with_reg:
+            args += [leaves[2], backend.put(reg_lbl), backend.put(reg_t)]
+        total = obj(*args, sample_split=1, sample_group_size=7, global_rows=rows)
+        parts = obj.parts.cpu().double()
+        assert abs(parts[0].item() - ce) < 1e-6 * max(1.0, abs(ce))
+        if rows is None:
+            assert rel_err(parts[1].reshape(1), torch.from_numpy(g["comp0_loss"]).reshape(1)) < 1e-6
+        if with_reg:
+            assert rel_err(parts[2].reshape(1), torch.from_numpy(g["reg_loss"]).reshape(1)) < 1e-6
+        else:
+            assert parts[2].item() == 0.0
+        want = parts[0] + wc * parts[1] + (wr * parts[2] if with_reg else 0.0)
+        assert abs(total.item() - want.item()) < 2e-7 * max(1.0, abs(want.item()))
+        total.backward()
+        sep = [backend.put(t.clone()).requires_grad_() for t in (act, comp, reg)]
+        ref_total = P.ActivityLoss()(sep[0], backend.put(act_t)) + wc * P.CompletenessLoss()(sep[1], backend.put(comp_t), 1, 7, global_rows=rows)
+        if with_reg:
+            ref_total = ref_total + wr * P.ClassWiseRegressionLoss()(sep[2], backend.put(reg_lbl), backend.put(reg_t))
+        ref_total.backward()
+        for k in range(3 if with_reg else 2):
+            assert rel_err(leaves[k].grad, sep[k].grad) < 1e-6, (with_reg, wc, wr, rows, k)
+        if rows is None and (wc, wr) == (0.1, 0.1):
+            assert np.array_equal(leaves[1].grad.cpu().numpy() != 0, g["comp0_grad"] != 0), "OHEM kept a different row set"
+        assert leaves[2].grad is None or with_reg
 
 
 def test_product_reorg_matches_reference(backend):
