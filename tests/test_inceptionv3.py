@@ -248,6 +248,33 @@ def test_inceptionv3_gradients_vs_mask_forced_referee_gpu(hip_library):
               % (k, n_t, worst[0], worst[1], prod.guard_stats()))
         assert n_t == 2 * 94 and worst[1] < 5e-5, worst
     assert prod.guard_stats()["fwd"] >= 1
+    # [r6] the same tight bar with TRAINING-mode BatchNorm on six layers (rectangular, strided, pooled, the first one): the
+    # forced referee is smooth with batch statistics as well, so this -- not the flip-dependent 2e-3 / 2e-2 caps of the test above -- is
+    # what a numeric regression of the batch-statistics kernels, the grouped weight gradients or the delayed input scale has to pass
+    train = ("conv_1a_3x3", "mixed_5b_5x5", "mixed_6b_1x7", "mixed_6a_3x3", "mixed_7b_3x3_3x1", "mixed_5c_pool_proj")
+    for lid in train:
+        getattr(prod, lid + "_bn").train()
+        getattr(orc, lid + "_bn").train()
+    orc.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in prod.state_dict().items()})
+    prod.zero_grad(set_to_none=True)
+    orc.zero_grad(set_to_none=True)
+    f = prod.features(x0.cuda())
+    (f * w.cuda()).sum().backward()
+    relu, pools = prod.export_decisions()
+    orc.forced = ({n: t.cpu() for n, t in relu.items()}, [t.cpu() for t in pools.values()])
+    fo = orc.features(x0.double())
+    assert rel_err(f, fo) < 5e-6, ("forced forward, training-mode BatchNorm", rel_err(f, fo))
+    (fo * w.double()).sum().backward()
+    ref = dict(orc.named_parameters())
+    worst, n_t = ("", 0.0), 0
+    for n, p in prod.named_parameters():
+        if p.grad is None or n in [lid + ".bias" for lid in train]:      # (a bias in front of batch statistics: true gradient zero)
+            continue
+        n_t += 1
+        e = rel_err(p.grad, ref[n].grad)
+        worst = (n, e) if e > worst[1] else worst
+    print("Inception-v3, 6 training-mode BatchNorms: worst of %d gradient tensors vs the mask-forced float64 referee: %s %.2e" % (n_t, worst[0], worst[1]))
+    assert n_t == 2 * 94 - 6 + 2 * 6 and worst[1] < 5e-5, worst
 
 
 @pytest.mark.gpu
