@@ -939,7 +939,7 @@ def export_decisions(net, saved):
                     name, c0 = op["dst"], op["dst_c0"] + off + (op["row_gap"] if off >= op.get("row_split", 1 << 30) else 0)
                 relu[lid] = hi_nchw(name)[:, c0:c0 + c] > 0
                 off += c
-        elif op["kind"] == "pool":
+        elif op["kind"] == "pool" and op["pool"] == "max":      # (a plain average pool -- plans with training-mode BatchNorm -- decides nothing)
             am = argmax[op["lid"]]
             _, ho, wo = shapes[op["dst"]]
             pool[op["lid"]] = am.permute(0, 1, 3, 2).reshape(am.shape[0], am.shape[1] * 8, ho, wo).long()
