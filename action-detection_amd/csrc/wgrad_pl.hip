@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -1290,6 +1291,14 @@ void plan_group(std::vector<WgGroupItem*>& fam, int slots, double fixed_cost, in
     }
 }
 
+bool group1_interleave() {
+    static const bool on = [] {
+        const char* e = std::getenv("SSN_WGRAD_INTERLEAVE");      // (tooling: 0 = the round-5 order, longest item first)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 }  // namespace
 
 // tooling (tools/trace_wgrad_pl.py): per-block phase stamps of the next launches into buf (8 qwords per block), null = off
@@ -1434,6 +1443,24 @@ extern "C" int ssn_conv_wgrad_pl_group(int count, const void* const* g_hi, const
         std::stable_sort(fam.begin(), fam.end(), [](const WgGroupItem* x, const WgGroupItem* y) {
             return x->a.ksteps_per_split * x->unit_cost > y->a.ksteps_per_split * y->unit_cost;
         });
+        if (f == WGF_1 && group1_interleave()) {
+            // One-tap / chunked family: its problems are of two kinds -- the 28 x 28 / 56 x 56 layers sit at their operand floor
+            // (0.5 GB for 20 - 30 GFLOP), the 14 x 14 / 7 x 7 ones are matrix work -- and their items are all about equally long, so
+            // "longest first" says nothing and happened to put the memory-bound half in front.  Dealt alternately from both ends of
+            // the bytes-per-MAC order, a memory-bound problem always runs beside a matrix-bound one (the in-order dispatch keeps
+            // ~ 1.5 problems in flight).  The order of the problems does not touch any problem's own summation order.
+            auto bytes_per_mac = [](const WgGroupItem* x) {
+                const double s2 = (double)x->a.stride * x->a.stride;
+                return ((double)x->a.M + (double)x->a.Cin * s2) / ((double)x->a.M * x->a.Cin * x->a.kh * x->a.kw);
+            };
+            std::stable_sort(fam.begin(), fam.end(), [&](const WgGroupItem* x, const WgGroupItem* y) { return bytes_per_mac(x) > bytes_per_mac(y); });
+            std::vector<WgGroupItem*> dealt;
+            for (size_t lo = 0, hi = fam.size(); lo < hi;) {
+                dealt.push_back(fam[lo++]);
+                if (lo < hi) dealt.push_back(fam[--hi]);
+            }
+            fam.swap(dealt);
+        }
         for (size_t base = 0; base < fam.size(); base += WGG_MAX) {
             const int n = (int)std::min<size_t>(WGG_MAX, fam.size() - base);
             WgGroupIndex ix;
