@@ -449,7 +449,8 @@ def test_planes_pools(backend):
     """max pool (ceil mode, argmax routing), average pool behind a projection, global pool, ReLU/BN backward, channel sums."""
     g = torch.Generator().manual_seed(6)
     n, c = (6, 64) if backend.is_gpu else (2, 16)
-    for (h, k, s, pad) in [(12, 3, 2, 0), (7, 3, 1, 1), (9, 3, 2, 0), (10, 3, 2, 1), (11, 3, 2, 1)]:
+    # (57 / 30 / 29: rows of several cache lines, with and without padding; also between slices of wider tensors)
+    for (h, k, s, pad) in [(12, 3, 2, 0), (7, 3, 1, 1), (9, 3, 2, 0), (10, 3, 2, 1), (11, 3, 2, 1), (57, 3, 2, 0), (30, 3, 2, 1), (29, 3, 2, 0)]:
         x = torch.randn(n, c, h, h, generator=g).clamp(min=0)          # post-ReLU: many exact-zero ties
         xd = x.double().requires_grad_()
         ref, idx = F.max_pool2d(xd, k, s, pad, ceil_mode=True, return_indices=True)
@@ -459,6 +460,14 @@ def test_planes_pools(backend):
         am = backend.put(torch.zeros((n, c // 8, ho * ho, 8), dtype=torch.uint8))
         _two_pass(lambda: P.maxpool_fwd(P.pfull(xp), P.pfull(y), am, k, s, pad), y)
         assert rel_err(P.to_f32(y), ref) < 2.0 ** -21
+        if h >= 24:      # the same pool between slices of wider tensors: bit-identical planes and argmax
+            xw = P.PlaneTensor(n, c + 16, h, h, backend.device).zero_()
+            P.from_f32(backend.put(x), P.PSlice(xw, 8, c))
+            yw = P.PlaneTensor(n, c + 8, ho, ho, backend.device).zero_()
+            am2 = backend.put(torch.zeros((n, c // 8, ho * ho, 8), dtype=torch.uint8))
+            _two_pass(lambda: P.maxpool_fwd(P.PSlice(xw, 8, c), P.PSlice(yw, 0, c), am2, k, s, pad), yw)
+            assert torch.equal(am2.cpu(), am.cpu()), ("argmax through slices", h)
+            assert rel_err(P.to_f32(P.PSlice(yw, 0, c)), ref) < 2.0 ** -21
         gy = torch.randn(ref.shape, generator=g)
         ref.backward(gy.double())
         gp = P.from_f32(backend.put(gy))
