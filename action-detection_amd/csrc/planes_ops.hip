@@ -799,11 +799,25 @@ __global__ __launch_bounds__(256) void pl_gap_fwd_kernel(const void* hi, const v
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int q = 0; q < HW; ++q) {
-        float v[8];
-        load8(hi, lo, base + q, v);
+    // eight pixels' loads in flight, summed in pixel order (one memory round trip per pixel made this 50 us for 58 MB)
+    constexpr int B = 8;
+    for (int q0 = 0; q0 < HW; q0 += B) {
+        u32x4 th[B], tl[B];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        for (int j = 0; j < B; ++j) {
+            const int q = q0 + j < HW ? q0 + j : HW - 1;
+            th[j] = reinterpret_cast<const u32x4*>(hi)[base + q];
+            tl[j] = reinterpret_cast<const u32x4*>(lo)[base + q];
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            float v[8];
+            pl_join8(th[j], tl[j], v);
+            if (q0 + j < HW) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+        }
     }
     const float inv = 1.f / ((float)HW * *scale);
 #pragma unroll
