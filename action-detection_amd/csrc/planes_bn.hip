@@ -241,9 +241,9 @@ __global__ __launch_bounds__(256) void pl_bn_bwd_apply_kernel(BnPlArgs p) {
     amax_emit(p.o_amax, vmax / so);
 }
 
-inline unsigned bnp_grid(long total) {
+inline unsigned bnp_grid(long total) {      // (grid-stride kernels: eight workgroups per CU, as planes_ops.hip's grid_for -- profiles/r6_grid_cap.txt)
     long b = (total + 255) / 256;
-    return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
 }  // namespace

@@ -824,6 +824,36 @@ __global__ __launch_bounds__(256) void pl_gap_fwd_kernel(const void* hi, const v
     for (int e = 0; e < 8; ++e) out[(long)n * G * 8 + 8 * g + e] = acc[e] * inv;
 }
 
+// ... the same sums (same order: bit-identical) with coalesced loads: a workgroup takes GAP_NG consecutive channel groups of one image --
+// one contiguous range of each plane -- through the LDS, then one thread per channel adds its HW values in pixel order.  (The kernel
+// above reads 16 bytes per lane from addresses HW * 16 bytes apart: 64 cache lines per load instruction, 40 - 50 us for 58 MB.)
+constexpr int GAP_NG = 16, GAP_MAX = 1024;      // channel groups per workgroup; 16-byte entries per plane in the LDS
+__global__ __launch_bounds__(256) void pl_gap_fwd_lds_kernel(const void* hi, const void* lo, long img_groups, float* out, int N, int G,
+                                                            int HW, const float* scale, int gblocks) {
+    __shared__ __attribute__((aligned(16))) u32x4 t_hi[GAP_MAX];
+    __shared__ __attribute__((aligned(16))) u32x4 t_lo[GAP_MAX];
+    const int n = blockIdx.x / gblocks, g0 = (blockIdx.x - n * gblocks) * GAP_NG;
+    const int ng = G - g0 < GAP_NG ? G - g0 : GAP_NG;
+    const long base = ((long)n * img_groups + g0) * HW;
+    const int cnt = ng * HW;
+#pragma unroll 2
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        t_hi[i] = reinterpret_cast<const u32x4*>(hi)[base + i];
+        t_lo[i] = reinterpret_cast<const u32x4*>(lo)[base + i];
+    }
+    __syncthreads();
+    const int j = threadIdx.x >> 3, e = threadIdx.x & 7;
+    if (j >= ng) return;
+    const uint32_t* ph = reinterpret_cast<const uint32_t*>(t_hi + j * HW) + (e >> 1);
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(t_lo + j * HW) + (e >> 1);
+    float acc = 0.f;
+    for (int q = 0; q < HW; ++q) {
+        const uint32_t h = ph[q * 4], l = pw[q * 4];
+        acc += (e & 1) ? f16_pair_hi(h) + f16_pair_hi(l) : f16_pair_lo(h) + f16_pair_lo(l);
+    }
+    out[(long)n * G * 8 + 8 * (g0 + j) + e] = acc * (1.f / ((float)HW * *scale));
+}
+
 // global average pool backward: dx[n][c][q] = dy[n][c] / HW, with the fused ReLU / frozen-BN backward of the pooled tensor
 // (PoolArgs: aff_shift = dy fp32 [N][C], y = dx planes, mask as usual)
 __global__ __launch_bounds__(256) void pl_gap_bwd_kernel(PoolArgs p) {
@@ -954,9 +984,18 @@ __global__ __launch_bounds__(256) void pl_channel_sum_multi_final_kernel(Channel
     t.out[ti][c - 8 * t.g0[ti]] = s / *t.scale[ti];
 }
 
+// Grid of the elementwise kernels of this file (all of them grid-stride loops): at most 2048 workgroups = eight per CU, the rest
+// of the elements by the loop.  [r6] The cap was 65536: one wave's worth of work per wave, and every wave ends in amax_emit's
+// read-compare-atomicMax on ONE address -- tens of thousands of short-lived waves per launch.  Measured on the bench step
+// (profiles/r6_grid_cap.txt): frames -> planes 142 -> 72 us, gap backward 50 - 74 -> 29, the stride-2 pools -7 %; step -0.22 ms;
+// flat between 512 and 3072.  Results do not depend on the grid (element-wise work + a maximum).  SSN_PL_GRID_CAP: tooling.
 int grid_for(long total) {
+    static const long cap = [] {
+        const char* e = std::getenv("SSN_PL_GRID_CAP");
+        return e ? std::atol(e) : 2048l;
+    }();
     long b = (total + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 }  // namespace
@@ -1236,8 +1275,14 @@ extern "C" int ssn_pl_relu_bn_bwd(void* g_hi, void* g_lo, long g_img_groups, con
 extern "C" int ssn_pl_gap_fwd(const void* x_hi, const void* x_lo, long x_img_groups, float* y, int N, int C, int HW,
                               const float* x_scale, hipStream_t stream) {
     SSN_CHECK_ARG(x_hi && x_lo && y && x_scale && C % 8 == 0, "pl gap fwd: bad arguments");
-    hipLaunchKernelGGL(pl_gap_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, stream, x_hi, x_lo, x_img_groups, y, N, C / 8,
-                       HW, x_scale);
+    if (GAP_NG * HW <= GAP_MAX) {
+        const int gblocks = (C / 8 + GAP_NG - 1) / GAP_NG;
+        hipLaunchKernelGGL(pl_gap_fwd_lds_kernel, dim3((unsigned)(N * gblocks)), dim3(256), 0, stream, x_hi, x_lo, x_img_groups, y, N, C / 8,
+                           HW, x_scale, gblocks);
+    } else {
+        hipLaunchKernelGGL(pl_gap_fwd_kernel, dim3((N * (C / 8) + 255) / 256), dim3(256), 0, stream, x_hi, x_lo, x_img_groups, y, N, C / 8,
+                           HW, x_scale);
+    }
     SSN_CHECK_LAUNCH("pl_gap_fwd");
     return SSN_OK;
 }

@@ -5,6 +5,7 @@ libssn_hip.so at the backbone's layer shapes.  Tolerances are relative to the la
 those of the fp32-layout split kernels (two f16 terms per operand = 22 significant bits, fp32 accumulation).
 """
 import pytest
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -536,6 +537,21 @@ def test_planes_pools(backend):
     feat = backend.put(torch.empty(n, c))
     P.gap_fwd(P.pfull(zp), feat)
     assert rel_err(feat, z.double().mean(dim=(2, 3))) < 1e-6
+    # 21 channel groups of a wider tensor (a workgroup takes 16: one full, one of five), 7 x 7 pixels; the sums run in pixel order in
+    # fp32: the host repeats them on the stored values and must get the same bits
+    cw = 21 * 8
+    zw = torch.randn(n, cw + 16, 7, 7, generator=g)
+    zwp = P.from_f32(backend.put(zw))
+    featw = backend.put(torch.empty(n, cw))
+    P.gap_fwd(P.PSlice(zwp, 8, cw), featw)
+    assert rel_err(featw, zw[:, 8:8 + cw].double().mean(dim=(2, 3))) < 1e-6
+    sc = np.float32(zwp.scale.cpu().item())
+    stored = (P.to_f32(P.PSlice(zwp, 8, cw)).cpu().numpy() * sc).reshape(n, cw, 49)      # (power-of-two scale: exact)
+    acc = np.zeros((n, cw), dtype=np.float32)
+    for q in range(49):
+        acc = (acc + stored[:, :, q]).astype(np.float32)
+    want = acc * (np.float32(1.0) / (np.float32(49.0) * sc))
+    assert np.array_equal(featw.cpu().numpy(), want), "global average pool: sums in pixel order"
     dfeat = torch.randn(n, c, generator=g)
     dxp = P.PlaneTensor(n, c, h, h, backend.device)
     actp = P.from_f32(backend.put(act))
