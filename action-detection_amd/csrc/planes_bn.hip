@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void pl_bn_apply_kernel(BnPlArgs p) {
         reinterpret_cast<u32x4*>(p.o_hi)[o] = hi;
         reinterpret_cast<u32x4*>(p.o_lo)[o] = lo;
     }
-    amax_emit(p.o_amax, vmax / so);
+    amax_emit_block(p.o_amax, vmax / so);
 }
 
 // g = dy * (y > 0 | 1) and xhat of one 8-channel group, real units
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void pl_bn_bwd_apply_kernel(BnPlArgs p) {
             reinterpret_cast<u32x4*>(p.o_lo)[o] = lo;
         }
     }
-    amax_emit(p.o_amax, vmax / so);
+    amax_emit_block(p.o_amax, vmax / so);
 }
 
 inline unsigned bnp_grid(long total) {      // (grid-stride kernels: eight workgroups per CU, as planes_ops.hip's grid_for -- profiles/r6_grid_cap.txt)

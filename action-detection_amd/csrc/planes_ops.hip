@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void pl_from_f32_kernel(CvtArgs p) {
         reinterpret_cast<u32x4*>(p.hi)[o] = hi;
         reinterpret_cast<u32x4*>(p.lo)[o] = lo;
     }
-    amax_emit(p.amax, vmax);
+    amax_emit_block(p.amax, vmax);
 }
 
 __global__ __launch_bounds__(256) void pl_to_f32_kernel(const void* hi, const void* lo, long img_groups, float* y,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void pl_maxpool_fwd_kernel(PoolArgs p) {
             reinterpret_cast<u32x2*>(p.argmax)[idx] = u32x2{a0, a1};
         }
     }
-    amax_emit(p.y_amax, vmax / *p.y_scale);
+    amax_emit_block(p.y_amax, vmax / *p.y_scale);
 }
 
 // 3x3 max pool forward written for instruction count (as pl_maxpool_bwd_k3s2_fast_kernel below: buffer loads with 32-bit offsets, no
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void pl_maxpool_fwd_k3_fast_kernel(PoolArgs p)
             reinterpret_cast<u32x2*>(p.argmax)[idx] = u32x2{a0, a1};
         }
     }
-    amax_emit(p.y_amax, vmax / *p.y_scale);
+    amax_emit_block(p.y_amax, vmax / *p.y_scale);
 }
 
 // finish a gradient element group: (+ old), fused ReLU / frozen-BN backward of the producer ...
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_kernel(PoolArgs p) {
         const long mo = ((long)n * p.mask_img_groups + g) * p.H * p.W + (long)h * p.W + w;
         vmax = fmaxf(vmax, finish_grad8(v, p, o, mo, 8 * g));
     }
-    amax_emit(p.y_amax, vmax / *p.y_scale);
+    amax_emit_block(p.y_amax, vmax / *p.y_scale);
 }
 
 // 3x3 / stride-2 max pool backward with one thread per 2 x 2 block of INPUT pixels: the four pixels of a block can only belong to
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_kernel(PoolArgs p) {
                 if (live[q]) vmax = fmaxf(vmax, store_grad8(v[q], p, oq[q], 8 * g));
         }
     }
-    amax_emit(p.y_amax, vmax / *p.y_scale);
+    amax_emit_block(p.y_amax, vmax / *p.y_scale);
 }
 
 // The same backward for the cases the training step runs (planes output, no accumulation; MASK: the pooled mask), written for
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void pl_maxpool_bwd_k3s2_fast_kernel(PoolArgs 
             }
         }
     }
-    amax_emit(p.y_amax, vmax / *p.y_scale);
+    amax_emit_block(p.y_amax, vmax / *p.y_scale);
 }
 
 // y = relu?(scale[c] * avgpool_kxk(x) + shift[c]), stride 1, zero padding counted (count_include_pad): the pool BEHIND its 1x1
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void pl_avgpool_affine_kernel(PoolArgs p) {
         reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
         reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
     }
-    amax_emit(p.y_amax, vmax / so);
+    amax_emit_block(p.y_amax, vmax / so);
 }
 
 // The 3x3 case (every average pool of the two backbones) with all nine taps in flight at once: buffer loads with 32-bit offsets, a tap
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void pl_avgpool3_fast_kernel(PoolArgs p) {
         reinterpret_cast<u32x4*>(p.y_hi)[o] = hi;
         reinterpret_cast<u32x4*>(p.y_lo)[o] = lo;
     }
-    amax_emit(p.y_amax, vmax / so);
+    amax_emit_block(p.y_amax, vmax / so);
 }
 
 // in place: g <- g * (y > 0) * scale[c]  (NaN scale: channel passes through) -- the ReLU / frozen-BN backward of a slice whose
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void pl_relu_bn_bwd_kernel(PoolArgs p) {
         load8(p.y_hi, p.y_lo, o, v);
         vmax = fmaxf(vmax, finish_grad8(v, p, o, mo, 8 * g));
     }
-    amax_emit(p.y_amax, vmax / *p.y_scale);
+    amax_emit_block(p.y_amax, vmax / *p.y_scale);
 }
 
 // global average pool: planes [N][G][HW][8] -> fp32 [N][C]
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void pl_gap_bwd_kernel(PoolArgs p) {
         const long mo = ((long)n * p.mask_img_groups + g) * HW + q;
         vmax = fmaxf(vmax, finish_grad8(v, p, o, mo, 8 * g));
     }
-    amax_emit(p.y_amax, vmax / *p.y_scale);
+    amax_emit_block(p.y_amax, vmax / *p.y_scale);
 }
 
 // per-channel sums of a planes slice (bias gradient of a projection in front of its pool): two passes, fixed order

@@ -186,6 +186,23 @@ __device__ __forceinline__ void amax_emit(float* slot, float lane_max) {
     }
 }
 
+// The same with ONE slot read (+ atomic) per WORKGROUP: every thread of the block calls it, once, at the end of the kernel.  Device-scope
+// atomics on one address -- and the read in front of them, a memory round trip at the very end of a wave's life -- are what recording a
+// maximum costs (profiles/r6_grid_cap.txt: per-wave -> per-workgroup in the convolution epilogue was -0.14 ms per step).
+__device__ __forceinline__ void amax_emit_block(float* slot, float lane_max) {
+    if (!slot) return;      // (block-uniform)
+    __shared__ float wave_maxima[16];
+    const float wv = wave_max(lane_max);
+    if ((threadIdx.x & 63) == 0) wave_maxima[threadIdx.x >> 6] = wv;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int nw = (int)(blockDim.x + 63) >> 6;
+        float m = wave_maxima[0];
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, wave_maxima[w]);
+        amax_emit(slot, m);
+    }
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
