@@ -123,7 +123,7 @@ def main():
     if boxes:
         boxes.sort()
         med = boxes[len(boxes) // 2][0] if len(boxes) % 2 else 0.5 * (boxes[len(boxes) // 2 - 1][0] + boxes[len(boxes) // 2][0])
-        out += ["", "Boxes at the closing library (default `bench.py` line, 20 timed steps, hipGraph replay; `r6_bench_final.json` is the evidence box "
+        out += ["", "Boxes of the round (default `bench.py` line, 20 timed steps, hipGraph replay; `r6_bench_final.json` and `r6_bench_boxK4.json` are the CLOSING tree, `boxK` / `K2` / `K3` trees before the last two changes of DESIGN 5.2 (-0.4 ms); `r6_bench_final.json` is the evidence box "
                 "every other file of this summary comes from): " + "; ".join("`%s` %.3f ms = %.1f proposals/s" % (n, ms, v) for ms, v, n in boxes)
                 + ".  Median %.2f ms." % med]
     with open(os.path.join(ROOT, "profiles", "r6_summary.md"), "w") as f:
